@@ -1,0 +1,295 @@
+"""ctypes binding of the C ABI in include/historian_hip.h.
+
+Plumbing only: it marshals numpy arrays into the POD structs and calls the shared
+library.  There is no CPU fallback -- if the HIP library is missing or the device
+is absent every entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhistorian_hip.so")
+
+HX_LSE_TABLE_ENTRIES = 100002
+HX_LSE_EXACT, HX_LSE_FAST, HX_KEEP_BACKWARD = 0, 1, 2
+IMM, IMD, IDM, IMI, IIW, EEE = 0, 1, 2, 3, 4, 5
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class HxProfile(C.Structure):
+    _fields_ = [("n_states", C.c_int32), ("n_trans", C.c_int32),
+                ("trans_src", _i32p), ("trans_dst", _i32p), ("trans_lp", _f64p),
+                ("in_off", _i32p), ("in_idx", _i32p),
+                ("aout_off", _i32p), ("aout_idx", _i32p),
+                ("nout_off", _i32p), ("nout_idx", _i32p),
+                ("is_null", _u8p), ("lp_absorb", _f64p), ("env_pos", _i32p)]
+
+
+class HxHmm(C.Structure):
+    _fields_ = [("alph_size", C.c_int32), ("components", C.c_int32),
+                ("lp_trans", (C.c_double * 6) * 5),
+                ("log_root", _f64p), ("log_sub_l", _f64p), ("log_sub_r", _f64p),
+                ("log_ins_l", _f64p), ("log_ins_r", _f64p),
+                ("log_cptw_l", _f64p), ("log_cptw_r", _f64p)]
+
+
+class HxPairJob(C.Structure):
+    _fields_ = [("x", C.POINTER(HxProfile)), ("y", C.POINTER(HxProfile)),
+                ("hmm", C.POINTER(HxHmm)), ("max_distance", C.c_int32)]
+
+
+class HxLayout(C.Structure):
+    _fields_ = [("n_rows", C.c_int32), ("n_cols", C.c_int32), ("strip_rows", C.c_int32),
+                ("n_strips", C.c_int32), ("strip_stride", C.c_int64), ("plane_stride", C.c_int64)]
+
+
+class HxCell(C.Structure):
+    _fields_ = [("xpos", C.c_int32), ("ypos", C.c_int32), ("state", C.c_int32), ("pad_", C.c_int32),
+                ("log_post_prob", C.c_double)]
+
+
+EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_create", "hx_batch_destroy",
+           "hx_batch_forward", "hx_batch_backward", "hx_batch_sync", "hx_batch_lp_end", "hx_batch_lp_start",
+           "hx_batch_layout", "hx_batch_read_matrix", "hx_batch_read_cells", "hx_batch_read_prepared",
+           "hx_batch_posterior_scan", "hx_batch_total_cells", "hx_batch_last_kernel_ms"]
+
+
+class HxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("historian_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the product path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.hx_init.argtypes = [C.c_int, _f64p, C.c_size_t]
+    lib.hx_last_error.restype = C.c_char_p
+    lib.hx_batch_create.argtypes = [C.POINTER(HxPairJob), C.c_int32, C.c_uint32, C.POINTER(vp)]
+    lib.hx_batch_destroy.argtypes = [vp]
+    lib.hx_batch_forward.argtypes = [vp, vp]
+    lib.hx_batch_backward.argtypes = [vp, vp]
+    lib.hx_batch_sync.argtypes = [vp]
+    lib.hx_batch_lp_end.argtypes = [vp, _f64p]
+    lib.hx_batch_lp_start.argtypes = [vp, _f64p]
+    lib.hx_batch_layout.argtypes = [vp, C.c_int32, C.POINTER(HxLayout)]
+    lib.hx_batch_read_matrix.argtypes = [vp, C.c_int32, C.c_int32, _f64p]
+    lib.hx_batch_read_cells.argtypes = [vp, C.c_int32, C.c_int32, _i32p, C.c_int64, _f64p]
+    lib.hx_batch_read_prepared.argtypes = [vp, C.c_int32] + [_f64p] * 6
+    lib.hx_batch_posterior_scan.argtypes = [vp, C.c_int32, C.c_double, C.POINTER(HxCell), C.c_int64,
+                                            C.POINTER(C.c_int64)]
+    lib.hx_batch_total_cells.argtypes = [vp]
+    lib.hx_batch_total_cells.restype = C.c_int64
+    lib.hx_batch_last_kernel_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise HxError(rc, load().hx_last_error().decode())
+
+
+def _p(a, typ):
+    return a.ctypes.data_as(typ) if a is not None and a.size else C.cast(None, typ)
+
+
+class ProfileImage:
+    """Owns the numpy arrays behind one hx_profile."""
+
+    def __init__(self, trans_src, trans_dst, trans_lp, in_lists, aout_lists, nout_lists, is_null, lp_absorb,
+                 env_pos=None):
+        n = len(is_null)
+        self.n_states = n
+        self.trans_src = np.ascontiguousarray(trans_src, dtype=np.int32)
+        self.trans_dst = np.ascontiguousarray(trans_dst, dtype=np.int32)
+        self.trans_lp = np.ascontiguousarray(trans_lp, dtype=np.float64)
+        self.in_off, self.in_idx = self._csr(in_lists)
+        self.aout_off, self.aout_idx = self._csr(aout_lists)
+        self.nout_off, self.nout_idx = self._csr(nout_lists)
+        self.is_null = np.ascontiguousarray(is_null, dtype=np.uint8)
+        self.lp_absorb = np.ascontiguousarray(lp_absorb, dtype=np.float64)   # [N][C][A]
+        self.env_pos = None if env_pos is None else np.ascontiguousarray(env_pos, dtype=np.int32)
+        s = HxProfile()
+        s.n_states, s.n_trans = n, len(self.trans_src)
+        s.trans_src, s.trans_dst, s.trans_lp = _p(self.trans_src, _i32p), _p(self.trans_dst, _i32p), _p(self.trans_lp, _f64p)
+        s.in_off, s.in_idx = _p(self.in_off, _i32p), _p(self.in_idx, _i32p)
+        s.aout_off, s.aout_idx = _p(self.aout_off, _i32p), _p(self.aout_idx, _i32p)
+        s.nout_off, s.nout_idx = _p(self.nout_off, _i32p), _p(self.nout_idx, _i32p)
+        s.is_null, s.lp_absorb = _p(self.is_null, _u8p), _p(self.lp_absorb, _f64p)
+        s.env_pos = _p(self.env_pos, _i32p) if self.env_pos is not None else C.cast(None, _i32p)
+        self.struct = s
+
+    @staticmethod
+    def _csr(lists):
+        off = np.zeros(len(lists) + 1, dtype=np.int32)
+        for i, l in enumerate(lists):
+            off[i + 1] = off[i] + len(l)
+        idx = np.fromiter((t for l in lists for t in l), dtype=np.int32, count=int(off[-1]))
+        return off, idx
+
+    @staticmethod
+    def chain(is_null, lp_absorb, env_pos=None):
+        """Linear-chain profile (a leaf: reference src/profile.cpp:23-76): state k -> k+1
+        with lpTrans 0; the last transition (into END) is a null transition."""
+        n = len(is_null)
+        t = np.arange(n - 1, dtype=np.int32)
+        in_lists = [[]] + [[k] for k in range(n - 1)]
+        aout = [[k] if (k < n - 1 and not is_null[k + 1]) else [] for k in range(n)]
+        nout = [[k] if (k < n - 1 and is_null[k + 1]) else [] for k in range(n)]
+        return ProfileImage(t, t + 1, np.zeros(n - 1), in_lists, aout, nout, is_null, lp_absorb, env_pos)
+
+
+class HmmImage:
+    def __init__(self, lp_trans, log_root, log_sub_l, log_sub_r, log_ins_l, log_ins_r, log_cptw_l, log_cptw_r):
+        self.log_root = np.ascontiguousarray(log_root, dtype=np.float64)
+        c, a = self.log_root.shape
+        self.log_sub_l = np.ascontiguousarray(log_sub_l, dtype=np.float64).reshape(c, a, a)
+        self.log_sub_r = np.ascontiguousarray(log_sub_r, dtype=np.float64).reshape(c, a, a)
+        self.log_ins_l = np.ascontiguousarray(log_ins_l, dtype=np.float64).reshape(c, a)
+        self.log_ins_r = np.ascontiguousarray(log_ins_r, dtype=np.float64).reshape(c, a)
+        self.log_cptw_l = np.ascontiguousarray(log_cptw_l, dtype=np.float64).reshape(c)
+        self.log_cptw_r = np.ascontiguousarray(log_cptw_r, dtype=np.float64).reshape(c)
+        self.lp_trans = np.ascontiguousarray(lp_trans, dtype=np.float64).reshape(5, 6)
+        s = HxHmm()
+        s.alph_size, s.components = a, c
+        for i in range(5):
+            for j in range(6):
+                s.lp_trans[i][j] = self.lp_trans[i, j]
+        s.log_root = _p(self.log_root, _f64p)
+        s.log_sub_l, s.log_sub_r = _p(self.log_sub_l, _f64p), _p(self.log_sub_r, _f64p)
+        s.log_ins_l, s.log_ins_r = _p(self.log_ins_l, _f64p), _p(self.log_ins_r, _f64p)
+        s.log_cptw_l, s.log_cptw_r = _p(self.log_cptw_l, _f64p), _p(self.log_cptw_r, _f64p)
+        self.struct = s
+        self.alph_size, self.components = a, c
+
+
+def make_jobs(triples):
+    """triples: list of (ProfileImage x, ProfileImage y, HmmImage hmm, max_distance)."""
+    arr = (HxPairJob * len(triples))()
+    for k, (x, y, h, md) in enumerate(triples):
+        arr[k].x = C.pointer(x.struct)
+        arr[k].y = C.pointer(y.struct)
+        arr[k].hmm = C.pointer(h.struct)
+        arr[k].max_distance = md
+    return arr
+
+
+def init(device=0, table=None):
+    from .hostmodel import lse_table
+    t = np.ascontiguousarray(lse_table() if table is None else table, dtype=np.float64)
+    _check(load().hx_init(device, _p(t, _f64p), t.size))
+
+
+def shutdown():
+    _check(load().hx_shutdown())
+
+
+def slot_index(layout, i, j):
+    """hx_layout cell addressing (include/historian_hip.h)."""
+    sr = layout.strip_rows
+    i = np.asarray(i, dtype=np.int64)
+    j = np.asarray(j, dtype=np.int64)
+    return (i // sr) * layout.strip_stride + (j + i % sr) * sr + i % sr
+
+
+class Batch:
+    """n independent pair DPs resident on the device."""
+
+    def __init__(self, triples, flags=0):
+        self._keep = triples
+        self.n = len(triples)
+        self._jobs = make_jobs(triples)
+        self._h = C.c_void_p()
+        _check(load().hx_batch_create(self._jobs, self.n, flags, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().hx_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, stream=None):
+        _check(load().hx_batch_forward(self._h, C.c_void_p(stream or 0)))
+
+    def backward(self, stream=None):
+        _check(load().hx_batch_backward(self._h, C.c_void_p(stream or 0)))
+
+    def sync(self):
+        _check(load().hx_batch_sync(self._h))
+
+    def lp_end(self):
+        out = np.empty(self.n)
+        _check(load().hx_batch_lp_end(self._h, _p(out, _f64p)))
+        return out
+
+    def lp_start(self):
+        out = np.empty(self.n)
+        _check(load().hx_batch_lp_start(self._h, _p(out, _f64p)))
+        return out
+
+    def layout(self, job):
+        l = HxLayout()
+        _check(load().hx_batch_layout(self._h, job, C.byref(l)))
+        return l
+
+    def total_cells(self):
+        return int(load().hx_batch_total_cells(self._h))
+
+    def kernel_ms(self, which=0):
+        ms = C.c_float()
+        _check(load().hx_batch_last_kernel_ms(self._h, which, C.byref(ms)))
+        return ms.value
+
+    def read_matrix(self, job, which=0):
+        """Dense [n_rows][n_cols][5] copy of a matrix (un-skewed on the host)."""
+        l = self.layout(job)
+        buf = np.empty(5 * l.plane_stride)
+        _check(load().hx_batch_read_matrix(self._h, job, which, _p(buf, _f64p)))
+        ii, jj = np.meshgrid(np.arange(l.n_rows), np.arange(l.n_cols), indexing="ij")
+        slot = slot_index(l, ii, jj)
+        planes = buf.reshape(5, l.plane_stride)
+        return np.stack([planes[s][slot] for s in range(5)], axis=-1)
+
+    def read_cells(self, job, ij, which=0):
+        ij = np.ascontiguousarray(ij, dtype=np.int32).reshape(-1, 2)
+        out = np.empty((len(ij), 5))
+        _check(load().hx_batch_read_cells(self._h, job, which, _p(ij, _i32p), len(ij), _p(out, _f64p)))
+        return out
+
+    def read_prepared(self, job):
+        x, y, h, _ = self._keep[job]
+        ca = h.alph_size * h.components
+        subx, suby = np.empty((x.n_states, ca)), np.empty((y.n_states, ca))
+        insx, rsx = np.empty(x.n_states), np.empty(x.n_states)
+        insy, rsy = np.empty(y.n_states), np.empty(y.n_states)
+        _check(load().hx_batch_read_prepared(self._h, job, _p(subx, _f64p), _p(suby, _f64p), _p(insx, _f64p),
+                                             _p(rsx, _f64p), _p(insy, _f64p), _p(rsy, _f64p)))
+        return dict(subx=subx, suby=suby, insx=insx, rootsubx=rsx, insy=insy, rootsuby=rsy)
+
+    def posterior_scan(self, job, min_post_prob, cap=1 << 20):
+        out = (HxCell * cap)()
+        n = C.c_int64()
+        _check(load().hx_batch_posterior_scan(self._h, job, min_post_prob, out, cap, C.byref(n)))
+        k = min(n.value, cap)
+        return n.value, [(out[i].xpos, out[i].ypos, out[i].state, out[i].log_post_prob) for i in range(k)]

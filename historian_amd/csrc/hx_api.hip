@@ -1,0 +1,547 @@
+// C-ABI implementation (include/historian_hip.h): host-side flattening, device
+// memory layout and kernel launches for batches of independent pair DPs.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/historian_hip.h"
+#include "hx_device.h"
+#include "hx_kernels.h"
+
+using namespace hx;
+
+namespace {
+
+thread_local char g_err[512] = "";
+int g_device = -1;
+double* g_tab = nullptr;      // device copy of the host-built log_sum_exp table
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                 \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return fail(e_ == hipErrorOutOfMemory ? HX_ERR_OUT_OF_MEMORY : HX_ERR_HIP,      \
+                  "%s failed: %s", #expr, hipGetErrorString(e_));                     \
+  } while (0)
+
+constexpr double NEG_INF = -std::numeric_limits<double>::infinity();
+
+// Grows a host staging image of the device arena; returns byte offsets.
+struct Arena {
+  std::vector<char> host;
+  size_t put(const void* src, size_t bytes) {
+    size_t off = (host.size() + 255) & ~size_t(255);
+    host.resize(off + bytes);
+    if (src && bytes) memcpy(host.data() + off, src, bytes);
+    return off;
+  }
+  size_t reserve(size_t bytes) { return put(nullptr, bytes); }
+};
+
+// offsets into the arena for one profile
+struct ProfOff {
+  size_t flags, in_off, in_src, in_lp, ao_off, ao_dst, ao_lp, no_off, no_dst, no_lp;
+  size_t lp_absorb, sub, ins, rootsub, env, cls, cls_rep;
+  bool has_env;
+  int n, empty, n_cls, chain;
+};
+
+int check_csr(const int32_t* off, const int32_t* idx, int N, int T, const char* what) {
+  if (!off) return fail(HX_ERR_INVALID_ARG, "%s offsets are null", what);
+  if (off[0] != 0) return fail(HX_ERR_INVALID_ARG, "%s offsets do not start at 0", what);
+  for (int i = 0; i < N; ++i)
+    if (off[i + 1] < off[i]) return fail(HX_ERR_INVALID_ARG, "%s offsets decrease at state %d", what, i);
+  if (off[N] > 0 && !idx) return fail(HX_ERR_INVALID_ARG, "%s index list is null", what);
+  for (int k = 0; k < off[N]; ++k)
+    if (idx[k] < 0 || idx[k] >= T) return fail(HX_ERR_RANGE, "%s transition index %d out of range", what, idx[k]);
+  return HX_OK;
+}
+
+int flatten_profile(const hx_profile* p, int CA, bool need_env, bool is_y, Arena& ar, ProfOff& o) {
+  if (!p) return fail(HX_ERR_INVALID_ARG, "null profile");
+  const int N = p->n_states, T = p->n_trans;
+  if (N < 2 || T < 0) return fail(HX_ERR_INVALID_ARG, "profile needs >= 2 states (got %d)", N);
+  if (!p->is_null || (T > 0 && (!p->trans_src || !p->trans_dst || !p->trans_lp)))
+    return fail(HX_ERR_INVALID_ARG, "null profile arrays");
+  if (!p->is_null[0] || !p->is_null[N - 1])
+    return fail(HX_ERR_INVALID_ARG, "START and END must be null states");
+  int rc;
+  if ((rc = check_csr(p->in_off, p->in_idx, N, T, "in")) != HX_OK) return rc;
+  if ((rc = check_csr(p->aout_off, p->aout_idx, N, T, "absorbOut")) != HX_OK) return rc;
+  if ((rc = check_csr(p->nout_off, p->nout_idx, N, T, "nullOut")) != HX_OK) return rc;
+  for (int t = 0; t < T; ++t) {
+    if (p->trans_src[t] < 0 || p->trans_dst[t] >= N) return fail(HX_ERR_RANGE, "transition %d out of range", t);
+    if (p->trans_src[t] >= p->trans_dst[t])
+      return fail(HX_ERR_NOT_TOPOSORTED, "transition #%d from %d -> %d is not toposorted", t, p->trans_src[t], p->trans_dst[t]);
+  }
+  bool any_emit = false;
+  for (int i = 0; i < N; ++i) any_emit |= !p->is_null[i];
+  if (any_emit && !p->lp_absorb) return fail(HX_ERR_INVALID_ARG, "lp_absorb is null");
+  if (need_env && !p->env_pos) return fail(HX_ERR_INVALID_ARG, "env_pos is null but max_distance >= 0");
+
+  std::vector<int32_t> in_src, ao_dst, no_dst;
+  std::vector<double> in_lp, ao_lp, no_lp;
+  for (int k = 0; k < p->in_off[N]; ++k) {
+    const int t = p->in_idx[k];
+    in_src.push_back(p->trans_src[t]);
+    in_lp.push_back(p->trans_lp[t]);
+  }
+  for (int i = 0; i < N; ++i) {
+    for (int k = p->in_off[i]; k < p->in_off[i + 1]; ++k)
+      if (p->trans_dst[p->in_idx[k]] != i) return fail(HX_ERR_INVALID_ARG, "incoming transition destination doesn't match state %d", i);
+    for (int k = p->aout_off[i]; k < p->aout_off[i + 1]; ++k) {
+      const int t = p->aout_idx[k];
+      if (p->trans_src[t] != i) return fail(HX_ERR_INVALID_ARG, "absorbing transition source doesn't match state %d", i);
+    }
+    for (int k = p->nout_off[i]; k < p->nout_off[i + 1]; ++k) {
+      const int t = p->nout_idx[k];
+      if (p->trans_src[t] != i) return fail(HX_ERR_INVALID_ARG, "null transition source doesn't match state %d", i);
+    }
+  }
+  for (int k = 0; k < p->aout_off[N]; ++k) { ao_dst.push_back(p->trans_dst[p->aout_idx[k]]); ao_lp.push_back(p->trans_lp[p->aout_idx[k]]); }
+  for (int k = 0; k < p->nout_off[N]; ++k) { no_dst.push_back(p->trans_dst[p->nout_idx[k]]); no_lp.push_back(p->trans_lp[p->nout_idx[k]]); }
+
+  // flags (reference src/profile.h:32-37, src/forward.cpp:58-65)
+  std::vector<uint8_t> flags(N, 0);
+  for (int i = 0; i < N; ++i) {
+    const bool isnull = p->is_null[i] != 0;
+    if (isnull) flags[i] |= F_NULL;
+    if (p->nout_off[i + 1] == p->nout_off[i]) flags[i] |= F_READY;
+    if (!isnull || p->in_off[i + 1] == p->in_off[i]) flags[i] |= F_EMIT_OR_START;
+  }
+  for (int k = p->in_off[N - 1]; k < p->in_off[N]; ++k) flags[in_src[k]] |= F_TO_END;
+  if (!is_y) {
+    std::vector<char> near(N, 0);
+    near[0] = 1;
+    for (int i = 0; i < N; ++i)
+      if (near[i])
+        for (int k = p->nout_off[i]; k < p->nout_off[i + 1]; ++k) near[no_dst[k]] = 1;
+    for (int i = 0; i < N; ++i)
+      if (near[i]) flags[i] |= F_EDGE;
+  } else {
+    for (int k = p->in_off[N - 1]; k < p->in_off[N]; ++k) flags[in_src[k]] |= F_EDGE;
+  }
+
+  // emission classes: states with byte-identical lpAbsorb rows share one class
+  std::vector<int32_t> cls(N, -1), cls_rep;
+  {
+    std::unordered_map<std::string, int> seen;
+    for (int i = 0; i < N; ++i) {
+      if (p->is_null[i]) continue;
+      std::string key(reinterpret_cast<const char*>(p->lp_absorb + (size_t)i * CA), (size_t)CA * sizeof(double));
+      auto it = seen.find(key);
+      if (it == seen.end()) {
+        it = seen.emplace(std::move(key), (int)cls_rep.size()).first;
+        cls_rep.push_back(i);
+      }
+      cls[i] = it->second;
+    }
+  }
+  int chain = 1;
+  for (int i = 1; i < N && chain; ++i)
+    if (p->in_off[i + 1] - p->in_off[i] != 1 || in_src[p->in_off[i]] != i - 1) chain = 0;
+  if (p->in_off[1] != 0) chain = 0;
+
+  o.n = N;
+  o.empty = any_emit ? 0 : 1;
+  o.n_cls = (int)cls_rep.size();
+  o.chain = chain;
+  o.flags = ar.put(flags.data(), N);
+  o.in_off = ar.put(p->in_off, sizeof(int32_t) * (N + 1));
+  o.in_src = ar.put(in_src.data(), sizeof(int32_t) * in_src.size());
+  o.in_lp = ar.put(in_lp.data(), sizeof(double) * in_lp.size());
+  o.ao_off = ar.put(p->aout_off, sizeof(int32_t) * (N + 1));
+  o.ao_dst = ar.put(ao_dst.data(), sizeof(int32_t) * ao_dst.size());
+  o.ao_lp = ar.put(ao_lp.data(), sizeof(double) * ao_lp.size());
+  o.no_off = ar.put(p->nout_off, sizeof(int32_t) * (N + 1));
+  o.no_dst = ar.put(no_dst.data(), sizeof(int32_t) * no_dst.size());
+  o.no_lp = ar.put(no_lp.data(), sizeof(double) * no_lp.size());
+  {
+    // null rows are never read by the reference; give them a defined value
+    std::vector<double> raw((size_t)N * CA, NEG_INF);
+    for (int i = 0; i < N; ++i)
+      if (!p->is_null[i]) memcpy(&raw[(size_t)i * CA], p->lp_absorb + (size_t)i * CA, sizeof(double) * CA);
+    o.lp_absorb = ar.put(raw.data(), sizeof(double) * raw.size());
+  }
+  o.sub = ar.reserve(sizeof(double) * (size_t)N * CA);
+  o.ins = ar.reserve(sizeof(double) * N);
+  o.rootsub = ar.reserve(sizeof(double) * N);
+  o.has_env = need_env;
+  o.env = need_env ? ar.put(p->env_pos, sizeof(int32_t) * N) : 0;
+  o.cls = ar.put(cls.data(), sizeof(int32_t) * N);
+  o.cls_rep = ar.put(cls_rep.data(), sizeof(int32_t) * cls_rep.size());
+  return HX_OK;
+}
+
+void bind_profile(DevProfile& d, const ProfOff& o, char* base) {
+  d.n = o.n;
+  d.empty = o.empty;
+  d.flags = reinterpret_cast<uint8_t*>(base + o.flags);
+  d.in_off = reinterpret_cast<int32_t*>(base + o.in_off);
+  d.in_src = reinterpret_cast<int32_t*>(base + o.in_src);
+  d.in_lp = reinterpret_cast<double*>(base + o.in_lp);
+  d.ao_off = reinterpret_cast<int32_t*>(base + o.ao_off);
+  d.ao_dst = reinterpret_cast<int32_t*>(base + o.ao_dst);
+  d.ao_lp = reinterpret_cast<double*>(base + o.ao_lp);
+  d.no_off = reinterpret_cast<int32_t*>(base + o.no_off);
+  d.no_dst = reinterpret_cast<int32_t*>(base + o.no_dst);
+  d.no_lp = reinterpret_cast<double*>(base + o.no_lp);
+  d.lp_absorb = reinterpret_cast<double*>(base + o.lp_absorb);
+  d.sub = reinterpret_cast<double*>(base + o.sub);
+  d.ins = reinterpret_cast<double*>(base + o.ins);
+  d.rootsub = reinterpret_cast<double*>(base + o.rootsub);
+  d.env = o.has_env ? reinterpret_cast<int32_t*>(base + o.env) : nullptr;
+  d.cls = reinterpret_cast<int32_t*>(base + o.cls);
+  d.cls_rep = reinterpret_cast<int32_t*>(base + o.cls_rep);
+  d.n_cls = o.n_cls;
+  d.pad_ = 0;
+}
+
+struct JobOff {
+  ProfOff x, y;
+  size_t log_root, log_sub_l, log_sub_r, log_ins_l, log_ins_r, log_cptw_l, log_cptw_r, emis, scalars;
+  bool table_emission;
+};
+
+}  // namespace
+
+struct hx_batch {
+  int n_jobs = 0;
+  uint32_t flags = 0;
+  std::vector<DevJob> jobs;         // host copies (device pointers inside)
+  std::vector<hx_layout> layouts;
+  DevJob* d_jobs = nullptr;
+  char* d_arena = nullptr;
+  double* d_fwd = nullptr;
+  double* d_bwd = nullptr;
+  int max_states = 0, max_ca = 0, max_cls_pairs = 0, max_rows = 0;
+  bool all_chain = true;
+  int64_t total_cells = 0;
+  bool forward_done = false, backward_done = false;
+  hipStream_t last_stream = nullptr;
+  hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  bool ev_valid[2] = {false, false};
+};
+
+extern "C" {
+
+int hx_version(void) { return 1; }
+
+const char* hx_last_error(void) { return g_err; }
+
+int hx_init(int device_ordinal, const double* lse_table, size_t n_entries) {
+  if (!lse_table || n_entries != HX_LSE_TABLE_ENTRIES)
+    return fail(HX_ERR_INVALID_ARG, "lse_table must hold %d doubles (got %zu)", HX_LSE_TABLE_ENTRIES, n_entries);
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(HX_ERR_NO_DEVICE, "no HIP device available");
+  if (device_ordinal < 0 || device_ordinal >= n_dev) return fail(HX_ERR_NO_DEVICE, "device %d out of range (%d devices)", device_ordinal, n_dev);
+  if (hipSetDevice(device_ordinal) != hipSuccess) return fail(HX_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device_ordinal);
+  if (g_tab) { (void)hipFree(g_tab); g_tab = nullptr; }
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_tab), n_entries * sizeof(double)));
+  HIP_TRY(hipMemcpy(g_tab, lse_table, n_entries * sizeof(double), hipMemcpyHostToDevice));
+  g_device = device_ordinal;
+  return HX_OK;
+}
+
+int hx_shutdown(void) {
+  if (g_tab) { (void)hipFree(g_tab); g_tab = nullptr; }
+  g_device = -1;
+  return HX_OK;
+}
+
+int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_batch** out) {
+  if (!out) return fail(HX_ERR_INVALID_ARG, "out is null");
+  *out = nullptr;
+  if (g_device < 0 || !g_tab) return fail(HX_ERR_NOT_INITIALIZED, "hx_init has not been called");
+  if (!jobs || n_jobs <= 0) return fail(HX_ERR_INVALID_ARG, "need at least one job");
+  HIP_TRY(hipSetDevice(g_device));
+
+  hx_batch* b = new (std::nothrow) hx_batch;
+  if (!b) return fail(HX_ERR_OUT_OF_MEMORY, "host allocation failed");
+  b->n_jobs = n_jobs;
+  b->flags = flags;
+  b->jobs.resize(n_jobs);
+  b->layouts.resize(n_jobs);
+
+  Arena ar;
+  std::vector<JobOff> offs(n_jobs);
+  std::vector<int64_t> mat_off(n_jobs);
+  int64_t mat_total = 0;
+  int rc = HX_OK;
+  for (int k = 0; k < n_jobs && rc == HX_OK; ++k) {
+    const hx_pair_job& pj = jobs[k];
+    const hx_hmm* h = pj.hmm;
+    if (!h || !pj.x || !pj.y) { rc = fail(HX_ERR_INVALID_ARG, "job %d has null members", k); break; }
+    const int A = h->alph_size, C = h->components, CA = A * C;
+    if (A <= 0 || C <= 0) { rc = fail(HX_ERR_INVALID_ARG, "job %d: bad alphabet/components", k); break; }
+    if (!h->log_root || !h->log_sub_l || !h->log_sub_r || !h->log_ins_l || !h->log_ins_r || !h->log_cptw_l || !h->log_cptw_r) {
+      rc = fail(HX_ERR_INVALID_ARG, "job %d: null hmm arrays", k);
+      break;
+    }
+    const bool need_env = pj.max_distance >= 0;
+    JobOff& jo = offs[k];
+    if ((rc = flatten_profile(pj.x, CA, need_env, false, ar, jo.x)) != HX_OK) break;
+    if ((rc = flatten_profile(pj.y, CA, need_env, true, ar, jo.y)) != HX_OK) break;
+    jo.log_root = ar.put(h->log_root, sizeof(double) * CA);
+    jo.log_sub_l = ar.put(h->log_sub_l, sizeof(double) * CA * A);
+    jo.log_sub_r = ar.put(h->log_sub_r, sizeof(double) * CA * A);
+    jo.log_ins_l = ar.put(h->log_ins_l, sizeof(double) * CA);
+    jo.log_ins_r = ar.put(h->log_ins_r, sizeof(double) * CA);
+    jo.log_cptw_l = ar.put(h->log_cptw_l, sizeof(double) * C);
+    jo.log_cptw_r = ar.put(h->log_cptw_r, sizeof(double) * C);
+    const int64_t pairs = (int64_t)jo.x.n_cls * jo.y.n_cls;
+    jo.table_emission = pairs > 0 && pairs <= (1 << 16);
+    jo.emis = jo.table_emission ? ar.reserve(sizeof(double) * pairs) : 0;
+    jo.scalars = ar.reserve(sizeof(double) * 2);
+
+    DevJob& J = b->jobs[k];
+    memset(&J, 0, sizeof(J));
+    for (int s = 0; s < 5; ++s)
+      for (int d = 0; d < 6; ++d) J.T[s][d] = h->lp_trans[s][d];
+    J.A = A; J.C = C; J.CA = CA;
+    J.max_dist = pj.max_distance;
+    J.n_rows = jo.x.n - 1;
+    J.n_cols = jo.y.n - 1;
+    J.n_strips = (J.n_rows + HX_STRIP - 1) / HX_STRIP;
+    J.strip_stride = ((int64_t)J.n_cols + HX_STRIP - 1) * HX_STRIP;
+    J.plane = J.n_strips * J.strip_stride;
+    J.chain = jo.x.chain && jo.y.chain;
+    hx_layout& L = b->layouts[k];
+    L.n_rows = J.n_rows; L.n_cols = J.n_cols; L.strip_rows = HX_STRIP; L.n_strips = J.n_strips;
+    L.strip_stride = J.strip_stride; L.plane_stride = J.plane;
+    mat_off[k] = mat_total;
+    mat_total += 5 * J.plane;
+    b->total_cells += (int64_t)J.n_rows * J.n_cols;
+    if (jo.x.n > b->max_states) b->max_states = jo.x.n;
+    if (jo.y.n > b->max_states) b->max_states = jo.y.n;
+    if (CA > b->max_ca) b->max_ca = CA;
+    if (jo.table_emission && pairs > b->max_cls_pairs) b->max_cls_pairs = (int)pairs;
+    if (J.n_rows > b->max_rows) b->max_rows = J.n_rows;
+    b->all_chain = b->all_chain && J.chain;
+  }
+  if (rc != HX_OK) { delete b; return rc; }
+
+  auto cleanup = [&](int code) { hx_batch_destroy(b); return code; };
+  if (hipMalloc(reinterpret_cast<void**>(&b->d_arena), ar.host.size() + 256) != hipSuccess)
+    return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %zu input bytes failed", ar.host.size()));
+  if (hipMemcpy(b->d_arena, ar.host.data(), ar.host.size(), hipMemcpyHostToDevice) != hipSuccess)
+    return cleanup(fail(HX_ERR_HIP, "input upload failed"));
+  if (hipMalloc(reinterpret_cast<void**>(&b->d_fwd), sizeof(double) * (size_t)mat_total) != hipSuccess)
+    return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld Forward-matrix bytes failed", (long long)(mat_total * 8)));
+  if (flags & HX_KEEP_BACKWARD)
+    if (hipMalloc(reinterpret_cast<void**>(&b->d_bwd), sizeof(double) * (size_t)mat_total) != hipSuccess)
+      return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld Backward-matrix bytes failed", (long long)(mat_total * 8)));
+
+  for (int k = 0; k < n_jobs; ++k) {
+    DevJob& J = b->jobs[k];
+    const JobOff& jo = offs[k];
+    char* base = b->d_arena;
+    bind_profile(J.x, jo.x, base);
+    bind_profile(J.y, jo.y, base);
+    J.log_root = reinterpret_cast<double*>(base + jo.log_root);
+    J.log_sub_l = reinterpret_cast<double*>(base + jo.log_sub_l);
+    J.log_sub_r = reinterpret_cast<double*>(base + jo.log_sub_r);
+    J.log_ins_l = reinterpret_cast<double*>(base + jo.log_ins_l);
+    J.log_ins_r = reinterpret_cast<double*>(base + jo.log_ins_r);
+    J.log_cptw_l = reinterpret_cast<double*>(base + jo.log_cptw_l);
+    J.log_cptw_r = reinterpret_cast<double*>(base + jo.log_cptw_r);
+    J.emis = jo.table_emission ? reinterpret_cast<double*>(base + jo.emis) : nullptr;
+    J.lp_end = reinterpret_cast<double*>(base + jo.scalars);
+    J.lp_start = J.lp_end + 1;
+    J.fwd = b->d_fwd + mat_off[k];
+    J.bwd = b->d_bwd ? b->d_bwd + mat_off[k] : nullptr;
+  }
+  if (hipMalloc(reinterpret_cast<void**>(&b->d_jobs), sizeof(DevJob) * n_jobs) != hipSuccess)
+    return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of job table failed"));
+  if (hipMemcpy(b->d_jobs, b->jobs.data(), sizeof(DevJob) * n_jobs, hipMemcpyHostToDevice) != hipSuccess)
+    return cleanup(fail(HX_ERR_HIP, "job table upload failed"));
+  for (int w = 0; w < 2; ++w)
+    for (int e = 0; e < 2; ++e)
+      if (hipEventCreate(&b->ev[w][e]) != hipSuccess) return cleanup(fail(HX_ERR_HIP, "hipEventCreate failed"));
+  *out = b;
+  return HX_OK;
+}
+
+int hx_batch_destroy(hx_batch* b) {
+  if (!b) return HX_OK;
+  (void)hipDeviceSynchronize();
+  for (int w = 0; w < 2; ++w)
+    for (int e = 0; e < 2; ++e)
+      if (b->ev[w][e]) (void)hipEventDestroy(b->ev[w][e]);
+  if (b->d_jobs) (void)hipFree(b->d_jobs);
+  if (b->d_arena) (void)hipFree(b->d_arena);
+  if (b->d_fwd) (void)hipFree(b->d_fwd);
+  if (b->d_bwd) (void)hipFree(b->d_bwd);
+  delete b;
+  return HX_OK;
+}
+
+int hx_batch_forward(hx_batch* b, void* stream) {
+  if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_ca, b->max_cls_pairs, g_tab, st);
+  HIP_TRY(hipEventRecord(b->ev[0][0], st));
+  launch_forward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
+  HIP_TRY(hipEventRecord(b->ev[0][1], st));
+  HIP_TRY(hipGetLastError());
+  b->ev_valid[0] = true;
+  b->forward_done = true;
+  b->last_stream = st;
+  return HX_OK;
+}
+
+int hx_batch_backward(hx_batch* b, void* stream) {
+  if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
+  if (!b->d_bwd) return fail(HX_ERR_STATE, "batch was created without HX_KEEP_BACKWARD");
+  if (!b->forward_done) return fail(HX_ERR_STATE, "hx_batch_backward needs a previous hx_batch_forward");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipEventRecord(b->ev[1][0], st));
+  launch_backward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
+  HIP_TRY(hipEventRecord(b->ev[1][1], st));
+  HIP_TRY(hipGetLastError());
+  b->ev_valid[1] = true;
+  b->backward_done = true;
+  b->last_stream = st;
+  return HX_OK;
+}
+
+int hx_batch_sync(hx_batch* b) {
+  if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
+  HIP_TRY(hipStreamSynchronize(b->last_stream));
+  return HX_OK;
+}
+
+int hx_batch_last_kernel_ms(hx_batch* b, int32_t which, float* ms) {
+  if (!b || !ms || which < 0 || which > 1) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (!b->ev_valid[which]) return fail(HX_ERR_STATE, "no such fill has been launched");
+  HIP_TRY(hipEventSynchronize(b->ev[which][1]));
+  HIP_TRY(hipEventElapsedTime(ms, b->ev[which][0], b->ev[which][1]));
+  return HX_OK;
+}
+
+static int read_scalars(hx_batch* b, double* out, int which) {
+  if (!b || !out) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (which == 0 ? !b->forward_done : !b->backward_done) return fail(HX_ERR_STATE, "fill has not been launched");
+  HIP_TRY(hipStreamSynchronize(b->last_stream));
+  for (int k = 0; k < b->n_jobs; ++k)
+    HIP_TRY(hipMemcpy(out + k, which == 0 ? b->jobs[k].lp_end : b->jobs[k].lp_start, sizeof(double), hipMemcpyDeviceToHost));
+  return HX_OK;
+}
+
+int hx_batch_lp_end(hx_batch* b, double* out) { return read_scalars(b, out, 0); }
+int hx_batch_lp_start(hx_batch* b, double* out) { return read_scalars(b, out, 1); }
+
+int hx_batch_layout(const hx_batch* b, int32_t job, hx_layout* out) {
+  if (!b || !out) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
+  *out = b->layouts[job];
+  return HX_OK;
+}
+
+int64_t hx_batch_total_cells(const hx_batch* b) { return b ? b->total_cells : 0; }
+
+static const double* matrix_of(hx_batch* b, int job, int which) {
+  return which == 0 ? b->jobs[job].fwd : b->jobs[job].bwd;
+}
+
+int hx_batch_read_matrix(hx_batch* b, int32_t job, int32_t which, double* out) {
+  if (!b || !out || which < 0 || which > 1) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
+  if (which == 0 ? !b->forward_done : !b->backward_done) return fail(HX_ERR_STATE, "fill has not been launched");
+  HIP_TRY(hipStreamSynchronize(b->last_stream));
+  HIP_TRY(hipMemcpy(out, matrix_of(b, job, which), sizeof(double) * 5 * (size_t)b->jobs[job].plane, hipMemcpyDeviceToHost));
+  return HX_OK;
+}
+
+int hx_batch_read_cells(hx_batch* b, int32_t job, int32_t which, const int32_t* ij, int64_t n, double* out) {
+  if (!b || !out || !ij || n < 0 || which < 0 || which > 1) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
+  if (which == 0 ? !b->forward_done : !b->backward_done) return fail(HX_ERR_STATE, "fill has not been launched");
+  if (n == 0) return HX_OK;
+  const DevJob& J = b->jobs[job];
+  int32_t* d_ij = nullptr;
+  double* d_out = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ij), sizeof(int32_t) * 2 * n));
+  if (hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(double) * 5 * n) != hipSuccess) {
+    (void)hipFree(d_ij);
+    return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+  }
+  int rc = HX_OK;
+  if (hipMemcpy(d_ij, ij, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice) != hipSuccess) rc = fail(HX_ERR_HIP, "upload failed");
+  if (rc == HX_OK) {
+    launch_gather_cells(matrix_of(b, job, which), J.plane, J.strip_stride, J.n_rows, J.n_cols, d_ij, n, d_out, b->last_stream);
+    if (hipStreamSynchronize(b->last_stream) != hipSuccess ||
+        hipMemcpy(out, d_out, sizeof(double) * 5 * n, hipMemcpyDeviceToHost) != hipSuccess)
+      rc = fail(HX_ERR_HIP, "cell gather failed");
+  }
+  (void)hipFree(d_ij);
+  (void)hipFree(d_out);
+  return rc;
+}
+
+int hx_batch_read_prepared(hx_batch* b, int32_t job, double* subx, double* suby, double* insx, double* rootsubx,
+                           double* insy, double* rootsuby) {
+  if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
+  if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
+  if (!b->forward_done) return fail(HX_ERR_STATE, "hx_batch_forward has not been launched");
+  HIP_TRY(hipStreamSynchronize(b->last_stream));
+  const DevJob& J = b->jobs[job];
+  if (subx) HIP_TRY(hipMemcpy(subx, J.x.sub, sizeof(double) * (size_t)J.x.n * J.CA, hipMemcpyDeviceToHost));
+  if (suby) HIP_TRY(hipMemcpy(suby, J.y.sub, sizeof(double) * (size_t)J.y.n * J.CA, hipMemcpyDeviceToHost));
+  if (insx) HIP_TRY(hipMemcpy(insx, J.x.ins, sizeof(double) * J.x.n, hipMemcpyDeviceToHost));
+  if (rootsubx) HIP_TRY(hipMemcpy(rootsubx, J.x.rootsub, sizeof(double) * J.x.n, hipMemcpyDeviceToHost));
+  if (insy) HIP_TRY(hipMemcpy(insy, J.y.ins, sizeof(double) * J.y.n, hipMemcpyDeviceToHost));
+  if (rootsuby) HIP_TRY(hipMemcpy(rootsuby, J.y.rootsub, sizeof(double) * J.y.n, hipMemcpyDeviceToHost));
+  return HX_OK;
+}
+
+int hx_batch_posterior_scan(hx_batch* b, int32_t job, double min_post_prob, hx_cell* out, int64_t cap, int64_t* n_out) {
+  if (!b || !n_out || cap < 0 || (cap > 0 && !out)) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
+  if (!b->forward_done || !b->backward_done) return fail(HX_ERR_STATE, "posterior scan needs Forward and Backward fills");
+  static_assert(sizeof(PostCell) == sizeof(hx_cell), "hx_cell layout");
+  const double thr = std::log(min_post_prob);   // host libm, as reference src/forward.cpp:1304
+  PostCell* d_out = nullptr;
+  unsigned long long* d_cnt = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cnt), sizeof(unsigned long long)));
+  if (cap > 0 && hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(PostCell) * cap) != hipSuccess) {
+    (void)hipFree(d_cnt);
+    return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+  }
+  int rc = HX_OK;
+  unsigned long long cnt = 0;
+  if (hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), b->last_stream) != hipSuccess) rc = fail(HX_ERR_HIP, "memset failed");
+  if (rc == HX_OK) {
+    launch_posterior_scan(b->d_jobs, job, thr, d_out, (unsigned long long)cap, d_cnt, b->last_stream);
+    if (hipStreamSynchronize(b->last_stream) != hipSuccess ||
+        hipMemcpy(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = fail(HX_ERR_HIP, "posterior scan failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  if (rc == HX_OK) {
+    *n_out = (int64_t)cnt;
+    const int64_t n_copy = (int64_t)cnt < cap ? (int64_t)cnt : cap;
+    if (n_copy > 0 && hipMemcpy(out, d_out, sizeof(PostCell) * n_copy, hipMemcpyDeviceToHost) != hipSuccess)
+      rc = fail(HX_ERR_HIP, "result download failed");
+  }
+  (void)hipFree(d_cnt);
+  if (d_out) (void)hipFree(d_out);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// Device-side data model shared by the kernels and the C-ABI host code.
+// Names follow the reference's domain: profiles, states, transitions, envelope, cells.
+#pragma once
+#include <stdint.h>
+
+namespace hx {
+
+// per-state flag byte
+enum : uint8_t {
+  F_NULL = 1,          // ProfileState::isNull()        (reference src/profile.h:32)
+  F_READY = 2,         // ProfileState::isReady()       (src/profile.h:36)
+  F_EMIT_OR_START = 4, // ProfileState::isEmitOrStart() (src/profile.h:35)
+  F_EDGE = 8,          // xNearStart[i] for x, yNearEnd[j] for y (src/forward.cpp:58-65)
+  F_TO_END = 16        // state is the source of a transition into END
+};
+
+struct DevProfile {
+  int32_t n;                  // number of states
+  int32_t empty;              // Profile::isEmpty()
+  const uint8_t* flags;       // [n]
+  const int32_t* in_off;      // [n+1] CSR over ProfileState::in (reference order)
+  const int32_t* in_src;
+  const double*  in_lp;
+  const int32_t* ao_off;      // absorbOut
+  const int32_t* ao_dst;
+  const double*  ao_lp;
+  const int32_t* no_off;      // nullOut
+  const int32_t* no_dst;
+  const double*  no_lp;
+  const double*  lp_absorb;   // [n][C*A] raw lpAbsorb
+  double* sub;                // [n][C*A] leftMultiply result (subx / suby)
+  double* ins;                // [n] insx / insy
+  double* rootsub;            // [n] rootsubx / rootsuby
+  const int32_t* env;         // [n] envelope coordinate, or nullptr
+  const int32_t* cls;         // [n] emission class of the state (-1 for null states)
+  const int32_t* cls_rep;     // [n_cls] a representative state of each class
+  int32_t n_cls;
+  int32_t pad_;
+};
+
+struct DevJob {
+  DevProfile x, y;
+  double T[5][6];             // PairHMM::lpTrans(src,dest), dest 5 = EEE
+  const double* log_root;     // [C][A]
+  const double* log_sub_l;    // [C][A][A]
+  const double* log_sub_r;
+  const double* log_ins_l;    // [C][A]
+  const double* log_ins_r;
+  const double* log_cptw_l;   // [C]
+  const double* log_cptw_r;
+  int32_t A, C, CA;
+  int32_t max_dist;           // < 0: no band
+  int32_t n_rows, n_cols;     // Nx-1, Ny-1
+  int32_t n_strips;
+  int32_t chain;              // both profiles are linear chains (state i's only in-transition comes from i-1)
+  int64_t strip_stride;       // doubles per 64-row strip per plane = (n_cols + 63) * 64
+  int64_t plane;              // doubles per state plane
+  double* fwd;                // [5][plane]
+  double* bwd;                // [5][plane] or nullptr
+  double* emis;               // [x.n_cls][y.n_cls] class-pair emission table, or nullptr (per-cell emission)
+  double* lp_end;             // -> one double
+  double* lp_start;           // -> one double
+};
+
+#define HX_STRIP 64
+
+__host__ __device__ inline int64_t cell_slot(int64_t strip_stride, int i, int j) {
+  const int l = i & (HX_STRIP - 1);
+  return (int64_t)(i >> 6) * strip_stride + ((int64_t)(j + l) << 6) + l;
+}
+
+}  // namespace hx

@@ -1,0 +1,19 @@
+// Kernel launchers (implemented in hx_kernels.hip / hx_chain.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hx_device.h"
+
+namespace hx {
+
+struct PostCell { int32_t xpos, ypos, state, pad; double lpp; };   // == hx_cell
+
+void launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_ca, int max_cls_pairs,
+                 const double* tab, hipStream_t st);
+void launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
+void launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
+void launch_posterior_scan(const DevJob* d_jobs, int job, double lpp_threshold, PostCell* out,
+                           unsigned long long cap, unsigned long long* counter, hipStream_t st);
+void launch_gather_cells(const double* M, int64_t plane, int64_t strip_stride, int n_rows, int n_cols,
+                         const int* ij, int64_t n, double* out, hipStream_t st);
+
+}  // namespace hx

@@ -1,0 +1,442 @@
+// HIP kernels (gfx950 / CDNA4) for the pair-HMM Forward/Backward hot path.
+//
+//   k_left_multiply   Profile::leftMultiply                (reference src/profile.cpp:78-91)
+//   k_ins_rootsub     insx/rootsubx/insy/rootsuby          (src/forward.cpp:44-56)
+//   k_emission_table  computeLogProbAbsorb per class pair  (src/forward.h:112-124)
+//   k_forward_dag     ForwardMatrix fill, any profile      (src/forward.cpp:68-223)
+//   k_backward_dag    BackwardMatrix fill, any profile     (src/forward.cpp:975-1088)
+//   k_posterior_scan  cellsAbovePostProbThreshold          (src/forward.cpp:1302-1319)
+//
+// Compiled with -ffp-contract=off (see hx_lse.h).
+#include <hip/hip_runtime.h>
+#include "hx_device.h"
+#include "hx_lse.h"
+#include "hx_kernels.h"
+
+namespace hx {
+
+// ---------------------------------------------------------------------------
+// profile preparation
+// ---------------------------------------------------------------------------
+// one thread per (state, cpt, c): out[i][cpt][c] = (+)_d logsub[cpt][c][d] + lpAbsorb[i][cpt][d]
+__global__ void k_left_multiply(const DevJob* __restrict__ jobs, const double* __restrict__ tab) {
+  const DevJob& J = jobs[blockIdx.y >> 1];
+  const int side = blockIdx.y & 1;
+  const DevProfile& P = side ? J.y : J.x;
+  const double* logsub = side ? J.log_sub_r : J.log_sub_l;
+  const int A = J.A, CA = J.CA;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P.n * CA) return;
+  const int i = idx / CA, k = idx - i * CA;
+  const int cpt = k / A, c = k - cpt * A;
+  if (P.flags[i] & F_NULL) { P.sub[idx] = HX_NEG_INF; return; }
+  const double* row = P.lp_absorb + (size_t)i * CA + cpt * A;
+  const double* ls = logsub + ((size_t)cpt * A + c) * A;
+  double lp = HX_NEG_INF;
+  for (int d = 0; d < A; ++d) lp = lse(lp, ls[d] + row[d], tab);
+  P.sub[idx] = lp;
+}
+
+// one thread per state
+__global__ void k_ins_rootsub(const DevJob* __restrict__ jobs, const double* __restrict__ tab) {
+  const DevJob& J = jobs[blockIdx.y >> 1];
+  const int side = blockIdx.y & 1;
+  const DevProfile& P = side ? J.y : J.x;
+  const double* logins = side ? J.log_ins_r : J.log_ins_l;
+  const double* logcw = side ? J.log_cptw_r : J.log_cptw_l;
+  const int A = J.A, C = J.C, CA = J.CA;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  double ins = HX_NEG_INF, rs = HX_NEG_INF;
+  if (i >= 1 && i < P.n - 1 && !(P.flags[i] & F_NULL)) {
+    for (int cpt = 0; cpt < C; ++cpt) {
+      const double* raw = P.lp_absorb + (size_t)i * CA + cpt * A;
+      const double* sub = P.sub + (size_t)i * CA + cpt * A;
+      double lipi = HX_NEG_INF, lipr = HX_NEG_INF;
+      for (int a = 0; a < A; ++a) lipi = lse(lipi, logins[cpt * A + a] + raw[a], tab);
+      ins = lse(ins, logcw[cpt] + lipi, tab);
+      for (int a = 0; a < A; ++a) lipr = lse(lipr, J.log_root[cpt * A + a] + sub[a], tab);
+      rs = lse(rs, lipr, tab);
+    }
+  }
+  P.ins[i] = ins;
+  P.rootsub[i] = rs;
+}
+
+__device__ __forceinline__ double emission_rows(const DevJob& J, const double* sx, const double* sy,
+                                                const double* __restrict__ tab) {
+  double lip = HX_NEG_INF;
+  for (int cpt = 0; cpt < J.C; ++cpt) {
+    double inner = HX_NEG_INF;
+    for (int a = 0; a < J.A; ++a) {
+      const int k = cpt * J.A + a;
+      inner = lse(inner, J.log_root[k] + (sx[k] + sy[k]), tab);
+    }
+    lip = lse(lip, inner, tab);
+  }
+  return lip;
+}
+
+// one thread per (x class, y class)
+__global__ void k_emission_table(const DevJob* __restrict__ jobs, const double* __restrict__ tab) {
+  const DevJob& J = jobs[blockIdx.y];
+  if (!J.emis) return;
+  const int Kx = J.x.n_cls, Ky = J.y.n_cls;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Kx * Ky) return;
+  const int kx = idx / Ky, ky = idx - kx * Ky;
+  const double* sx = J.x.sub + (size_t)J.x.cls_rep[kx] * J.CA;
+  const double* sy = J.y.sub + (size_t)J.y.cls_rep[ky] * J.CA;
+  J.emis[idx] = emission_rows(J, sx, sy, tab);
+}
+
+__device__ __forceinline__ double emission(const DevJob& J, int i, int j, const double* __restrict__ tab) {
+  if (J.emis) {
+    // a hand-edited profile may route an absorbing transition into a null state
+    // (reference t/testnullforward.cpp:37-39); such a pair emits nothing
+    const int cx = J.x.cls[i], cy = J.y.cls[j];
+    return (cx < 0 || cy < 0) ? HX_NEG_INF : J.emis[(size_t)cx * J.y.n_cls + cy];
+  }
+  return emission_rows(J, J.x.sub + (size_t)i * J.CA, J.y.sub + (size_t)j * J.CA, tab);
+}
+
+__device__ __forceinline__ bool in_envelope(const DevJob& J, int i, int j) {
+  if ((J.x.flags[i] | J.y.flags[j]) & F_EDGE) return true;
+  if (J.max_dist < 0) return true;
+  int d = J.x.env[i] - J.y.env[j];
+  d = d < 0 ? -d : d;
+  return d <= J.max_dist;
+}
+
+struct Cell5 { double v[5]; };
+
+__device__ __forceinline__ Cell5 load_cell(const double* __restrict__ m, int64_t plane, int64_t slot) {
+  Cell5 c;
+#pragma unroll
+  for (int s = 0; s < 5; ++s) c.v[s] = m[s * plane + slot];
+  return c;
+}
+
+// ---------------------------------------------------------------------------
+// Forward fill, general profiles (DAG, null states, ready/wait flags, envelope).
+// One workgroup per pair; thread <-> row; one anti-diagonal per barrier.  Sources are
+// re-read from the matrix itself (L1/L2); a 64-row strip's anti-diagonal segment is
+// contiguous in the strip-skewed layout, so loads and stores are coalesced.
+// ---------------------------------------------------------------------------
+__device__ void forward_cell(const DevJob& J, int i, int j, const double* __restrict__ tab) {
+  const int64_t plane = J.plane, ss = J.strip_stride;
+  double* __restrict__ M = J.fwd;
+  const int64_t slot = cell_slot(ss, i, j);
+  double imm = HX_NEG_INF, imd = HX_NEG_INF, idm = HX_NEG_INF, imi = HX_NEG_INF, iiw = HX_NEG_INF;
+  if (in_envelope(J, i, j)) {
+    if (i == 0 && j == 0) imm = 0.0;
+    const uint8_t xf = J.x.flags[i], yf = J.y.flags[j];
+    const bool xnull = xf & F_NULL, ynull = yf & F_NULL;
+    const bool yok = (yf & F_READY) || J.y.empty;   // yState.isReady() || yEmpty
+    const bool xok = (xf & F_READY) || J.x.empty;
+    const int xb = J.x.in_off[i], xe = J.x.in_off[i + 1];
+    const int yb = J.y.in_off[j], ye = J.y.in_off[j + 1];
+    const double (*T)[6] = J.T;
+
+    if (!xnull) {
+      if (yok) {
+        for (int t = xb; t < xe; ++t) {
+          const Cell5 s = load_cell(M, plane, cell_slot(ss, J.x.in_src[t], j));
+          const double lp = J.x.in_lp[t];
+          double a = lse(s.v[0] + T[0][1], s.v[1] + T[1][1], tab);
+          a = lse(a, s.v[2] + T[2][1], tab);
+          a = lse(a, s.v[3] + T[3][1], tab);
+          imd = lse(imd, a + lp, tab);
+          double b = lse(s.v[0] + T[0][4], s.v[3] + T[3][4], tab);
+          b = lse(b, s.v[4] + T[4][4], tab);
+          iiw = lse(iiw, b + lp, tab);
+        }
+        imd += J.x.rootsub[i];
+        iiw += J.x.ins[i];
+      }
+    } else if (yok) {
+      for (int t = xb; t < xe; ++t) {
+        const int64_t sl = cell_slot(ss, J.x.in_src[t], j);
+        const double lp = J.x.in_lp[t];
+        imd = lse(imd, M[1 * plane + sl] + lp, tab);
+        iiw = lse(iiw, M[4 * plane + sl] + lp, tab);
+      }
+    }
+
+    if (!ynull) {
+      if (xok) {
+        for (int t = yb; t < ye; ++t) {
+          const Cell5 s = load_cell(M, plane, cell_slot(ss, i, J.y.in_src[t]));
+          const double lp = J.y.in_lp[t];
+          double a = lse(s.v[0] + T[0][2], s.v[1] + T[1][2], tab);
+          a = lse(a, s.v[2] + T[2][2], tab);
+          a = lse(a, s.v[4] + T[4][2], tab);
+          idm = lse(idm, a + lp, tab);
+          const double b = lse(s.v[0] + T[0][3], s.v[3] + T[3][3], tab);
+          imi = lse(imi, b + lp, tab);
+        }
+        idm += J.y.rootsub[j];
+        imi += J.y.ins[j];
+      }
+    } else {
+      for (int t = yb; t < ye; ++t) {
+        const int64_t sl = cell_slot(ss, i, J.y.in_src[t]);
+        const double lp = J.y.in_lp[t];
+        idm = lse(idm, M[2 * plane + sl] + lp, tab);
+        imi = lse(imi, M[3 * plane + sl] + lp, tab);
+      }
+    }
+
+    if (!xnull && !ynull) {
+      for (int tx = xb; tx < xe; ++tx) {
+        const int sx = J.x.in_src[tx];
+        const double lpx = J.x.in_lp[tx];
+        for (int ty = yb; ty < ye; ++ty) {
+          const Cell5 s = load_cell(M, plane, cell_slot(ss, sx, J.y.in_src[ty]));
+          double a = lse(s.v[0] + T[0][0], s.v[1] + T[1][0], tab);
+          a = lse(a, s.v[2] + T[2][0], tab);
+          a = lse(a, s.v[3] + T[3][0], tab);
+          a = lse(a, s.v[4] + T[4][0], tab);
+          imm = lse(imm, a + lpx + J.y.in_lp[ty], tab);
+        }
+      }
+      imm += emission(J, i, j, tab);
+    } else if (ynull && (xf & F_EMIT_OR_START)) {
+      for (int t = yb; t < ye; ++t)
+        imm = lse(imm, M[cell_slot(ss, i, J.y.in_src[t])] + J.y.in_lp[t], tab);
+    } else if (yok) {
+      for (int t = xb; t < xe; ++t)
+        imm = lse(imm, M[cell_slot(ss, J.x.in_src[t], j)] + J.x.in_lp[t], tab);
+    }
+  }
+  M[slot] = imm;
+  M[1 * plane + slot] = imd;
+  M[2 * plane + slot] = idm;
+  M[3 * plane + slot] = imi;
+  M[4 * plane + slot] = iiw;
+}
+
+// transitions into EEE (reference src/forward.cpp:205-220)
+__device__ double forward_lp_end(const DevJob& J, const double* __restrict__ tab) {
+  double lp_end = HX_NEG_INF;
+  const int xe = J.x.n - 1, ye = J.y.n - 1;
+  for (int tx = J.x.in_off[xe]; tx < J.x.in_off[xe + 1]; ++tx)
+    for (int ty = J.y.in_off[ye]; ty < J.y.in_off[ye + 1]; ++ty) {
+      const Cell5 s = load_cell(J.fwd, J.plane, cell_slot(J.strip_stride, J.x.in_src[tx], J.y.in_src[ty]));
+      double a = lse(s.v[0] + J.T[0][5], s.v[1] + J.T[1][5], tab);
+      a = lse(a, s.v[2] + J.T[2][5], tab);
+      a = lse(a, s.v[3] + J.T[3][5], tab);
+      a = lse(a, s.v[4] + J.T[4][5], tab);
+      lp_end = lse(lp_end, a + J.x.in_lp[tx] + J.y.in_lp[ty], tab);
+    }
+  return lp_end;
+}
+
+__global__ void __launch_bounds__(1024) k_forward_dag(const DevJob* __restrict__ jobs, const double* __restrict__ tab) {
+  const DevJob& J = jobs[blockIdx.x];
+  const int R = J.n_rows, Cc = J.n_cols;
+  const int nd = R + Cc - 1;
+  for (int d = 0; d < nd; ++d) {
+    for (int i = threadIdx.x; i < R; i += blockDim.x) {
+      const int j = d - i;
+      if (j >= 0 && j < Cc) forward_cell(J, i, j, tab);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *J.lp_end = forward_lp_end(J, tab);
+}
+
+// ---------------------------------------------------------------------------
+// Backward fill, general profiles (reference src/forward.cpp:975-1088)
+// ---------------------------------------------------------------------------
+__device__ void backward_cell(const DevJob& J, int i, int j, const double* __restrict__ tab) {
+  const int64_t plane = J.plane, ss = J.strip_stride;
+  double* __restrict__ M = J.bwd;
+  const int64_t slot = cell_slot(ss, i, j);
+  double imm = HX_NEG_INF, imd = HX_NEG_INF, idm = HX_NEG_INF, imi = HX_NEG_INF, iiw = HX_NEG_INF;
+  if (in_envelope(J, i, j)) {
+    const uint8_t xf = J.x.flags[i], yf = J.y.flags[j];
+    const double (*T)[6] = J.T;
+    // cells that feed END are initialised by assignment (src/forward.cpp:981-995)
+    if ((xf & F_TO_END) && (yf & F_TO_END)) {
+      const int xe = J.x.n - 1, ye = J.y.n - 1;
+      for (int tx = J.x.in_off[xe]; tx < J.x.in_off[xe + 1]; ++tx)
+        for (int ty = J.y.in_off[ye]; ty < J.y.in_off[ye + 1]; ++ty)
+          if (J.x.in_src[tx] == i && J.y.in_src[ty] == j) {
+            const double lp = J.x.in_lp[tx] + J.y.in_lp[ty];
+            imm = lp + T[0][5]; imd = lp + T[1][5]; idm = lp + T[2][5]; imi = lp + T[3][5]; iiw = lp + T[4][5];
+          }
+    }
+    const bool yok = (yf & F_READY) || J.y.empty;
+    const bool xok = (xf & F_READY) || J.x.empty;
+    const int xab = J.x.ao_off[i], xae = J.x.ao_off[i + 1];
+    const int yab = J.y.ao_off[j], yae = J.y.ao_off[j + 1];
+    const int xnb = J.x.no_off[i], xne = J.x.no_off[i + 1];
+    const int ynb = J.y.no_off[j], yne = J.y.no_off[j + 1];
+
+    for (int tx = xab; tx < xae; ++tx) {
+      const int dx = J.x.ao_dst[tx];
+      const double lpx = J.x.ao_lp[tx];
+      for (int ty = yab; ty < yae; ++ty) {
+        const int dy = J.y.ao_dst[ty];
+        const double d = lpx + J.y.ao_lp[ty] + emission(J, dx, dy, tab) + M[cell_slot(ss, dx, dy)];
+        imm = lse(imm, T[0][0] + d, tab);
+        imd = lse(imd, T[1][0] + d, tab);
+        idm = lse(idm, T[2][0] + d, tab);
+        imi = lse(imi, T[3][0] + d, tab);
+        iiw = lse(iiw, T[4][0] + d, tab);
+      }
+    }
+    if (yok)
+      for (int tx = xab; tx < xae; ++tx) {
+        const int dx = J.x.ao_dst[tx];
+        const double lpx = J.x.ao_lp[tx];
+        const int64_t sl = cell_slot(ss, dx, j);
+        const double d1 = lpx + J.x.rootsub[dx] + M[1 * plane + sl];
+        const double d2 = lpx + J.x.ins[dx] + M[4 * plane + sl];
+        imm = lse(imm, T[0][1] + d1, tab);
+        imd = lse(imd, T[1][1] + d1, tab);
+        idm = lse(idm, T[2][1] + d1, tab);
+        imi = lse(imi, T[3][1] + d1, tab);
+        imm = lse(imm, T[0][4] + d2, tab);
+        imi = lse(imi, T[3][4] + d2, tab);
+        iiw = lse(iiw, T[4][4] + d2, tab);
+      }
+    if (xok)
+      for (int ty = yab; ty < yae; ++ty) {
+        const int dy = J.y.ao_dst[ty];
+        const double lpy = J.y.ao_lp[ty];
+        const int64_t sl = cell_slot(ss, i, dy);
+        const double d1 = lpy + J.y.rootsub[dy] + M[2 * plane + sl];
+        const double d2 = lpy + J.y.ins[dy] + M[3 * plane + sl];
+        imm = lse(imm, T[0][2] + d1, tab);
+        imd = lse(imd, T[1][2] + d1, tab);
+        idm = lse(idm, T[2][2] + d1, tab);
+        iiw = lse(iiw, T[4][2] + d1, tab);
+        imm = lse(imm, T[0][3] + d2, tab);
+        imi = lse(imi, T[3][3] + d2, tab);
+      }
+    if (yok)
+      for (int tx = xnb; tx < xne; ++tx) {
+        const int dx = J.x.no_dst[tx];
+        if (dx >= J.n_rows) continue;   // END column is not stored: xyCell(END,.) is the empty cell
+        const double lpx = J.x.no_lp[tx];
+        const int64_t sl = cell_slot(ss, dx, j);
+        imd = lse(imd, lpx + M[1 * plane + sl], tab);
+        iiw = lse(iiw, lpx + M[4 * plane + sl], tab);
+        imm = lse(imm, lpx + M[sl], tab);
+      }
+    for (int ty = ynb; ty < yne; ++ty) {
+      const int dy = J.y.no_dst[ty];
+      if (dy >= J.n_cols) continue;
+      const double lpy = J.y.no_lp[ty];
+      const int64_t sl = cell_slot(ss, i, dy);
+      idm = lse(idm, lpy + M[2 * plane + sl], tab);
+      imi = lse(imi, lpy + M[3 * plane + sl], tab);
+      if (xf & F_EMIT_OR_START) imm = lse(imm, lpy + M[sl], tab);
+    }
+  }
+  M[slot] = imm;
+  M[1 * plane + slot] = imd;
+  M[2 * plane + slot] = idm;
+  M[3 * plane + slot] = imi;
+  M[4 * plane + slot] = iiw;
+}
+
+__global__ void __launch_bounds__(1024) k_backward_dag(const DevJob* __restrict__ jobs, const double* __restrict__ tab) {
+  const DevJob& J = jobs[blockIdx.x];
+  const int R = J.n_rows, Cc = J.n_cols;
+  for (int d = R + Cc - 2; d >= 0; --d) {
+    for (int i = threadIdx.x; i < R; i += blockDim.x) {
+      const int j = d - i;
+      if (j >= 0 && j < Cc) backward_cell(J, i, j, tab);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *J.lp_start = J.bwd[cell_slot(J.strip_stride, 0, 0)];
+}
+
+// ---------------------------------------------------------------------------
+// posterior threshold scan with stream compaction
+// ---------------------------------------------------------------------------
+__global__ void k_posterior_scan(const DevJob* __restrict__ jobs, int job, double lpp_threshold,
+                                 PostCell* __restrict__ out, unsigned long long cap,
+                                 unsigned long long* __restrict__ counter) {
+  const DevJob& J = jobs[job];
+  const double fwd_end = *J.lp_end;
+  const int64_t total = (int64_t)J.n_rows * J.n_cols;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(c / J.n_cols), j = (int)(c - (int64_t)i * J.n_cols);
+    if (!in_envelope(J, i, j)) continue;
+    const int64_t slot = cell_slot(J.strip_stride, i, j);
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const double lpp = J.bwd[s * J.plane + slot] + J.fwd[s * J.plane + slot] - fwd_end;
+      if (lpp >= lpp_threshold) {
+        const unsigned long long k = atomicAdd(counter, 1ull);
+        if (k < cap) { out[k].xpos = i; out[k].ypos = j; out[k].state = s; out[k].pad = 0; out[k].lpp = lpp; }
+      }
+    }
+  }
+}
+
+// gather of individual cells (traceback support)
+__global__ void k_gather_cells(const double* __restrict__ M, int64_t plane, int64_t strip_stride,
+                               int n_rows, int n_cols, const int* __restrict__ ij, int64_t n,
+                               double* __restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int i = ij[2 * k], j = ij[2 * k + 1];
+  const bool ok = i >= 0 && j >= 0 && i < n_rows && j < n_cols;
+  const int64_t slot = ok ? cell_slot(strip_stride, i, j) : 0;
+#pragma unroll
+  for (int s = 0; s < 5; ++s) out[5 * k + s] = ok ? M[s * plane + slot] : HX_NEG_INF;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+void launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_ca, int max_cls_pairs,
+                 const double* tab, hipStream_t st) {
+  const int tpb = 256;
+  {
+    dim3 grid((unsigned)((max_states * max_ca + tpb - 1) / tpb), (unsigned)(2 * n_jobs));
+    hipLaunchKernelGGL(k_left_multiply, grid, dim3(tpb), 0, st, d_jobs, tab);
+  }
+  {
+    dim3 grid((unsigned)((max_states + tpb - 1) / tpb), (unsigned)(2 * n_jobs));
+    hipLaunchKernelGGL(k_ins_rootsub, grid, dim3(tpb), 0, st, d_jobs, tab);
+  }
+  if (max_cls_pairs > 0) {
+    dim3 grid((unsigned)((max_cls_pairs + tpb - 1) / tpb), (unsigned)n_jobs);
+    hipLaunchKernelGGL(k_emission_table, grid, dim3(tpb), 0, st, d_jobs, tab);
+  }
+}
+
+void launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st) {
+  int threads = ((max_rows + 63) / 64) * 64;
+  if (threads > 1024) threads = 1024;
+  if (threads < 64) threads = 64;
+  hipLaunchKernelGGL(k_forward_dag, dim3(n_jobs), dim3(threads), 0, st, d_jobs, tab);
+}
+
+void launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st) {
+  int threads = ((max_rows + 63) / 64) * 64;
+  if (threads > 1024) threads = 1024;
+  if (threads < 64) threads = 64;
+  hipLaunchKernelGGL(k_backward_dag, dim3(n_jobs), dim3(threads), 0, st, d_jobs, tab);
+}
+
+void launch_posterior_scan(const DevJob* d_jobs, int job, double lpp_threshold, PostCell* out,
+                           unsigned long long cap, unsigned long long* counter, hipStream_t st) {
+  hipLaunchKernelGGL(k_posterior_scan, dim3(1024), dim3(256), 0, st, d_jobs, job, lpp_threshold, out, cap, counter);
+}
+
+void launch_gather_cells(const double* M, int64_t plane, int64_t strip_stride, int n_rows, int n_cols,
+                         const int* ij, int64_t n, double* out, hipStream_t st) {
+  const int tpb = 256;
+  hipLaunchKernelGGL(k_gather_cells, dim3((unsigned)((n + tpb - 1) / tpb)), dim3(tpb), 0, st, M, plane,
+                     strip_stride, n_rows, n_cols, ij, n, out);
+}
+
+}  // namespace hx

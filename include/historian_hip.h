@@ -1,0 +1,181 @@
+/*
+ * historian_hip.h -- C ABI of the MI355X (gfx950) pair-HMM Forward/Backward engine.
+ *
+ * This is the drop-in boundary for the hot path of `historian reconstruct`: what
+ * the constructors of the reference's DPMatrix / ForwardMatrix / BackwardMatrix
+ * (reference src/forward.h:11-227, src/forward.cpp:11-223, 975-1097) compute.
+ * The reference has no FFI; its boundary is that C++ class interface, which
+ * historian_amd/csrc/host/ mirrors on top of the entry points below
+ * (see INTEGRATION.md for the binding a maintainer would add).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, caller-owned input buffers (copied to
+ *     the device inside hx_batch_create; the caller may free them afterwards).
+ *   - every function returns HX_OK (0) or a negative hx_status; nothing aborts or
+ *     throws across the ABI.  A zero-likelihood fill is NOT an error: lp_end is
+ *     -inf and the caller widens the band (reference src/recon.cpp:956-975).
+ *   - all log-probabilities are IEEE fp64; -inf means probability zero.
+ *   - "stream" arguments are a hipStream_t passed as void* (NULL = default stream).
+ */
+#ifndef HISTORIAN_HIP_H
+#define HISTORIAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum hx_status {
+  HX_OK = 0,
+  HX_ERR_INVALID_ARG = -1,   /* null pointer, negative size, malformed CSR ...        */
+  HX_ERR_NOT_INITIALIZED = -2,
+  HX_ERR_NO_DEVICE = -3,     /* no HIP device / HIP runtime error at init             */
+  HX_ERR_HIP = -4,           /* a HIP call failed; see hx_last_error()                */
+  HX_ERR_NOT_TOPOSORTED = -5,/* a transition has src >= dest (reference profile.cpp:122-125) */
+  HX_ERR_OUT_OF_MEMORY = -6,
+  HX_ERR_STATE = -7,         /* call order violated (e.g. backward before forward)    */
+  HX_ERR_RANGE = -8          /* index out of range                                    */
+} hx_status;
+
+/* Pair-HMM state indices, as reference src/pairhmm.h:14-18. */
+enum { HX_IMM = 0, HX_IMD = 1, HX_IDM = 2, HX_IMI = 3, HX_IIW = 4, HX_STATES = 5, HX_EEE = 5 };
+
+/* Number of doubles in the log_sum_exp lookup table the caller must supply:
+ * LOG_SUM_EXP_LOOKUP_ENTRIES (100001, reference src/logsumexp.h:22-25) plus one
+ * guard entry, because (int)(x/1e-4) can reach 100000 and the reference then reads
+ * lookup[n+1] (src/logsumexp.h:53-57).  The table must be built by HOST libm
+ * (log(1+exp(-n*1e-4)), reference src/logsumexp.cpp:8-16): device libm differs. */
+#define HX_LSE_TABLE_ENTRIES 100002
+
+/* ---- fill modes (hx_batch_create flags) ---------------------------------- */
+#define HX_LSE_EXACT 0u  /* table + linear interpolation + d>=10 truncation: every cell
+                            bit-identical to the reference recursion (default)        */
+#define HX_LSE_FAST  1u  /* same truncation, higher-order LDS-resident table; cells
+                            differ from HX_LSE_EXACT by <= ~1e-9 per op               */
+#define HX_KEEP_BACKWARD 2u /* allocate the Backward matrix too                       */
+
+/* POD image of a reference Profile (src/profile.h:13-76) restricted to what the
+ * fills read.  Transitions are listed once; the three per-state lists hold
+ * transition indices in the reference's vector order (ProfileState::in, absorbOut,
+ * nullOut), CSR-encoded.  That order is the accumulation order of the fills. */
+typedef struct hx_profile {
+  int32_t n_states;          /* N = state.size() (START ... END)                      */
+  int32_t n_trans;           /* T = trans.size()                                      */
+  const int32_t* trans_src;  /* [T] ProfileTransition::src                            */
+  const int32_t* trans_dst;  /* [T] ProfileTransition::dest                           */
+  const double*  trans_lp;   /* [T] ProfileTransition::lpTrans                        */
+  const int32_t* in_off;     /* [N+1]                                                 */
+  const int32_t* in_idx;     /* [in_off[N]] transition indices, ProfileState::in      */
+  const int32_t* aout_off;   /* [N+1]                                                 */
+  const int32_t* aout_idx;   /* ProfileState::absorbOut                               */
+  const int32_t* nout_off;   /* [N+1]                                                 */
+  const int32_t* nout_idx;   /* ProfileState::nullOut                                 */
+  const uint8_t* is_null;    /* [N] ProfileState::isNull() (lpAbsorb.empty())         */
+  const double*  lp_absorb;  /* [N][C][A] ProfileState::lpAbsorb; ignored rows for null states */
+  const int32_t* env_pos;    /* [N] cumulativeMatches[rowPosToCol[closestLeafPos[i]]]
+                                (reference src/forward.cpp:36-42, alignpath.h:56-61);
+                                may be NULL when max_distance < 0                     */
+} hx_profile;
+
+/* POD image of a reference PairHMM (src/pairhmm.h, src/pairhmm.cpp:5-44) plus the
+ * per-branch LogProbModel / log substitution matrices the DPMatrix constructor
+ * reads (src/forward.cpp:20-21,44-56; src/profile.cpp:78-91). */
+typedef struct hx_hmm {
+  int32_t alph_size;         /* A */
+  int32_t components;        /* C */
+  double  lp_trans[5][6];    /* [src][dest], dest 5 = EEE; -inf where PairHMM::lpTrans has no case */
+  const double* log_root;    /* [C][A] PairHMM::logRoot (log cptWeight folded in)      */
+  const double* log_sub_l;   /* [C][A][A] log(l.subMat[cpt](c,d)), host libm log       */
+  const double* log_sub_r;   /* [C][A][A]                                              */
+  const double* log_ins_l;   /* [C][A] logl.logInsProb                                 */
+  const double* log_ins_r;   /* [C][A]                                                 */
+  const double* log_cptw_l;  /* [C] logl.logCptWeight                                  */
+  const double* log_cptw_r;  /* [C]                                                    */
+} hx_hmm;
+
+typedef struct hx_pair_job {
+  const hx_profile* x;       /* left child profile                                     */
+  const hx_profile* y;       /* right child profile                                    */
+  const hx_hmm* hmm;
+  int32_t max_distance;      /* GuideAlignmentEnvelope::maxDistance; < 0 = no band     */
+} hx_pair_job;
+
+/* Where cell (i,j), 0 <= i < n_rows = Nx-1, 0 <= j < n_cols = Ny-1, lives in the
+ * buffers returned by hx_batch_read_matrix:
+ *     slot(i,j) = (i / strip_rows) * strip_stride + (j + i % strip_rows) * strip_rows + i % strip_rows
+ *     value(i,j,state) = buf[state * plane_stride + slot(i,j)]
+ * (64-row strips, anti-diagonal-major inside a strip: one wavefront step writes 64
+ * consecutive doubles per state plane).  Cells outside the envelope hold -inf, as
+ * DPMatrix::cell() returns for them (reference src/forward.h:79-84). */
+typedef struct hx_layout {
+  int32_t n_rows, n_cols;
+  int32_t strip_rows;        /* 64 */
+  int32_t n_strips;
+  int64_t strip_stride;      /* doubles per strip per plane                            */
+  int64_t plane_stride;      /* doubles per state plane = n_strips * strip_stride      */
+} hx_layout;
+
+typedef struct hx_cell {
+  int32_t xpos, ypos, state;
+  int32_t pad_;
+  double  log_post_prob;
+} hx_cell;
+
+typedef struct hx_batch hx_batch;   /* opaque: inputs + matrices of n independent pair DPs, device resident */
+
+/* -- lifetime ---------------------------------------------------------------- */
+/* Select the device, upload the host-built lookup table.  Replaces the reference's
+ * static LogSumExpLookupTable (src/logsumexp.cpp:6-16). */
+int hx_init(int device_ordinal, const double* lse_table, size_t n_entries);
+int hx_shutdown(void);
+const char* hx_last_error(void);
+int hx_version(void);
+
+/* -- batch of independent pair DPs -------------------------------------------- */
+/* Validates the jobs, plans the layouts, allocates device memory and copies the
+ * inputs.  Replaces the member initialisers of DPMatrix::DPMatrix
+ * (src/forward.cpp:11-35). */
+int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_batch** out);
+int hx_batch_destroy(hx_batch* b);
+
+/* Asynchronous on `stream`: profile prep (leftMultiply, insx/rootsubx: reference
+ * src/profile.cpp:78-91, src/forward.cpp:44-56) + Forward fill + lpEnd
+ * (src/forward.cpp:68-223) for every job of the batch. */
+int hx_batch_forward(hx_batch* b, void* stream);
+/* Asynchronous: Backward fill (src/forward.cpp:975-1088).  Needs HX_KEEP_BACKWARD
+ * and a previous hx_batch_forward (the prepared vectors are shared, unlike the
+ * reference which recomputes them at src/forward.cpp:976). */
+int hx_batch_backward(hx_batch* b, void* stream);
+int hx_batch_sync(hx_batch* b);
+
+/* Results.  All of these synchronise with the batch's last stream. */
+int hx_batch_lp_end(hx_batch* b, double* out /* [n_jobs] ForwardMatrix::lpEnd */);
+int hx_batch_lp_start(hx_batch* b, double* out /* [n_jobs] BackwardMatrix::lpStart() */);
+int hx_batch_layout(const hx_batch* b, int32_t job, hx_layout* out);
+/* which: 0 = Forward, 1 = Backward.  out holds 5 * plane_stride doubles. */
+int hx_batch_read_matrix(hx_batch* b, int32_t job, int32_t which, double* out);
+/* Gather n cells (ij[2k], ij[2k+1]) -> out[5k..5k+4] without copying the matrix. */
+int hx_batch_read_cells(hx_batch* b, int32_t job, int32_t which, const int32_t* ij, int64_t n, double* out);
+/* Prepared per-state vectors of DPMatrix (src/forward.h:24-25,54): any pointer may be NULL.
+ * subx/suby: [N][C][A] leftMultiply results; insx..rootsuby: [N]. */
+int hx_batch_read_prepared(hx_batch* b, int32_t job, double* subx, double* suby,
+                           double* insx, double* rootsubx, double* insy, double* rootsuby);
+/* BackwardMatrix::cellsAbovePostProbThreshold (src/forward.cpp:1302-1319): all
+ * (cell,state) with fwd+back-lpEnd >= log(min_post_prob), unordered.  *n_out gets the
+ * number found; at most cap are written. */
+int hx_batch_posterior_scan(hx_batch* b, int32_t job, double min_post_prob,
+                            hx_cell* out, int64_t cap, int64_t* n_out);
+
+/* Total in-envelope-or-not lattice cells of the batch, sum (Nx-1)(Ny-1). */
+int64_t hx_batch_total_cells(const hx_batch* b);
+
+/* Duration in milliseconds of the most recent hx_batch_forward / hx_batch_backward
+ * fill kernel (HIP events recorded around that kernel on its stream). */
+int hx_batch_last_kernel_ms(hx_batch* b, int32_t which, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HISTORIAN_HIP_H */

@@ -1,0 +1,181 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle on
+the same seeded inputs.  Exact fill mode: every cell, lpEnd/lpStart and every prepared
+vector bit-identical (fp64 compared as uint64)."""
+import numpy as np
+import pytest
+
+from historian_amd import capi
+from oracle import c_oracle
+from oracle import historian_oracle as ho
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def engine():
+    capi.init(0, c_oracle.table())      # host-libm table (identical to hostmodel.lse_table())
+    yield
+    capi.shutdown()
+
+
+def run_and_check(cases, backward=True, python_oracle=False):
+    """cases: list of unfilled oracle ForwardMatrix objects, run as ONE batch."""
+    imgs = [H.job_images(f) for f in cases]
+    b = capi.Batch(imgs, capi.HX_KEEP_BACKWARD if backward else 0)
+    b.forward()
+    if backward:
+        b.backward()
+    lp_end = b.lp_end()
+    lp_start = b.lp_start() if backward else None
+    for k, (f, (x, y, hmm, md)) in enumerate(zip(cases, imgs)):
+        want = c_oracle.forward(x, y, hmm, md)
+        H.assert_same_bits(b.read_matrix(k, 0), want["cells"], "job %d forward cells" % k)
+        H.assert_same_bits([lp_end[k]], [want["lp_end"]], "job %d lpEnd" % k)
+        prep = b.read_prepared(k)
+        for name in ("insx", "rootsubx", "insy", "rootsuby"):
+            H.assert_same_bits(prep[name], want[name], name)
+        emit_x = x.is_null == 0
+        emit_y = y.is_null == 0
+        H.assert_same_bits(prep["subx"][emit_x], want["subx"][emit_x], "subx")
+        H.assert_same_bits(prep["suby"][emit_y], want["suby"][emit_y], "suby")
+        if backward:
+            wb = c_oracle.backward(x, y, hmm, md)
+            H.assert_same_bits(b.read_matrix(k, 1), wb["cells"], "job %d backward cells" % k)
+            H.assert_same_bits([lp_start[k]], [wb["lp_start"]], "job %d lpStart" % k)
+        if python_oracle:
+            f.fill()
+            H.assert_same_bits(b.read_matrix(k, 0), H.oracle_dense(f), "vs python oracle")
+    b.close()
+    return lp_end
+
+
+def test_reference_fixture_inputs_known_answers():
+    # reference data/testbackward.*.out: Forward == Backward == -6.54519 / -12.7452
+    G = "tests/golden/reference_data/"
+    rates = ho.RateModel.from_file(G + "testforward.jukescantor.json")
+    hmm = ho.PairHMM(ho.ProbModel(rates, 1), ho.ProbModel(rates, 1), rates.ins_prob)
+    cases = [ho.ForwardMatrix(ho.Profile.from_seq(1, rates.alphabet, sx, 1, "x"),
+                              ho.Profile.from_seq(1, rates.alphabet, sy, 2, "y"), hmm, 0,
+                              ho.GuideAlignmentEnvelope(), fill=False) for sx, sy in (("ag", "ct"), ("ag", "actg"))]
+    imgs = [H.job_images(f) for f in cases]
+    b = capi.Batch(imgs, capi.HX_KEEP_BACKWARD)
+    b.forward()
+    b.backward()
+    assert ["%g" % v for v in b.lp_end()] == ["-6.54519", "-12.7452"]
+    assert ["%g" % v for v in b.lp_start()] == ["-6.54519", "-12.7452"]
+    # cells with posterior > .5 (reference data/testbackward.len2-4.out)
+    n, cells = b.posterior_scan(1, .5)
+    assert sorted((c[0], c[1], c[2]) for c in cells) == [(0, 0, 0), (2, 4, 0)]
+    assert all("%g" % np.exp(c[3]) == "1" for c in cells)
+    b.close()
+    run_and_check(cases, python_oracle=True)
+
+
+def test_xdel_fixture_cells_to_six_decimals():
+    # reference data/testforward.len2-4.xdel.out fwdLogProb values
+    G = "tests/golden/reference_data/"
+    rates = ho.RateModel.from_file(G + "testforward.jukescantor.json")
+    hmm = ho.PairHMM(ho.ProbModel(rates, .1), ho.ProbModel(rates, .01), rates.ins_prob)
+    f = ho.ForwardMatrix(ho.Profile.from_seq(1, rates.alphabet, "ag", 1, "x"),
+                         ho.Profile.from_seq(1, rates.alphabet, "actg", 2, "y"), hmm, 0,
+                         ho.GuideAlignmentEnvelope(), fill=False)
+    b = capi.Batch([H.job_images(f)])
+    b.forward()
+    m = b.read_matrix(0)
+    got = ["%f" % m[1, 1, 0], "%f" % m[1, 2, 2], "%f" % m[1, 3, 2], "%f" % m[2, 4, 0], "%f" % b.lp_end()[0]]
+    assert got == ["-1.718867", "-7.726982", "-9.220487", "-13.012149", "-13.023149"]
+    b.close()
+
+
+def test_leaf_pairs_small_batch_including_empty_sequences():
+    cases = [H.leaf_case(s, lx, ly) for s, lx, ly in
+             [(1, 7, 9), (2, 1, 1), (3, 12, 5), (4, 0, 3), (5, 3, 0), (6, 0, 0), (7, 70, 66), (8, 130, 64)]]
+    run_and_check(cases, python_oracle=True)
+
+
+def test_leaf_protein_and_mixture():
+    aa = "arndcqeghilkmfpstwyv"
+    cases = [H.leaf_case(11, 40, 45, alphabet=aa, jc=False, tl=.3, tr=.2),
+             H.leaf_case(12, 33, 30, alphabet=aa, components=2, jc=False),
+             H.leaf_case(13, 65, 70, alphabet="ACGT", components=4, jc=False)]
+    run_and_check(cases)
+
+
+def test_null_state_profile_of_testnullforward():
+    G = "tests/golden/reference_data/"
+    rates = ho.RateModel.from_file(G + "testforward.nosub.json")
+    hmm = ho.PairHMM(ho.ProbModel(rates, 1), ho.ProbModel(rates, 1), rates.ins_prob)
+    xp = ho.Profile.from_seq(1, rates.alphabet, "acg", 1, "x")
+    yp = ho.Profile.from_seq(1, rates.alphabet, "cag", 2, "y")
+    xp.state[2].lp_absorb = []
+    yp.state[1].lp_absorb = []
+    run_and_check([ho.ForwardMatrix(xp, yp, hmm, 0, ho.GuideAlignmentEnvelope(), fill=False)], backward=False,
+                  python_oracle=True)
+
+
+def test_dag_profiles_unbanded_banded_and_null_heavy():
+    cases = [H.dag_case(31), H.dag_case(32), H.dag_case(33), H.dag_case(34),
+             H.dag_case(41, band=0), H.dag_case(42, band=1), H.dag_case(43, band=3), H.dag_case(44, band=2),
+             H.dag_case(51, n=10, components=2),
+             H.dag_case(61, n=9, keep_all=True), H.dag_case(67, n=9, band=2, keep_all=True),
+             H.dag_case(68, n=9, band=1, keep_all=True)]
+    run_and_check(cases)
+
+
+def test_dag_profiles_larger_than_one_strip():
+    cases = [H.dag_case(71, n=90, samples=4), H.dag_case(72, n=150, band=6, samples=3)]
+    assert cases[0].x_size > 64
+    run_and_check(cases)
+
+
+def test_zero_likelihood_band_reports_minus_inf():
+    # band 0 on a bad guide can leave no path: lpEnd must be -inf, not NaN (reference recon.cpp:956-975)
+    f = H.dag_case(45, band=0)
+    lp = run_and_check([f], backward=False)
+    assert lp[0] == H.NEG_INF or np.isfinite(lp[0])
+    assert not np.isnan(lp[0])
+
+
+def test_medium_leaf_pair_dna_500_forward_equals_backward():
+    f = H.leaf_case(81, 500, 480)
+    lp = run_and_check([f])
+    assert np.isfinite(lp[0])
+
+
+def test_read_cells_gather_matches_full_matrix():
+    f = H.leaf_case(91, 100, 90)
+    b = capi.Batch([H.job_images(f)])
+    b.forward()
+    m = b.read_matrix(0)
+    ij = np.array([[0, 0], [5, 7], [99, 89], [100, 90], [64, 0], [63, 90], [101, 3], [-1, 2]])
+    got = b.read_cells(0, ij)
+    for k, (i, j) in enumerate(ij):
+        if 0 <= i <= 100 and 0 <= j <= 90:
+            H.assert_same_bits(got[k], m[i, j], "gather")
+        else:
+            assert np.all(got[k] == H.NEG_INF)
+    b.close()
+
+
+def test_error_codes():
+    f = H.leaf_case(92, 5, 5)
+    x, y, hmm, md = H.job_images(f)
+    b = capi.Batch([(x, y, hmm, md)])           # no HX_KEEP_BACKWARD
+    with pytest.raises(capi.HxError) as e:
+        b.backward()
+    assert e.value.code == -7
+    with pytest.raises(capi.HxError) as e:
+        b.lp_end()                               # before forward
+    assert e.value.code == -7
+    b.close()
+    # non-toposorted transition
+    bad = capi.ProfileImage(x.trans_src.copy(), x.trans_dst.copy(), x.trans_lp,
+                            [list(x.in_idx[x.in_off[i]:x.in_off[i + 1]]) for i in range(x.n_states)],
+                            [list(x.aout_idx[x.aout_off[i]:x.aout_off[i + 1]]) for i in range(x.n_states)],
+                            [list(x.nout_idx[x.nout_off[i]:x.nout_off[i + 1]]) for i in range(x.n_states)],
+                            x.is_null, x.lp_absorb)
+    bad.trans_src[2], bad.trans_dst[2] = bad.trans_dst[2], bad.trans_src[2]
+    with pytest.raises(capi.HxError) as e:
+        capi.Batch([(bad, y, hmm, md)])
+    assert e.value.code == -5
