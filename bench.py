@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Forward-DP throughput bench (BASELINE.json metric: forward-DP cells/s and % of the
+HBM roofline on LxL profile pairs; 1/2/4/8 GPUs).
+
+One "step" = one pass of the hot path (profile prep + Forward fill + lpEnd) over one
+batch of independent synthetic pair DPs, inputs already resident in HBM.  Workload at
+every N: BASELINE.json configs[3] -- a batch of independent 2x2000-residue protein
+profile pairs under WAG -- `--pairs` of them PER GPU (weak scaling: independent tree
+nodes are farmed across ranks, no data-path collective; the only RCCL traffic is the
+one-off broadcast of the rate-model constant block).
+
+  python bench.py                      # 1 GPU, defaults finish in a few minutes
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_CELL = 40          # 5 fp64 states written once per cell (reference forward.h:13-15,107)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=512, help="independent pair DPs per GPU")
+    ap.add_argument("--len", type=int, default=2000, dest="length", help="residues per sequence")
+    ap.add_argument("--model", default="wag")
+    ap.add_argument("--tl", type=float, default=0.2)
+    ap.add_argument("--tr", type=float, default=0.3)
+    ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs timed by the CPU baseline (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per launch from a PMC run (else null)")
+    return ap.parse_args()
+
+
+def synth_pair(rng, pi, length):
+    """x ~ pi; y = x with ~20% substitutions (~pi) and ~2% indels, cut/padded to `length`."""
+    a = len(pi)
+    x = rng.choice(a, size=length, p=pi)
+    keep = rng.random(length) >= .02
+    y = x[keep]
+    sub = rng.random(len(y)) < .2
+    y = np.where(sub, rng.choice(a, size=len(y), p=pi), y)
+    ins_at = np.flatnonzero(rng.random(len(y)) < .02)
+    y = np.insert(y, ins_at, rng.choice(a, size=len(ins_at), p=pi))
+    if len(y) < length:
+        y = np.concatenate([y, rng.choice(a, size=length - len(y), p=pi)])
+    return x, y[:length]
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from historian_amd import capi, hostmodel
+
+    # ---- rate-model constant block: built on rank 0, broadcast over RCCL/xGMI ----------------
+    model = hostmodel.RateModel.load(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json"))
+    a, c = len(model.alphabet), model.components()
+    n_tab = capi.HX_LSE_TABLE_ENTRIES
+    block_len = n_tab + 2 * c * a * a
+    if rank == 0:
+        sub_l, sub_r = model.sub_prob(args.tl), model.sub_prob(args.tr)
+        block = np.concatenate([hostmodel.lse_table(), np.stack(sub_l).ravel(), np.stack(sub_r).ravel()])
+    else:
+        block = np.zeros(block_len)
+    if world > 1:
+        t = torch.from_numpy(block).to(dev)
+        dist.broadcast(t, src=0)
+        block = t.cpu().numpy()
+    table = block[:n_tab]
+    sub_l = list(block[n_tab:n_tab + c * a * a].reshape(c, a, a))
+    sub_r = list(block[n_tab + c * a * a:].reshape(c, a, a))
+
+    capi.init(local_rank, table)
+    hmm = hostmodel.make_hmm(model, args.tl, args.tr, sub_l, sub_r)
+    pi = np.asarray(model.root[0], dtype=float)
+    pi = pi / pi.sum()
+
+    triples = []
+    for k in range(args.pairs):
+        rng = np.random.default_rng(1000 + rank * args.pairs + k)     # pair seeds 1000+k
+        xs, ys = synth_pair(rng, pi, args.length)
+        triples.append((hostmodel.leaf_profile(xs, a, c), hostmodel.leaf_profile(ys, a, c), hmm, -1))
+    batch = capi.Batch(triples)
+    cells = batch.total_cells()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.forward(stream)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        batch.forward(stream)
+        kernel_ms.append(batch.kernel_ms(0))        # HIP events around the fill kernel, on its stream
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    lp_end = batch.lp_end()
+    assert np.all(np.isfinite(lp_end)), "non-finite Forward log-likelihood"
+
+    if rank == 0:
+        total_cells = cells * world * args.steps
+        value = total_cells / dt
+        k_ms = float(np.mean(kernel_ms))
+        achieved = cells * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "forward-DP cells/s", "value": value, "unit": "cells/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "batch of independent 2x%d-residue protein leaf-profile pairs, %s, t=%g/%g, "
+                                   "full (unbanded) Forward DP, exact table log-sum-exp" %
+                                   (args.length, args.model.upper(), args.tl, args.tr),
+                       "pairs_per_gpu": args.pairs, "cells_per_gpu_per_step": cells,
+                       "parallelism": "pairs farmed across %d rank(s); RCCL broadcast of model constants only" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic,
+                         "kernel": "k_forward", "kernel_ms": k_ms, "bytes_per_cell": BYTES_PER_CELL},
+            "lp_end_pair0": float(lp_end[0]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import c_oracle           # the checker, timed as the CPU baseline ("port")
+            c_oracle.load()
+            n_cpu = max(1, min(args.cpu_pairs, args.pairs))
+            t1 = time.perf_counter()
+            cpu_cells = 0
+            rel = 0.0
+            for k in range(n_cpu):
+                x, y, h, md = triples[k]
+                r = c_oracle.forward(x, y, h, md)
+                cpu_cells += (x.n_states - 1) * (y.n_states - 1)
+                rel = max(rel, abs(r["lp_end"] - lp_end[k]) / abs(r["lp_end"]))
+            cpu_dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": cpu_cells / cpu_dt, "unit": "cells/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d pair(s) of the same batch, oracle/oracle_fill.c "
+                                             "(dense-array restatement of the reference fill), 1 thread, %.1f s"
+                                             % (n_cpu, cpu_dt)}
+            out["lp_end_max_rel_err_vs_cpu"] = rel
+        print(json.dumps(out))
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
