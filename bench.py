@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--tr", type=float, default=0.3)
     ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs timed by the CPU baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["exact", "fast"], default="exact", help="log-sum-exp policy of the fill")
     ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per launch from a PMC run (else null)")
     return ap.parse_args()
 
@@ -106,7 +107,7 @@ def main():
         rng = np.random.default_rng(1000 + rank * args.pairs + k)     # pair seeds 1000+k
         xs, ys = synth_pair(rng, pi, args.length)
         triples.append((hostmodel.leaf_profile(xs, a, c), hostmodel.leaf_profile(ys, a, c), hmm, -1))
-    batch = capi.Batch(triples)
+    batch = capi.Batch(triples, capi.HX_LSE_FAST if args.mode == "fast" else capi.HX_LSE_EXACT)
     cells = batch.total_cells()
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -145,8 +146,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "batch of independent 2x%d-residue protein leaf-profile pairs, %s, t=%g/%g, "
-                                   "full (unbanded) Forward DP, exact table log-sum-exp" %
-                                   (args.length, args.model.upper(), args.tl, args.tr),
+                                   "full (unbanded) Forward DP, %s log-sum-exp" %
+                                   (args.length, args.model.upper(), args.tl, args.tr,
+                                    "exact table (bit-identical cells)" if args.mode == "exact" else "fast LDS-table"),
                        "pairs_per_gpu": args.pairs, "cells_per_gpu_per_step": cells,
                        "parallelism": "pairs farmed across %d rank(s); RCCL broadcast of model constants only" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

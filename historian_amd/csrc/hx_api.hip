@@ -23,6 +23,39 @@ namespace {
 thread_local char g_err[512] = "";
 int g_device = -1;
 double* g_tab = nullptr;      // device copy of the host-built log_sum_exp table
+double* g_fast_tab = nullptr; // device copy of the cubic table of the fast fill mode
+
+// Cubic pieces of T(d) = log(1 + exp(-d)) on [0,10): piece k covers [k h, (k+1) h), h = 10/N,
+// as c0 + c1 t + c2 t^2 + c3 t^3 with t = (d - k h)/h, interpolating T at the four Chebyshev
+// nodes of the piece (long double arithmetic).  One extra piece guards k == N.
+void build_fast_table(std::vector<double>& out) {
+  const int N = HX_FAST_INTERVALS;
+  out.assign((size_t)(N + 1) * 4, 0.0);
+  const long double h = 10.0L / N;
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (int k = 0; k <= N; ++k) {
+    long double t[4], y[4];
+    for (int m = 0; m < 4; ++m) {
+      t[m] = 0.5L + 0.5L * cosl((2 * m + 1) * pi / 8);
+      y[m] = log1pl(expl(-(k + t[m]) * h));
+    }
+    // Newton divided differences -> monomial coefficients
+    long double dd[4] = {y[0], y[1], y[2], y[3]};
+    for (int lev = 1; lev < 4; ++lev)
+      for (int m = 3; m >= lev; --m) dd[m] = (dd[m] - dd[m - 1]) / (t[m] - t[m - lev]);
+    long double c[4] = {dd[3], 0, 0, 0};   // Horner expansion of the Newton form
+    int deg = 0;
+    for (int m = 2; m >= 0; --m) {
+      // c(t) <- c(t) * (t - t[m]) + dd[m]
+      long double nc[4] = {0, 0, 0, 0};
+      for (int q = 0; q <= deg; ++q) { nc[q + 1] += c[q]; nc[q] -= c[q] * t[m]; }
+      nc[0] += dd[m];
+      ++deg;
+      for (int q = 0; q < 4; ++q) c[q] = nc[q];
+    }
+    for (int q = 0; q < 4; ++q) out[(size_t)k * 4 + q] = (double)c[q];
+  }
+}
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -255,12 +288,20 @@ int hx_init(int device_ordinal, const double* lse_table, size_t n_entries) {
   if (g_tab) { (void)hipFree(g_tab); g_tab = nullptr; }
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_tab), n_entries * sizeof(double)));
   HIP_TRY(hipMemcpy(g_tab, lse_table, n_entries * sizeof(double), hipMemcpyHostToDevice));
+  {
+    std::vector<double> ft;
+    build_fast_table(ft);
+    if (g_fast_tab) { (void)hipFree(g_fast_tab); g_fast_tab = nullptr; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_fast_tab), ft.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(g_fast_tab, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   g_device = device_ordinal;
   return HX_OK;
 }
 
 int hx_shutdown(void) {
   if (g_tab) { (void)hipFree(g_tab); g_tab = nullptr; }
+  if (g_fast_tab) { (void)hipFree(g_fast_tab); g_fast_tab = nullptr; }
   g_device = -1;
   return HX_OK;
 }
@@ -397,7 +438,10 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_ca, b->max_cls_pairs, g_tab, st);
   HIP_TRY(hipEventRecord(b->ev[0][0], st));
-  launch_forward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
+  if (b->all_chain && !(b->flags & HX_FORCE_GENERIC))
+    launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0, st);
+  else
+    launch_forward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
   HIP_TRY(hipEventRecord(b->ev[0][1], st));
   HIP_TRY(hipGetLastError());
   b->ev_valid[0] = true;

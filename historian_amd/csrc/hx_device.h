@@ -63,6 +63,7 @@ struct DevJob {
 };
 
 #define HX_STRIP 64
+#define HX_FAST_INTERVALS 1024   // cubic pieces of the fast log-sum-exp table over [0,10)
 
 __host__ __device__ inline int64_t cell_slot(int64_t strip_stride, int i, int j) {
   const int l = i & (HX_STRIP - 1);

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include "hx_device.h"
 #include "hx_lse.h"
+#include "hx_common.h"
 #include "hx_kernels.h"
 
 namespace hx {
@@ -63,20 +64,6 @@ __global__ void k_ins_rootsub(const DevJob* __restrict__ jobs, const double* __r
   P.rootsub[i] = rs;
 }
 
-__device__ __forceinline__ double emission_rows(const DevJob& J, const double* sx, const double* sy,
-                                                const double* __restrict__ tab) {
-  double lip = HX_NEG_INF;
-  for (int cpt = 0; cpt < J.C; ++cpt) {
-    double inner = HX_NEG_INF;
-    for (int a = 0; a < J.A; ++a) {
-      const int k = cpt * J.A + a;
-      inner = lse(inner, J.log_root[k] + (sx[k] + sy[k]), tab);
-    }
-    lip = lse(lip, inner, tab);
-  }
-  return lip;
-}
-
 // one thread per (x class, y class)
 __global__ void k_emission_table(const DevJob* __restrict__ jobs, const double* __restrict__ tab) {
   const DevJob& J = jobs[blockIdx.y];
@@ -87,34 +74,7 @@ __global__ void k_emission_table(const DevJob* __restrict__ jobs, const double* 
   const int kx = idx / Ky, ky = idx - kx * Ky;
   const double* sx = J.x.sub + (size_t)J.x.cls_rep[kx] * J.CA;
   const double* sy = J.y.sub + (size_t)J.y.cls_rep[ky] * J.CA;
-  J.emis[idx] = emission_rows(J, sx, sy, tab);
-}
-
-__device__ __forceinline__ double emission(const DevJob& J, int i, int j, const double* __restrict__ tab) {
-  if (J.emis) {
-    // a hand-edited profile may route an absorbing transition into a null state
-    // (reference t/testnullforward.cpp:37-39); such a pair emits nothing
-    const int cx = J.x.cls[i], cy = J.y.cls[j];
-    return (cx < 0 || cy < 0) ? HX_NEG_INF : J.emis[(size_t)cx * J.y.n_cls + cy];
-  }
-  return emission_rows(J, J.x.sub + (size_t)i * J.CA, J.y.sub + (size_t)j * J.CA, tab);
-}
-
-__device__ __forceinline__ bool in_envelope(const DevJob& J, int i, int j) {
-  if ((J.x.flags[i] | J.y.flags[j]) & F_EDGE) return true;
-  if (J.max_dist < 0) return true;
-  int d = J.x.env[i] - J.y.env[j];
-  d = d < 0 ? -d : d;
-  return d <= J.max_dist;
-}
-
-struct Cell5 { double v[5]; };
-
-__device__ __forceinline__ Cell5 load_cell(const double* __restrict__ m, int64_t plane, int64_t slot) {
-  Cell5 c;
-#pragma unroll
-  for (int s = 0; s < 5; ++s) c.v[s] = m[s * plane + slot];
-  return c;
+  J.emis[idx] = emission_rows(J, sx, sy, ExactLse{tab});
 }
 
 // ---------------------------------------------------------------------------
@@ -216,22 +176,6 @@ __device__ void forward_cell(const DevJob& J, int i, int j, const double* __rest
   M[4 * plane + slot] = iiw;
 }
 
-// transitions into EEE (reference src/forward.cpp:205-220)
-__device__ double forward_lp_end(const DevJob& J, const double* __restrict__ tab) {
-  double lp_end = HX_NEG_INF;
-  const int xe = J.x.n - 1, ye = J.y.n - 1;
-  for (int tx = J.x.in_off[xe]; tx < J.x.in_off[xe + 1]; ++tx)
-    for (int ty = J.y.in_off[ye]; ty < J.y.in_off[ye + 1]; ++ty) {
-      const Cell5 s = load_cell(J.fwd, J.plane, cell_slot(J.strip_stride, J.x.in_src[tx], J.y.in_src[ty]));
-      double a = lse(s.v[0] + J.T[0][5], s.v[1] + J.T[1][5], tab);
-      a = lse(a, s.v[2] + J.T[2][5], tab);
-      a = lse(a, s.v[3] + J.T[3][5], tab);
-      a = lse(a, s.v[4] + J.T[4][5], tab);
-      lp_end = lse(lp_end, a + J.x.in_lp[tx] + J.y.in_lp[ty], tab);
-    }
-  return lp_end;
-}
-
 __global__ void __launch_bounds__(1024) k_forward_dag(const DevJob* __restrict__ jobs, const double* __restrict__ tab) {
   const DevJob& J = jobs[blockIdx.x];
   const int R = J.n_rows, Cc = J.n_cols;
@@ -243,7 +187,7 @@ __global__ void __launch_bounds__(1024) k_forward_dag(const DevJob* __restrict__
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *J.lp_end = forward_lp_end(J, tab);
+  if (threadIdx.x == 0) *J.lp_end = forward_lp_end(J, ExactLse{tab});
 }
 
 // ---------------------------------------------------------------------------

@@ -55,6 +55,7 @@ enum { HX_IMM = 0, HX_IMD = 1, HX_IDM = 2, HX_IMI = 3, HX_IIW = 4, HX_STATES = 5
 #define HX_LSE_FAST  1u  /* same truncation, higher-order LDS-resident table; cells
                             differ from HX_LSE_EXACT by <= ~1e-9 per op               */
 #define HX_KEEP_BACKWARD 2u /* allocate the Backward matrix too                       */
+#define HX_FORCE_GENERIC 4u /* always use the general (DAG) kernels, even for chain profiles */
 
 /* POD image of a reference Profile (src/profile.h:13-76) restricted to what the
  * fills read.  Transitions are listed once; the three per-state lists hold

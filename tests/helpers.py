@@ -164,7 +164,7 @@ def dag_case(seed, n=14, alphabet="ACGT", components=1, band=None, samples=6, ke
     return ho.ForwardMatrix(p1, p2, hmm, 6, env, fill=False)
 
 
-def leaf_case(seed, lx, ly, alphabet="ACGT", components=1, jc=True, tl=.1, tr=.1):
+def leaf_case(seed, lx, ly, alphabet="ACGT", components=1, jc=True, tl=.1, tr=.1, band=None):
     rng = random.Random(seed)
     model = jc_model(alphabet) if jc else random_reversible_model(rng, alphabet, components)
     sx = random_seq(rng, alphabet, lx)
@@ -172,5 +172,7 @@ def leaf_case(seed, lx, ly, alphabet="ACGT", components=1, jc=True, tl=.1, tr=.1
     while len(sy) < ly:
         sy += rng.choice(alphabet)
     hmm = make_hmm(model, tl, tr)
-    return ho.ForwardMatrix(leaf(model, sx, 1, "x"), leaf(model, sy, 2, "y"), hmm, 0, ho.GuideAlignmentEnvelope(),
-                            fill=False)
+    env = ho.GuideAlignmentEnvelope()
+    if band is not None:
+        env = ho.GuideAlignmentEnvelope(left_justified_guide({1: sx, 2: sy}), 1, 2, band)
+    return ho.ForwardMatrix(leaf(model, sx, 1, "x"), leaf(model, sy, 2, "y"), hmm, 0, env, fill=False)

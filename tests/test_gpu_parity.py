@@ -19,10 +19,10 @@ def engine():
     capi.shutdown()
 
 
-def run_and_check(cases, backward=True, python_oracle=False):
+def run_and_check(cases, backward=True, python_oracle=False, flags=0):
     """cases: list of unfilled oracle ForwardMatrix objects, run as ONE batch."""
     imgs = [H.job_images(f) for f in cases]
-    b = capi.Batch(imgs, capi.HX_KEEP_BACKWARD if backward else 0)
+    b = capi.Batch(imgs, (capi.HX_KEEP_BACKWARD if backward else 0) | flags)
     b.forward()
     if backward:
         b.backward()
@@ -92,6 +92,30 @@ def test_leaf_pairs_small_batch_including_empty_sequences():
     cases = [H.leaf_case(s, lx, ly) for s, lx, ly in
              [(1, 7, 9), (2, 1, 1), (3, 12, 5), (4, 0, 3), (5, 3, 0), (6, 0, 0), (7, 70, 66), (8, 130, 64)]]
     run_and_check(cases, python_oracle=True)
+
+
+def test_leaf_pairs_through_the_general_kernels_too():
+    cases = [H.leaf_case(s, lx, ly) for s, lx, ly in [(1, 7, 9), (4, 0, 3), (6, 0, 0), (7, 70, 66), (8, 130, 64)]]
+    run_and_check(cases, flags=capi.HX_FORCE_GENERIC)
+
+
+def test_leaf_pairs_banded():
+    cases = [H.leaf_case(101, 90, 80, band=4), H.leaf_case(102, 200, 190, band=10), H.leaf_case(103, 40, 70, band=0)]
+    run_and_check(cases)
+    run_and_check(cases, flags=capi.HX_FORCE_GENERIC)
+
+
+def test_leaf_pair_with_more_rows_than_one_pass():
+    # > 2048 rows: the chain kernel sweeps the matrix in two row passes
+    f = H.leaf_case(104, 2150, 150)
+    run_and_check([f], backward=False)
+
+
+def test_leaf_pairs_mid_sizes_hit_every_chain_variant():
+    cases = [H.leaf_case(105, 255, 300), H.leaf_case(106, 256, 100), H.leaf_case(107, 1023, 120),
+             H.leaf_case(108, 1024, 90), H.leaf_case(109, 1100, 64)]
+    for c in cases:
+        run_and_check([c], backward=False)
 
 
 def test_leaf_protein_and_mixture():
@@ -179,3 +203,23 @@ def test_error_codes():
     with pytest.raises(capi.HxError) as e:
         capi.Batch([(bad, y, hmm, md)])
     assert e.value.code == -5
+
+
+def test_fast_mode_stays_within_tolerance_of_exact():
+    # north_star tolerance: forward log-likelihoods within 1e-4 relative; the fast fill is far inside it
+    cases = [H.leaf_case(201, 300, 280), H.leaf_case(202, 64, 700, alphabet="arndcqeghilkmfpstwyv", jc=False),
+             H.leaf_case(203, 600, 90, band=12), H.leaf_case(204, 5, 3), H.leaf_case(205, 0, 4)]
+    imgs = [H.job_images(f) for f in cases]
+    be = capi.Batch(imgs)
+    bf = capi.Batch(imgs, capi.HX_LSE_FAST)
+    be.forward()
+    bf.forward()
+    le, lf = be.lp_end(), bf.lp_end()
+    for k in range(len(cases)):
+        me, mf = be.read_matrix(k), bf.read_matrix(k)
+        assert np.array_equal(np.isneginf(me), np.isneginf(mf))
+        fin = np.isfinite(me)
+        assert np.max(np.abs(me[fin] - mf[fin]), initial=0.) < 1e-7
+        assert abs(le[k] - lf[k]) <= 1e-9 * abs(le[k])
+    be.close()
+    bf.close()
