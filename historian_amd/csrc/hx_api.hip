@@ -55,6 +55,7 @@ void build_fast_table(std::vector<double>& out) {
     }
     for (int q = 0; q < 4; ++q) out[(size_t)k * 4 + q] = (double)c[q];
   }
+  for (int q = 0; q < 4; ++q) out[(size_t)N * 4 + q] = 0.0;   // guard piece: T = 0 beyond the table
 }
 
 int fail(int code, const char* fmt, ...) {
@@ -90,9 +91,9 @@ struct Arena {
 // offsets into the arena for one profile
 struct ProfOff {
   size_t flags, in_off, in_src, in_lp, ao_off, ao_dst, ao_lp, no_off, no_dst, no_lp;
-  size_t lp_absorb, sub, ins, rootsub, env, cls, cls_rep;
+  size_t lp_absorb, sub, ins, rootsub, env, cls, cls_rep, pack, ecls;
   bool has_env;
-  int n, empty, n_cls, chain;
+  int n, empty, n_cls, chain, interior_emit;
 };
 
 int check_csr(const int32_t* off, const int32_t* idx, int N, int T, const char* what) {
@@ -219,6 +220,15 @@ int flatten_profile(const hx_profile* p, int CA, bool need_env, bool is_y, Arena
   o.env = need_env ? ar.put(p->env_pos, sizeof(int32_t) * N) : 0;
   o.cls = ar.put(cls.data(), sizeof(int32_t) * N);
   o.cls_rep = ar.put(cls_rep.data(), sizeof(int32_t) * cls_rep.size());
+  {
+    std::vector<int32_t> ecls(N);
+    for (int i = 0; i < N; ++i) ecls[i] = cls[i] < 0 ? (int32_t)cls_rep.size() : cls[i];
+    o.ecls = ar.put(ecls.data(), sizeof(int32_t) * N);
+  }
+  o.pack = ar.reserve(sizeof(double) * 4 * (size_t)N);
+  o.interior_emit = 1;
+  for (int i = 1; i < N - 1; ++i)
+    if (p->is_null[i]) o.interior_emit = 0;
   return HX_OK;
 }
 
@@ -244,11 +254,13 @@ void bind_profile(DevProfile& d, const ProfOff& o, char* base) {
   d.cls_rep = reinterpret_cast<int32_t*>(base + o.cls_rep);
   d.n_cls = o.n_cls;
   d.pad_ = 0;
+  d.pack = reinterpret_cast<double*>(base + o.pack);
+  d.ecls = reinterpret_cast<int32_t*>(base + o.ecls);
 }
 
 struct JobOff {
   ProfOff x, y;
-  size_t log_root, log_sub_l, log_sub_r, log_ins_l, log_ins_r, log_cptw_l, log_cptw_r, emis, scalars;
+  size_t log_root, log_sub_l, log_sub_r, log_ins_l, log_ins_r, log_cptw_l, log_cptw_r, emis, emis_pad, scalars;
   bool table_emission;
 };
 
@@ -264,7 +276,7 @@ struct hx_batch {
   double* d_fwd = nullptr;
   double* d_bwd = nullptr;
   int max_states = 0, max_ca = 0, max_cls_pairs = 0, max_rows = 0;
-  bool all_chain = true;
+  bool all_chain = true, all_leaf = true;
   int64_t total_cells = 0;
   bool forward_done = false, backward_done = false;
   hipStream_t last_stream = nullptr;
@@ -349,6 +361,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     const int64_t pairs = (int64_t)jo.x.n_cls * jo.y.n_cls;
     jo.table_emission = pairs > 0 && pairs <= (1 << 16);
     jo.emis = jo.table_emission ? ar.reserve(sizeof(double) * pairs) : 0;
+    jo.emis_pad = jo.table_emission ? ar.reserve(sizeof(double) * (jo.x.n_cls + 1) * (jo.y.n_cls + 1)) : 0;
     jo.scalars = ar.reserve(sizeof(double) * 2);
 
     DevJob& J = b->jobs[k];
@@ -363,6 +376,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     J.strip_stride = ((int64_t)J.n_cols + HX_STRIP - 1) * HX_STRIP;
     J.plane = J.n_strips * J.strip_stride;
     J.chain = jo.x.chain && jo.y.chain;
+    J.leaf_like = J.chain && jo.x.interior_emit && jo.y.interior_emit && jo.table_emission;
     hx_layout& L = b->layouts[k];
     L.n_rows = J.n_rows; L.n_cols = J.n_cols; L.strip_rows = HX_STRIP; L.n_strips = J.n_strips;
     L.strip_stride = J.strip_stride; L.plane_stride = J.plane;
@@ -375,6 +389,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     if (jo.table_emission && pairs > b->max_cls_pairs) b->max_cls_pairs = (int)pairs;
     if (J.n_rows > b->max_rows) b->max_rows = J.n_rows;
     b->all_chain = b->all_chain && J.chain;
+    b->all_leaf = b->all_leaf && J.leaf_like;
   }
   if (rc != HX_OK) { delete b; return rc; }
 
@@ -403,6 +418,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     J.log_cptw_l = reinterpret_cast<double*>(base + jo.log_cptw_l);
     J.log_cptw_r = reinterpret_cast<double*>(base + jo.log_cptw_r);
     J.emis = jo.table_emission ? reinterpret_cast<double*>(base + jo.emis) : nullptr;
+    J.emis_pad = jo.table_emission ? reinterpret_cast<double*>(base + jo.emis_pad) : nullptr;
     J.lp_end = reinterpret_cast<double*>(base + jo.scalars);
     J.lp_start = J.lp_end + 1;
     J.fwd = b->d_fwd + mat_off[k];
@@ -439,7 +455,8 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_ca, b->max_cls_pairs, g_tab, st);
   HIP_TRY(hipEventRecord(b->ev[0][0], st));
   if (b->all_chain && !(b->flags & HX_FORCE_GENERIC))
-    launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0, st);
+    launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,
+                         b->all_leaf, st);
   else
     launch_forward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
   HIP_TRY(hipEventRecord(b->ev[0][1], st));

@@ -36,6 +36,11 @@ struct DevProfile {
   const int32_t* cls_rep;     // [n_cls] a representative state of each class
   int32_t n_cls;
   int32_t pad_;
+  // chain kernels: per-state constants packed for one 32-byte fetch
+  //   pack[i] = { lpTrans of the in-transition (0 for state 0), rootsub, ins, ok-penalty }
+  // ok-penalty is 0 when (isReady() || profile empty) else -inf (reference forward.cpp:97,133)
+  double* pack;               // [n][4]
+  const int32_t* ecls;        // [n] emission class, n_cls for null states (-> zero row of emis_pad)
 };
 
 struct DevJob {
@@ -58,6 +63,9 @@ struct DevJob {
   double* fwd;                // [5][plane]
   double* bwd;                // [5][plane] or nullptr
   double* emis;               // [x.n_cls][y.n_cls] class-pair emission table, or nullptr (per-cell emission)
+  double* emis_pad;           // [x.n_cls+1][y.n_cls+1]: emis plus a zero row/column for null states
+  int32_t leaf_like;          // chain profiles whose interior states all emit (leaves)
+  int32_t pad2_;
   double* lp_end;             // -> one double
   double* lp_start;           // -> one double
 };

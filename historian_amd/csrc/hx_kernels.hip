@@ -62,6 +62,13 @@ __global__ void k_ins_rootsub(const DevJob* __restrict__ jobs, const double* __r
   }
   P.ins[i] = ins;
   P.rootsub[i] = rs;
+  // packed per-state constants of the chain kernels
+  const bool ok = (P.flags[i] & F_READY) || P.empty;
+  double* pk = P.pack + 4 * (size_t)i;
+  pk[0] = (i > 0 && P.in_off[i + 1] > P.in_off[i]) ? P.in_lp[P.in_off[i]] : 0.0;
+  pk[1] = rs;
+  pk[2] = ins;
+  pk[3] = ok ? 0.0 : HX_NEG_INF;
 }
 
 // one thread per (x class, y class)
@@ -74,7 +81,12 @@ __global__ void k_emission_table(const DevJob* __restrict__ jobs, const double* 
   const int kx = idx / Ky, ky = idx - kx * Ky;
   const double* sx = J.x.sub + (size_t)J.x.cls_rep[kx] * J.CA;
   const double* sy = J.y.sub + (size_t)J.y.cls_rep[ky] * J.CA;
-  J.emis[idx] = emission_rows(J, sx, sy, ExactLse{tab});
+  const double e = emission_rows(J, sx, sy, ExactLse{tab});
+  J.emis[idx] = e;
+  J.emis_pad[(size_t)kx * (Ky + 1) + ky] = e;
+  if (ky == 0) J.emis_pad[(size_t)kx * (Ky + 1) + Ky] = 0.0;
+  if (kx == 0) J.emis_pad[(size_t)Kx * (Ky + 1) + ky] = 0.0;
+  if (idx == 0) J.emis_pad[(size_t)Kx * (Ky + 1) + Ky] = 0.0;
 }
 
 // ---------------------------------------------------------------------------

@@ -23,26 +23,25 @@ __device__ __forceinline__ double div_by_1em4(double a) {
 
 // log(1 + exp(-x)) for x >= 0 by table lookup + linear interpolation;
 // 0 for x >= 10, NaN or inf (reference src/logsumexp.h:42-64).
+// Branch-free: for x >= 10, +inf or NaN the lookup is redirected to entry 0 (one
+// broadcast address, no extra L2 traffic) and the result replaced by 0.
 __device__ __forceinline__ double lse_unary(double x, const double* __restrict__ tab) {
-  double ret = 0.0;
-  if (x < 10.0) {                       // false for x >= 10, +inf and NaN
-    const int n = (int)div_by_1em4(x);
-    // lookup[n], lookup[n+1] as one 16-byte access (8-byte aligned)
-    const double f0 = tab[n];
-    const double f1 = tab[n + 1];
-    const double dx = x - ((double)n * 1e-4);
-    const double df = f1 - f0;
-    ret = f0 + df * div_by_1em4(dx);
-  }
-  return ret;
+  const bool in = x < 10.0;             // false for x >= 10, +inf and NaN
+  const int n = in ? (int)div_by_1em4(x) : 0;
+  // lookup[n], lookup[n+1]: one 16-byte access (8-byte aligned)
+  const double f0 = tab[n];
+  const double f1 = tab[n + 1];
+  const double dx = x - ((double)n * 1e-4);
+  const double df = f1 - f0;
+  const double ret = f0 + df * div_by_1em4(dx);
+  return in ? ret : 0.0;
 }
 
 // reference src/logsumexp.h:66-84.  a == b (incl. -inf,-inf) gives diff 0; here the
 // -inf,-inf case yields diff NaN -> unary 0 -> -inf + 0: the same value.
 __device__ __forceinline__ double lse(double a, double b, const double* __restrict__ tab) {
-  const double mx = (a < b) ? b : a;
-  const double mn = (a < b) ? a : b;
-  const double diff = (a == b) ? 0.0 : (mx - mn);
+  const double mx = __builtin_fmax(a, b);
+  const double diff = mx - __builtin_fmin(a, b);   // NaN for (-inf,-inf): handled as "no lookup"
   return mx + lse_unary(diff, tab);
 }
 
