@@ -205,7 +205,9 @@ def slot_index(layout, i, j):
     sr = layout.strip_rows
     i = np.asarray(i, dtype=np.int64)
     j = np.asarray(j, dtype=np.int64)
-    return (i // sr) * layout.strip_stride + (j + i % sr) * sr + i % sr
+    l = i % sr
+    t = j + l
+    return (i // sr) * layout.strip_stride + (t // 2) * (2 * sr) + l * 2 + t % 2
 
 
 class Batch:

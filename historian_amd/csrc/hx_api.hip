@@ -25,37 +25,36 @@ int g_device = -1;
 double* g_tab = nullptr;      // device copy of the host-built log_sum_exp table
 double* g_fast_tab = nullptr; // device copy of the cubic table of the fast fill mode
 
-// Cubic pieces of T(d) = log(1 + exp(-d)) on [0,10): piece k covers [k h, (k+1) h), h = 10/N,
-// as c0 + c1 t + c2 t^2 + c3 t^3 with t = (d - k h)/h, interpolating T at the four Chebyshev
-// nodes of the piece (long double arithmetic).  One extra piece guards k == N.
+// Quadratic pieces of T(d) = log(1 + exp(-d)) on [0,10): piece k covers [k h, (k+1) h),
+// h = 10/N, as c0 + c1 t + c2 t^2 with t = (d - k h)/h, interpolating T at the three Chebyshev
+// nodes of the piece (long double arithmetic; |error| < 1e-11).  c1 and c2 are stored as fp32
+// (their terms are < 1.3e-3 and < 8e-7), c0 absorbs the mean of their rounding; 16 bytes per
+// piece = one ds_read_b128.  One extra all-zero piece implements T = 0 for d >= 10.
+struct FastPieceHost { double c0; float c1, c2; };
 void build_fast_table(std::vector<double>& out) {
   const int N = HX_FAST_INTERVALS;
-  out.assign((size_t)(N + 1) * 4, 0.0);
+  static_assert(sizeof(FastPieceHost) == 16, "fast table piece layout");
+  out.assign((size_t)(N + 1) * 2, 0.0);
+  FastPieceHost* tabp = reinterpret_cast<FastPieceHost*>(out.data());
   const long double h = 10.0L / N;
   const long double pi = 3.14159265358979323846264338327950288L;
-  for (int k = 0; k <= N; ++k) {
-    long double t[4], y[4];
-    for (int m = 0; m < 4; ++m) {
-      t[m] = 0.5L + 0.5L * cosl((2 * m + 1) * pi / 8);
+  for (int k = 0; k < N; ++k) {
+    long double t[3], y[3];
+    for (int m = 0; m < 3; ++m) {
+      t[m] = 0.5L + 0.5L * cosl((2 * m + 1) * pi / 6);
       y[m] = log1pl(expl(-(k + t[m]) * h));
     }
-    // Newton divided differences -> monomial coefficients
-    long double dd[4] = {y[0], y[1], y[2], y[3]};
-    for (int lev = 1; lev < 4; ++lev)
-      for (int m = 3; m >= lev; --m) dd[m] = (dd[m] - dd[m - 1]) / (t[m] - t[m - lev]);
-    long double c[4] = {dd[3], 0, 0, 0};   // Horner expansion of the Newton form
-    int deg = 0;
-    for (int m = 2; m >= 0; --m) {
-      // c(t) <- c(t) * (t - t[m]) + dd[m]
-      long double nc[4] = {0, 0, 0, 0};
-      for (int q = 0; q <= deg; ++q) { nc[q + 1] += c[q]; nc[q] -= c[q] * t[m]; }
-      nc[0] += dd[m];
-      ++deg;
-      for (int q = 0; q < 4; ++q) c[q] = nc[q];
-    }
-    for (int q = 0; q < 4; ++q) out[(size_t)k * 4 + q] = (double)c[q];
+    const long double d01 = (y[1] - y[0]) / (t[1] - t[0]);
+    const long double d12 = (y[2] - y[1]) / (t[2] - t[1]);
+    const long double c2 = (d12 - d01) / (t[2] - t[0]);
+    const long double c1 = d01 - c2 * (t[0] + t[1]);
+    const long double c0 = y[0] - t[0] * (c1 + c2 * t[0]);
+    const float c1f = (float)c1, c2f = (float)c2;
+    tabp[k].c1 = c1f;
+    tabp[k].c2 = c2f;
+    tabp[k].c0 = (double)(c0 + 0.5L * (c1 - (long double)c1f) + (c2 - (long double)c2f) / 3.0L);
   }
-  for (int q = 0; q < 4; ++q) out[(size_t)N * 4 + q] = 0.0;   // guard piece: T = 0 beyond the table
+  tabp[N].c0 = 0.0; tabp[N].c1 = 0.0f; tabp[N].c2 = 0.0f;
 }
 
 int fail(int code, const char* fmt, ...) {
@@ -373,7 +372,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     J.n_rows = jo.x.n - 1;
     J.n_cols = jo.y.n - 1;
     J.n_strips = (J.n_rows + HX_STRIP - 1) / HX_STRIP;
-    J.strip_stride = ((int64_t)J.n_cols + HX_STRIP - 1) * HX_STRIP;
+    J.strip_stride = strip_stride_for(J.n_cols);
     J.plane = J.n_strips * J.strip_stride;
     J.chain = jo.x.chain && jo.y.chain;
     J.leaf_like = J.chain && jo.x.interior_emit && jo.y.interior_emit && jo.table_emission;

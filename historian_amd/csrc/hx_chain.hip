@@ -30,22 +30,94 @@
 
 namespace hx {
 
+// global-address-space views of pointers that were loaded from the job table (the compiler
+// would otherwise have to use flat_* instructions, which tie up both memory counters)
+#define HX_GLOBAL __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ HX_GLOBAL T* as_global(T* p) { return (HX_GLOBAL T*)p; }
+template <class T> __device__ __forceinline__ const HX_GLOBAL T* as_global(const T* p) { return (const HX_GLOBAL T*)p; }
+
+typedef double d4v __attribute__((ext_vector_type(4)));
+
+struct FastPiece { double c0; float c1, c2; };   // 16 bytes: one ds_read_b128 per log-sum-exp
+
+// v_max_f64 / v_min_f64 without the canonicalisation moves the builtins add for sNaN inputs
+// (v_min_f64 returns the non-NaN operand, which the clamping below relies on).
+__device__ __forceinline__ double vmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double vmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// A log-sum-exp policy is used in three phases so that the independent table look-ups of a
+// cell can be issued back to back:  prep (index arithmetic) -> fetch (the memory access) ->
+// finish (interpolation + add).  operator() runs the three in sequence.
 struct FastLse {
-  const double* lds;   // [HX_FAST_INTERVALS + 1][4] cubic coefficients in t in [0,1); last piece all zero
+  const FastPiece* lds;   // [HX_FAST_INTERVALS + 1] quadratic pieces in t in [0,1); last piece all zero
+  struct Prep { double mx, t; int k; };
+  typedef FastPiece Piece;
   // Branch- and select-free.  d = |a - b| is scaled to table units and clamped to the
   // all-zero guard piece, which yields T = 0 for d >= 10, d = +inf and d = NaN (-inf - -inf):
-  // exactly the reference's truncation (v_min_f64 returns the non-NaN operand).
-  __device__ __forceinline__ double operator()(double a, double b) const {
-    const double mx = __builtin_fmax(a, b);
+  // exactly the reference's truncation.
+  __device__ __forceinline__ Prep prep(double a, double b) const {
+    Prep p;
+    p.mx = vmax(a, b);
     const double d = a - b;
-    const double s = __builtin_fmin(__builtin_fabs(d) * (HX_FAST_INTERVALS / 10.0), (double)HX_FAST_INTERVALS);
-    const int k = (int)s;
-    const double t = __builtin_amdgcn_fract(s);
-    const double2* c = reinterpret_cast<const double2*>(lds) + 2 * k;
-    const double2 c01 = c[0], c23 = c[1];
-    const double r = __builtin_fma(__builtin_fma(__builtin_fma(c23.y, t, c23.x), t, c01.y), t, c01.x);
-    return mx + r;
+#if HX_ABLATE == 5
+    p.k = 3; p.t = d * 1e-9; return p;
+#endif
+    const double s = vmin(__builtin_fabs(d) * (HX_FAST_INTERVALS / 10.0), (double)HX_FAST_INTERVALS);
+    p.k = (int)s;
+    p.t = __builtin_amdgcn_fract(s);
+    return p;
   }
+#ifndef HX_ABLATE
+#define HX_ABLATE 0
+#endif
+#if HX_ABLATE == 2
+  __device__ __forceinline__ Piece fetch(const Prep& p) const { return Piece{0.6931 + p.k * 1e-9, -0.0049f, 3e-6f}; }
+#else
+  __device__ __forceinline__ Piece fetch(const Prep& p) const { return lds[p.k]; }
+#endif
+  __device__ __forceinline__ double finish(const Prep& p, const Piece& c) const {
+    return p.mx + __builtin_fma(__builtin_fma((double)c.c2, p.t, (double)c.c1), p.t, c.c0);
+  }
+  __device__ __forceinline__ double operator()(double a, double b) const {
+    const Prep p = prep(a, b);
+    return finish(p, fetch(p));
+  }
+  static __device__ __forceinline__ FastLse make(const double* p) { return FastLse{reinterpret_cast<const FastPiece*>(p)}; }
+};
+
+// The reference's table operator (hx_lse.h), phased the same way; bit-identical to lse().
+struct ExactLse3 {
+  const double* __restrict__ tab;
+  struct Prep { double mx, x; int n; bool in; };
+  struct Piece { double f0, f1; };
+  __device__ __forceinline__ Prep prep(double a, double b) const {
+    Prep p;
+    p.mx = vmax(a, b);
+    p.x = p.mx - vmin(a, b);                 // NaN for (-inf,-inf): "no lookup"
+    p.in = p.x < 10.0;
+    p.n = p.in ? (int)div_by_1em4(p.x) : 0;
+    return p;
+  }
+  __device__ __forceinline__ Piece fetch(const Prep& p) const { return Piece{tab[p.n], tab[p.n + 1]}; }
+  __device__ __forceinline__ double finish(const Prep& p, const Piece& c) const {
+    const double dx = p.x - ((double)p.n * 1e-4);
+    const double df = c.f1 - c.f0;
+    const double ret = c.f0 + df * div_by_1em4(dx);
+    return p.mx + (p.in ? ret : 0.0);
+  }
+  __device__ __forceinline__ double operator()(double a, double b) const {
+    const Prep p = prep(a, b);
+    return finish(p, fetch(p));
+  }
+  static __device__ __forceinline__ ExactLse3 make(const double* p) { return ExactLse3{p}; }
 };
 
 struct C5 { double imm, imd, idm, imi, iiw; };
@@ -58,6 +130,18 @@ __device__ __forceinline__ double wave_shr1(double v) {
   lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
   hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
+}
+
+// dst lane l >= 1 receives src of lane l-1; lane 0 keeps `old` (DPP leaves lanes without a
+// source untouched when bound_ctrl is off)
+__device__ __forceinline__ double wave_shr1_keep0(double old, double v) {
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x138, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ C5 wave_shr1_keep0(const C5& o, const C5& c) {
+  return C5{wave_shr1_keep0(o.imm, c.imm), wave_shr1_keep0(o.imd, c.imd), wave_shr1_keep0(o.idm, c.idm),
+            wave_shr1_keep0(o.imi, c.imi), wave_shr1_keep0(o.iiw, c.iiw)};
 }
 
 __device__ __forceinline__ C5 wave_shr1(const C5& c) {
@@ -158,28 +242,49 @@ struct XLeaf {
 };
 
 template <class LSE>
-__device__ __forceinline__ C5 leaf_cell(const double (*T)[6], const LSE& L, const XLeaf& X, const double4& Y,
+__device__ __forceinline__ C5 leaf_cell(const double (*T)[6], const LSE& L, const XLeaf& X, const d4v& Y,
                                         double e, double pj, const C5& up, const C5& left, const C5& diag) {
-  double a_imd = L(up.imm + T[0][1], up.imd + T[1][1]);
-  double a_iiw = L(up.imm + T[0][4], up.imi + T[3][4]);
-  double a_idm = L(left.imm + T[0][2], left.imd + T[1][2]);
-  const double a_imi = L(left.imm + T[0][3], left.imi + T[3][3]);
-  double a_imm = L(diag.imm + T[0][0], diag.imd + T[1][0]);
-  a_imd = L(a_imd, up.idm + T[2][1]);
-  a_iiw = L(a_iiw, up.iiw + T[4][4]);
-  a_idm = L(a_idm, left.idm + T[2][2]);
-  a_imm = L(a_imm, diag.idm + T[2][0]);
-  a_imd = L(a_imd, up.imi + T[3][1]);
-  a_idm = L(a_idm, left.iiw + T[4][2]);
-  a_imm = L(a_imm, diag.imi + T[3][0]);
+  // the five left-nested n-ary sums of reference src/forward.cpp:103-115,139-150,171-180,
+  // evaluated level by level: 5 + 4 + 3 + 1 look-ups, each level's fetches issued together
+  typename LSE::Prep p0 = L.prep(up.imm + T[0][1], up.imd + T[1][1]);
+  typename LSE::Prep p1 = L.prep(up.imm + T[0][4], up.imi + T[3][4]);
+  typename LSE::Prep p2 = L.prep(left.imm + T[0][2], left.imd + T[1][2]);
+  typename LSE::Prep p3 = L.prep(left.imm + T[0][3], left.imi + T[3][3]);
+  typename LSE::Prep p4 = L.prep(diag.imm + T[0][0], diag.imd + T[1][0]);
+  typename LSE::Piece c0 = L.fetch(p0), c1 = L.fetch(p1), c2 = L.fetch(p2), c3 = L.fetch(p3), c4 = L.fetch(p4);
+  double a_imd = L.finish(p0, c0);
+  double a_iiw = L.finish(p1, c1);
+  double a_idm = L.finish(p2, c2);
+  const double a_imi = L.finish(p3, c3);
+  double a_imm = L.finish(p4, c4);
+
+  p0 = L.prep(a_imd, up.idm + T[2][1]);
+  p1 = L.prep(a_iiw, up.iiw + T[4][4]);
+  p2 = L.prep(a_idm, left.idm + T[2][2]);
+  p4 = L.prep(a_imm, diag.idm + T[2][0]);
+  c0 = L.fetch(p0); c1 = L.fetch(p1); c2 = L.fetch(p2); c4 = L.fetch(p4);
+  a_imd = L.finish(p0, c0);
+  a_iiw = L.finish(p1, c1);
+  a_idm = L.finish(p2, c2);
+  a_imm = L.finish(p4, c4);
+
+  p0 = L.prep(a_imd, up.imi + T[3][1]);
+  p2 = L.prep(a_idm, left.iiw + T[4][2]);
+  p4 = L.prep(a_imm, diag.imi + T[3][0]);
+  c0 = L.fetch(p0); c2 = L.fetch(p2); c4 = L.fetch(p4);
+  a_imd = L.finish(p0, c0);
+  a_idm = L.finish(p2, c2);
+  a_imm = L.finish(p4, c4);
+
   a_imm = L(a_imm, diag.iiw + T[4][0]);
-  const double p1 = Y.w + pj;      // y state ready (or y empty), and the cell exists
-  const double p2 = X.pen + pj;    // x state ready (or x empty), and the cell exists
+
+  const double q1 = Y.w + pj;      // y state ready (or y empty), and the cell exists
+  const double q2 = X.pen + pj;    // x state ready (or x empty), and the cell exists
   C5 r;
-  r.imd = ((a_imd + X.lp) + X.rootsub) + p1;
-  r.iiw = ((a_iiw + X.lp) + X.ins) + p1;
-  r.idm = ((a_idm + Y.x) + Y.y) + p2;
-  r.imi = ((a_imi + Y.x) + Y.z) + p2;
+  r.imd = ((a_imd + X.lp) + X.rootsub) + q1;
+  r.iiw = ((a_iiw + X.lp) + X.ins) + q1;
+  r.idm = ((a_idm + Y.x) + Y.y) + q2;
+  r.imi = ((a_imi + Y.x) + Y.z) + q2;
   r.imm = ((a_imm + X.lp + Y.x) + e) + pj;
   return r;
 }
@@ -190,30 +295,35 @@ __device__ __forceinline__ C5 leaf_cell(const double (*T)[6], const LSE& L, cons
 // strip's last row, which the wave above has already written to the matrix: the consumer
 // block-loads 64 columns of it at a time (L1-bypassing loads) once the producer's
 // progress counter (LDS, monotonic) says those columns are complete and drained.
+#define HX_PUBLISH_LAG 16
+
 template <int RPT, int W, class LSE, bool FAST, bool LEAF, int MINW = 1>
 __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __restrict__ jobs,
                                                                 const double* __restrict__ exact_tab,
                                                                 const double* __restrict__ fast_tab) {
   constexpr int THREADS = W * 64;
   constexpr int SR = 64 * RPT;                      // rows per strip
-  __shared__ int prog[W];
-  __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 4 : 2];
+  __shared__ volatile int prog[W];
+  __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : 2];
   if (FAST) {
-    for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 4; k += THREADS) ftab[k] = fast_tab[k];
+    for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 2; k += THREADS) ftab[k] = fast_tab[k];
   }
   if (threadIdx.x < W) prog[threadIdx.x] = 0;
   __syncthreads();
-  LSE L{FAST ? (const double*)ftab : exact_tab};
+  const LSE L = LSE::make(FAST ? (const double*)ftab : exact_tab);
   const ExactLse LX{exact_tab};
 
   const DevJob& J = jobs[blockIdx.x];
   const int R = J.n_rows, Cc = J.n_cols;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t plane = J.plane, ss = J.strip_stride;
-  double* __restrict__ M = J.fwd;
+  HX_GLOBAL double* __restrict__ M = as_global(J.fwd);
+  const HX_GLOBAL d4v* ypack = (const HX_GLOBAL d4v*)as_global(J.y.pack);
+  const HX_GLOBAL d4v* xpack = (const HX_GLOBAL d4v*)as_global(J.x.pack);
+  const HX_GLOBAL int32_t* yecls = as_global(J.y.ecls);
+  const HX_GLOBAL double* epad = as_global(J.emis_pad);
   const int n_strips = (R + SR - 1) / SR;
   const int prev_wave = (wave + W - 1) % W;
-  volatile int* vprog = prog;
 
   for (int s = wave; s < n_strips; s += W) {
     const int row0 = s * SR;
@@ -226,7 +336,7 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
       X[k].valid = i < R;
       const int ic = X[k].valid ? i : 0;
       if (LEAF) {
-        const double4 p = reinterpret_cast<const double4*>(J.x.pack)[ic];
+        const d4v p = xpack[ic];
         XL[k].lp = p.x; XL[k].rootsub = p.y; XL[k].ins = p.z; XL[k].pen = p.w;
         XL[k].eoff = (unsigned)J.x.ecls[ic] * (unsigned)(J.y.n_cls + 1);
         XL[k].valid = X[k].valid;
@@ -247,29 +357,31 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
     const bool has_above = s > 0;
     const int above_base = ((s - 1) / W) * Cc;     // columns the producer wave published in earlier strips
     const int my_base = (s / W) * Cc;
-    // strip-skewed store base: slot = strip64 * ss + ((j + l) << 6) + l, the lane's rows are contiguous
+    // strip-skewed store base (hx_device.h cell_slot): a lane's rows are adjacent pairs
     const int strip64 = i0 >> 6;
-    const int64_t store_base = (int64_t)strip64 * ss + (i0 & 63);
+    const int64_t store_base2 = (int64_t)strip64 * ss + ((i0 & 63) << 1);
     const int t_off = row0 - (strip64 << 6) + 0;   // t64 = j + (i & 63) = step + t_off  (see below)
     const bool store_rows = i0 < ((R + 63) & ~63);
 
     const int nsteps = Cc + SR - 1;
-    for (int t = 0; t < nsteps; ++t) {
+    // one anti-diagonal step of the strip; the lane's RPT new cells are returned in out[]
+    auto step = [&](const int t, C5 (&out)[RPT], const d4v (&Yp)[RPT], const double (&ep)[RPT]) {
       if (has_above) {
         if ((t & 63) == 0 && t < Cc) {
           // wait until the strip above has finished (and drained) columns t .. t+63
           const int hi = (t + 64 < Cc) ? t + 64 : Cc;
           const int need = above_base + hi;
-          while (vprog[prev_wave] < need) __builtin_amdgcn_s_sleep(1);
+          while (prog[prev_wave] < need) __builtin_amdgcn_s_sleep(1);
           const int jj = t + lane;
           bnd = c5_neg_inf();
           if (jj < Cc) {
             const int64_t sl = cell_slot(ss, row0 - 1, jj);
-            bnd.imm = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bnd.imd = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bnd.idm = __hip_atomic_load(M + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bnd.imi = __hip_atomic_load(M + 3 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bnd.iiw = __hip_atomic_load(M + 4 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double* Mg = J.fwd;
+            bnd.imm = __hip_atomic_load(Mg + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bnd.imd = __hip_atomic_load(Mg + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bnd.idm = __hip_atomic_load(Mg + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bnd.imi = __hip_atomic_load(Mg + 3 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bnd.iiw = __hip_atomic_load(Mg + 4 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
         const int sel = t & 63;
@@ -281,7 +393,6 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
       // rows in descending order: row k reads row k-1's old values, so each row's window can
       // be rotated as soon as its new cell is known
       C5 last = c5_neg_inf();
-      C5 out[RPT];
 #pragma unroll
       for (int k = RPT - 1; k >= 0; --k) {
         const int i = i0 + k;
@@ -300,9 +411,7 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
             ok = ok && ((ef & F_EDGE) || dd <= J.max_dist);
           }
           const double pj = ok ? 0.0 : HX_NEG_INF;
-          const double4 Y = reinterpret_cast<const double4*>(J.y.pack)[(unsigned)jc];
-          const double e = J.emis_pad[XL[k].eoff + (unsigned)J.y.ecls[(unsigned)jc]];
-          nw = leaf_cell(J.T, L, XL[k], Y, e, pj, up, v1[k], dg);
+          nw = leaf_cell(J.T, L, XL[k], Yp[k], ep[k], pj, up, v1[k], dg);
           if (i == 0 && j == 0) nw.imm = 0.0;
         } else {
           nw = chain_cell(J, L, X[k], X[k].valid ? i : 0, jc, valid, up, v1[k], dg);
@@ -312,34 +421,79 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
         v1[k] = nw;
         out[k] = nw;
       }
-      // store RPT consecutive doubles per plane; t64 = j + (i & 63) is the same for all rows
-      // of the lane: j + (i & 63) = t - (i - row0) + (i & 63) = t + row0 - 64 * strip64
-      {
-        const int t64 = t + t_off;
-#if HX_ABLATE == 3 || HX_ABLATE == 4
-        if (t64 == 12345678) {
-#else
-        if (t64 >= 0 && t64 < Cc + 63 && store_rows) {
-#endif
-          const int64_t sl = store_base + ((int64_t)t64 << 6);
+      u2 = u1;
+      u1 = wave_shr1_keep0(u1, last);   // lanes >= 1: lane-1's last row; lane 0 keeps its value
+    };
+
+    // y-side constants and emission terms of step t, fetched ahead of use: vector-memory
+    // operations retire in issue order, so a load issued after the previous steps' stores
+    // would wait for those stores to reach memory; issued before them it does not.
+    auto prefetch = [&](const int t, d4v (&Yp)[RPT], double (&ep)[RPT]) {
+      if (!LEAF) return;
 #pragma unroll
-          for (int k = 0; k < RPT; ++k) {
-            M[sl + k] = out[k].imm;
-            M[plane + sl + k] = out[k].imd;
-            M[2 * plane + sl + k] = out[k].idm;
-            M[3 * plane + sl + k] = out[k].imi;
-            M[4 * plane + sl + k] = out[k].iiw;
-          }
+      for (int k = 0; k < RPT; ++k) {
+        const int j = t - (lane * RPT + k);
+        const int jc = j < 0 ? 0 : (j >= Cc ? Cc - 1 : j);
+        Yp[k] = ypack[(unsigned)jc];
+        ep[k] = epad[XL[k].eoff + (unsigned)yecls[(unsigned)jc]];
+      }
+    };
+    d4v Ya[RPT], Yb[RPT];
+    double ea[RPT], eb[RPT];
+    prefetch(0, Ya, ea);
+    prefetch(1, Yb, eb);
+
+    // Two steps per iteration: in the strip-skewed layout the two cells a row produces on
+    // consecutive anti-diagonals are adjacent, so a lane stores RPT*16 contiguous bytes per
+    // state plane every second step (a wave: RPT KiB, fully coalesced).
+    for (int t = 0; t < nsteps; t += 2) {
+      C5 oa[RPT], ob[RPT];
+      step(t, oa, Ya, ea);
+      if (t + 1 < nsteps) {
+        step(t + 1, ob, Yb, eb);
+      } else {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) ob[k] = c5_neg_inf();
+      }
+      prefetch(t + 2, Ya, ea);                     // before this pair's stores (see above)
+      prefetch(t + 3, Yb, eb);
+      const int t64 = t + t_off;                   // even: j + (i & 63) of the first of the two steps
+#if HX_ABLATE == 3
+      if (t64 == 123456789) {
+#else
+      if (t64 >= 0 && t64 < Cc + 63 && store_rows) {
+#endif
+        typedef double d2v __attribute__((ext_vector_type(2)));
+#if HX_ABLATE == 8
+        const int64_t sl = (store_base2 + ((int64_t)(t64 >> 1) << 7)) & 0xFFFF;   // stay in L2
+#else
+        const int64_t sl = store_base2 + ((int64_t)(t64 >> 1) << 7);
+#endif
+        HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
+        const int64_t plane2 = plane >> 1;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          M2[k] = d2v{oa[k].imm, ob[k].imm};
+          M2[plane2 + k] = d2v{oa[k].imd, ob[k].imd};
+          M2[2 * plane2 + k] = d2v{oa[k].idm, ob[k].idm};
+          M2[3 * plane2 + k] = d2v{oa[k].imi, ob[k].imi};
+          M2[4 * plane2 + k] = d2v{oa[k].iiw, ob[k].iiw};
         }
       }
-      u2 = u1;
-      const C5 sh = wave_shr1(last);
-      if (lane != 0) u1 = sh;
-      // publish progress: the strip's last row has finished column t - (SR - 1)
-      const int done = t - (SR - 1) + 1;
-      if (done > 0 && ((done & 63) == 0 || done == Cc)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's stores have reached L2
-        if (lane == 0) vprog[wave] = my_base + done;
+      // publish progress.  The strip's last row has finished column (t + 1) - (SR - 1); a
+      // column counts as published once its stores have left the wave.  Vector-memory
+      // operations retire in issue order and every step issues >= 4 of them, so everything
+      // stored HX_PUBLISH_LAG steps ago is older than the wave's 40 youngest operations.
+      const int fin = (t + 2 < nsteps ? t + 2 : nsteps) - (SR - 1);
+      if (fin >= Cc) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) prog[wave] = my_base + Cc;
+      } else {
+        const int done = fin - HX_PUBLISH_LAG;
+        if (done > 0 && ((done >> 6) != ((done - 2) >> 6))) {
+          asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+          if (lane == 0) prog[wave] = my_base + done;
+        }
       }
     }
   }
@@ -356,9 +510,9 @@ static void launch_variant(const DevJob* d_jobs, int n_jobs, const double* tab, 
   else if (fast)
     hipLaunchKernelGGL((k_forward_chain<RPT, W, FastLse, true, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
   else if (leaf)
-    hipLaunchKernelGGL((k_forward_chain<RPT, W, ExactLse, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+    hipLaunchKernelGGL((k_forward_chain<RPT, W, ExactLse3, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
   else
-    hipLaunchKernelGGL((k_forward_chain<RPT, W, ExactLse, false, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+    hipLaunchKernelGGL((k_forward_chain<RPT, W, ExactLse3, false, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
 }
 
 void launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,

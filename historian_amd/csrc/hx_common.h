@@ -10,6 +10,7 @@ namespace hx {
 struct ExactLse {
   const double* __restrict__ tab;
   __device__ __forceinline__ double operator()(double a, double b) const { return lse(a, b, tab); }
+  static __device__ __forceinline__ ExactLse make(const double* p) { return ExactLse{p}; }
 };
 
 // computeLogProbAbsorb (reference src/forward.h:112-124) from two leftMultiplied rows

@@ -71,11 +71,19 @@ struct DevJob {
 };
 
 #define HX_STRIP 64
-#define HX_FAST_INTERVALS 1024   // cubic pieces of the fast log-sum-exp table over [0,10)
+#define HX_FAST_INTERVALS 4096   // quadratic pieces of the fast log-sum-exp table over [0,10)
 
+// Strip-skewed layout.  Rows are grouped in strips of 64; inside a strip, cell (i,j) with
+// l = i % 64 and skewed column t = j + l lives at  (t / 2) * 128 + l * 2 + t % 2.
+// A wavefront stepping along anti-diagonals (lane <-> row) therefore writes, every two
+// steps, 16 contiguous bytes per lane = 1 KiB contiguous per wave and state plane.
 __host__ __device__ inline int64_t cell_slot(int64_t strip_stride, int i, int j) {
   const int l = i & (HX_STRIP - 1);
-  return (int64_t)(i >> 6) * strip_stride + ((int64_t)(j + l) << 6) + l;
+  const int t = j + l;
+  return (int64_t)(i >> 6) * strip_stride + ((int64_t)(t >> 1) << 7) + (l << 1) + (t & 1);
+}
+__host__ __device__ inline int64_t strip_stride_for(int n_cols) {
+  return ((int64_t)((n_cols + HX_STRIP - 1) >> 1) + 1) * (2 * HX_STRIP);
 }
 
 }  // namespace hx

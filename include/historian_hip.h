@@ -105,10 +105,12 @@ typedef struct hx_pair_job {
 
 /* Where cell (i,j), 0 <= i < n_rows = Nx-1, 0 <= j < n_cols = Ny-1, lives in the
  * buffers returned by hx_batch_read_matrix:
- *     slot(i,j) = (i / strip_rows) * strip_stride + (j + i % strip_rows) * strip_rows + i % strip_rows
+ *     l = i % strip_rows,  t = j + l
+ *     slot(i,j) = (i / strip_rows) * strip_stride + (t / 2) * (2 * strip_rows) + l * 2 + t % 2
  *     value(i,j,state) = buf[state * plane_stride + slot(i,j)]
- * (64-row strips, anti-diagonal-major inside a strip: one wavefront step writes 64
- * consecutive doubles per state plane).  Cells outside the envelope hold -inf, as
+ * (64-row strips, anti-diagonal-major inside a strip, two anti-diagonals interleaved: a
+ * wavefront stepping along anti-diagonals writes 16 contiguous bytes per lane and state
+ * plane every second step).  Cells outside the envelope hold -inf, as
  * DPMatrix::cell() returns for them (reference src/forward.h:79-84). */
 typedef struct hx_layout {
   int32_t n_rows, n_cols;

@@ -48,8 +48,8 @@ def test_struct_sizes_match_the_header():
 
 
 def test_slot_formula_is_a_bijection():
-    l = capi.HxLayout(n_rows=130, n_cols=77, strip_rows=64, n_strips=3, strip_stride=(77 + 63) * 64,
-                      plane_stride=3 * (77 + 63) * 64)
+    ss = (((77 + 63) >> 1) + 1) * 128
+    l = capi.HxLayout(n_rows=130, n_cols=77, strip_rows=64, n_strips=3, strip_stride=ss, plane_stride=3 * ss)
     ii, jj = np.meshgrid(np.arange(130), np.arange(77), indexing="ij")
     s = capi.slot_index(l, ii, jj).ravel()
     assert len(np.unique(s)) == s.size and s.min() >= 0 and s.max() < l.plane_stride
