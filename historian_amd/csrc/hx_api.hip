@@ -92,7 +92,7 @@ struct ProfOff {
   size_t flags, in_off, in_src, in_lp, ao_off, ao_dst, ao_lp, no_off, no_dst, no_lp;
   size_t lp_absorb, sub, ins, rootsub, env, cls, cls_rep, pack, ecls;
   bool has_env;
-  int n, empty, n_cls, chain, interior_emit;
+  int n, empty, n_cls, chain, interior_emit, lp_zero;
 };
 
 int check_csr(const int32_t* off, const int32_t* idx, int N, int T, const char* what) {
@@ -225,6 +225,9 @@ int flatten_profile(const hx_profile* p, int CA, bool need_env, bool is_y, Arena
     o.ecls = ar.put(ecls.data(), sizeof(int32_t) * N);
   }
   o.pack = ar.reserve(sizeof(double) * 4 * (size_t)N);
+  o.lp_zero = 1;
+  for (int t = 0; t < T; ++t)
+    if (p->trans_lp[t] != 0.0) o.lp_zero = 0;
   o.interior_emit = 1;
   for (int i = 1; i < N - 1; ++i)
     if (p->is_null[i]) o.interior_emit = 0;
@@ -275,7 +278,7 @@ struct hx_batch {
   double* d_fwd = nullptr;
   double* d_bwd = nullptr;
   int max_states = 0, max_ca = 0, max_cls_pairs = 0, max_rows = 0;
-  bool all_chain = true, all_leaf = true;
+  bool all_chain = true, all_leaf = true, all_ylds = true;
   int64_t total_cells = 0;
   bool forward_done = false, backward_done = false;
   hipStream_t last_stream = nullptr;
@@ -389,6 +392,9 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     if (J.n_rows > b->max_rows) b->max_rows = J.n_rows;
     b->all_chain = b->all_chain && J.chain;
     b->all_leaf = b->all_leaf && J.leaf_like;
+    // y side small enough for LDS (hx_chain.hip HX_YL_*) and all its transitions have lpTrans 0
+    b->all_ylds = b->all_ylds && J.leaf_like && jo.y.lp_zero && jo.y.n <= 6144 && jo.y.n_cls + 1 <= 64 &&
+                  (int64_t)(jo.x.n_cls + 1) * (jo.y.n_cls + 1) <= 1024;
   }
   if (rc != HX_OK) { delete b; return rc; }
 
@@ -455,7 +461,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   HIP_TRY(hipEventRecord(b->ev[0][0], st));
   if (b->all_chain && !(b->flags & HX_FORCE_GENERIC))
     launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,
-                         b->all_leaf, st);
+                         b->all_leaf ? (b->all_ylds ? 2 : 1) : 0, st);
   else
     launch_forward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
   HIP_TRY(hipEventRecord(b->ev[0][1], st));

@@ -33,6 +33,7 @@ namespace hx {
 // global-address-space views of pointers that were loaded from the job table (the compiler
 // would otherwise have to use flat_* instructions, which tie up both memory counters)
 #define HX_GLOBAL __attribute__((address_space(1)))
+#define HX_LDS __attribute__((address_space(3)))
 template <class T> __device__ __forceinline__ HX_GLOBAL T* as_global(T* p) { return (HX_GLOBAL T*)p; }
 template <class T> __device__ __forceinline__ const HX_GLOBAL T* as_global(const T* p) { return (const HX_GLOBAL T*)p; }
 
@@ -78,7 +79,7 @@ struct FastLse {
 #ifndef HX_ABLATE
 #define HX_ABLATE 0
 #endif
-#if HX_ABLATE == 2
+#if HX_ABLATE == 2 || HX_ABLATE == 9
   __device__ __forceinline__ Piece fetch(const Prep& p) const { return Piece{0.6931 + p.k * 1e-9, -0.0049f, 3e-6f}; }
 #else
   __device__ __forceinline__ Piece fetch(const Prep& p) const { return lds[p.k]; }
@@ -296,8 +297,11 @@ __device__ __forceinline__ C5 leaf_cell(const double (*T)[6], const LSE& L, cons
 // block-loads 64 columns of it at a time (L1-bypassing loads) once the producer's
 // progress counter (LDS, monotonic) says those columns are complete and drained.
 #define HX_PUBLISH_LAG 16
+#define HX_YL_MAX_COLS 6144
+#define HX_YL_MAX_CLS 64
+#define HX_YL_MAX_EMIS 1024
 
-template <int RPT, int W, class LSE, bool FAST, bool LEAF, int MINW = 1>
+template <int RPT, int W, class LSE, bool FAST, bool LEAF, bool YL, int MINW = 1>
 __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __restrict__ jobs,
                                                                 const double* __restrict__ exact_tab,
                                                                 const double* __restrict__ fast_tab) {
@@ -309,11 +313,30 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
     for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 2; k += THREADS) ftab[k] = fast_tab[k];
   }
   if (threadIdx.x < W) prog[threadIdx.x] = 0;
-  __syncthreads();
   const LSE L = LSE::make(FAST ? (const double*)ftab : exact_tab);
   const ExactLse LX{exact_tab};
 
   const DevJob& J = jobs[blockIdx.x];
+  // YL: the whole y side lives in LDS (leaf-like y profile whose transitions all have
+  // lpTrans 0): per column one word {emission class, not-ready bit}, per class
+  // {rootsuby, insy}, and the padded class-pair emission table.  The step loop then
+  // issues no vector-memory loads at all, only its write-once stores.
+  __shared__ unsigned ycol[YL ? HX_YL_MAX_COLS : 1];
+  __shared__ __attribute__((aligned(16))) double yclass[YL ? 2 * HX_YL_MAX_CLS : 2];
+  __shared__ double elds[YL ? HX_YL_MAX_EMIS : 1];
+  if (YL) {
+    const int Ky1 = J.y.n_cls + 1, Kx1 = J.x.n_cls + 1;
+    for (int j = threadIdx.x; j < J.y.n; j += THREADS)
+      ycol[j] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0x10000u : 0u);
+    for (int c = threadIdx.x; c < Ky1; c += THREADS) {
+      const bool real = c < J.y.n_cls;
+      const int rep = real ? J.y.cls_rep[c] : 0;
+      yclass[2 * c] = real ? J.y.pack[4 * (size_t)rep + 1] : HX_NEG_INF;
+      yclass[2 * c + 1] = real ? J.y.pack[4 * (size_t)rep + 2] : HX_NEG_INF;
+    }
+    for (int e = threadIdx.x; e < Kx1 * Ky1; e += THREADS) elds[e] = J.emis_pad[e];
+  }
+  __syncthreads();
   const int R = J.n_rows, Cc = J.n_cols;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t plane = J.plane, ss = J.strip_stride;
@@ -322,6 +345,9 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
   const HX_GLOBAL d4v* xpack = (const HX_GLOBAL d4v*)as_global(J.x.pack);
   const HX_GLOBAL int32_t* yecls = as_global(J.y.ecls);
   const HX_GLOBAL double* epad = as_global(J.emis_pad);
+  const HX_GLOBAL uint8_t* yflags = as_global(J.y.flags);
+  const HX_GLOBAL int32_t* yenv = as_global(J.y.env);
+  volatile HX_LDS int* progp = (volatile HX_LDS int*)prog;   // keep the LDS address space through the lambdas
   const int n_strips = (R + SR - 1) / SR;
   const int prev_wave = (wave + W - 1) % W;
 
@@ -371,18 +397,21 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
           // wait until the strip above has finished (and drained) columns t .. t+63
           const int hi = (t + 64 < Cc) ? t + 64 : Cc;
           const int need = above_base + hi;
-          while (prog[prev_wave] < need) __builtin_amdgcn_s_sleep(1);
+          while (progp[prev_wave] < need) __builtin_amdgcn_s_sleep(1);
           const int jj = t + lane;
           bnd = c5_neg_inf();
           if (jj < Cc) {
             const int64_t sl = cell_slot(ss, row0 - 1, jj);
-            double* Mg = J.fwd;
-            bnd.imm = __hip_atomic_load(Mg + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bnd.imd = __hip_atomic_load(Mg + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bnd.idm = __hip_atomic_load(Mg + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bnd.imi = __hip_atomic_load(Mg + 3 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bnd.iiw = __hip_atomic_load(Mg + 4 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // agent-scope relaxed loads (global_load ... sc1): served by L2, never by a stale L1 line
+            bnd.imm = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bnd.imd = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bnd.idm = __hip_atomic_load(M + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bnd.imi = __hip_atomic_load(M + 3 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bnd.iiw = __hip_atomic_load(M + 4 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+          // consume the loads here, so that the wait for them sits in this once-per-64-steps
+          // block and not at the merge point every step passes
+          asm volatile("" : "+v"(bnd.imm), "+v"(bnd.imd), "+v"(bnd.idm), "+v"(bnd.imi), "+v"(bnd.iiw));
         }
         const int sel = t & 63;
         C5 a = C5{read_lane(bnd.imm, sel), read_lane(bnd.imd, sel), read_lane(bnd.idm, sel),
@@ -405,8 +434,8 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
         if (LEAF) {
           bool ok = valid;
           if (J.max_dist >= 0) {
-            const uint8_t ef = X[k].flags | J.y.flags[jc];
-            int dd = X[k].env - J.y.env[jc];
+            const uint8_t ef = X[k].flags | yflags[jc];
+            int dd = X[k].env - yenv[jc];
             dd = dd < 0 ? -dd : dd;
             ok = ok && ((ef & F_EDGE) || dd <= J.max_dist);
           }
@@ -434,8 +463,21 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
       for (int k = 0; k < RPT; ++k) {
         const int j = t - (lane * RPT + k);
         const int jc = j < 0 ? 0 : (j >= Cc ? Cc - 1 : j);
+        if (YL) {
+          const unsigned w = ycol[jc];
+          const unsigned c = w & 0xFFFFu;
+          const double2 rc = reinterpret_cast<const double2*>(yclass)[c];
+          Yp[k] = d4v{0.0, rc.x, rc.y, __hiloint2double((w & 0x10000u) ? (int)0xFFF00000 : 0, 0)};
+          ep[k] = elds[XL[k].eoff + c];
+          continue;
+        }
+#if HX_ABLATE == 9 || HX_ABLATE == 10
+        Yp[k] = d4v{0.0, -1.5 + jc * 1e-9, -2.5, 0.0};
+        ep[k] = -3.0;
+#else
         Yp[k] = ypack[(unsigned)jc];
         ep[k] = epad[XL[k].eoff + (unsigned)yecls[(unsigned)jc]];
+#endif
       }
     };
     d4v Ya[RPT], Yb[RPT];
@@ -448,17 +490,21 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
     // state plane every second step (a wave: RPT KiB, fully coalesced).
     for (int t = 0; t < nsteps; t += 2) {
       C5 oa[RPT], ob[RPT];
+      if (YL) prefetch(t, Ya, ea);
       step(t, oa, Ya, ea);
       if (t + 1 < nsteps) {
+        if (YL) prefetch(t + 1, Yb, eb);
         step(t + 1, ob, Yb, eb);
       } else {
 #pragma unroll
         for (int k = 0; k < RPT; ++k) ob[k] = c5_neg_inf();
       }
-      prefetch(t + 2, Ya, ea);                     // before this pair's stores (see above)
-      prefetch(t + 3, Yb, eb);
+      if (!YL) {
+        prefetch(t + 2, Ya, ea);                   // before this pair's stores (see above)
+        prefetch(t + 3, Yb, eb);
+      }
       const int t64 = t + t_off;                   // even: j + (i & 63) of the first of the two steps
-#if HX_ABLATE == 3
+#if HX_ABLATE == 3 || HX_ABLATE == 9 || HX_ABLATE == 10
       if (t64 == 123456789) {
 #else
       if (t64 >= 0 && t64 < Cc + 63 && store_rows) {
@@ -487,12 +533,12 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
       const int fin = (t + 2 < nsteps ? t + 2 : nsteps) - (SR - 1);
       if (fin >= Cc) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) prog[wave] = my_base + Cc;
+        if (lane == 0) progp[wave] = my_base + Cc;
       } else {
         const int done = fin - HX_PUBLISH_LAG;
         if (done > 0 && ((done >> 6) != ((done - 2) >> 6))) {
           asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-          if (lane == 0) prog[wave] = my_base + done;
+          if (lane == 0) progp[wave] = my_base + done;
         }
       }
     }
@@ -503,20 +549,25 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
 
 template <int RPT, int W, int MINW = 1>
 static void launch_variant(const DevJob* d_jobs, int n_jobs, const double* tab, const double* fast_tab, bool fast,
-                           bool leaf, hipStream_t st) {
+                           int leaf, hipStream_t st) {
   const dim3 g(n_jobs), b(W * 64);
-  if (fast && leaf)
-    hipLaunchKernelGGL((k_forward_chain<RPT, W, FastLse, true, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+  if (fast && leaf == 2)
+    hipLaunchKernelGGL((k_forward_chain<RPT, W, FastLse, true, true, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+  else if (fast && leaf == 1)
+    hipLaunchKernelGGL((k_forward_chain<RPT, W, FastLse, true, true, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
   else if (fast)
-    hipLaunchKernelGGL((k_forward_chain<RPT, W, FastLse, true, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
-  else if (leaf)
-    hipLaunchKernelGGL((k_forward_chain<RPT, W, ExactLse3, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+    hipLaunchKernelGGL((k_forward_chain<RPT, W, FastLse, true, false, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+  else if (leaf == 2)
+    hipLaunchKernelGGL((k_forward_chain<RPT, W, ExactLse3, false, true, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+  else if (leaf == 1)
+    hipLaunchKernelGGL((k_forward_chain<RPT, W, ExactLse3, false, true, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
   else
-    hipLaunchKernelGGL((k_forward_chain<RPT, W, ExactLse3, false, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+    hipLaunchKernelGGL((k_forward_chain<RPT, W, ExactLse3, false, false, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
 }
 
+// leaf: 0 = general chain profiles, 1 = leaf-like, 2 = leaf-like with the y side in LDS
 void launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                          bool fast, bool leaf, hipStream_t st) {
+                          bool fast, int leaf, hipStream_t st) {
   const char* v = getenv("HX_CHAIN_VARIANT");   // tuning hook
   const int vi = v ? atoi(v) : 0;
   if (max_rows <= 64)
