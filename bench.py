@@ -39,10 +39,13 @@ def parse():
     ap.add_argument("--model", default="wag")
     ap.add_argument("--tl", type=float, default=0.2)
     ap.add_argument("--tr", type=float, default=0.3)
-    ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs timed by the CPU baseline (rank 0, N=1)")
+    ap.add_argument("--cpu-pairs", type=int, default=10, help="pairs timed by the CPU baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["exact", "fast"], default="exact", help="log-sum-exp policy of the fill")
-    ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per launch from a PMC run (else null)")
+    ap.add_argument("--mode", choices=["exact", "fast"], default="fast",
+                    help="log-sum-exp policy of the headline fill (the other mode is timed too and reported)")
+    ap.add_argument("--single-mode", action="store_true", help="time only --mode")
+    ap.add_argument("--traffic", type=float, default=None,
+                    help="HBM bytes per launch from a PMC run (default: profiles/traffic.json entry for this workload)")
     return ap.parse_args()
 
 
@@ -107,8 +110,6 @@ def main():
         rng = np.random.default_rng(1000 + rank * args.pairs + k)     # pair seeds 1000+k
         xs, ys = synth_pair(rng, pi, args.length)
         triples.append((hostmodel.leaf_profile(xs, a, c), hostmodel.leaf_profile(ys, a, c), hmm, -1))
-    batch = capi.Batch(triples, capi.HX_LSE_FAST if args.mode == "fast" else capi.HX_LSE_EXACT)
-    cells = batch.total_cells()
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -116,29 +117,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        batch.forward(stream)
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    for _ in range(args.steps):
-        batch.forward(stream)
-        kernel_ms.append(batch.kernel_ms(0))        # HIP events around the fill kernel, on its stream
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    lp_end = batch.lp_end()
-    assert np.all(np.isfinite(lp_end)), "non-finite Forward log-likelihood"
+    def run_mode(mode):
+        """K timed passes of the hot path in one fill mode; returns (seconds, kernel ms list, lp_end, cells)."""
+        batch = capi.Batch(triples, capi.HX_LSE_FAST if mode == "fast" else capi.HX_LSE_EXACT)
+        n_cells = batch.total_cells()
+        for _ in range(args.warmup):
+            batch.forward(stream)
+        barrier()
+        t0 = time.perf_counter()
+        k_ms = []
+        for _ in range(args.steps):
+            batch.forward(stream)
+            k_ms.append(batch.kernel_ms(0))         # HIP events around the fill kernel, on its stream
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        lp = batch.lp_end()
+        batch.close()
+        assert np.all(np.isfinite(lp)), "non-finite Forward log-likelihood"
+        return dt, k_ms, lp, n_cells
+
+    dt, kernel_ms, lp_end, cells = run_mode(args.mode)
+    other = "exact" if args.mode == "fast" else "fast"
+    dt_o, kernel_ms_o, lp_end_o, _ = run_mode(other) if not args.single_mode else (None, None, None, None)
 
     if rank == 0:
         total_cells = cells * world * args.steps
         value = total_cells / dt
         k_ms = float(np.mean(kernel_ms))
+        traffic = args.traffic
+        if traffic is None:
+            try:        # measured once with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes), see DESIGN.md
+                with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                    traffic = json.load(f).get("%s:%d:%d" % (args.mode, args.pairs, args.length))
+            except OSError:
+                traffic = None
         achieved = cells * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "forward-DP cells/s", "value": value, "unit": "cells/s", "n_gpus": world,
@@ -148,14 +166,24 @@ def main():
             "config": {"workload": "batch of independent 2x%d-residue protein leaf-profile pairs, %s, t=%g/%g, "
                                    "full (unbanded) Forward DP, %s log-sum-exp" %
                                    (args.length, args.model.upper(), args.tl, args.tr,
-                                    "exact table (bit-identical cells)" if args.mode == "exact" else "fast LDS-table"),
+                                    "exact table (cells bit-identical to the reference recursion)" if args.mode == "exact"
+                                    else "fast LDS-table (same truncation; lpEnd within 1e-9 rel., tracebacks identical)"),
                        "pairs_per_gpu": args.pairs, "cells_per_gpu_per_step": cells,
                        "parallelism": "pairs farmed across %d rank(s); RCCL broadcast of model constants only" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": args.traffic,
-                         "kernel": "k_forward", "kernel_ms": k_ms, "bytes_per_cell": BYTES_PER_CELL},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "hx::k_forward_chain", "kernel_ms": k_ms, "bytes_per_cell": BYTES_PER_CELL},
+            "fill_mode": args.mode,
             "lp_end_pair0": float(lp_end[0]),
         }
+        if dt_o is not None:
+            k_o = float(np.mean(kernel_ms_o))
+            ach_o = cells * BYTES_PER_CELL / (k_o * 1e-3) / 1e9
+            out["other_mode"] = {"fill_mode": other, "value": cells * world * args.steps / dt_o, "unit": "cells/s",
+                                 "ms_per_step": dt_o / args.steps * 1e3, "kernel_ms": k_o,
+                                 "roofline_frac": ach_o / HBM_PEAK_GBS,
+                                 "lp_end_max_rel_diff_between_modes":
+                                     float(np.max(np.abs(lp_end - lp_end_o) / np.abs(lp_end_o)))}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import c_oracle           # the checker, timed as the CPU baseline ("port")
             c_oracle.load()

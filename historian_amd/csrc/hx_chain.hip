@@ -568,7 +568,7 @@ static void launch_variant(const DevJob* d_jobs, int n_jobs, const double* tab, 
 // leaf: 0 = general chain profiles, 1 = leaf-like, 2 = leaf-like with the y side in LDS
 void launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
                           bool fast, int leaf, hipStream_t st) {
-  const char* v = getenv("HX_CHAIN_VARIANT");   // tuning hook
+  const char* v = getenv("HX_CHAIN_VARIANT");   // tuning hook: "RPT,W" override for long profiles
   const int vi = v ? atoi(v) : 0;
   if (max_rows <= 64)
     launch_variant<1, 1>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
@@ -577,10 +577,9 @@ void launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const 
   else if (max_rows <= 256)
     launch_variant<1, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
   else if (vi == 1) launch_variant<2, 8>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
-  else if (vi == 2) launch_variant<1, 8>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
-  else if (vi == 3) launch_variant<1, 16>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
-  else if (vi == 4) launch_variant<4, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
-  else launch_variant<2, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
+  else if (vi == 2 || (vi == 0 && max_rows <= 512)) launch_variant<1, 8>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
+  else if (vi == 4) launch_variant<2, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
+  else launch_variant<1, 16>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);   // measured fastest on 2x2000
 }
 
 }  // namespace hx

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round profile of the default bench: kernel-trace stats + HBM traffic counters (separate PMC passes,
+# as /opt/skills/guides/MI355X_MICROARCH.md prescribes).  Run on the GPU box; copy summaries to profiles/.
+tag=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/$tag
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/trace -- python bench.py --steps 3 --warmup 1 > gpurun_out/$tag/bench.log 2>&1
+cp $(find gpurun_out/$tag/trace -name "*kernel_stats.csv" | head -1) gpurun_out/$tag/kernel_stats.csv
+grep '^{' gpurun_out/$tag/bench.log > gpurun_out/$tag/bench.json
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/$tag/pmc_$c -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/$tag/pmc_$c.log 2>&1
+done
+python - <<PY
+import csv,glob,collections,json
+res={}
+for c in ("FETCH_SIZE","WRITE_SIZE"):
+    for f in glob.glob("gpurun_out/$tag/pmc_%s/*/*counter_collection.csv"%c):
+        agg=collections.defaultdict(lambda: [0.0,0])
+        for r in csv.DictReader(open(f)):
+            if "k_forward_chain" in r["Kernel_Name"] and r["Counter_Name"]==c:
+                key="fast" if "FastLse" in r["Kernel_Name"] else "exact"
+                agg[key][0]+=float(r["Counter_Value"]); agg[key][1]+=1
+        for k,(v,n) in agg.items(): res[c+":"+k]=v/n
+print(json.dumps(res))
+open("gpurun_out/$tag/pmc_summary.json","w").write(json.dumps(res,indent=1))
+PY
+cat gpurun_out/$tag/kernel_stats.csv; cat gpurun_out/$tag/bench.json
