@@ -80,25 +80,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from historian_amd import capi, hostmodel
+    from historian_amd import capi, farm, hostmodel
 
     # ---- rate-model constant block: built on rank 0, broadcast over RCCL/xGMI ----------------
     model = hostmodel.RateModel.load(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json"))
     a, c = len(model.alphabet), model.components()
-    n_tab = capi.HX_LSE_TABLE_ENTRIES
-    block_len = n_tab + 2 * c * a * a
-    if rank == 0:
-        sub_l, sub_r = model.sub_prob(args.tl), model.sub_prob(args.tr)
-        block = np.concatenate([hostmodel.lse_table(), np.stack(sub_l).ravel(), np.stack(sub_r).ravel()])
-    else:
-        block = np.zeros(block_len)
-    if world > 1:
-        t = torch.from_numpy(block).to(dev)
-        dist.broadcast(t, src=0)
-        block = t.cpu().numpy()
-    table = block[:n_tab]
-    sub_l = list(block[n_tab:n_tab + c * a * a].reshape(c, a, a))
-    sub_r = list(block[n_tab + c * a * a:].reshape(c, a, a))
+    block = farm.constant_block(model, args.tl, args.tr) if rank == 0 else None
+    block = farm.broadcast_block(block, farm.block_len(model), rank, world, dev)
+    table, sub_l, sub_r = farm.split_block(model, block)
 
     capi.init(local_rank, table)
     hmm = hostmodel.make_hmm(model, args.tl, args.tr, sub_l, sub_r)
@@ -107,7 +96,7 @@ def main():
 
     triples = []
     for k in range(args.pairs):
-        rng = np.random.default_rng(1000 + rank * args.pairs + k)     # pair seeds 1000+k
+        rng = np.random.default_rng(farm.pair_seed(rank, args.pairs, k))
         xs, ys = synth_pair(rng, pi, args.length)
         triples.append((hostmodel.leaf_profile(xs, a, c), hostmodel.leaf_profile(ys, a, c), hmm, -1))
     stream = torch.cuda.current_stream().cuda_stream
@@ -133,10 +122,7 @@ def main():
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+        dt = farm.max_over_ranks(dt, world, dev)
         lp = batch.lp_end()
         batch.close()
         assert np.all(np.isfinite(lp)), "non-finite Forward log-likelihood"

@@ -1,0 +1,444 @@
+// Host-side C++ mirror of the reference's interface for the pair-HMM hot path, on top of
+// the C ABI (include/historian_hip.h).  Class, member and function names, argument
+// meaning and error behaviour follow the reference so that its callers
+// (Reconstructor::reconstruct, reference src/recon.cpp:938-1033) and its test mains
+// (t/testforward.cpp, t/testbackward.cpp, t/testnullforward.cpp, t/testseqprofile.cpp,
+// t/testlogsumexp.cpp) compile against it with only the GSL vector/matrix types replaced
+// by std::vector.  The Forward/Backward fills, leftMultiply and the insx/rootsubx vectors
+// are computed on the GPU; traceback, sampling and profile construction are host code over
+// the device-filled matrix, as O(path length) routines are in the reference.
+//
+//   reference file                         here
+//   src/util.h, util.cpp                   Abort / Warn / Fail / Assert / Require / Test
+//   src/logsumexp.h, logsumexp.cpp         log_sum_exp*, LogSumExpLookupTable, logInnerProduct
+//   src/alignpath.h, alignpath.cpp         AlignPath algebra, Alignment, GuideAlignmentEnvelope
+//   src/fastseq.h (subset)                 FastSeq, tokenize, readFastSeqs
+//   src/model.h (subset)                   AlphabetOwner, RateModel, ProbModel, LogProbModel
+//   src/profile.h                          ProfileTransition, ProfileState, Profile
+//   src/pairhmm.h                          PairHMM
+//   src/forward.h                          DPMatrix, ForwardMatrix, BackwardMatrix
+// Out of scope: event/eigen counts -- the CountSubstEvents /
+// CountIndelEvents strategy bits are accepted and ignored, SumProduct* must be NULL.
+#pragma once
+#include <cmath>
+#include <limits>
+#include <list>
+#include <map>
+#include <queue>
+#include <random>
+#include <set>
+#include <string>
+#include <vector>
+#include <iostream>
+
+struct hx_batch;
+
+namespace historian {
+
+using std::list;
+using std::map;
+using std::set;
+using std::string;
+using std::vector;
+
+template <class T> using vguard = std::vector<T>;
+
+// ---- src/util.h:30-37, src/util.cpp:37-54 -------------------------------------------------
+void Abort(const char* error, ...);   // message + terminate (reference: `throw;` with no active exception)
+void Warn(const char* warning, ...);
+void Fail(const char* error, ...);    // message + exit(EXIT_FAILURE)
+#define Test(assertion, ...) ((assertion) ? true : (::historian::Warn(__VA_ARGS__), false))
+#define Assert(assertion, ...) do { if (!(assertion)) ::historian::Abort("Assertion Failed: " __VA_ARGS__); } while (0)
+#define Require(assertion, ...) do { if (!(assertion)) ::historian::Fail(__VA_ARGS__); } while (0)
+
+// ---- src/logsumexp.h ----------------------------------------------------------------------
+#define LOG_SUM_EXP_LOOKUP_MAX 10
+#define LOG_SUM_EXP_LOOKUP_PRECISION .0001
+#define LOG_SUM_EXP_LOOKUP_ENTRIES (((int)(LOG_SUM_EXP_LOOKUP_MAX / LOG_SUM_EXP_LOOKUP_PRECISION)) + 1)
+
+typedef double LogProb;
+
+double log_sum_exp_unary_slow(double x);
+
+struct LogSumExpLookupTable {
+  double* lookup;   // LOG_SUM_EXP_LOOKUP_ENTRIES + 1 entries (the guard entry the reference reads past its end)
+  LogSumExpLookupTable();
+  ~LogSumExpLookupTable();
+};
+extern LogSumExpLookupTable logSumExpLookupTable;
+
+inline double log_sum_exp_unary(double x) {
+  if (x >= LOG_SUM_EXP_LOOKUP_MAX || std::isnan(x) || std::isinf(x)) return 0;
+  if (x < 0) {
+    std::cerr << "Called log_sum_exp_unary(x) for negative x = " << x << std::endl;
+    return -x;
+  }
+  const int n = (int)(x / LOG_SUM_EXP_LOOKUP_PRECISION);
+  const double f0 = logSumExpLookupTable.lookup[n];
+  const double dx = x - (n * LOG_SUM_EXP_LOOKUP_PRECISION);
+  const double f1 = logSumExpLookupTable.lookup[n + 1];
+  const double df = f1 - f0;
+  return f0 + df * (dx / LOG_SUM_EXP_LOOKUP_PRECISION);
+}
+
+inline double log_sum_exp(double a, double b) {
+  double max, diff;
+  if (a == b) { max = a; diff = 0; }
+  else if (a < b) { max = b; diff = b - a; }
+  else { max = a; diff = a - b; }
+  return max + log_sum_exp_unary(diff);
+}
+inline double log_sum_exp(double a, double b, double c) { return log_sum_exp(log_sum_exp(a, b), c); }
+inline double log_sum_exp(double a, double b, double c, double d) { return log_sum_exp(log_sum_exp(log_sum_exp(a, b), c), d); }
+inline double log_sum_exp(double a, double b, double c, double d, double e) {
+  return log_sum_exp(log_sum_exp(log_sum_exp(log_sum_exp(a, b), c), d), e);
+}
+inline void log_accum_exp(double& a, double b) { a = log_sum_exp(a, b); }
+double log_sum_exp_slow(double a, double b);
+double log_sum_exp_slow(double a, double b, double c);
+double log_sum_exp_slow(double a, double b, double c, double d);
+void log_accum_exp_slow(double& a, double b);
+
+inline LogProb logInnerProduct(const vguard<LogProb>& v1, const vguard<LogProb>& v2) {
+  LogProb lip = -std::numeric_limits<double>::infinity();
+  for (size_t k = 0; k < v1.size(); ++k) lip = log_sum_exp(lip, v1[k] + v2[k]);
+  return lip;
+}
+inline LogProb logInnerProduct(const vguard<vguard<LogProb> >& v1, const vguard<vguard<LogProb> >& v2) {
+  LogProb lip = -std::numeric_limits<double>::infinity();
+  for (size_t k = 0; k < v1.size(); ++k) lip = log_sum_exp(lip, logInnerProduct(v1[k], v2[k]));
+  return lip;
+}
+vguard<LogProb> log_vector(const vguard<double>& v);
+
+// ---- src/fastseq.h (subset) -----------------------------------------------------------------
+typedef unsigned int SeqIdx;
+typedef unsigned int AlphTok;
+typedef int UnvalidatedAlphTok;
+#define InvalidAlphabetToken -1
+
+UnvalidatedAlphTok tokenize(char c, const string& alphabet);
+
+struct FastSeq {
+  string name, comment, seq, qual;
+  SeqIdx length() const { return (SeqIdx)seq.size(); }
+};
+vguard<FastSeq> readFastSeqs(const char* filename);
+
+// ---- src/alignpath.h ------------------------------------------------------------------------
+typedef size_t AlignRowIndex;
+typedef size_t AlignColIndex;
+typedef vguard<bool> AlignRowPath;
+typedef map<AlignRowIndex, AlignRowPath> AlignPath;
+
+AlignColIndex alignPathColumns(const AlignPath& a);
+SeqIdx alignPathResiduesInRow(const AlignRowPath& r);
+AlignPath alignPathUnion(const AlignPath& a1, const AlignPath& a2);
+AlignPath alignPathConcat(const AlignPath& a1, const AlignPath& a2);
+AlignPath alignPathConcat(const AlignPath& a1, const AlignPath& a2, const AlignPath& a3);
+void ensureAlignPathHasRow(AlignPath&, AlignRowIndex);
+string alignPathString(const AlignPath& a);
+
+struct Alignment {
+  static const char gapChar, wildcardChar;
+  static inline bool isGap(char c) { return c == '-' || c == '.'; }
+  static inline bool isWildcard(char c) { return c == wildcardChar; }
+};
+
+struct GuideAlignmentEnvelope {
+  vguard<int> cumulativeMatches;
+  vguard<AlignColIndex> row1PosToCol, row2PosToCol;
+  AlignRowIndex row1, row2;
+  int maxDistance;
+  GuideAlignmentEnvelope() : row1(0), row2(0), maxDistance(-1) {}
+  GuideAlignmentEnvelope(const AlignPath& guide, AlignRowIndex row1, AlignRowIndex row2, int maxDistance);
+  inline bool initialized() const { return maxDistance >= 0; }
+  inline bool inRange(SeqIdx pos1, SeqIdx pos2) const {
+    if (!initialized()) return true;
+    const int d = cumulativeMatches[row1PosToCol[pos1]] - cumulativeMatches[row2PosToCol[pos2]];
+    return abs(d) <= maxDistance;
+  }
+};
+
+// ---- src/model.h (subset) -------------------------------------------------------------------
+typedef vguard<double> Vec;            // stands in for gsl_vector*
+typedef vguard<vguard<double> > Mat;   // stands in for gsl_matrix*
+
+struct AlphabetOwner {
+  string alphabet;
+  char wildcard;
+  AlphabetOwner() : wildcard('*') {}
+  inline size_t alphabetSize() const { return alphabet.size(); }
+};
+
+struct RateModel : AlphabetOwner {
+  double insRate, delRate, insExtProb, delExtProb;
+  vguard<Mat> subRate;
+  vguard<Vec> insProb;
+  vguard<double> cptWeight;
+  RateModel() : insRate(0), delRate(0), insExtProb(0), delExtProb(0) {}
+  inline int components() const { return (int)subRate.size(); }
+  void readFile(const char* filename);     // JSON, reference src/model.cpp:172-232
+  void read(const string& jsonText);
+  static Vec getEqmProbVector(const Mat& sr);   // src/model.cpp:282-320
+  vguard<Mat> getSubProbMatrix(double t) const; // src/model.cpp:322-334 (own scaling-and-squaring exp(Rt))
+};
+
+struct ProbModel : AlphabetOwner {
+  double t, ins, del, insExt, delExt;
+  vguard<double> cptWeight;
+  vguard<Vec> insVec;
+  vguard<Mat> subMat;
+  ProbModel(const RateModel& model, double t);
+  inline int components() const { return (int)subMat.size(); }
+};
+
+struct LogProbModel {
+  vguard<LogProb> logCptWeight;
+  vguard<vguard<LogProb> > logInsProb;
+  LogProbModel(const ProbModel& pm);
+  inline int components() const { return (int)logCptWeight.size(); }
+};
+
+// ---- src/profile.h --------------------------------------------------------------------------
+typedef size_t ProfileStateIndex;
+typedef size_t ProfileTransitionIndex;
+
+struct ProfileTransition {
+  ProfileStateIndex src, dest;
+  LogProb lpTrans;
+  AlignPath alignPath;
+  ProfileTransition();
+};
+
+struct ProfileState {
+  typedef map<AlignRowIndex, SeqIdx> SeqCoords;
+  string name;
+  map<string, string> meta;
+  vguard<ProfileTransitionIndex> in, nullOut, absorbOut;
+  vguard<vguard<LogProb> > lpAbsorb;
+  AlignPath alignPath;
+  SeqCoords seqCoords;
+  ProfileState();
+  ProfileState(size_t components, AlphTok alphSize);
+  inline bool isNull() const { return lpAbsorb.empty(); }
+  inline bool isEmit() const { return !lpAbsorb.empty(); }
+  inline bool isStart() const { return in.empty(); }
+  inline bool isEmitOrStart() const { return isEmit() || isStart(); }
+  inline bool isReady() const { return nullOut.empty(); }
+  inline bool isWait() const { return absorbOut.empty(); }
+  static void assertSeqCoordsConsistent(const SeqCoords& srcCoords, const ProfileState& dest, const AlignPath& transPath);
+  static void assertSeqCoordsConsistent(const SeqCoords& srcCoords, const SeqCoords& destCoords, const AlignPath& transPath, const AlignPath& destPath);
+};
+
+struct Profile {
+  AlphTok alphSize;
+  size_t components;
+  string name;
+  map<string, string> meta;
+  vguard<ProfileState> state;
+  vguard<ProfileTransition> trans;
+  map<AlignRowIndex, string> seq;
+  map<ProfileStateIndex, ProfileStateIndex> equivAbsorbState;
+  AlignRowIndex rootRowIndex;
+  Profile() : alphSize(0), components(0), rootRowIndex(0) {}
+  Profile(size_t components, AlphTok alphSize, AlignRowIndex rowIndex) : alphSize(alphSize), components(components), rootRowIndex(rowIndex) {}
+  Profile(size_t components, const string& alphabet, const FastSeq& seq, AlignRowIndex rowIndex);
+  ProfileStateIndex size() const { return state.size(); }
+  const ProfileState& start() const { return state.front(); }
+  const ProfileState& end() const { return state.back(); }
+  const ProfileTransition* getTrans(ProfileStateIndex src, ProfileStateIndex dest) const;
+  LogProb calcSumPathAbsorbProbs(const vguard<LogProb>& logCptWeight, const vguard<vguard<LogProb> >& logInsProb, const char* tag = "cumLogProb");
+  void writeJson(std::ostream& out) const;
+  string toJson() const;
+  void assertTransitionsConsistent() const;
+  void assertSeqCoordsConsistent() const;
+  void assertAllStatesWaitOrReady() const;
+  void assertPathToEndExists() const;
+  Profile addReadyStates() const;
+  bool isEmpty() const;
+  vguard<ProfileStateIndex> examplePathToEnd() const;
+};
+
+// ---- src/pairhmm.h --------------------------------------------------------------------------
+struct PairHMM : AlphabetOwner {
+  const ProbModel& l;
+  const ProbModel& r;
+  const LogProbModel logl, logr;
+  vguard<vguard<LogProb> > logRoot;
+  typedef enum { IMM = 0, IMD = 1, IDM = 2, IMI = 3, IIW = 4, TotalStates = 5, SSS = 0, SSI = 3, SIW = 4, EEE = 5 } State;
+  inline int components() const { return (int)logRoot.size(); }
+  static const char* stateName(State s, bool xAtStart, bool yAtStart);
+  LogProb imm_imi, imm_iiw, imm_imm, imm_imd, imm_idm, imm_eee;
+  LogProb imd_imm, imd_imd, imd_idm, imd_eee;
+  LogProb idm_imm, idm_imd, idm_idm, idm_eee;
+  LogProb imi_imi, imi_iiw, imi_imm, imi_imd, imi_eee;
+  LogProb iiw_iiw, iiw_imm, iiw_idm, iiw_eee;
+  PairHMM(const ProbModel& l, const ProbModel& r, const vguard<Vec>& root);
+  static vguard<State> states();
+  static vguard<State> sources(State dest);
+  LogProb lpTrans(State src, State dest) const;
+};
+
+// ---- src/forward.h --------------------------------------------------------------------------
+class SumProduct;   // counts path: out of scope, only ever passed as NULL
+
+class DPMatrix {
+public:
+  struct XYCell {
+    LogProb lp[PairHMM::TotalStates];
+    XYCell() { for (size_t s = 0; s < PairHMM::TotalStates; ++s) lp[s] = -std::numeric_limits<double>::infinity(); }
+    LogProb operator()(PairHMM::State s) const { return lp[s]; }
+  };
+  struct CellCoords {
+    ProfileStateIndex xpos, ypos;
+    PairHMM::State state;
+    CellCoords() : xpos(0), ypos(0), state(PairHMM::EEE) {}
+    CellCoords(ProfileStateIndex xpos, ProfileStateIndex ypos, PairHMM::State state) : xpos(xpos), ypos(ypos), state(state) {}
+    bool operator<(const CellCoords& c) const { return xpos == c.xpos ? ypos == c.ypos ? state < c.state : ypos < c.ypos : xpos < c.xpos; }
+    bool operator==(const CellCoords& c) const { return xpos == c.xpos && ypos == c.ypos && state == c.state; }
+  };
+  enum ProfilingStrategy { KeepAll = 0, CollapseChains = 1, DontCountSubstEvents = 0, CountSubstEvents = 2,
+                           DontCountIndelEvents = 0, CountIndelEvents = 4, DontIncludeBestTrace = 0, IncludeBestTrace = 8,
+                           DontKeepGapsOpen = 0, KeepGapsOpen = 16 };
+  typedef list<CellCoords> Path;
+  typedef std::mt19937 random_engine;
+  static const char* random_engine_name() { return "mt19937"; }
+
+  const Profile& x, y;
+  const bool xEmpty, yEmpty;
+  Profile subx, suby;           // x, y with lpAbsorb left-multiplied by the branch matrices (device result)
+  const PairHMM& hmm;
+  const AlphTok alphSize;
+  const ProfileStateIndex xSize, ySize;
+  const CellCoords startCell, endCell;
+  LogProb lpEnd;
+  const GuideAlignmentEnvelope envelope;
+  vguard<SeqIdx> xClosestLeafPos, yClosestLeafPos;
+  vguard<bool> xNearStart, yNearEnd;
+
+  DPMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, const GuideAlignmentEnvelope& env);
+  virtual ~DPMatrix();
+
+  // cell accessors: -inf outside storage (src/forward.h:68-88)
+  LogProb cell(ProfileStateIndex xpos, ProfileStateIndex ypos, PairHMM::State state) const;
+  inline LogProb cell(const CellCoords& c) const { return cell(c.xpos, c.ypos, c.state); }
+  XYCell xyCell(ProfileStateIndex xpos, ProfileStateIndex ypos) const;
+  inline LogProb lpStart() const { return cell(0, 0, PairHMM::IMM); }
+
+  inline bool atEdge(ProfileStateIndex xpos, ProfileStateIndex ypos) const { return xNearStart[xpos] || yNearEnd[ypos]; }
+  inline bool inEnvelope(ProfileStateIndex xpos, ProfileStateIndex ypos) const {
+    return atEdge(xpos, ypos) || envelope.inRange(xClosestLeafPos[xpos], yClosestLeafPos[ypos]);
+  }
+  void write(std::ostream& out, bool edgeOnly = false) const;
+  string toString(bool edgeOnly = false) const;
+  string cellName(const CellCoords& cell) const;
+  static random_engine newRNG();
+  static size_t cellSize() { return sizeof(XYCell); }
+  inline int components() const { return hmm.components(); }
+
+  // log-sum-exp policy of the device fills: 0 = exact (bit-identical to the reference, default), 1 = fast
+  static void setFillMode(unsigned hxFlags);
+  static unsigned fillMode();
+
+protected:
+  vguard<LogProb> insx, insy, rootsubx, rootsuby;
+  vguard<vguard<LogProb> > absorbScratch;
+  hx_batch* batch;               // device-resident job (owned by the ForwardMatrix; shared with its BackwardMatrix)
+  bool ownsBatch;
+  int which;                     // 0 Forward, 1 Backward matrix of the batch
+  mutable vguard<double> hostCells;   // lazy copy of the device matrix (strip-skewed layout)
+  mutable bool haveHostCells;
+  long long stripStride, planeStride;
+
+  void createBatchAndPrepare();  // flatten inputs -> hx_batch_create; run the fill; fetch the prepared vectors
+  void fetchPrepared();
+  void ensureHostCells() const;
+  inline void initAbsorbScratch(ProfileStateIndex xpos, ProfileStateIndex ypos) {
+    for (int cpt = 0; cpt < components(); ++cpt)
+      for (size_t n = 0; n < hmm.alphabetSize(); ++n)
+        absorbScratch[cpt][n] = subx.state[xpos].lpAbsorb[cpt][n] + suby.state[ypos].lpAbsorb[cpt][n];
+  }
+  inline LogProb computeLogProbAbsorb(ProfileStateIndex xpos, ProfileStateIndex ypos) {
+    initAbsorbScratch(xpos, ypos);
+    return logInnerProduct(hmm.logRoot, absorbScratch);
+  }
+  LogProb lpCellEmitOrAbsorb(const CellCoords& c);
+  bool isAbsorbing(const CellCoords& c) const;
+  bool changesX(const CellCoords& c) const;
+  bool changesY(const CellCoords& c) const;
+  list<CellCoords> equivAbsorbCells(const CellCoords& c) const;
+  CellCoords sampleCell(const map<CellCoords, LogProb>& cellLogProb, random_engine& generator) const;
+  static CellCoords bestCell(const map<CellCoords, LogProb>& cellLogProb);
+  friend class BackwardMatrix;
+};
+
+class ForwardMatrix : public DPMatrix {
+public:
+  const AlignRowIndex parentRowIndex;
+  SumProduct* sumProd;
+
+  struct EffectiveTransition {
+    LogProb lpPath, lpBestAlignPath;
+    AlignPath bestAlignPath;
+    EffectiveTransition();
+  };
+
+  ForwardMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, AlignRowIndex parentRowIndex,
+                const GuideAlignmentEnvelope& env, SumProduct* sumProd = NULL);
+
+  Path sampleTrace(random_engine& generator);
+  Path bestTrace();
+  Path bestTrace(const CellCoords& end);
+  AlignPath bestAlignPath();
+
+  Profile makeProfile(const set<CellCoords>& cells, ProfilingStrategy strategy = CollapseChains);
+  Profile sampleProfile(random_engine& generator, size_t profileSamples, size_t maxCells = 0,
+                        ProfilingStrategy strategy = CollapseChains, size_t minLen = 0,
+                        size_t maxLen = std::numeric_limits<size_t>::max());
+  Profile bestProfile(ProfilingStrategy strategy = CollapseChains);
+
+  map<CellCoords, LogProb> sourceTransitions(const CellCoords& destCell);
+  map<CellCoords, LogProb> sourceTransitionsWithoutEmitOrAbsorb(const CellCoords& destCell);
+  void slowFillTest();
+
+private:
+  map<CellCoords, LogProb> sourceCells(const CellCoords& destCell);
+  LogProb eliminatedLogProbInsert(const CellCoords& cell) const;
+  AlignPath cellAlignPath(const CellCoords& cell) const;
+  AlignPath transitionAlignPath(const CellCoords& src, const CellCoords& dest) const;
+  AlignPath traceAlignPath(const Path& path) const;
+  ProfileState::SeqCoords cellSeqCoords(const CellCoords& cell) const;
+  friend class BackwardMatrix;
+};
+
+class BackwardMatrix : public DPMatrix {
+public:
+  struct CellPostProb : CellCoords {
+    LogProb logPostProb;
+    CellPostProb(ProfileStateIndex xpos, ProfileStateIndex ypos, PairHMM::State state, LogProb lpp) : CellCoords(xpos, ypos, state), logPostProb(lpp) {}
+    bool operator<(const CellPostProb& cpp) const { return logPostProb < cpp.logPostProb; }
+  };
+  ForwardMatrix& fwd;
+
+  BackwardMatrix(ForwardMatrix& fwd);
+
+  double cellPostProb(const CellCoords& cell) const;
+  double transPostProb(const CellCoords& src, const CellCoords& dest) const;
+  Path bestTrace(const CellCoords& start);
+  std::priority_queue<CellPostProb> cellsAbovePostProbThreshold(double minPostProb) const;
+  Profile postProbProfile(double minPostProb, size_t maxCells = 0, ProfilingStrategy strategy = CollapseChains);
+  Profile bestProfile(ProfilingStrategy strategy = CollapseChains);
+  map<CellCoords, LogProb> destTransitions(const CellCoords& srcCell);
+  void slowFillTest();
+  void sourceDestTransTest();
+
+private:
+  map<CellCoords, LogProb> destCells(const CellCoords& srcCell);
+  bool addCells(set<CellCoords>& cells, size_t maxCells, const list<CellCoords>& fwdTrace, const list<CellCoords>& backTrace, bool keepGapsOpen);
+  bool addTrace(const CellCoords& cell, set<CellCoords>& cells, size_t maxCells, bool keepGapsOpen);
+};
+
+string pairParentName(const string& lChildName, double lTime, const string& rChildName, double rTime);  // Tree::pairParentName
+
+}  // namespace historian

@@ -1,0 +1,447 @@
+// util, logsumexp, fastseq, alignpath and model parts of the host mirror (see hx_host.h).
+#include "hx_host.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <fstream>
+#include <iomanip>
+#include <sstream>
+
+namespace historian {
+
+// ---- errors (reference src/util.cpp:26-54) --------------------------------------------------
+void Warn(const char* warning, ...) {
+  va_list argptr;
+  fprintf(stderr, "Warning: ");
+  va_start(argptr, warning);
+  vfprintf(stderr, warning, argptr);
+  fprintf(stderr, "\n");
+  va_end(argptr);
+}
+
+void Abort(const char* error, ...) {
+  va_list argptr;
+  va_start(argptr, error);
+  fprintf(stderr, "Abort: ");
+  vfprintf(stderr, error, argptr);
+  fprintf(stderr, "\n");
+  va_end(argptr);
+  std::terminate();   // the reference executes `throw;` with no active exception, i.e. std::terminate
+}
+
+void Fail(const char* error, ...) {
+  va_list argptr;
+  va_start(argptr, error);
+  vfprintf(stderr, error, argptr);
+  fprintf(stderr, "\n");
+  va_end(argptr);
+  exit(EXIT_FAILURE);
+}
+
+// ---- log-sum-exp table (reference src/logsumexp.cpp:6-53) -----------------------------------
+LogSumExpLookupTable logSumExpLookupTable = LogSumExpLookupTable();
+
+LogSumExpLookupTable::LogSumExpLookupTable() {
+  lookup = new double[LOG_SUM_EXP_LOOKUP_ENTRIES + 1];
+  for (int n = 0; n < LOG_SUM_EXP_LOOKUP_ENTRIES + 1; ++n) lookup[n] = log_sum_exp_unary_slow(n * LOG_SUM_EXP_LOOKUP_PRECISION);
+}
+LogSumExpLookupTable::~LogSumExpLookupTable() { delete[] lookup; }
+
+double log_sum_exp_unary_slow(double x) { return log(1. + exp(-x)); }
+
+double log_sum_exp_slow(double a, double b) {
+  double min, max;
+  if (a < b) { min = a; max = b; } else { min = b; max = a; }
+  if (min == -std::numeric_limits<double>::infinity()) return max;
+  return max + log_sum_exp_unary_slow(max - min);
+}
+double log_sum_exp_slow(double a, double b, double c) { return log_sum_exp_slow(log_sum_exp_slow(a, b), c); }
+double log_sum_exp_slow(double a, double b, double c, double d) { return log_sum_exp_slow(log_sum_exp_slow(log_sum_exp_slow(a, b), c), d); }
+void log_accum_exp_slow(double& a, double b) { a = log_sum_exp_slow(a, b); }
+
+vguard<LogProb> log_vector(const vguard<double>& v) {
+  vguard<LogProb> l(v.size());
+  for (size_t i = 0; i < v.size(); ++i) l[i] = log(v[i]);
+  return l;
+}
+
+// ---- sequences (reference src/fastseq.cpp:10-16) --------------------------------------------
+UnvalidatedAlphTok tokenize(char c, const string& alphabet) {
+  const char* alphStr = alphabet.c_str();
+  const char* ptok = strchr(alphStr, c);
+  if (ptok == NULL) ptok = strchr(alphStr, isupper(c) ? tolower(c) : toupper(c));
+  return ptok ? (UnvalidatedAlphTok)(ptok - alphStr) : InvalidAlphabetToken;
+}
+
+vguard<FastSeq> readFastSeqs(const char* filename) {
+  std::ifstream in(filename);
+  Require(in.good(), "Couldn't open %s", filename);
+  vguard<FastSeq> seqs;
+  string line;
+  while (std::getline(in, line)) {
+    while (!line.empty() && (line.back() == '\r' || line.back() == '\n' || line.back() == ' ')) line.pop_back();
+    if (line.empty()) continue;
+    if (line[0] == '>') {
+      FastSeq fs;
+      const size_t sp = line.find_first_of(" \t");
+      fs.name = line.substr(1, sp == string::npos ? string::npos : sp - 1);
+      if (sp != string::npos) fs.comment = line.substr(sp + 1);
+      seqs.push_back(fs);
+    } else if (!seqs.empty()) {
+      for (char c : line)
+        if (!isspace((unsigned char)c)) seqs.back().seq.push_back(c);
+    }
+  }
+  return seqs;
+}
+
+// ---- alignment paths (reference src/alignpath.cpp:6-81, 282-318) ----------------------------
+const char Alignment::gapChar = '-';
+const char Alignment::wildcardChar = '*';
+
+AlignColIndex alignPathColumns(const AlignPath& a) {
+  AlignColIndex cols = 0;
+  bool first = true;
+  AlignRowIndex firstRow = 0;
+  for (auto& row_path : a) {
+    if (first) {
+      firstRow = row_path.first;
+      cols = row_path.second.size();
+      first = false;
+    } else
+      Assert(cols == row_path.second.size(), "Alignment path is not flush: row %u has %u columns, but row %u has %u columns",
+             (unsigned)firstRow, (unsigned)cols, (unsigned)row_path.first, (unsigned)row_path.second.size());
+  }
+  return cols;
+}
+
+SeqIdx alignPathResiduesInRow(const AlignRowPath& r) {
+  SeqIdx l = 0;
+  for (bool b : r)
+    if (b) ++l;
+  return l;
+}
+
+AlignPath alignPathUnion(const AlignPath& a1, const AlignPath& a2) {
+  AlignPath a = a1;
+  a.insert(a2.begin(), a2.end());
+  return a;
+}
+
+AlignPath alignPathConcat(const AlignPath& a1, const AlignPath& a2) {
+  AlignPath a = a1;
+  const AlignColIndex c1 = alignPathColumns(a1), c2 = alignPathColumns(a2);
+  for (auto& iter : a)
+    if (a2.find(iter.first) == a2.end()) iter.second.insert(iter.second.end(), c2, false);
+  for (auto& iter2 : a2) {
+    AlignRowPath& lPath = a[iter2.first];
+    if (lPath.empty()) lPath.insert(lPath.end(), c1, false);
+    lPath.insert(lPath.end(), iter2.second.begin(), iter2.second.end());
+  }
+  return a;
+}
+
+AlignPath alignPathConcat(const AlignPath& a1, const AlignPath& a2, const AlignPath& a3) {
+  return alignPathConcat(alignPathConcat(a1, a2), a3);
+}
+
+void ensureAlignPathHasRow(AlignPath& a, AlignRowIndex r) {
+  const AlignColIndex cols = alignPathColumns(a);
+  if (!a.count(r)) a[r] = AlignRowPath(cols, false);
+}
+
+string alignPathString(const AlignPath& a) {
+  std::ostringstream out;
+  for (auto& row_path : a) {
+    out << std::setw(4) << row_path.first << ' ';
+    for (bool s : row_path.second) out << (s ? '*' : '-');
+    out << std::endl;
+  }
+  return out.str();
+}
+
+GuideAlignmentEnvelope::GuideAlignmentEnvelope(const AlignPath& guide, AlignRowIndex row1, AlignRowIndex row2, int maxDistance)
+    : row1(row1), row2(row2), maxDistance(maxDistance) {
+  Assert(guide.find(row1) != guide.end(), "Guide alignment is missing row #%u", (unsigned)row1);
+  Assert(guide.find(row2) != guide.end(), "Guide alignment is missing row #%u", (unsigned)row2);
+  const AlignColIndex cols = alignPathColumns(guide);
+  cumulativeMatches.reserve(cols + 1);
+  int matches = 0;
+  row1PosToCol.push_back(0);
+  row2PosToCol.push_back(0);
+  cumulativeMatches.push_back(0);
+  for (AlignColIndex col = 0; col < cols; ++col) {
+    if (guide.at(row1)[col]) row1PosToCol.push_back(col + 1);
+    if (guide.at(row2)[col]) row2PosToCol.push_back(col + 1);
+    if (guide.at(row1)[col] && guide.at(row2)[col]) ++matches;
+    cumulativeMatches.push_back(matches);
+  }
+}
+
+// ---- minimal JSON reader (the reference vendors gason; only what RateModel::read needs) -----
+namespace {
+struct Json {
+  enum Kind { Null, Num, Str, Arr, Obj } kind = Null;
+  double num = 0;
+  string str;
+  vguard<Json> arr;
+  vguard<std::pair<string, Json> > obj;
+  const Json* find(const string& k) const {
+    for (auto& kv : obj)
+      if (kv.first == k) return &kv.second;
+    return NULL;
+  }
+};
+
+struct JsonParser {
+  const string& s;
+  size_t p;
+  explicit JsonParser(const string& s) : s(s), p(0) {}
+  void ws() { while (p < s.size() && isspace((unsigned char)s[p])) ++p; }
+  Json parse() {
+    ws();
+    Require(p < s.size(), "JSON: unexpected end of input");
+    Json j;
+    const char c = s[p];
+    if (c == '{') {
+      j.kind = Json::Obj;
+      ++p; ws();
+      if (s[p] == '}') { ++p; return j; }
+      while (true) {
+        ws();
+        Require(s[p] == '"', "JSON: expected string key at offset %u", (unsigned)p);
+        Json k = parse();
+        ws();
+        Require(s[p] == ':', "JSON: expected ':' at offset %u", (unsigned)p);
+        ++p;
+        Json v = parse();
+        j.obj.push_back(std::make_pair(k.str, v));
+        ws();
+        if (s[p] == ',') { ++p; continue; }
+        Require(s[p] == '}', "JSON: expected '}' at offset %u", (unsigned)p);
+        ++p;
+        break;
+      }
+    } else if (c == '[') {
+      j.kind = Json::Arr;
+      ++p; ws();
+      if (s[p] == ']') { ++p; return j; }
+      while (true) {
+        j.arr.push_back(parse());
+        ws();
+        if (s[p] == ',') { ++p; continue; }
+        Require(s[p] == ']', "JSON: expected ']' at offset %u", (unsigned)p);
+        ++p;
+        break;
+      }
+    } else if (c == '"') {
+      j.kind = Json::Str;
+      ++p;
+      while (p < s.size() && s[p] != '"') {
+        if (s[p] == '\\' && p + 1 < s.size()) ++p;
+        j.str.push_back(s[p++]);
+      }
+      ++p;
+    } else if (c == '-' || isdigit((unsigned char)c)) {
+      j.kind = Json::Num;
+      char* end = NULL;
+      j.num = strtod(s.c_str() + p, &end);
+      p = end - s.c_str();
+    } else {
+      // true / false / null
+      while (p < s.size() && isalpha((unsigned char)s[p])) ++p;
+    }
+    return j;
+  }
+};
+
+double jnum(const Json& o, const char* key) {
+  const Json* v = o.find(key);
+  Assert(v != NULL && v->kind == Json::Num, "Couldn't find JSON number %s", key);
+  return v->num;
+}
+}  // namespace
+
+// ---- rate / probability models (reference src/model.cpp:172-232, 282-334, 374-391, 492-504) --
+void RateModel::readFile(const char* filename) {
+  std::ifstream in(filename);
+  Require(in.good(), "Couldn't open %s", filename);
+  std::stringstream ss;
+  ss << in.rdbuf();
+  read(ss.str());
+}
+
+void RateModel::read(const string& text) {
+  Assert(subRate.empty(), "RateModel already initialized");
+  JsonParser parser(text);
+  const Json js = parser.parse();
+  Assert(js.kind == Json::Obj, "JSON value is not an object");
+  const Json* alph = js.find("alphabet");
+  Assert(alph != NULL && alph->kind == Json::Str, "Couldn't find JSON tag alphabet");
+  alphabet = alph->str;
+  const Json* wc = js.find("wildcard");
+  if (wc && wc->kind == Json::Str && !wc->str.empty()) wildcard = wc->str[0];
+  insRate = jnum(js, "insrate");
+  insExtProb = jnum(js, "insextprob");
+  delRate = jnum(js, "delrate");
+  delExtProb = jnum(js, "delextprob");
+  auto readComponent = [&](const Json& jm) {
+    const size_t A = alphabet.size();
+    Mat sr(A, Vec(A, 0.));
+    const Json* rm = jm.find("subrate");
+    Assert(rm != NULL && rm->kind == Json::Obj, "Couldn't find JSON tag subrate");
+    for (size_t i = 0; i < A; ++i) {
+      const Json* row = rm->find(string(1, alphabet[i]));
+      if (row)
+        for (size_t j = 0; j < A; ++j)
+          if (j != i) {
+            const Json* r = row->find(string(1, alphabet[j]));
+            if (r) {
+              sr[i][j] += r->num;
+              sr[i][i] -= r->num;
+            }
+          }
+    }
+    Vec ip;
+    const Json* rp = jm.find("rootprob");
+    if (rp) {
+      ip.assign(A, 0.);
+      for (size_t i = 0; i < A; ++i) {
+        const Json* v = rp->find(string(1, alphabet[i]));
+        if (v) ip[i] = v->num;
+      }
+    } else
+      ip = getEqmProbVector(sr);
+    const Json* w = jm.find("weight");
+    cptWeight.push_back(w && w->kind == Json::Num ? w->num : 1);
+    insProb.push_back(ip);
+    subRate.push_back(sr);
+  };
+  const Json* mix = js.find("mixture");
+  if (mix && mix->kind == Json::Arr)
+    for (auto& c : mix->arr) readComponent(c);
+  else
+    readComponent(js);
+  double norm = 0;
+  for (double w : cptWeight) norm += w;
+  for (auto& cw : cptWeight) cw /= norm;
+}
+
+// Least-squares solution of [R^T; 1 ... 1] pi = [0; 1] by Householder QR (the reference calls
+// gsl_linalg_QR_decomp / QR_lssolve, src/model.cpp:282-303), then clamp at 0 and renormalise.
+Vec RateModel::getEqmProbVector(const Mat& sr) {
+  const size_t n = sr.size(), m = n + 1;
+  vguard<Vec> a(m, Vec(n));
+  for (size_t j = 0; j < n; ++j) {
+    for (size_t i = 0; i < n; ++i) a[i][j] = sr[j][i];
+    a[n][j] = 1;
+  }
+  Vec b(m, 0.);
+  b[n] = 1;
+  for (size_t k = 0; k < n; ++k) {
+    double norm = 0;
+    for (size_t i = k; i < m; ++i) norm += a[i][k] * a[i][k];
+    norm = sqrt(norm);
+    if (norm == 0) continue;
+    const double alpha = a[k][k] > 0 ? -norm : norm;
+    Vec v(m, 0.);
+    for (size_t i = k; i < m; ++i) v[i] = a[i][k];
+    v[k] -= alpha;
+    double vnorm2 = 0;
+    for (size_t i = k; i < m; ++i) vnorm2 += v[i] * v[i];
+    if (vnorm2 == 0) continue;
+    for (size_t j = k; j < n; ++j) {
+      double dot = 0;
+      for (size_t i = k; i < m; ++i) dot += v[i] * a[i][j];
+      const double f = 2 * dot / vnorm2;
+      for (size_t i = k; i < m; ++i) a[i][j] -= f * v[i];
+    }
+    double dot = 0;
+    for (size_t i = k; i < m; ++i) dot += v[i] * b[i];
+    const double f = 2 * dot / vnorm2;
+    for (size_t i = k; i < m; ++i) b[i] -= f * v[i];
+  }
+  Vec eqm(n, 0.);
+  for (size_t kk = n; kk-- > 0;) {
+    double s = b[kk];
+    for (size_t j = kk + 1; j < n; ++j) s -= a[kk][j] * eqm[j];
+    eqm[kk] = a[kk][kk] != 0 ? s / a[kk][kk] : 0;
+  }
+  double eqmNorm = 0;
+  for (size_t i = 0; i < n; ++i) {
+    eqm[i] = std::max(0., eqm[i]);
+    eqmNorm += eqm[i];
+  }
+  for (size_t i = 0; i < n; ++i) eqm[i] /= eqmNorm;
+  return eqm;
+}
+
+// exp(R t) by scaling and squaring of a Taylor series (the reference calls
+// gsl_linalg_exponential_ss, src/model.cpp:322-334; GSL is not vendored, so the substitution
+// matrix is an explicit input of every DP parity definition -- SURVEY.md 8c).
+static Mat matmul(const Mat& a, const Mat& b) {
+  const size_t n = a.size();
+  Mat c(n, Vec(n, 0.));
+  for (size_t i = 0; i < n; ++i)
+    for (size_t k = 0; k < n; ++k) {
+      const double aik = a[i][k];
+      if (aik != 0)
+        for (size_t j = 0; j < n; ++j) c[i][j] += aik * b[k][j];
+    }
+  return c;
+}
+
+vguard<Mat> RateModel::getSubProbMatrix(double t) const {
+  vguard<Mat> v;
+  for (int c = 0; c < components(); ++c) {
+    const size_t n = subRate[c].size();
+    Mat rt = subRate[c];
+    double norm = 0;
+    for (size_t i = 0; i < n; ++i) {
+      double row = 0;
+      for (size_t j = 0; j < n; ++j) { rt[i][j] *= t; row += fabs(rt[i][j]); }
+      norm = std::max(norm, row);
+    }
+    int squarings = 0;
+    while (norm > 0.25) { norm /= 2; ++squarings; }
+    const double scale = ldexp(1.0, -squarings);
+    for (auto& row : rt)
+      for (auto& x : row) x *= scale;
+    Mat result(n, Vec(n, 0.)), term(n, Vec(n, 0.));
+    for (size_t i = 0; i < n; ++i) result[i][i] = term[i][i] = 1;
+    for (int k = 1; k <= 24; ++k) {
+      term = matmul(term, rt);
+      for (auto& row : term)
+        for (auto& x : row) x /= k;
+      for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < n; ++j) result[i][j] += term[i][j];
+    }
+    for (int s = 0; s < squarings; ++s) result = matmul(result, result);
+    v.push_back(result);
+  }
+  return v;
+}
+
+ProbModel::ProbModel(const RateModel& model, double t)
+    : AlphabetOwner(model), t(t), ins(1 - exp(-model.insRate * t)), del(1 - exp(-model.delRate * t)),
+      insExt(model.insExtProb), delExt(model.delExtProb), cptWeight(model.cptWeight), insVec(model.insProb),
+      subMat(model.getSubProbMatrix(t)) {}
+
+LogProbModel::LogProbModel(const ProbModel& pm) : logCptWeight(pm.components()), logInsProb(pm.components()) {
+  for (int c = 0; c < pm.components(); ++c) {
+    logCptWeight[c] = log(pm.cptWeight[c]);
+    logInsProb[c] = log_vector(pm.insVec[c]);
+  }
+}
+
+string pairParentName(const string& lChildName, double lTime, const string& rChildName, double rTime) {
+  std::ostringstream o;
+  o.unsetf(std::ios_base::floatfield);
+  o << "(" << lChildName << ":" << lTime << "," << rChildName << ":" << rTime << ")";
+  return o.str();
+}
+
+}  // namespace historian

@@ -474,9 +474,22 @@ int hx_batch_forward(hx_batch* b, void* stream) {
 
 int hx_batch_backward(hx_batch* b, void* stream) {
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
-  if (!b->d_bwd) return fail(HX_ERR_STATE, "batch was created without HX_KEEP_BACKWARD");
   if (!b->forward_done) return fail(HX_ERR_STATE, "hx_batch_backward needs a previous hx_batch_forward");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!b->d_bwd) {
+    // not pre-allocated with HX_KEEP_BACKWARD: allocate the Backward matrices now and re-publish the job table
+    size_t total = 0;
+    for (int k = 0; k < b->n_jobs; ++k) total += 5 * (size_t)b->jobs[k].plane;
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    if (hipMalloc(reinterpret_cast<void**>(&b->d_bwd), sizeof(double) * total) != hipSuccess)
+      return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %zu Backward-matrix bytes failed", total * 8);
+    size_t off = 0;
+    for (int k = 0; k < b->n_jobs; ++k) {
+      b->jobs[k].bwd = b->d_bwd + off;
+      off += 5 * (size_t)b->jobs[k].plane;
+    }
+    HIP_TRY(hipMemcpy(b->d_jobs, b->jobs.data(), sizeof(DevJob) * b->n_jobs, hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipEventRecord(b->ev[1][0], st));
   launch_backward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
   HIP_TRY(hipEventRecord(b->ev[1][1], st));

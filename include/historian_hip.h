@@ -54,7 +54,7 @@ enum { HX_IMM = 0, HX_IMD = 1, HX_IDM = 2, HX_IMI = 3, HX_IIW = 4, HX_STATES = 5
                             bit-identical to the reference recursion (default)        */
 #define HX_LSE_FAST  1u  /* same truncation, higher-order LDS-resident table; cells
                             differ from HX_LSE_EXACT by <= ~1e-9 per op               */
-#define HX_KEEP_BACKWARD 2u /* allocate the Backward matrix too                       */
+#define HX_KEEP_BACKWARD 2u /* pre-allocate the Backward matrices at hx_batch_create        */
 #define HX_FORCE_GENERIC 4u /* always use the general (DAG) kernels, even for chain profiles */
 
 /* POD image of a reference Profile (src/profile.h:13-76) restricted to what the
@@ -147,9 +147,11 @@ int hx_batch_destroy(hx_batch* b);
  * src/profile.cpp:78-91, src/forward.cpp:44-56) + Forward fill + lpEnd
  * (src/forward.cpp:68-223) for every job of the batch. */
 int hx_batch_forward(hx_batch* b, void* stream);
-/* Asynchronous: Backward fill (src/forward.cpp:975-1088).  Needs HX_KEEP_BACKWARD
- * and a previous hx_batch_forward (the prepared vectors are shared, unlike the
- * reference which recomputes them at src/forward.cpp:976). */
+/* Asynchronous: Backward fill (src/forward.cpp:975-1088).  Needs a previous
+ * hx_batch_forward (the prepared vectors are shared, unlike the reference which
+ * recomputes them at src/forward.cpp:976).  The Backward matrices are allocated on
+ * the first call unless HX_KEEP_BACKWARD pre-allocated them (that first call then
+ * synchronises). */
 int hx_batch_backward(hx_batch* b, void* stream);
 int hx_batch_sync(hx_batch* b);
 

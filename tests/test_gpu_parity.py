@@ -187,11 +187,14 @@ def test_error_codes():
     x, y, hmm, md = H.job_images(f)
     b = capi.Batch([(x, y, hmm, md)])           # no HX_KEEP_BACKWARD
     with pytest.raises(capi.HxError) as e:
-        b.backward()
+        b.backward()                             # before forward
     assert e.value.code == -7
     with pytest.raises(capi.HxError) as e:
         b.lp_end()                               # before forward
     assert e.value.code == -7
+    b.forward()
+    b.backward()                                 # Backward matrix is allocated on demand
+    assert abs(b.lp_start()[0] - b.lp_end()[0]) < 1e-6
     b.close()
     # non-toposorted transition
     bad = capi.ProfileImage(x.trans_src.copy(), x.trans_dst.copy(), x.trans_lp,
