@@ -441,4 +441,53 @@ private:
 
 string pairParentName(const string& lChildName, double lTime, const string& rChildName, double rTime);  // Tree::pairParentName
 
+// ---- src/recon.h / recon.cpp:864-915, 917-1052 (subset) ----------------------------------------
+// The progressive loop that calls the DP: one ForwardMatrix per internal node in post-order,
+// band-doubling retry on zero likelihood, sampled (or posterior) profiles for non-root nodes,
+// best alignment path at the root.  Tree building, guide-alignment construction, file formats,
+// refinement and counts are outside this build's scope: the tree arrives as post-order arrays
+// and the guide as an AlignPath over leaf rows.
+typedef int TreeNodeIndex;
+
+struct ReconTree {
+  vguard<TreeNodeIndex> parent;          // -1 for the root (last node)
+  vguard<double> branchLen;              // length of the branch above each node
+  vguard<string> nodeName;
+  vguard<vguard<TreeNodeIndex> > child;
+  void addNode(TreeNodeIndex parentNode, double len, const string& name);
+  void finish();                         // builds child lists, asserts post-order and binary
+  inline TreeNodeIndex nodes() const { return (TreeNodeIndex)parent.size(); }
+  inline bool isLeaf(TreeNodeIndex n) const { return child[n].empty(); }
+  inline TreeNodeIndex root() const { return nodes() - 1; }
+  inline TreeNodeIndex getChild(TreeNodeIndex n, size_t k) const { return child[n][k]; }
+  inline double branchLength(TreeNodeIndex n) const { return branchLen[n]; }
+};
+
+struct Reconstructor {
+  RateModel model;
+  int maxDistanceFromGuide;              // -band, default 20 (src/recon.h:16)
+  size_t profileSamples;                 // -profsamples, default 10
+  size_t profileMaxStates;               // -profmaxstates; 0 = unlimited (the reference default is RAM dependent)
+  bool includeBestTraceInProfile, keepGapsOpen, usePosteriorsForProfile, reconstructRoot;
+  double minPostProb;                    // -profminpost
+  unsigned rndSeed;                      // mt19937::default_seed
+  DPMatrix::random_engine generator;
+
+  struct Dataset {
+    ReconTree tree;
+    map<TreeNodeIndex, FastSeq> seqs;    // ungapped sequence of every leaf node
+    AlignPath guide;                     // rows = leaf node indices; empty = no band
+    vguard<TreeNodeIndex> closestLeaf;
+    AlignPath path;                      // result: root alignment path
+    LogProb lpFinalFwd, lpFinalTrace;
+    map<TreeNodeIndex, int> bandUsed;
+    void prepareRecon();
+    vguard<FastSeq> gappedRecon() const; // Alignment(ungapped, path).gapped()
+  };
+
+  Reconstructor();
+  void seedGenerator();
+  void reconstruct(Dataset& dataset);
+};
+
 }  // namespace historian

@@ -1613,3 +1613,161 @@ class _StdMaxHeap:
             parent = (hole - 1) // 2
         a[hole] = last
         return top
+
+
+# ----------------------------------------------------------------------------
+# Progressive reconstruction driver: Reconstructor::prepareRecon / reconstruct
+# (reference src/recon.cpp:864-915, 917-1052), default options (sampled profiles,
+# IncludeBestTrace | CollapseChains, band-doubling retry), root reconstruction only.
+# ----------------------------------------------------------------------------
+def sub_prob_matrix_ss(sr, t):
+    """exp(R t) by scaling-and-squaring of a 24-term Taylor series.  This is NOT the
+    reference's arithmetic (GSL gsl_linalg_exponential_ss, un-vendored): it is the same
+    plain-IEEE sequence of operations as RateModel::getSubProbMatrix of the C++ host
+    mirror, restated here so that both sides of a whole-tree parity test feed the DP the
+    bit-identical substitution matrix (the matrix is an input of the parity definition)."""
+    n = len(sr)
+    rt = [[float(sr[i][j]) * t for j in range(n)] for i in range(n)]
+    norm = 0.
+    for i in range(n):
+        row = 0.
+        for j in range(n):
+            row += abs(rt[i][j])
+        norm = max(norm, row)
+    squarings = 0
+    while norm > 0.25:
+        norm /= 2
+        squarings += 1
+    scale = math.ldexp(1.0, -squarings)
+    rt = [[v * scale for v in row] for row in rt]
+
+    def matmul(a, b):
+        c = [[0.] * n for _ in range(n)]
+        for i in range(n):
+            ci = c[i]
+            for k in range(n):
+                aik = a[i][k]
+                if aik != 0:
+                    bk = b[k]
+                    for j in range(n):
+                        ci[j] += aik * bk[j]
+        return c
+
+    result = [[1. if i == j else 0. for j in range(n)] for i in range(n)]
+    term = [[1. if i == j else 0. for j in range(n)] for i in range(n)]
+    for k in range(1, 25):
+        term = matmul(term, rt)
+        term = [[v / k for v in row] for row in term]
+        for i in range(n):
+            for j in range(n):
+                result[i][j] += term[i][j]
+    for _ in range(squarings):
+        result = matmul(result, result)
+    return result
+
+
+class ReconTree:
+    """Post-order node arrays (children before parents, root last; reference tree.cpp:214-218)."""
+
+    def __init__(self, parent, branch_length, name):
+        self.parent, self.branch_length, self.name = list(parent), list(branch_length), list(name)
+        self.child = [[] for _ in parent]
+        for n, p in enumerate(parent):
+            if p >= 0:
+                assert p > n, "tree nodes are not sorted in postorder"
+                self.child[p].append(n)
+
+    def nodes(self):
+        return len(self.parent)
+
+    def is_leaf(self, n):
+        return not self.child[n]
+
+    def root(self):
+        return len(self.parent) - 1
+
+
+def closest_leaves(tree):
+    """reference src/recon.cpp:885-906"""
+    closest, dist = [], []
+    for node in range(tree.nodes()):
+        if tree.is_leaf(node):
+            closest.append(node)
+            dist.append(0.)
+        else:
+            cl, dcl = -1, 0.
+            for nc, c in enumerate(tree.child[node]):
+                dc = dist[c] + tree.branch_length[c]
+                if nc == 0 or dc < dcl:
+                    cl, dcl = closest[c], dc
+            closest.append(cl)
+            dist.append(dcl)
+    return closest
+
+
+def reconstruct(model, tree, seqs, guide, max_distance_from_guide=20, profile_samples=10, max_profile_states=0,
+                seed=5489, forward_factory=None, sub_prob=sub_prob_matrix_ss):
+    """seqs: dict leaf node -> (name, sequence); guide: AlignPath over leaf node rows (or {}).
+    forward_factory(x, y, hmm, node, env) -> filled ForwardMatrix (default: the Python fill).
+    Returns dict(path, lp_final_fwd, lp_final_trace, bands, prof)."""
+    if forward_factory is None:
+        forward_factory = lambda x, y, hmm, node, env: ForwardMatrix(x, y, hmm, node, env)
+    closest = closest_leaves(tree)
+    gen = MT19937(seed)
+    strategy = DPMatrix.CollapseChains | DPMatrix.IncludeBestTrace
+    prof, bands = {}, {}
+    path, lp_final_fwd, lp_final_trace = {}, NEG_INF, NEG_INF
+    log_cptw = [safe_log(w) for w in model.cpt_weight]
+    log_root = [[safe_log(v) for v in rv] for rv in model.ins_prob]
+    for node in range(tree.nodes()):
+        if tree.is_leaf(node):
+            name, s = seqs[node]
+            prof[node] = Profile.from_seq(model.components(), model.alphabet, s, node, name)
+            continue
+        lc, rc = tree.child[node]
+        lprobs = ProbModel(model, tree.branch_length[lc], [sub_prob(sr, tree.branch_length[lc]) for sr in model.sub_rate])
+        rprobs = ProbModel(model, tree.branch_length[rc], [sub_prob(sr, tree.branch_length[rc]) for sr in model.sub_rate])
+        hmm = PairHMM(lprobs, rprobs, model.ins_prob)
+        max_dist = max_distance_from_guide
+        while True:
+            env = (GuideAlignmentEnvelope() if not guide
+                   else GuideAlignmentEnvelope(guide, closest[lc], closest[rc], max_dist))
+            fwd = forward_factory(prof[lc], prof[rc], hmm, node, env)
+            if fwd.lp_end > NEG_INF:
+                break
+            assert max_dist >= 0, "Zero forward likelihood even in the absence of guide alignment constraints"
+            if max_dist * 2 > align_path_columns(guide):
+                max_dist = -1
+            elif max_dist == 0:
+                max_dist = 1
+            else:
+                max_dist *= 2
+        bands[node] = max_dist
+        if node == tree.root():
+            path = fwd.best_align_path()
+            node_prof = fwd.best_profile()
+            lp_final_fwd = fwd.lp_end
+        else:
+            node_prof = fwd.sample_profile(gen, profile_samples, max_profile_states, strategy)
+        lp_trace = node_prof.calc_sum_path_absorb_probs(log_cptw, log_root, None)
+        if node == tree.root():
+            lp_final_trace = lp_trace
+        prof[node] = node_prof
+    return dict(path=path, lp_final_fwd=lp_final_fwd, lp_final_trace=lp_final_trace, bands=bands, prof=prof)
+
+
+def gapped_rows(tree, seqs, path):
+    """Alignment(ungapped, path).gapped() (reference src/alignpath.cpp:232-280, recon.cpp:1410-1421):
+    leaves show their residues, internal nodes the wildcard character."""
+    rows = {}
+    for node in sorted(path):
+        s = seqs[node][1] if node in seqs else None
+        out, k = [], 0
+        for b in path[node]:
+            if b:
+                out.append(s[k] if s is not None else WILDCARD_CHAR)
+                k += 1
+            else:
+                out.append("-")
+        rows[node] = "".join(out)
+    return rows
