@@ -189,7 +189,6 @@ def main():
                                              % (n_cpu, cpu_dt)}
             out["lp_end_max_rel_err_vs_cpu"] = rel
         print(json.dumps(out))
-    batch.close()
     if world > 1:
         dist.destroy_process_group()
 
