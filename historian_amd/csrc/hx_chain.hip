@@ -39,7 +39,7 @@ template <class T> __device__ __forceinline__ const HX_GLOBAL T* as_global(const
 
 typedef double d4v __attribute__((ext_vector_type(4)));
 
-struct FastPiece { double c0; float c1, c2; };   // 16 bytes: one ds_read_b128 per log-sum-exp
+struct alignas(16) FastPiece { double c0; float c1, c2; };   // 16 bytes: one ds_read_b128 per log-sum-exp
 
 // v_max_f64 / v_min_f64 without the canonicalisation moves the builtins add for sNaN inputs
 // (v_min_f64 returns the non-NaN operand, which the clamping below relies on).
@@ -82,7 +82,16 @@ struct FastLse {
 #if HX_ABLATE == 2 || HX_ABLATE == 9
   __device__ __forceinline__ Piece fetch(const Prep& p) const { return Piece{0.6931 + p.k * 1e-9, -0.0049f, 3e-6f}; }
 #else
-  __device__ __forceinline__ Piece fetch(const Prep& p) const { return lds[p.k]; }
+  __device__ __forceinline__ Piece fetch(const Prep& p) const {
+    // one 16-byte LDS access (ds_read_b128); a struct load is split into two 8-byte halves
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    const u4v v = reinterpret_cast<const u4v*>(lds)[p.k];
+    Piece c;
+    c.c0 = __hiloint2double((int)v.y, (int)v.x);
+    c.c1 = __uint_as_float(v.z);
+    c.c2 = __uint_as_float(v.w);
+    return c;
+  }
 #endif
   __device__ __forceinline__ double finish(const Prep& p, const Piece& c) const {
     return p.mx + __builtin_fma(__builtin_fma((double)c.c2, p.t, (double)c.c1), p.t, c.c0);

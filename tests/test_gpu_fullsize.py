@@ -1,0 +1,89 @@
+"""BASELINE.json-size cases, checked through size-independent properties plus the CPU oracle where
+it finishes in seconds: a 2x2000-residue protein pair (configs[3] unit), a 2x1000 DNA pair under
+JC69 (configs[1]) and a 4-component mixture with 5000-column profiles (configs[4] shape)."""
+import numpy as np
+import pytest
+
+from historian_amd import capi
+from oracle import c_oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+AA = "arndcqeghilkmfpstwyv"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def engine():
+    capi.init(0, c_oracle.table())
+    yield
+    capi.shutdown()
+
+
+def fills(f, backward=True):
+    img = H.job_images(f)
+    be, bf = capi.Batch([img]), capi.Batch([img], capi.HX_LSE_FAST)
+    be.forward()
+    bf.forward()
+    out = dict(img=img, lp_exact=float(be.lp_end()[0]), lp_fast=float(bf.lp_end()[0]))
+    if backward:
+        be.backward()
+        out["lp_start"] = float(be.lp_start()[0])
+    out["be"], out["bf"] = be, bf
+    return out
+
+
+def test_protein_2x2000_pair():
+    f = H.leaf_case(401, 2000, 2000, alphabet=AA, jc=False, tl=.2, tr=.3)
+    r = fills(f)
+    want = c_oracle.forward(*r["img"])
+    assert r["lp_exact"] == want["lp_end"]                                   # bit-identical
+    assert abs(r["lp_fast"] - want["lp_end"]) <= 1e-4 * abs(want["lp_end"])   # north_star tolerance
+    assert abs(r["lp_fast"] - want["lp_end"]) <= 1e-9 * abs(want["lp_end"])   # what it actually achieves
+    # Forward == Backward.  The two recursions drop different terms under the reference's
+    # |a-b| >= 10 truncation, so they agree to ~1e-7 relative, not to rounding; the reference
+    # itself only checks gsl_fcmp(..., 0.01) (src/forward.cpp:9,1091).
+    assert abs(r["lp_start"] - r["lp_exact"]) <= 1e-5 * abs(r["lp_exact"])
+    # spot cells against the oracle, bit for bit
+    ij = np.array([[0, 0], [1, 1], [777, 801], [1999, 2000], [2000, 2000], [2000, 1], [64, 63], [63, 64], [1024, 1023]])
+    got = r["be"].read_cells(0, ij)
+    for k, (i, j) in enumerate(ij):
+        H.assert_same_bits(got[k], want["cells"][i, j], "cell (%d,%d)" % (i, j))
+    # every cell of the exact fill, bit for bit
+    H.assert_same_bits(r["be"].read_matrix(0), want["cells"], "2x2000 forward cells")
+    r["be"].close()
+    r["bf"].close()
+
+
+def test_dna_2x1000_jc69_pair():
+    f = H.leaf_case(402, 1000, 1000, tl=.1, tr=.1)
+    r = fills(f)
+    want = c_oracle.forward(*r["img"])
+    assert r["lp_exact"] == want["lp_end"]
+    assert abs(r["lp_start"] - r["lp_exact"]) <= 1e-5 * abs(r["lp_exact"])
+    assert abs(r["lp_fast"] - want["lp_end"]) <= 1e-9 * abs(want["lp_end"])
+    H.assert_same_bits(r["be"].read_matrix(0), want["cells"], "2x1000 forward cells")
+    fast = r["bf"].read_matrix(0)
+    fin = np.isfinite(want["cells"])
+    assert np.array_equal(np.isneginf(fast), np.isneginf(want["cells"]))
+    assert np.max(np.abs(fast[fin] - want["cells"][fin])) < 1e-6
+    r["be"].close()
+    r["bf"].close()
+
+
+def test_four_component_mixture_5000_columns():
+    # configs[4] shape: 4-component mixture, 5000-column profile (300 rows keep the oracle quick)
+    f = H.leaf_case(403, 300, 5000, alphabet=AA, components=4, jc=False, tl=.05, tr=.05)
+    r = fills(f)
+    want = c_oracle.forward(*r["img"])
+    assert r["lp_exact"] == want["lp_end"]
+    assert abs(r["lp_fast"] - want["lp_end"]) <= 1e-9 * abs(want["lp_end"])
+    assert abs(r["lp_start"] - r["lp_exact"]) <= 1e-5 * abs(r["lp_exact"])
+    H.assert_same_bits(r["be"].read_matrix(0), want["cells"], "mixture forward cells")
+    # and the transposed shape: 5000 rows x 300 columns (many strips per wave)
+    g = H.leaf_case(404, 5000, 300, alphabet=AA, components=4, jc=False, tl=.05, tr=.05)
+    r2 = fills(g, backward=False)
+    w2 = c_oracle.forward(*r2["img"])
+    assert r2["lp_exact"] == w2["lp_end"]
+    H.assert_same_bits(r2["be"].read_matrix(0), w2["cells"], "tall mixture forward cells")
+    for b in (r["be"], r["bf"], r2["be"], r2["bf"]):
+        b.close()
