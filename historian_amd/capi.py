@@ -45,7 +45,8 @@ class HxPairJob(C.Structure):
 
 class HxLayout(C.Structure):
     _fields_ = [("n_rows", C.c_int32), ("n_cols", C.c_int32), ("strip_rows", C.c_int32),
-                ("n_strips", C.c_int32), ("strip_stride", C.c_int64), ("plane_stride", C.c_int64)]
+                ("n_strips", C.c_int32), ("strip_stride", C.c_int64), ("plane_stride", C.c_int64),
+                ("mirrored", C.c_int32), ("pad_", C.c_int32)]
 
 
 class HxCell(C.Structure):
@@ -87,7 +88,7 @@ def load():
     lib.hx_batch_sync.argtypes = [vp]
     lib.hx_batch_lp_end.argtypes = [vp, _f64p]
     lib.hx_batch_lp_start.argtypes = [vp, _f64p]
-    lib.hx_batch_layout.argtypes = [vp, C.c_int32, C.POINTER(HxLayout)]
+    lib.hx_batch_layout.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(HxLayout)]
     lib.hx_batch_read_matrix.argtypes = [vp, C.c_int32, C.c_int32, _f64p]
     lib.hx_batch_read_cells.argtypes = [vp, C.c_int32, C.c_int32, _i32p, C.c_int64, _f64p]
     lib.hx_batch_read_prepared.argtypes = [vp, C.c_int32] + [_f64p] * 6
@@ -205,6 +206,8 @@ def slot_index(layout, i, j):
     sr = layout.strip_rows
     i = np.asarray(i, dtype=np.int64)
     j = np.asarray(j, dtype=np.int64)
+    if layout.mirrored:
+        i, j = layout.n_rows - 1 - i, layout.n_cols - 1 - j
     l = i % sr
     t = j + l
     return (i // sr) * layout.strip_stride + (t // 2) * (2 * sr) + l * 2 + t % 2
@@ -250,9 +253,9 @@ class Batch:
         _check(load().hx_batch_lp_start(self._h, _p(out, _f64p)))
         return out
 
-    def layout(self, job):
+    def layout(self, job, which=0):
         l = HxLayout()
-        _check(load().hx_batch_layout(self._h, job, C.byref(l)))
+        _check(load().hx_batch_layout(self._h, job, which, C.byref(l)))
         return l
 
     def total_cells(self):
@@ -265,7 +268,7 @@ class Batch:
 
     def read_matrix(self, job, which=0):
         """Dense [n_rows][n_cols][5] copy of a matrix (un-skewed on the host)."""
-        l = self.layout(job)
+        l = self.layout(job, which)
         buf = np.empty(5 * l.plane_stride)
         _check(load().hx_batch_read_matrix(self._h, job, which, _p(buf, _f64p)))
         ii, jj = np.meshgrid(np.arange(l.n_rows), np.arange(l.n_cols), indexing="ij")

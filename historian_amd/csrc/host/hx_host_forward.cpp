@@ -150,7 +150,7 @@ void DPMatrix::createBatchAndPrepare() {
   hxCheck(hx_batch_forward(batch, NULL), "hx_batch_forward");
   hxCheck(hx_batch_lp_end(batch, &lpEnd), "hx_batch_lp_end");
   hx_layout lay;
-  hxCheck(hx_batch_layout(batch, 0, &lay), "hx_batch_layout");
+  hxCheck(hx_batch_layout(batch, 0, 0, &lay), "hx_batch_layout");
   stripStride = lay.strip_stride;
   planeStride = lay.plane_stride;
   fetchPrepared();
@@ -181,6 +181,10 @@ void DPMatrix::ensureHostCells() const {
 LogProb DPMatrix::cell(ProfileStateIndex xpos, ProfileStateIndex ypos, PairHMM::State state) const {
   if (xpos + 1 >= xSize || ypos + 1 >= ySize || state >= PairHMM::TotalStates) return NEG_INF;
   ensureHostCells();
+  if (which == 1) {   // the Backward matrix is stored in mirrored coordinates (hx_layout::mirrored)
+    xpos = xSize - 2 - xpos;
+    ypos = ySize - 2 - ypos;
+  }
   const long long l = xpos & 63, t = ypos + l;
   const long long slot = (long long)(xpos >> 6) * stripStride + ((t >> 1) << 7) + (l << 1) + (t & 1);
   return hostCells[(size_t)state * planeStride + slot];

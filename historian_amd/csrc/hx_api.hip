@@ -382,6 +382,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     hx_layout& L = b->layouts[k];
     L.n_rows = J.n_rows; L.n_cols = J.n_cols; L.strip_rows = HX_STRIP; L.n_strips = J.n_strips;
     L.strip_stride = J.strip_stride; L.plane_stride = J.plane;
+    L.mirrored = 0; L.pad_ = 0;
     mat_off[k] = mat_total;
     mat_total += 5 * J.plane;
     b->total_cells += (int64_t)J.n_rows * J.n_cols;
@@ -491,7 +492,11 @@ int hx_batch_backward(hx_batch* b, void* stream) {
     HIP_TRY(hipMemcpy(b->d_jobs, b->jobs.data(), sizeof(DevJob) * b->n_jobs, hipMemcpyHostToDevice));
   }
   HIP_TRY(hipEventRecord(b->ev[1][0], st));
-  launch_backward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
+  if (b->all_leaf && !(b->flags & HX_FORCE_GENERIC))
+    launch_backward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,
+                          b->all_ylds ? 2 : 1, st);
+  else
+    launch_backward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
   HIP_TRY(hipEventRecord(b->ev[1][1], st));
   HIP_TRY(hipGetLastError());
   b->ev_valid[1] = true;
@@ -526,10 +531,11 @@ static int read_scalars(hx_batch* b, double* out, int which) {
 int hx_batch_lp_end(hx_batch* b, double* out) { return read_scalars(b, out, 0); }
 int hx_batch_lp_start(hx_batch* b, double* out) { return read_scalars(b, out, 1); }
 
-int hx_batch_layout(const hx_batch* b, int32_t job, hx_layout* out) {
-  if (!b || !out) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+int hx_batch_layout(const hx_batch* b, int32_t job, int32_t which, hx_layout* out) {
+  if (!b || !out || which < 0 || which > 1) return fail(HX_ERR_INVALID_ARG, "bad arguments");
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
   *out = b->layouts[job];
+  out->mirrored = which;      // the Backward matrix is stored in mirrored coordinates
   return HX_OK;
 }
 
@@ -564,7 +570,7 @@ int hx_batch_read_cells(hx_batch* b, int32_t job, int32_t which, const int32_t* 
   int rc = HX_OK;
   if (hipMemcpy(d_ij, ij, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice) != hipSuccess) rc = fail(HX_ERR_HIP, "upload failed");
   if (rc == HX_OK) {
-    launch_gather_cells(matrix_of(b, job, which), J.plane, J.strip_stride, J.n_rows, J.n_cols, d_ij, n, d_out, b->last_stream);
+    launch_gather_cells(matrix_of(b, job, which), J.plane, J.strip_stride, J.n_rows, J.n_cols, which, d_ij, n, d_out, b->last_stream);
     if (hipStreamSynchronize(b->last_stream) != hipSuccess ||
         hipMemcpy(out, d_out, sizeof(double) * 5 * n, hipMemcpyDeviceToHost) != hipSuccess)
       rc = fail(HX_ERR_HIP, "cell gather failed");

@@ -308,6 +308,44 @@ __device__ __forceinline__ C5 leaf_cell(const double (*T)[6], const LSE& L, cons
   return r;
 }
 
+// Backward counterpart (reference src/forward.cpp:1018-1065 for in-degree/out-degree-1 leaf-like
+// profiles), in mirrored coordinates: `up` = B(i+1,j), `left` = B(i,j+1), `diag` = B(i+1,j+1).
+// X holds the constants of x state i+1 (lpTrans of i->i+1, rootsubx, insx, emission class) and the
+// ready-penalty of state i; Y likewise for the y side.  The reference accumulates, in this order,
+// the xy-absorbing term D, the x-absorbing terms d1x,d2x and the y-absorbing terms d1y,d2y into
+// each state with log_accum_exp; the first accumulate into -inf is exact, the rest are left-nested.
+template <class LSE>
+__device__ __forceinline__ C5 leaf_cell_bwd(const double (*T)[6], const LSE& L, const XLeaf& X, const d4v& Y,
+                                            double e, double pj, const C5& up, const C5& left, const C5& diag) {
+  const double D = ((X.lp + Y.x) + e) + diag.imm;
+  const double d1x = ((X.lp + X.rootsub) + up.imd) + Y.w;     // gated by the y state being ready
+  const double d2x = ((X.lp + X.ins) + up.iiw) + Y.w;
+  const double d1y = ((Y.x + Y.y) + left.idm) + X.pen;        // gated by the x state being ready
+  const double d2y = ((Y.x + Y.z) + left.imi) + X.pen;
+  typename LSE::Prep p0 = L.prep(T[0][0] + D, T[0][1] + d1x);
+  typename LSE::Prep p1 = L.prep(T[1][0] + D, T[1][1] + d1x);
+  typename LSE::Prep p2 = L.prep(T[2][0] + D, T[2][1] + d1x);
+  typename LSE::Prep p3 = L.prep(T[3][0] + D, T[3][1] + d1x);
+  typename LSE::Prep p4 = L.prep(T[4][0] + D, T[4][4] + d2x);
+  typename LSE::Piece c0 = L.fetch(p0), c1 = L.fetch(p1), c2 = L.fetch(p2), c3 = L.fetch(p3), c4 = L.fetch(p4);
+  double imm = L.finish(p0, c0), imd = L.finish(p1, c1), idm = L.finish(p2, c2), imi = L.finish(p3, c3), iiw = L.finish(p4, c4);
+  p0 = L.prep(imm, T[0][4] + d2x);
+  p1 = L.prep(imd, T[1][2] + d1y);
+  p2 = L.prep(idm, T[2][2] + d1y);
+  p3 = L.prep(imi, T[3][4] + d2x);
+  p4 = L.prep(iiw, T[4][2] + d1y);
+  c0 = L.fetch(p0); c1 = L.fetch(p1); c2 = L.fetch(p2); c3 = L.fetch(p3); c4 = L.fetch(p4);
+  imm = L.finish(p0, c0); imd = L.finish(p1, c1); idm = L.finish(p2, c2); imi = L.finish(p3, c3); iiw = L.finish(p4, c4);
+  p0 = L.prep(imm, T[0][2] + d1y);
+  p3 = L.prep(imi, T[3][3] + d2y);
+  c0 = L.fetch(p0); c3 = L.fetch(p3);
+  imm = L.finish(p0, c0); imi = L.finish(p3, c3);
+  imm = L(imm, T[0][3] + d2y);
+  C5 r;
+  r.imm = imm + pj; r.imd = imd + pj; r.idm = idm + pj; r.imi = imi + pj; r.iiw = iiw + pj;
+  return r;
+}
+
 // Strip pipeline.  A workgroup of W waves owns one pair; 64*RPT-row strips are dealt to
 // its waves round-robin and every wave sweeps its strip left to right on its own clock
 // (no workgroup barrier in the loop).  A strip's only input from the strip above is that
@@ -319,8 +357,8 @@ __device__ __forceinline__ C5 leaf_cell(const double (*T)[6], const LSE& L, cons
 #define HX_YL_MAX_CLS 64
 #define HX_YL_MAX_EMIS 1024
 
-template <int RPT, int W, class LSE, bool FAST, bool LEAF, bool YL, int MINW = 1>
-__global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __restrict__ jobs,
+template <int DIR, int RPT, int W, class LSE, bool FAST, bool LEAF, bool YL, int MINW = 1>
+__global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __restrict__ jobs,
                                                                 const double* __restrict__ exact_tab,
                                                                 const double* __restrict__ fast_tab) {
   constexpr int THREADS = W * 64;
@@ -358,7 +396,8 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
   const int R = J.n_rows, Cc = J.n_cols;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t plane = J.plane, ss = J.strip_stride;
-  HX_GLOBAL double* __restrict__ M = as_global(J.fwd);
+  static_assert(DIR == 0 || LEAF, "the Backward strip pipeline exists for leaf-like profiles only");
+  HX_GLOBAL double* __restrict__ M = as_global(DIR ? J.bwd : J.fwd);
   const HX_GLOBAL d4v* ypack = (const HX_GLOBAL d4v*)as_global(J.y.pack);
   const HX_GLOBAL d4v* xpack = (const HX_GLOBAL d4v*)as_global(J.x.pack);
   const HX_GLOBAL int32_t* yecls = as_global(J.y.ecls);
@@ -376,17 +415,23 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
     XLeaf XL[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
-      const int i = i0 + k;
+      const int i = i0 + k;                      // row in sweep coordinates (mirrored for Backward)
       X[k].valid = i < R;
-      const int ic = X[k].valid ? i : 0;
+      const int ic = X[k].valid ? (DIR ? R - 1 - i : i) : 0;   // actual x state
       if (LEAF) {
         const d4v p = xpack[ic];
-        XL[k].lp = p.x; XL[k].rootsub = p.y; XL[k].ins = p.z; XL[k].pen = p.w;
-        XL[k].eoff = (unsigned)J.x.ecls[ic] * (unsigned)(J.y.n_cls + 1);
+        if (DIR == 0) {
+          XL[k].lp = p.x; XL[k].rootsub = p.y; XL[k].ins = p.z; XL[k].pen = p.w;
+          XL[k].eoff = (unsigned)J.x.ecls[ic] * (unsigned)(J.y.n_cls + 1);
+        } else {
+          const d4v q = xpack[ic + 1];             // the state the absorbing transition leads to
+          XL[k].lp = q.x; XL[k].rootsub = q.y; XL[k].ins = q.z; XL[k].pen = p.w;
+          XL[k].eoff = (unsigned)J.x.ecls[ic + 1] * (unsigned)(J.y.n_cls + 1);
+        }
         XL[k].valid = X[k].valid;
       }
       X[k].flags = J.x.flags[ic];
-      X[k].lp = ic > 0 ? J.x.in_lp[ic - 1] : 0.0;
+      X[k].lp = ic > 0 ? J.x.in_lp[ic - 1] : 0.0;      // (chain_cell path, Forward only)
       X[k].rootsub = J.x.rootsub[ic];
       X[k].ins = J.x.ins[ic];
       X[k].env = (J.max_dist >= 0) ? J.x.env[ic] : 0;
@@ -445,7 +490,8 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
         const int i = i0 + k;
         const int j = t - (lane * RPT + k);
         const bool valid = X[k].valid && j >= 0 && j < Cc;
-        const int jc = j < 0 ? 0 : (j >= Cc ? Cc - 1 : j);
+        const int jm = j < 0 ? 0 : (j >= Cc ? Cc - 1 : j);
+        const int jc = DIR ? Cc - 1 - jm : jm;       // actual y state
         const C5& up = (k == 0) ? u1 : v1[k - 1];
         const C5& dg = (k == 0) ? u2 : v2[k - 1];
         C5 nw;
@@ -458,8 +504,17 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
             ok = ok && ((ef & F_EDGE) || dd <= J.max_dist);
           }
           const double pj = ok ? 0.0 : HX_NEG_INF;
-          nw = leaf_cell(J.T, L, XL[k], Yp[k], ep[k], pj, up, v1[k], dg);
-          if (i == 0 && j == 0) nw.imm = 0.0;
+          if (DIR == 0) {
+            nw = leaf_cell(J.T, L, XL[k], Yp[k], ep[k], pj, up, v1[k], dg);
+            if (i == 0 && j == 0) nw.imm = 0.0;
+          } else {
+            nw = leaf_cell_bwd(J.T, L, XL[k], Yp[k], ep[k], pj, up, v1[k], dg);
+            if (i == 0 && j == 0) {
+              // the cell feeding END is initialised by assignment (reference src/forward.cpp:981-995)
+              const double lpe = J.x.pack[4 * (size_t)R] + J.y.pack[4 * (size_t)Cc];
+              nw = C5{lpe + J.T[0][5], lpe + J.T[1][5], lpe + J.T[2][5], lpe + J.T[3][5], lpe + J.T[4][5]};
+            }
+          }
         } else {
           nw = chain_cell(J, L, X[k], X[k].valid ? i : 0, jc, valid, up, v1[k], dg);
         }
@@ -480,13 +535,20 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         const int j = t - (lane * RPT + k);
-        const int jc = j < 0 ? 0 : (j >= Cc ? Cc - 1 : j);
+        const int jm = j < 0 ? 0 : (j >= Cc ? Cc - 1 : j);
+        const int jc = DIR ? Cc - 1 - jm : jm;       // actual y state
         if (YL) {
           const unsigned w = ycol[jc];
-          const unsigned c = w & 0xFFFFu;
+          const unsigned c = (DIR ? ycol[jc + 1] : w) & 0xFFFFu;
           const double2 rc = reinterpret_cast<const double2*>(yclass)[c];
           Yp[k] = d4v{0.0, rc.x, rc.y, __hiloint2double((w & 0x10000u) ? (int)0xFFF00000 : 0, 0)};
           ep[k] = elds[XL[k].eoff + c];
+          continue;
+        }
+        if (DIR) {
+          const d4v y0 = ypack[(unsigned)jc], y1 = ypack[(unsigned)jc + 1];
+          Yp[k] = d4v{y1.x, y1.y, y1.z, y0.w};
+          ep[k] = epad[XL[k].eoff + (unsigned)yecls[(unsigned)jc + 1]];
           continue;
         }
 #if HX_ABLATE == 9 || HX_ABLATE == 10
@@ -562,42 +624,61 @@ __global__ void __launch_bounds__(W * 64, MINW) k_forward_chain(const DevJob* __
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) *J.lp_end = forward_lp_end(J, LX);
+  if (threadIdx.x == 0) {
+    if (DIR == 0) *J.lp_end = forward_lp_end(J, LX);
+    else *J.lp_start = J.bwd[cell_slot(ss, R - 1, Cc - 1)];   // B(0,0).IMM in mirrored coordinates
+  }
 }
 
-template <int RPT, int W, int MINW = 1>
+template <int DIR, int RPT, int W, int MINW = 1>
 static void launch_variant(const DevJob* d_jobs, int n_jobs, const double* tab, const double* fast_tab, bool fast,
                            int leaf, hipStream_t st) {
   const dim3 g(n_jobs), b(W * 64);
   if (fast && leaf == 2)
-    hipLaunchKernelGGL((k_forward_chain<RPT, W, FastLse, true, true, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+    hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, FastLse, true, true, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
   else if (fast && leaf == 1)
-    hipLaunchKernelGGL((k_forward_chain<RPT, W, FastLse, true, true, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
-  else if (fast)
-    hipLaunchKernelGGL((k_forward_chain<RPT, W, FastLse, true, false, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+    hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, FastLse, true, true, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
   else if (leaf == 2)
-    hipLaunchKernelGGL((k_forward_chain<RPT, W, ExactLse3, false, true, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+    hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, ExactLse3, false, true, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
   else if (leaf == 1)
-    hipLaunchKernelGGL((k_forward_chain<RPT, W, ExactLse3, false, true, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+    hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, ExactLse3, false, true, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+  else if (DIR == 0) {
+    if (fast)
+      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, FastLse, true, false, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+    else
+      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, ExactLse3, false, false, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+  }
+}
+
+template <int DIR>
+static void launch_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+                         bool fast, int leaf, hipStream_t st) {
+  const char* v = getenv("HX_CHAIN_VARIANT");   // tuning hook: override for long profiles
+  const int vi = v ? atoi(v) : 0;
+  if (max_rows <= 64)
+    launch_variant<DIR, 1, 1>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
+  else if (max_rows <= 128)
+    launch_variant<DIR, 1, 2>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
+  else if (max_rows <= 256)
+    launch_variant<DIR, 1, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
+  else if (vi == 2 || (vi == 0 && max_rows <= 512))
+    launch_variant<DIR, 1, 8>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
+  else if (vi == 4)
+    launch_variant<DIR, 2, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
   else
-    hipLaunchKernelGGL((k_forward_chain<RPT, W, ExactLse3, false, false, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+    launch_variant<DIR, 1, 16>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);   // measured fastest on 2x2000
 }
 
 // leaf: 0 = general chain profiles, 1 = leaf-like, 2 = leaf-like with the y side in LDS
 void launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
                           bool fast, int leaf, hipStream_t st) {
-  const char* v = getenv("HX_CHAIN_VARIANT");   // tuning hook: "RPT,W" override for long profiles
-  const int vi = v ? atoi(v) : 0;
-  if (max_rows <= 64)
-    launch_variant<1, 1>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
-  else if (max_rows <= 128)
-    launch_variant<1, 2>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
-  else if (max_rows <= 256)
-    launch_variant<1, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
-  else if (vi == 1) launch_variant<2, 8>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
-  else if (vi == 2 || (vi == 0 && max_rows <= 512)) launch_variant<1, 8>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
-  else if (vi == 4) launch_variant<2, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
-  else launch_variant<1, 16>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);   // measured fastest on 2x2000
+  launch_chain<0>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, st);
+}
+
+// leaf-like profiles only (leaf >= 1)
+void launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+                           bool fast, int leaf, hipStream_t st) {
+  launch_chain<1>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, st);
 }
 
 }  // namespace hx

@@ -82,6 +82,11 @@ __host__ __device__ inline int64_t cell_slot(int64_t strip_stride, int i, int j)
   const int t = j + l;
   return (int64_t)(i >> 6) * strip_stride + ((int64_t)(t >> 1) << 7) + (l << 1) + (t & 1);
 }
+// The Backward matrix uses the same layout in mirrored coordinates (i -> R-1-i, j -> C-1-j): its
+// fill sweeps from the bottom-right corner, and this keeps the sweep's stores coalesced.
+__host__ __device__ inline int64_t bwd_slot(int64_t strip_stride, int n_rows, int n_cols, int i, int j) {
+  return cell_slot(strip_stride, n_rows - 1 - i, n_cols - 1 - j);
+}
 __host__ __device__ inline int64_t strip_stride_for(int n_cols) {
   return ((int64_t)((n_cols + HX_STRIP - 1) >> 1) + 1) * (2 * HX_STRIP);
 }

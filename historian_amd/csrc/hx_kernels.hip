@@ -208,7 +208,9 @@ __global__ void __launch_bounds__(1024) k_forward_dag(const DevJob* __restrict__
 __device__ void backward_cell(const DevJob& J, int i, int j, const double* __restrict__ tab) {
   const int64_t plane = J.plane, ss = J.strip_stride;
   double* __restrict__ M = J.bwd;
-  const int64_t slot = cell_slot(ss, i, j);
+  const int R = J.n_rows, Cc = J.n_cols;
+#define BS(a, b) bwd_slot(ss, R, Cc, (a), (b))
+  const int64_t slot = BS(i, j);
   double imm = HX_NEG_INF, imd = HX_NEG_INF, idm = HX_NEG_INF, imi = HX_NEG_INF, iiw = HX_NEG_INF;
   if (in_envelope(J, i, j)) {
     const uint8_t xf = J.x.flags[i], yf = J.y.flags[j];
@@ -235,7 +237,7 @@ __device__ void backward_cell(const DevJob& J, int i, int j, const double* __res
       const double lpx = J.x.ao_lp[tx];
       for (int ty = yab; ty < yae; ++ty) {
         const int dy = J.y.ao_dst[ty];
-        const double d = lpx + J.y.ao_lp[ty] + emission(J, dx, dy, tab) + M[cell_slot(ss, dx, dy)];
+        const double d = lpx + J.y.ao_lp[ty] + emission(J, dx, dy, tab) + M[BS(dx, dy)];
         imm = lse(imm, T[0][0] + d, tab);
         imd = lse(imd, T[1][0] + d, tab);
         idm = lse(idm, T[2][0] + d, tab);
@@ -247,7 +249,7 @@ __device__ void backward_cell(const DevJob& J, int i, int j, const double* __res
       for (int tx = xab; tx < xae; ++tx) {
         const int dx = J.x.ao_dst[tx];
         const double lpx = J.x.ao_lp[tx];
-        const int64_t sl = cell_slot(ss, dx, j);
+        const int64_t sl = BS(dx, j);
         const double d1 = lpx + J.x.rootsub[dx] + M[1 * plane + sl];
         const double d2 = lpx + J.x.ins[dx] + M[4 * plane + sl];
         imm = lse(imm, T[0][1] + d1, tab);
@@ -262,7 +264,7 @@ __device__ void backward_cell(const DevJob& J, int i, int j, const double* __res
       for (int ty = yab; ty < yae; ++ty) {
         const int dy = J.y.ao_dst[ty];
         const double lpy = J.y.ao_lp[ty];
-        const int64_t sl = cell_slot(ss, i, dy);
+        const int64_t sl = BS(i, dy);
         const double d1 = lpy + J.y.rootsub[dy] + M[2 * plane + sl];
         const double d2 = lpy + J.y.ins[dy] + M[3 * plane + sl];
         imm = lse(imm, T[0][2] + d1, tab);
@@ -277,7 +279,7 @@ __device__ void backward_cell(const DevJob& J, int i, int j, const double* __res
         const int dx = J.x.no_dst[tx];
         if (dx >= J.n_rows) continue;   // END column is not stored: xyCell(END,.) is the empty cell
         const double lpx = J.x.no_lp[tx];
-        const int64_t sl = cell_slot(ss, dx, j);
+        const int64_t sl = BS(dx, j);
         imd = lse(imd, lpx + M[1 * plane + sl], tab);
         iiw = lse(iiw, lpx + M[4 * plane + sl], tab);
         imm = lse(imm, lpx + M[sl], tab);
@@ -286,7 +288,7 @@ __device__ void backward_cell(const DevJob& J, int i, int j, const double* __res
       const int dy = J.y.no_dst[ty];
       if (dy >= J.n_cols) continue;
       const double lpy = J.y.no_lp[ty];
-      const int64_t sl = cell_slot(ss, i, dy);
+      const int64_t sl = BS(i, dy);
       idm = lse(idm, lpy + M[2 * plane + sl], tab);
       imi = lse(imi, lpy + M[3 * plane + sl], tab);
       if (xf & F_EMIT_OR_START) imm = lse(imm, lpy + M[sl], tab);
@@ -297,19 +299,21 @@ __device__ void backward_cell(const DevJob& J, int i, int j, const double* __res
   M[2 * plane + slot] = idm;
   M[3 * plane + slot] = imi;
   M[4 * plane + slot] = iiw;
+#undef BS
 }
 
 __global__ void __launch_bounds__(1024) k_backward_dag(const DevJob* __restrict__ jobs, const double* __restrict__ tab) {
   const DevJob& J = jobs[blockIdx.x];
   const int R = J.n_rows, Cc = J.n_cols;
-  for (int d = R + Cc - 2; d >= 0; --d) {
-    for (int i = threadIdx.x; i < R; i += blockDim.x) {
-      const int j = d - i;
-      if (j >= 0 && j < Cc) backward_cell(J, i, j, tab);
+  // mirrored sweep: thread <-> mirrored row, so that a wave's stores are contiguous in the mirrored layout
+  for (int d = 0; d < R + Cc - 1; ++d) {
+    for (int im = threadIdx.x; im < R; im += blockDim.x) {
+      const int jm = d - im;
+      if (jm >= 0 && jm < Cc) backward_cell(J, R - 1 - im, Cc - 1 - jm, tab);
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *J.lp_start = J.bwd[cell_slot(J.strip_stride, 0, 0)];
+  if (threadIdx.x == 0) *J.lp_start = J.bwd[bwd_slot(J.strip_stride, R, Cc, 0, 0)];
 }
 
 // ---------------------------------------------------------------------------
@@ -325,9 +329,10 @@ __global__ void k_posterior_scan(const DevJob* __restrict__ jobs, int job, doubl
     const int i = (int)(c / J.n_cols), j = (int)(c - (int64_t)i * J.n_cols);
     if (!in_envelope(J, i, j)) continue;
     const int64_t slot = cell_slot(J.strip_stride, i, j);
+    const int64_t bslot = bwd_slot(J.strip_stride, J.n_rows, J.n_cols, i, j);
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
-      const double lpp = J.bwd[s * J.plane + slot] + J.fwd[s * J.plane + slot] - fwd_end;
+      const double lpp = J.bwd[s * J.plane + bslot] + J.fwd[s * J.plane + slot] - fwd_end;
       if (lpp >= lpp_threshold) {
         const unsigned long long k = atomicAdd(counter, 1ull);
         if (k < cap) { out[k].xpos = i; out[k].ypos = j; out[k].state = s; out[k].pad = 0; out[k].lpp = lpp; }
@@ -338,13 +343,13 @@ __global__ void k_posterior_scan(const DevJob* __restrict__ jobs, int job, doubl
 
 // gather of individual cells (traceback support)
 __global__ void k_gather_cells(const double* __restrict__ M, int64_t plane, int64_t strip_stride,
-                               int n_rows, int n_cols, const int* __restrict__ ij, int64_t n,
+                               int n_rows, int n_cols, int mirrored, const int* __restrict__ ij, int64_t n,
                                double* __restrict__ out) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const int i = ij[2 * k], j = ij[2 * k + 1];
   const bool ok = i >= 0 && j >= 0 && i < n_rows && j < n_cols;
-  const int64_t slot = ok ? cell_slot(strip_stride, i, j) : 0;
+  const int64_t slot = !ok ? 0 : (mirrored ? bwd_slot(strip_stride, n_rows, n_cols, i, j) : cell_slot(strip_stride, i, j));
 #pragma unroll
   for (int s = 0; s < 5; ++s) out[5 * k + s] = ok ? M[s * plane + slot] : HX_NEG_INF;
 }
@@ -388,11 +393,11 @@ void launch_posterior_scan(const DevJob* d_jobs, int job, double lpp_threshold, 
   hipLaunchKernelGGL(k_posterior_scan, dim3(1024), dim3(256), 0, st, d_jobs, job, lpp_threshold, out, cap, counter);
 }
 
-void launch_gather_cells(const double* M, int64_t plane, int64_t strip_stride, int n_rows, int n_cols,
+void launch_gather_cells(const double* M, int64_t plane, int64_t strip_stride, int n_rows, int n_cols, int mirrored,
                          const int* ij, int64_t n, double* out, hipStream_t st) {
   const int tpb = 256;
   hipLaunchKernelGGL(k_gather_cells, dim3((unsigned)((n + tpb - 1) / tpb)), dim3(tpb), 0, st, M, plane,
-                     strip_stride, n_rows, n_cols, ij, n, out);
+                     strip_stride, n_rows, n_cols, mirrored, ij, n, out);
 }
 
 }  // namespace hx

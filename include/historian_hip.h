@@ -118,6 +118,9 @@ typedef struct hx_layout {
   int32_t n_strips;
   int64_t strip_stride;      /* doubles per strip per plane                            */
   int64_t plane_stride;      /* doubles per state plane = n_strips * strip_stride      */
+  int32_t mirrored;          /* 1 for the Backward matrix: apply the formula to
+                                (n_rows-1-i, n_cols-1-j) -- its fill sweeps from the far corner */
+  int32_t pad_;
 } hx_layout;
 
 typedef struct hx_cell {
@@ -158,7 +161,7 @@ int hx_batch_sync(hx_batch* b);
 /* Results.  All of these synchronise with the batch's last stream. */
 int hx_batch_lp_end(hx_batch* b, double* out /* [n_jobs] ForwardMatrix::lpEnd */);
 int hx_batch_lp_start(hx_batch* b, double* out /* [n_jobs] BackwardMatrix::lpStart() */);
-int hx_batch_layout(const hx_batch* b, int32_t job, hx_layout* out);
+int hx_batch_layout(const hx_batch* b, int32_t job, int32_t which, hx_layout* out);
 /* which: 0 = Forward, 1 = Backward.  out holds 5 * plane_stride doubles. */
 int hx_batch_read_matrix(hx_batch* b, int32_t job, int32_t which, double* out);
 /* Gather n cells (ij[2k], ij[2k+1]) -> out[5k..5k+4] without copying the matrix. */

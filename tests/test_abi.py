@@ -42,7 +42,7 @@ def test_version_and_error_codes_without_a_device():
 
 def test_struct_sizes_match_the_header():
     assert C.sizeof(capi.HxCell) == 24
-    assert C.sizeof(capi.HxLayout) == 32
+    assert C.sizeof(capi.HxLayout) == 40
     assert C.sizeof(capi.HxHmm) == 8 + 5 * 6 * 8 + 7 * 8
     assert C.sizeof(capi.HxPairJob) == 32
 

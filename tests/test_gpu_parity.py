@@ -217,12 +217,17 @@ def test_fast_mode_stays_within_tolerance_of_exact():
     bf = capi.Batch(imgs, capi.HX_LSE_FAST)
     be.forward()
     bf.forward()
+    be.backward()
+    bf.backward()
     le, lf = be.lp_end(), bf.lp_end()
+    se, sf = be.lp_start(), bf.lp_start()
     for k in range(len(cases)):
-        me, mf = be.read_matrix(k), bf.read_matrix(k)
-        assert np.array_equal(np.isneginf(me), np.isneginf(mf))
-        fin = np.isfinite(me)
-        assert np.max(np.abs(me[fin] - mf[fin]), initial=0.) < 1e-7
+        for which in (0, 1):
+            me, mf = be.read_matrix(k, which), bf.read_matrix(k, which)
+            assert np.array_equal(np.isneginf(me), np.isneginf(mf))
+            fin = np.isfinite(me)
+            assert np.max(np.abs(me[fin] - mf[fin]), initial=0.) < 1e-7
         assert abs(le[k] - lf[k]) <= 1e-9 * abs(le[k])
+        assert abs(se[k] - sf[k]) <= 1e-9 * abs(se[k])
     be.close()
     bf.close()

@@ -10,7 +10,7 @@ for d in ("pmc_${tag}_1","pmc_${tag}_2"):
     for f in glob.glob("gpurun_out/%s/*/*counter_collection.csv"%d):
         agg=collections.defaultdict(float)
         for r in csv.DictReader(open(f)):
-            if "k_forward" in r["Kernel_Name"]:
+            if "k_fill_chain" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]]+=float(r["Counter_Value"])
         for k,v in sorted(agg.items()): print("%-24s %.4g"%(k,v))
 PY
