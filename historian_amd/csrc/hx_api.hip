@@ -90,7 +90,7 @@ struct Arena {
 // offsets into the arena for one profile
 struct ProfOff {
   size_t flags, in_off, in_src, in_lp, ao_off, ao_dst, ao_lp, no_off, no_dst, no_lp;
-  size_t lp_absorb, sub, ins, rootsub, env, cls, cls_rep, pack, ecls;
+  size_t lp_absorb, sub, ins, rootsub, env, cls, cls_rep, pack, ecls, subc, insc, rootsubc;
   bool has_env;
   int n, empty, n_cls, chain, interior_emit, lp_zero;
 };
@@ -225,6 +225,9 @@ int flatten_profile(const hx_profile* p, int CA, bool need_env, bool is_y, Arena
     o.ecls = ar.put(ecls.data(), sizeof(int32_t) * N);
   }
   o.pack = ar.reserve(sizeof(double) * 4 * (size_t)N);
+  o.subc = ar.reserve(sizeof(double) * cls_rep.size() * (size_t)CA);
+  o.insc = ar.reserve(sizeof(double) * cls_rep.size());
+  o.rootsubc = ar.reserve(sizeof(double) * cls_rep.size());
   o.lp_zero = 1;
   for (int t = 0; t < T; ++t)
     if (p->trans_lp[t] != 0.0) o.lp_zero = 0;
@@ -257,6 +260,9 @@ void bind_profile(DevProfile& d, const ProfOff& o, char* base) {
   d.n_cls = o.n_cls;
   d.pad_ = 0;
   d.pack = reinterpret_cast<double*>(base + o.pack);
+  d.subc = reinterpret_cast<double*>(base + o.subc);
+  d.insc = reinterpret_cast<double*>(base + o.insc);
+  d.rootsubc = reinterpret_cast<double*>(base + o.rootsubc);
   d.ecls = reinterpret_cast<int32_t*>(base + o.ecls);
 }
 
@@ -277,7 +283,7 @@ struct hx_batch {
   char* d_arena = nullptr;
   double* d_fwd = nullptr;
   double* d_bwd = nullptr;
-  int max_states = 0, max_ca = 0, max_cls_pairs = 0, max_rows = 0;
+  int max_states = 0, max_ca = 0, max_cls_pairs = 0, max_rows = 0, max_cls = 0;
   bool all_chain = true, all_leaf = true, all_ylds = true;
   int64_t total_cells = 0;
   bool forward_done = false, backward_done = false;
@@ -388,6 +394,8 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     b->total_cells += (int64_t)J.n_rows * J.n_cols;
     if (jo.x.n > b->max_states) b->max_states = jo.x.n;
     if (jo.y.n > b->max_states) b->max_states = jo.y.n;
+    if (jo.x.n_cls > b->max_cls) b->max_cls = jo.x.n_cls;
+    if (jo.y.n_cls > b->max_cls) b->max_cls = jo.y.n_cls;
     if (CA > b->max_ca) b->max_ca = CA;
     if (jo.table_emission && pairs > b->max_cls_pairs) b->max_cls_pairs = (int)pairs;
     if (J.n_rows > b->max_rows) b->max_rows = J.n_rows;
@@ -458,7 +466,7 @@ int hx_batch_destroy(hx_batch* b) {
 int hx_batch_forward(hx_batch* b, void* stream) {
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_ca, b->max_cls_pairs, g_tab, st);
+  launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_cls, b->max_ca, b->max_cls_pairs, g_tab, st);
   HIP_TRY(hipEventRecord(b->ev[0][0], st));
   if (b->all_chain && !(b->flags & HX_FORCE_GENERIC))
     launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,

@@ -40,6 +40,10 @@ struct DevProfile {
   //   pack[i] = { lpTrans of the in-transition (0 for state 0), rootsub, ins, ok-penalty }
   // ok-penalty is 0 when (isReady() || profile empty) else -inf (reference forward.cpp:97,133)
   double* pack;               // [n][4]
+  // profile prep runs once per emission class and is scattered to the states
+  double* subc;               // [n_cls][C*A] leftMultiply of the class representative
+  double* insc;               // [n_cls]
+  double* rootsubc;           // [n_cls]
   const int32_t* ecls;        // [n] emission class, n_cls for null states (-> zero row of emis_pad)
 };
 

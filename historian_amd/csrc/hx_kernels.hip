@@ -19,7 +19,10 @@ namespace hx {
 // ---------------------------------------------------------------------------
 // profile preparation
 // ---------------------------------------------------------------------------
-// one thread per (state, cpt, c): out[i][cpt][c] = (+)_d logsub[cpt][c][d] + lpAbsorb[i][cpt][d]
+// States with byte-identical lpAbsorb rows form an emission class (a leaf has at most A+1 of them);
+// leftMultiply / insx / rootsubx depend on the row only, so they are evaluated once per class --
+// the same operations on the same inputs as the per-state loops of the reference -- and scattered.
+// one thread per (class, cpt, c): subc[k][cpt][c] = (+)_d logsub[cpt][c][d] + lpAbsorb[rep(k)][cpt][d]
 __global__ void k_left_multiply(const DevJob* __restrict__ jobs, const double* __restrict__ tab) {
   const DevJob& J = jobs[blockIdx.y >> 1];
   const int side = blockIdx.y & 1;
@@ -27,18 +30,17 @@ __global__ void k_left_multiply(const DevJob* __restrict__ jobs, const double* _
   const double* logsub = side ? J.log_sub_r : J.log_sub_l;
   const int A = J.A, CA = J.CA;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= P.n * CA) return;
-  const int i = idx / CA, k = idx - i * CA;
+  if (idx >= P.n_cls * CA) return;
+  const int kc = idx / CA, k = idx - kc * CA;
   const int cpt = k / A, c = k - cpt * A;
-  if (P.flags[i] & F_NULL) { P.sub[idx] = HX_NEG_INF; return; }
-  const double* row = P.lp_absorb + (size_t)i * CA + cpt * A;
+  const double* row = P.lp_absorb + (size_t)P.cls_rep[kc] * CA + cpt * A;
   const double* ls = logsub + ((size_t)cpt * A + c) * A;
   double lp = HX_NEG_INF;
   for (int d = 0; d < A; ++d) lp = lse(lp, ls[d] + row[d], tab);
-  P.sub[idx] = lp;
+  P.subc[idx] = lp;
 }
 
-// one thread per state
+// one thread per class: insx / rootsubx (reference src/forward.cpp:44-56)
 __global__ void k_ins_rootsub(const DevJob* __restrict__ jobs, const double* __restrict__ tab) {
   const DevJob& J = jobs[blockIdx.y >> 1];
   const int side = blockIdx.y & 1;
@@ -46,23 +48,37 @@ __global__ void k_ins_rootsub(const DevJob* __restrict__ jobs, const double* __r
   const double* logins = side ? J.log_ins_r : J.log_ins_l;
   const double* logcw = side ? J.log_cptw_r : J.log_cptw_l;
   const int A = J.A, C = J.C, CA = J.CA;
+  const int kc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (kc >= P.n_cls) return;
+  double ins = HX_NEG_INF, rs = HX_NEG_INF;
+  for (int cpt = 0; cpt < C; ++cpt) {
+    const double* raw = P.lp_absorb + (size_t)P.cls_rep[kc] * CA + cpt * A;
+    const double* sub = P.subc + (size_t)kc * CA + cpt * A;
+    double lipi = HX_NEG_INF, lipr = HX_NEG_INF;
+    for (int a = 0; a < A; ++a) lipi = lse(lipi, logins[cpt * A + a] + raw[a], tab);
+    ins = lse(ins, logcw[cpt] + lipi, tab);
+    for (int a = 0; a < A; ++a) lipr = lse(lipr, J.log_root[cpt * A + a] + sub[a], tab);
+    rs = lse(rs, lipr, tab);
+  }
+  P.insc[kc] = ins;
+  P.rootsubc[kc] = rs;
+}
+
+// one thread per state: scatter the class results, pack the chain kernels' per-state constants
+__global__ void k_scatter_prepared(const DevJob* __restrict__ jobs) {
+  const DevJob& J = jobs[blockIdx.y >> 1];
+  const int side = blockIdx.y & 1;
+  const DevProfile& P = side ? J.y : J.x;
+  const int CA = J.CA;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n) return;
-  double ins = HX_NEG_INF, rs = HX_NEG_INF;
-  if (i >= 1 && i < P.n - 1 && !(P.flags[i] & F_NULL)) {
-    for (int cpt = 0; cpt < C; ++cpt) {
-      const double* raw = P.lp_absorb + (size_t)i * CA + cpt * A;
-      const double* sub = P.sub + (size_t)i * CA + cpt * A;
-      double lipi = HX_NEG_INF, lipr = HX_NEG_INF;
-      for (int a = 0; a < A; ++a) lipi = lse(lipi, logins[cpt * A + a] + raw[a], tab);
-      ins = lse(ins, logcw[cpt] + lipi, tab);
-      for (int a = 0; a < A; ++a) lipr = lse(lipr, J.log_root[cpt * A + a] + sub[a], tab);
-      rs = lse(rs, lipr, tab);
-    }
-  }
+  const int kc = P.cls[i];
+  const bool emit = kc >= 0 && i >= 1 && i < P.n - 1;     // the reference fills insx/rootsubx for 1 <= i < size-1
+  const double ins = emit ? P.insc[kc] : HX_NEG_INF;
+  const double rs = emit ? P.rootsubc[kc] : HX_NEG_INF;
+  for (int k = 0; k < CA; ++k) P.sub[(size_t)i * CA + k] = kc >= 0 ? P.subc[(size_t)kc * CA + k] : HX_NEG_INF;
   P.ins[i] = ins;
   P.rootsub[i] = rs;
-  // packed per-state constants of the chain kernels
   const bool ok = (P.flags[i] & F_READY) || P.empty;
   double* pk = P.pack + 4 * (size_t)i;
   pk[0] = (i > 0 && P.in_off[i + 1] > P.in_off[i]) ? P.in_lp[P.in_off[i]] : 0.0;
@@ -79,8 +95,8 @@ __global__ void k_emission_table(const DevJob* __restrict__ jobs, const double* 
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= Kx * Ky) return;
   const int kx = idx / Ky, ky = idx - kx * Ky;
-  const double* sx = J.x.sub + (size_t)J.x.cls_rep[kx] * J.CA;
-  const double* sy = J.y.sub + (size_t)J.y.cls_rep[ky] * J.CA;
+  const double* sx = J.x.subc + (size_t)kx * J.CA;
+  const double* sy = J.y.subc + (size_t)ky * J.CA;
   const double e = emission_rows(J, sx, sy, ExactLse{tab});
   J.emis[idx] = e;
   J.emis_pad[(size_t)kx * (Ky + 1) + ky] = e;
@@ -357,16 +373,18 @@ __global__ void k_gather_cells(const double* __restrict__ M, int64_t plane, int6
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-void launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_ca, int max_cls_pairs,
+void launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, int max_ca, int max_cls_pairs,
                  const double* tab, hipStream_t st) {
   const int tpb = 256;
-  {
-    dim3 grid((unsigned)((max_states * max_ca + tpb - 1) / tpb), (unsigned)(2 * n_jobs));
+  if (max_cls > 0) {
+    dim3 grid((unsigned)((max_cls * max_ca + tpb - 1) / tpb), (unsigned)(2 * n_jobs));
     hipLaunchKernelGGL(k_left_multiply, grid, dim3(tpb), 0, st, d_jobs, tab);
+    dim3 grid2((unsigned)((max_cls + tpb - 1) / tpb), (unsigned)(2 * n_jobs));
+    hipLaunchKernelGGL(k_ins_rootsub, grid2, dim3(tpb), 0, st, d_jobs, tab);
   }
   {
     dim3 grid((unsigned)((max_states + tpb - 1) / tpb), (unsigned)(2 * n_jobs));
-    hipLaunchKernelGGL(k_ins_rootsub, grid, dim3(tpb), 0, st, d_jobs, tab);
+    hipLaunchKernelGGL(k_scatter_prepared, grid, dim3(tpb), 0, st, d_jobs);
   }
   if (max_cls_pairs > 0) {
     dim3 grid((unsigned)((max_cls_pairs + tpb - 1) / tpb), (unsigned)n_jobs);
