@@ -506,10 +506,12 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
           const double pj = ok ? 0.0 : HX_NEG_INF;
           if (DIR == 0) {
             nw = leaf_cell(J.T, L, XL[k], Yp[k], ep[k], pj, up, v1[k], dg);
-            if (i == 0 && j == 0) nw.imm = 0.0;
+            if (s == 0 && t == 0 && k == 0) {        // wave-uniform: only the very first step of strip 0
+              if (lane == 0) nw.imm = 0.0;           // cell (0,0): lpStart() = 0 (reference src/forward.cpp:73)
+            }
           } else {
             nw = leaf_cell_bwd(J.T, L, XL[k], Yp[k], ep[k], pj, up, v1[k], dg);
-            if (i == 0 && j == 0) {
+            if (s == 0 && t == 0 && k == 0 && lane == 0) {
               // the cell feeding END is initialised by assignment (reference src/forward.cpp:981-995)
               const double lpe = J.x.pack[4 * (size_t)R] + J.y.pack[4 * (size_t)Cc];
               nw = C5{lpe + J.T[0][5], lpe + J.T[1][5], lpe + J.T[2][5], lpe + J.T[3][5], lpe + J.T[4][5]};
