@@ -438,10 +438,14 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
       const int cx = J.x.cls[ic];
       X[k].emis_off = cx < 0 ? -1 : cx * J.y.n_cls;
     }
-    C5 v1[RPT], v2[RPT];
+    // Register window, ping-ponged between two sets so that no value is ever copied: at an even step
+    // the lane's previous cells are in cb[] (and those of two steps ago in ca[], which the new cells
+    // overwrite); the previous lane's last row of one / two steps ago is in ua / ub, and the new
+    // shifted-in row overwrites ub.  The next (odd) step swaps the roles.
+    C5 ca[RPT], cb[RPT];
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) { v1[k] = c5_neg_inf(); v2[k] = c5_neg_inf(); }
-    C5 u1 = c5_neg_inf(), u2 = c5_neg_inf();
+    for (int k = 0; k < RPT; ++k) { ca[k] = c5_neg_inf(); cb[k] = c5_neg_inf(); }
+    C5 ua = c5_neg_inf(), ub = c5_neg_inf();
     C5 bnd = c5_neg_inf();                         // 64 columns of the strip above's last row
     const bool has_above = s > 0;
     const int above_base = ((s - 1) / W) * Cc;     // columns the producer wave published in earlier strips
@@ -454,7 +458,8 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
 
     const int nsteps = Cc + SR - 1;
     // one anti-diagonal step of the strip; the lane's RPT new cells are returned in out[]
-    auto step = [&](const int t, C5 (&out)[RPT], const d4v (&Yp)[RPT], const double (&ep)[RPT]) {
+    auto step = [&](const int t, const C5 (&left)[RPT], C5 (&out)[RPT], C5& u1, C5& u2, const d4v (&Yp)[RPT],
+                    const double (&ep)[RPT]) {
       if (has_above) {
         if ((t & 63) == 0 && t < Cc) {
           // wait until the strip above has finished (and drained) columns t .. t+63
@@ -492,8 +497,8 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
         const bool valid = X[k].valid && j >= 0 && j < Cc;
         const int jm = j < 0 ? 0 : (j >= Cc ? Cc - 1 : j);
         const int jc = DIR ? Cc - 1 - jm : jm;       // actual y state
-        const C5& up = (k == 0) ? u1 : v1[k - 1];
-        const C5& dg = (k == 0) ? u2 : v2[k - 1];
+        const C5& up = (k == 0) ? u1 : left[k - 1];
+        const C5& dg = (k == 0) ? u2 : out[k - 1];   // still the value of two steps ago: rows go in descending order
         C5 nw;
         if (LEAF) {
           bool ok = valid;
@@ -505,12 +510,12 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
           }
           const double pj = ok ? 0.0 : HX_NEG_INF;
           if (DIR == 0) {
-            nw = leaf_cell(J.T, L, XL[k], Yp[k], ep[k], pj, up, v1[k], dg);
+            nw = leaf_cell(J.T, L, XL[k], Yp[k], ep[k], pj, up, left[k], dg);
             if (s == 0 && t == 0 && k == 0) {        // wave-uniform: only the very first step of strip 0
               if (lane == 0) nw.imm = 0.0;           // cell (0,0): lpStart() = 0 (reference src/forward.cpp:73)
             }
           } else {
-            nw = leaf_cell_bwd(J.T, L, XL[k], Yp[k], ep[k], pj, up, v1[k], dg);
+            nw = leaf_cell_bwd(J.T, L, XL[k], Yp[k], ep[k], pj, up, left[k], dg);
             if (s == 0 && t == 0 && k == 0 && lane == 0) {
               // the cell feeding END is initialised by assignment (reference src/forward.cpp:981-995)
               const double lpe = J.x.pack[4 * (size_t)R] + J.y.pack[4 * (size_t)Cc];
@@ -518,15 +523,14 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
             }
           }
         } else {
-          nw = chain_cell(J, L, X[k], X[k].valid ? i : 0, jc, valid, up, v1[k], dg);
+          nw = chain_cell(J, L, X[k], X[k].valid ? i : 0, jc, valid, up, left[k], dg);
         }
         if (k == RPT - 1) last = nw;
-        v2[k] = v1[k];
-        v1[k] = nw;
         out[k] = nw;
       }
-      u2 = u1;
-      u1 = wave_shr1_keep0(u1, last);   // lanes >= 1: lane-1's last row; lane 0 keeps its value
+      // the previous lane's new last row lands in the u2 slot, which becomes next step's u1
+      // (lane 0 keeps the old content; it is re-filled from the boundary block when there is a strip above)
+      u2 = wave_shr1_keep0(u2, last);
     };
 
     // y-side constants and emission terms of step t, fetched ahead of use: vector-memory
@@ -571,15 +575,13 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
     // consecutive anti-diagonals are adjacent, so a lane stores RPT*16 contiguous bytes per
     // state plane every second step (a wave: RPT KiB, fully coalesced).
     for (int t = 0; t < nsteps; t += 2) {
-      C5 oa[RPT], ob[RPT];
+      C5 (&oa)[RPT] = ca;
+      C5 (&ob)[RPT] = cb;
       if (YL) prefetch(t, Ya, ea);
-      step(t, oa, Ya, ea);
+      step(t, cb, ca, ua, ub, Ya, ea);
       if (t + 1 < nsteps) {
         if (YL) prefetch(t + 1, Yb, eb);
-        step(t + 1, ob, Yb, eb);
-      } else {
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) ob[k] = c5_neg_inf();
+        step(t + 1, ca, cb, ub, ua, Yb, eb);
       }
       if (!YL) {
         prefetch(t + 2, Ya, ea);                   // before this pair's stores (see above)
