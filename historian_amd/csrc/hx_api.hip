@@ -284,7 +284,7 @@ struct hx_batch {
   double* d_fwd = nullptr;
   double* d_bwd = nullptr;
   int max_states = 0, max_ca = 0, max_cls_pairs = 0, max_rows = 0, max_cls = 0;
-  bool all_chain = true, all_leaf = true, all_ylds = true;
+  bool all_chain = true, all_leaf = true, all_ylds = true, any_banded = false;
   int64_t total_cells = 0;
   bool forward_done = false, backward_done = false;
   hipStream_t last_stream = nullptr;
@@ -401,6 +401,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     if (J.n_rows > b->max_rows) b->max_rows = J.n_rows;
     b->all_chain = b->all_chain && J.chain;
     b->all_leaf = b->all_leaf && J.leaf_like;
+    b->any_banded = b->any_banded || pj.max_distance >= 0;
     // y side small enough for LDS (hx_chain.hip HX_YL_*) and all its transitions have lpTrans 0
     b->all_ylds = b->all_ylds && J.leaf_like && jo.y.lp_zero && jo.y.n <= 6144 && jo.y.n_cls + 1 <= 64 &&
                   (int64_t)(jo.x.n_cls + 1) * (jo.y.n_cls + 1) <= 1024;
@@ -470,7 +471,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   HIP_TRY(hipEventRecord(b->ev[0][0], st));
   if (b->all_chain && !(b->flags & HX_FORCE_GENERIC))
     launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,
-                         b->all_leaf ? (b->all_ylds ? 2 : 1) : 0, st);
+                         b->all_leaf ? (b->all_ylds ? 2 : 1) : 0, b->any_banded, st);
   else
     launch_forward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
   HIP_TRY(hipEventRecord(b->ev[0][1], st));
@@ -502,7 +503,7 @@ int hx_batch_backward(hx_batch* b, void* stream) {
   HIP_TRY(hipEventRecord(b->ev[1][0], st));
   if (b->all_leaf && !(b->flags & HX_FORCE_GENERIC))
     launch_backward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,
-                          b->all_ylds ? 2 : 1, st);
+                          b->all_ylds ? 2 : 1, b->any_banded, st);
   else
     launch_backward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
   HIP_TRY(hipEventRecord(b->ev[1][1], st));

@@ -357,7 +357,7 @@ __device__ __forceinline__ C5 leaf_cell_bwd(const double (*T)[6], const LSE& L, 
 #define HX_YL_MAX_CLS 64
 #define HX_YL_MAX_EMIS 1024
 
-template <int DIR, int RPT, int W, class LSE, bool FAST, bool LEAF, bool YL, int MINW = 1>
+template <int DIR, int RPT, int W, class LSE, bool FAST, bool LEAF, bool YL, bool BANDED, int MINW = 1>
 __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __restrict__ jobs,
                                                                 const double* __restrict__ exact_tab,
                                                                 const double* __restrict__ fast_tab) {
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
         C5 nw;
         if (LEAF) {
           bool ok = valid;
-          if (J.max_dist >= 0) {
+          if (BANDED || !LEAF) if (J.max_dist >= 0) {
             const uint8_t ef = X[k].flags | yflags[jc];
             int dd = X[k].env - yenv[jc];
             dd = dd < 0 ? -dd : dd;
@@ -536,6 +536,16 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
     // y-side constants and emission terms of step t, fetched ahead of use: vector-memory
     // operations retire in issue order, so a load issued after the previous steps' stores
     // would wait for those stores to reach memory; issued before them it does not.
+    // YL: per-row column word of the next step (and, for Backward, the word of the column the previous
+    // step visited: in mirrored order that is actual column j+1, whose class the absorbing move needs)
+    unsigned wnext[RPT], wprev1[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int j0 = 0 - (lane * RPT + k);
+      const int jm0 = j0 < 0 ? 0 : (j0 >= Cc ? Cc - 1 : j0);
+      wnext[k] = YL ? ycol[DIR ? Cc - 1 - jm0 : jm0] : 0u;
+      wprev1[k] = YL ? ycol[DIR ? Cc : 0] : 0u;
+    }
     auto prefetch = [&](const int t, d4v (&Yp)[RPT], double (&ep)[RPT]) {
       if (!LEAF) return;
 #pragma unroll
@@ -544,8 +554,15 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
         const int jm = j < 0 ? 0 : (j >= Cc ? Cc - 1 : j);
         const int jc = DIR ? Cc - 1 - jm : jm;       // actual y state
         if (YL) {
-          const unsigned w = ycol[jc];
-          const unsigned c = (DIR ? ycol[jc + 1] : w) & 0xFFFFu;
+          // the column word was fetched one step ahead (wnext); fetch the next one now
+          const unsigned w = wnext[k];
+          {
+            const int jn = j + 1;
+            const int jnm = jn < 0 ? 0 : (jn >= Cc ? Cc - 1 : jn);
+            wnext[k] = ycol[DIR ? Cc - 1 - jnm : jnm];
+          }
+          const unsigned c = (DIR ? wprev1[k] : w) & 0xFFFFu;
+          if (DIR && j >= 0) wprev1[k] = w;    // (before the row starts, the clamped column is not a visit)
           const double2 rc = reinterpret_cast<const double2*>(yclass)[c];
           Yp[k] = d4v{0.0, rc.x, rc.y, __hiloint2double((w & 0x10000u) ? (int)0xFFF00000 : 0, 0)};
           ep[k] = elds[XL[k].eoff + c];
@@ -568,8 +585,10 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
     };
     d4v Ya[RPT], Yb[RPT];
     double ea[RPT], eb[RPT];
-    prefetch(0, Ya, ea);
-    prefetch(1, Yb, eb);
+    if (!YL) {
+      prefetch(0, Ya, ea);
+      prefetch(1, Yb, eb);
+    }
 
     // Two steps per iteration: in the strip-skewed layout the two cells a row produces on
     // consecutive anti-diagonals are adjacent, so a lane stores RPT*16 contiguous bytes per
@@ -636,53 +655,54 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
 
 template <int DIR, int RPT, int W, int MINW = 1>
 static void launch_variant(const DevJob* d_jobs, int n_jobs, const double* tab, const double* fast_tab, bool fast,
-                           int leaf, hipStream_t st) {
+                           int leaf, bool banded, hipStream_t st) {
   const dim3 g(n_jobs), b(W * 64);
-  if (fast && leaf == 2)
-    hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, FastLse, true, true, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
-  else if (fast && leaf == 1)
-    hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, FastLse, true, true, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
-  else if (leaf == 2)
-    hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, ExactLse3, false, true, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
-  else if (leaf == 1)
-    hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, ExactLse3, false, true, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
-  else if (DIR == 0) {
+#define HX_LAUNCH(LSE_, FAST_, LEAF_, YL_, BANDED_) \
+  hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, LSE_, FAST_, LEAF_, YL_, BANDED_, MINW>), g, b, 0, st, d_jobs, tab, fast_tab)
+  if (leaf == 2 && !banded) {             // the headline configuration: unbanded leaf pairs, y side in LDS
+    if (fast) HX_LAUNCH(FastLse, true, true, true, false); else HX_LAUNCH(ExactLse3, false, true, true, false);
+  } else if (leaf == 2) {
+    if (fast) HX_LAUNCH(FastLse, true, true, true, true); else HX_LAUNCH(ExactLse3, false, true, true, true);
+  } else if (leaf == 1) {
+    if (fast) HX_LAUNCH(FastLse, true, true, false, true); else HX_LAUNCH(ExactLse3, false, true, false, true);
+  } else if (DIR == 0) {
     if (fast)
-      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, FastLse, true, false, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, FastLse, true, false, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
     else
-      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, ExactLse3, false, false, false, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, ExactLse3, false, false, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
   }
+#undef HX_LAUNCH
 }
 
 template <int DIR>
 static void launch_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                         bool fast, int leaf, hipStream_t st) {
+                         bool fast, int leaf, bool banded, hipStream_t st) {
   const char* v = getenv("HX_CHAIN_VARIANT");   // tuning hook: override for long profiles
   const int vi = v ? atoi(v) : 0;
   if (max_rows <= 64)
-    launch_variant<DIR, 1, 1>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
+    launch_variant<DIR, 1, 1>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, st);
   else if (max_rows <= 128)
-    launch_variant<DIR, 1, 2>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
+    launch_variant<DIR, 1, 2>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, st);
   else if (max_rows <= 256)
-    launch_variant<DIR, 1, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
+    launch_variant<DIR, 1, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, st);
   else if (vi == 2 || (vi == 0 && max_rows <= 512))
-    launch_variant<DIR, 1, 8>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
+    launch_variant<DIR, 1, 8>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, st);
   else if (vi == 4)
-    launch_variant<DIR, 2, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);
+    launch_variant<DIR, 2, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, st);
   else
-    launch_variant<DIR, 1, 16>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, st);   // measured fastest on 2x2000
+    launch_variant<DIR, 1, 16>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, st);   // measured fastest on 2x2000
 }
 
 // leaf: 0 = general chain profiles, 1 = leaf-like, 2 = leaf-like with the y side in LDS
 void launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                          bool fast, int leaf, hipStream_t st) {
-  launch_chain<0>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, st);
+                          bool fast, int leaf, bool banded, hipStream_t st) {
+  launch_chain<0>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, st);
 }
 
 // leaf-like profiles only (leaf >= 1)
 void launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                           bool fast, int leaf, hipStream_t st) {
-  launch_chain<1>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, st);
+                           bool fast, int leaf, bool banded, hipStream_t st) {
+  launch_chain<1>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, st);
 }
 
 }  // namespace hx

@@ -11,9 +11,9 @@ void launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, 
                  const double* tab, hipStream_t st);
 void launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
 void launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                          bool fast, int leaf, hipStream_t st);
+                          bool fast, int leaf, bool banded, hipStream_t st);
 void launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                           bool fast, int leaf, hipStream_t st);
+                           bool fast, int leaf, bool banded, hipStream_t st);
 void launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
 void launch_posterior_scan(const DevJob* d_jobs, int job, double lpp_threshold, PostCell* out,
                            unsigned long long cap, unsigned long long* counter, hipStream_t st);
