@@ -83,13 +83,14 @@ struct FastLse {
   __device__ __forceinline__ Piece fetch(const Prep& p) const { return Piece{0.6931 + p.k * 1e-9, -0.0049f, 3e-6f}; }
 #else
   __device__ __forceinline__ Piece fetch(const Prep& p) const {
-    // one 16-byte LDS access (ds_read_b128); a struct load is split into two 8-byte halves
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    const u4v v = reinterpret_cast<const u4v*>(lds)[p.k];
+    // exactly one 16-byte LDS access (ds_read_b128): c0 is the first double, the two fp32
+    // coefficients are the halves of the second
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const d2v v = reinterpret_cast<const d2v*>(lds)[p.k];
     Piece c;
-    c.c0 = __hiloint2double((int)v.y, (int)v.x);
-    c.c1 = __uint_as_float(v.z);
-    c.c2 = __uint_as_float(v.w);
+    c.c0 = v.x;
+    c.c1 = __uint_as_float((unsigned)__double2loint(v.y));
+    c.c2 = __uint_as_float((unsigned)__double2hiint(v.y));
     return c;
   }
 #endif
