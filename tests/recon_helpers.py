@@ -94,15 +94,18 @@ def write_job(path, model_path, tree, seqs, guide, seqs_fa, guide_fa, **opts):
     with open(seqs_fa, "w") as f:
         for n, (nm, s) in seqs.items():
             f.write(">%s\n%s\n" % (nm, s))
-    with open(guide_fa, "w") as f:
-        for n, (nm, s) in seqs.items():
-            k, row = 0, []
-            for b in guide[n]:
-                row.append(s[k] if b else "-")
-                k += 1 if b else 0
-            f.write(">%s\n%s\n" % (nm, "".join(row)))
+    if guide:
+        with open(guide_fa, "w") as f:
+            for n, (nm, s) in seqs.items():
+                k, row = 0, []
+                for b in guide[n]:
+                    row.append(s[k] if b else "-")
+                    k += 1 if b else 0
+                f.write(">%s\n%s\n" % (nm, "".join(row)))
     with open(path, "w") as f:
-        f.write("model %s\nseqs %s\nguide %s\n" % (model_path, seqs_fa, guide_fa))
+        f.write("model %s\nseqs %s\n" % (model_path, seqs_fa))
+        if guide:
+            f.write("guide %s\n" % guide_fa)
         for k, v in opts.items():
             f.write("%s %s\n" % (k, v))
         f.write("tree %d\n" % tree.nodes())
@@ -129,3 +132,28 @@ def parse_hxrecon(text):
         elif f[0] == "row":
             out["rows"][int(f[1])] = f[3] if len(f) > 3 else ""
     return out
+
+
+def balanced_family(n_leaves, length, alphabet, seed, branch=.05):
+    """Balanced binary tree with n_leaves (power of two) synthetic sequences evolved down the tree
+    (substitutions and indels); post-order ReconTree + {leaf: (name, seq)}; no guide alignment."""
+    import random
+    rng = random.Random(seed)
+    parent, blen, name, seqs = [], [], [], {}
+
+    def build(depth, anc):
+        if depth == 0:
+            idx = len(parent)
+            parent.append(-1); blen.append(branch); name.append("leaf%d" % idx)
+            seqs[idx] = (name[idx], anc if anc else alphabet[0])
+            return idx
+        kids = [build(depth - 1, H.mutate(rng, anc, alphabet, .08, .02)) for _ in range(2)]
+        idx = len(parent)
+        parent.append(-1); blen.append(branch); name.append("node%d" % idx)
+        for k in kids:
+            parent[k] = idx
+        return idx
+
+    depth = n_leaves.bit_length() - 1
+    build(depth, H.random_seq(rng, alphabet, length))
+    return ho.ReconTree(parent, blen, name), seqs

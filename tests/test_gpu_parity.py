@@ -118,6 +118,12 @@ def test_leaf_pairs_mid_sizes_hit_every_chain_variant():
         run_and_check([c], backward=False)
 
 
+def test_leaf_pair_too_wide_for_the_lds_y_side():
+    # > 6144 columns: the leaf kernel variant that streams the y side from memory
+    f = H.leaf_case(110, 70, 6400)
+    run_and_check([f], backward=True)
+
+
 def test_leaf_protein_and_mixture():
     aa = "arndcqeghilkmfpstwyv"
     cases = [H.leaf_case(11, 40, 45, alphabet=aa, jc=False, tl=.3, tr=.2),

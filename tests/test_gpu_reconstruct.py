@@ -68,3 +68,21 @@ def test_gp120_full_fast_mode(tmp_path):
     got, res, rows = run_case(tmp_path, None, 20, fast=True)
     assert abs(got["lpFinalFwd"] - res["lp_final_fwd"]) <= 1e-4 * abs(res["lp_final_fwd"])
     assert got["rows"] == rows
+
+
+def test_mixture_family_unbanded_exact(tmp_path):
+    # BASELINE configs[4] shape in miniature: 4-component mixture (prot4), balanced 8-leaf tree, no guide band
+    prot4 = os.path.join(ROOT, "tests", "golden", "models", "prot4.json")
+    import json
+    alphabet = json.load(open(prot4))["alphabet"]
+    tree, seqs = R.balanced_family(8, 60, alphabet, seed=11)
+    job = str(tmp_path / "job.txt")
+    R.write_job(job, prot4, tree, seqs, {}, str(tmp_path / "seqs.fa"), str(tmp_path / "guide.fa"), samples=5,
+                maxstates=0, seed=5489)
+    out = subprocess.run([HXRECON, job], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()
+    got = R.parse_hxrecon(out.stdout.decode())
+    res, rows = R.oracle_reconstruct(prot4, tree, seqs, {}, profile_samples=5)
+    assert got["lpFinalFwd"] == res["lp_final_fwd"]
+    assert got["lpFinalTrace"] == res["lp_final_trace"]
+    assert got["rows"] == rows
