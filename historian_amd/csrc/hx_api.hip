@@ -5,6 +5,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -90,7 +93,7 @@ struct Arena {
 // offsets into the arena for one profile
 struct ProfOff {
   size_t flags, in_off, in_src, in_lp, ao_off, ao_dst, ao_lp, no_off, no_dst, no_lp;
-  size_t lp_absorb, sub, ins, rootsub, env, cls, cls_rep, pack, ecls, subc, insc, rootsubc;
+  size_t lp_absorb, sub, ins, rootsub, env, cls, cls_rep, pack, ecls, subc, insc, rootsubc, fpack;
   bool has_env;
   int n, empty, n_cls, chain, interior_emit, lp_zero;
 };
@@ -225,6 +228,7 @@ int flatten_profile(const hx_profile* p, int CA, bool need_env, bool is_y, Arena
     o.ecls = ar.put(ecls.data(), sizeof(int32_t) * N);
   }
   o.pack = ar.reserve(sizeof(double) * 4 * (size_t)N);
+  o.fpack = ar.reserve(sizeof(FwdPack) * (size_t)N);
   o.subc = ar.reserve(sizeof(double) * cls_rep.size() * (size_t)CA);
   o.insc = ar.reserve(sizeof(double) * cls_rep.size());
   o.rootsubc = ar.reserve(sizeof(double) * cls_rep.size());
@@ -260,6 +264,7 @@ void bind_profile(DevProfile& d, const ProfOff& o, char* base) {
   d.n_cls = o.n_cls;
   d.pad_ = 0;
   d.pack = reinterpret_cast<double*>(base + o.pack);
+  d.fpack = reinterpret_cast<FwdPack*>(base + o.fpack);
   d.subc = reinterpret_cast<double*>(base + o.subc);
   d.insc = reinterpret_cast<double*>(base + o.insc);
   d.rootsubc = reinterpret_cast<double*>(base + o.rootsubc);
@@ -269,8 +274,67 @@ void bind_profile(DevProfile& d, const ProfOff& o, char* base) {
 struct JobOff {
   ProfOff x, y;
   size_t log_root, log_sub_l, log_sub_r, log_ins_l, log_ins_r, log_cptw_l, log_cptw_r, emis, emis_pad, scalars;
+  size_t fwd_windows, bwd_windows;
+  int64_t eplane_off;     // into hx_batch::d_eplane, or -1
   bool table_emission;
 };
+
+// Step windows of the general-profile strip pipeline (hx_dag.hip): for every 64-row strip of the sweep
+// (mirrored for Backward) up to two half-open ranges of steps t = column + row-in-strip that together
+// contain all of the strip's in-envelope cells (reference src/forward.h:92-98: a cell is in the envelope
+// when it is at an edge or within max_distance of the guide alignment).  Supersets are harmless.
+std::vector<int32_t> strip_windows(const uint8_t* xf, const int32_t* xenv, const uint8_t* yf, const int32_t* yenv,
+                                   int R, int Cc, int band, bool mirrored) {
+  const int n_strips = (R + HX_STRIP - 1) / HX_STRIP;
+  const int nsteps = Cc + HX_STRIP - 1;
+  std::vector<int32_t> w(4 * (size_t)n_strips, 0);
+  int V = 0;
+  for (int j = 0; j < Cc; ++j) V = std::max(V, (int)yenv[j]);
+  for (int i = 0; i < R; ++i) V = std::max(V, (int)xenv[i]);
+  const bool cheap = (int64_t)R * (2 * (int64_t)band + 1) <= (int64_t)1 << 26;
+  std::vector<int> minj(V + 1, INT_MAX), maxj(V + 1, -1);
+  for (int j = 0; j < Cc; ++j) {
+    const int v = yenv[j] < 0 ? 0 : yenv[j];
+    minj[v] = std::min(minj[v], j);
+    maxj[v] = std::max(maxj[v], j);
+  }
+  int ejmin = INT_MAX, ejmax = -1;
+  for (int j = 0; j < Cc; ++j)
+    if (yf[j] & F_EDGE) { ejmin = std::min(ejmin, j); ejmax = std::max(ejmax, j); }
+  for (int s = 0; s < n_strips; ++s) {
+    int lo = INT_MAX, hi = -1;            // band window (inclusive steps)
+    bool whole = !cheap;
+    const int rows = std::min(HX_STRIP, R - s * HX_STRIP);
+    for (int l = 0; l < rows && !whole; ++l) {
+      const int im = s * HX_STRIP + l, i = mirrored ? R - 1 - im : im;
+      if (xf[i] & F_EDGE) { whole = true; break; }
+      int jmin = INT_MAX, jmax = -1;
+      const int xe = xenv[i] < 0 ? 0 : xenv[i];
+      for (int v = std::max(0, xe - band); v <= std::min(V, xe + band); ++v) {
+        jmin = std::min(jmin, minj[v]);
+        jmax = std::max(jmax, maxj[v]);
+      }
+      if (jmax < 0) continue;
+      const int a = mirrored ? Cc - 1 - jmax : jmin, b = mirrored ? Cc - 1 - jmin : jmax;
+      lo = std::min(lo, a + l);
+      hi = std::max(hi, b + l);
+    }
+    int32_t* o = &w[4 * (size_t)s];
+    if (whole) { o[0] = 0; o[1] = nsteps; continue; }
+    int elo = INT_MAX, ehi = -1;          // edge-column window
+    if (ejmax >= 0) {
+      const int a = mirrored ? Cc - 1 - ejmax : ejmin, b = mirrored ? Cc - 1 - ejmin : ejmax;
+      elo = a; ehi = b + rows - 1;
+    }
+    if (hi < 0 && ehi < 0) continue;      // nothing in the envelope: both windows empty
+    if (hi < 0) { o[0] = elo; o[1] = ehi + 1; continue; }
+    if (ehi < 0) { o[0] = lo; o[1] = hi + 1; continue; }
+    if (elo <= hi + 1 && lo <= ehi + 1) { o[0] = std::min(lo, elo); o[1] = std::max(hi, ehi) + 1; continue; }
+    if (lo < elo) { o[0] = lo; o[1] = hi + 1; o[2] = elo; o[3] = ehi + 1; }
+    else { o[0] = elo; o[1] = ehi + 1; o[2] = lo; o[3] = hi + 1; }
+  }
+  return w;
+}
 
 }  // namespace
 
@@ -283,6 +347,9 @@ struct hx_batch {
   char* d_arena = nullptr;
   double* d_fwd = nullptr;
   double* d_bwd = nullptr;
+  double* d_eplane = nullptr;       // per-cell emission planes of the jobs without a class-pair table
+  double* d_agg = nullptr;          // outgoing-sum planes of the general-profile Forward pipeline (same size as d_fwd)
+  int64_t fwd_total = 0, max_eplane = 0;
   int max_states = 0, max_ca = 0, max_cls_pairs = 0, max_rows = 0, max_cls = 0;
   bool all_chain = true, all_leaf = true, all_ylds = true, any_banded = false;
   int64_t total_cells = 0;
@@ -343,7 +410,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
   Arena ar;
   std::vector<JobOff> offs(n_jobs);
   std::vector<int64_t> mat_off(n_jobs);
-  int64_t mat_total = 0;
+  int64_t mat_total = 0, eplane_total = 0;
   int rc = HX_OK;
   for (int k = 0; k < n_jobs && rc == HX_OK; ++k) {
     const hx_pair_job& pj = jobs[k];
@@ -371,6 +438,17 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     jo.emis = jo.table_emission ? ar.reserve(sizeof(double) * pairs) : 0;
     jo.emis_pad = jo.table_emission ? ar.reserve(sizeof(double) * (jo.x.n_cls + 1) * (jo.y.n_cls + 1)) : 0;
     jo.scalars = ar.reserve(sizeof(double) * 2);
+    jo.fwd_windows = jo.bwd_windows = 0;
+    if (need_env) {
+      const int R = jo.x.n - 1, Cc = jo.y.n - 1;
+      // (copies: put() may reallocate the staging image the pointers would point into)
+      const std::vector<uint8_t> xf(ar.host.data() + jo.x.flags, ar.host.data() + jo.x.flags + jo.x.n);
+      const std::vector<uint8_t> yf(ar.host.data() + jo.y.flags, ar.host.data() + jo.y.flags + jo.y.n);
+      const std::vector<int32_t> wf = strip_windows(xf.data(), pj.x->env_pos, yf.data(), pj.y->env_pos, R, Cc, pj.max_distance, false);
+      const std::vector<int32_t> wb = strip_windows(xf.data(), pj.x->env_pos, yf.data(), pj.y->env_pos, R, Cc, pj.max_distance, true);
+      jo.fwd_windows = ar.put(wf.data(), sizeof(int32_t) * wf.size());
+      jo.bwd_windows = ar.put(wb.data(), sizeof(int32_t) * wb.size());
+    }
 
     DevJob& J = b->jobs[k];
     memset(&J, 0, sizeof(J));
@@ -391,6 +469,12 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     L.mirrored = 0; L.pad_ = 0;
     mat_off[k] = mat_total;
     mat_total += 5 * J.plane;
+    jo.eplane_off = -1;
+    if (!jo.table_emission && pairs > 0) {
+      jo.eplane_off = eplane_total;
+      eplane_total += J.plane;
+      if (J.plane > b->max_eplane) b->max_eplane = J.plane;
+    }
     b->total_cells += (int64_t)J.n_rows * J.n_cols;
     if (jo.x.n > b->max_states) b->max_states = jo.x.n;
     if (jo.y.n > b->max_states) b->max_states = jo.y.n;
@@ -415,6 +499,13 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     return cleanup(fail(HX_ERR_HIP, "input upload failed"));
   if (hipMalloc(reinterpret_cast<void**>(&b->d_fwd), sizeof(double) * (size_t)mat_total) != hipSuccess)
     return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld Forward-matrix bytes failed", (long long)(mat_total * 8)));
+  b->fwd_total = mat_total;
+  if (eplane_total > 0)
+    if (hipMalloc(reinterpret_cast<void**>(&b->d_eplane), sizeof(double) * (size_t)eplane_total) != hipSuccess)
+      return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld emission-plane bytes failed", (long long)(eplane_total * 8)));
+  if ((!b->all_chain || getenv("HX_FORCE_DAG")) && !(flags & HX_FORCE_GENERIC))
+    if (hipMalloc(reinterpret_cast<void**>(&b->d_agg), sizeof(double) * (size_t)mat_total) != hipSuccess)
+      return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld scratch bytes failed", (long long)(mat_total * 8)));
   if (flags & HX_KEEP_BACKWARD)
     if (hipMalloc(reinterpret_cast<void**>(&b->d_bwd), sizeof(double) * (size_t)mat_total) != hipSuccess)
       return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld Backward-matrix bytes failed", (long long)(mat_total * 8)));
@@ -434,6 +525,10 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     J.log_cptw_r = reinterpret_cast<double*>(base + jo.log_cptw_r);
     J.emis = jo.table_emission ? reinterpret_cast<double*>(base + jo.emis) : nullptr;
     J.emis_pad = jo.table_emission ? reinterpret_cast<double*>(base + jo.emis_pad) : nullptr;
+    J.emis_plane = jo.eplane_off >= 0 ? b->d_eplane + jo.eplane_off : nullptr;
+    J.agg = b->d_agg ? b->d_agg + mat_off[k] : nullptr;
+    J.fwd_windows = J.max_dist >= 0 ? reinterpret_cast<int32_t*>(base + jo.fwd_windows) : nullptr;
+    J.bwd_windows = J.max_dist >= 0 ? reinterpret_cast<int32_t*>(base + jo.bwd_windows) : nullptr;
     J.lp_end = reinterpret_cast<double*>(base + jo.scalars);
     J.lp_start = J.lp_end + 1;
     J.fwd = b->d_fwd + mat_off[k];
@@ -460,6 +555,8 @@ int hx_batch_destroy(hx_batch* b) {
   if (b->d_arena) (void)hipFree(b->d_arena);
   if (b->d_fwd) (void)hipFree(b->d_fwd);
   if (b->d_bwd) (void)hipFree(b->d_bwd);
+  if (b->d_eplane) (void)hipFree(b->d_eplane);
+  if (b->d_agg) (void)hipFree(b->d_agg);
   delete b;
   return HX_OK;
 }
@@ -469,11 +566,23 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_cls, b->max_ca, b->max_cls_pairs, g_tab, st);
   HIP_TRY(hipEventRecord(b->ev[0][0], st));
-  if (b->all_chain && !(b->flags & HX_FORCE_GENERIC))
+  // per-cell emission terms of the jobs without a class-pair table (general profiles).  Part of the fill:
+  // the reference evaluates them inside its fill loop, so the launch is inside the timed region.
+  if (!(b->flags & HX_FORCE_GENERIC)) launch_emission_plane(b->d_jobs, b->n_jobs, b->max_eplane, g_tab, st);
+  static const bool force_dag = getenv("HX_FORCE_DAG") != nullptr;   // tuning hook: general pipeline for chain profiles too
+  if (b->all_chain && !(b->flags & HX_FORCE_GENERIC) && !(force_dag && b->d_agg))
     launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,
                          b->all_leaf ? (b->all_ylds ? 2 : 1) : 0, b->any_banded, st);
-  else
+  else if (b->flags & HX_FORCE_GENERIC)
     launch_forward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
+  else {
+    // general profiles: the strip pipeline; with a band it only visits in-envelope windows, the rest is -inf
+    if (b->any_banded) {
+      launch_fill_neg_inf(b->d_fwd, b->fwd_total, st);
+      launch_fill_neg_inf(b->d_agg, b->fwd_total, st);
+    }
+    launch_forward_dag_pipe(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0, st);
+  }
   HIP_TRY(hipEventRecord(b->ev[0][1], st));
   HIP_TRY(hipGetLastError());
   b->ev_valid[0] = true;
@@ -504,8 +613,12 @@ int hx_batch_backward(hx_batch* b, void* stream) {
   if (b->all_leaf && !(b->flags & HX_FORCE_GENERIC))
     launch_backward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,
                           b->all_ylds ? 2 : 1, b->any_banded, st);
-  else
+  else if (b->flags & HX_FORCE_GENERIC)
     launch_backward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
+  else {
+    if (b->any_banded) launch_fill_neg_inf(b->d_bwd, b->fwd_total, st);
+    launch_backward_dag_pipe(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0, st);
+  }
   HIP_TRY(hipEventRecord(b->ev[1][1], st));
   HIP_TRY(hipGetLastError());
   b->ev_valid[1] = true;

@@ -26,122 +26,10 @@
 #include "hx_device.h"
 #include "hx_lse.h"
 #include "hx_common.h"
+#include "hx_policy.h"
 #include "hx_kernels.h"
 
 namespace hx {
-
-// global-address-space views of pointers that were loaded from the job table (the compiler
-// would otherwise have to use flat_* instructions, which tie up both memory counters)
-#define HX_GLOBAL __attribute__((address_space(1)))
-#define HX_LDS __attribute__((address_space(3)))
-template <class T> __device__ __forceinline__ HX_GLOBAL T* as_global(T* p) { return (HX_GLOBAL T*)p; }
-template <class T> __device__ __forceinline__ const HX_GLOBAL T* as_global(const T* p) { return (const HX_GLOBAL T*)p; }
-
-typedef double d4v __attribute__((ext_vector_type(4)));
-
-struct alignas(16) FastPiece { double c0; float c1, c2; };   // 16 bytes: one ds_read_b128 per log-sum-exp
-
-// v_max_f64 / v_min_f64 without the canonicalisation moves the builtins add for sNaN inputs
-// (v_min_f64 returns the non-NaN operand, which the clamping below relies on).
-__device__ __forceinline__ double vmax(double a, double b) {
-  double r;
-  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ double vmin(double a, double b) {
-  double r;
-  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
-// A log-sum-exp policy is used in three phases so that the independent table look-ups of a
-// cell can be issued back to back:  prep (index arithmetic) -> fetch (the memory access) ->
-// finish (interpolation + add).  operator() runs the three in sequence.
-struct FastLse {
-  const FastPiece* lds;   // [HX_FAST_INTERVALS + 1] quadratic pieces in t in [0,1); last piece all zero
-  struct Prep { double mx, t; int k; };
-  typedef FastPiece Piece;
-  // Branch- and select-free.  d = |a - b| is scaled to table units and clamped to the
-  // all-zero guard piece, which yields T = 0 for d >= 10, d = +inf and d = NaN (-inf - -inf):
-  // exactly the reference's truncation.
-  __device__ __forceinline__ Prep prep(double a, double b) const {
-    Prep p;
-    p.mx = vmax(a, b);
-    const double d = a - b;
-#if HX_ABLATE == 5
-    p.k = 3; p.t = d * 1e-9; return p;
-#endif
-    const double s = vmin(__builtin_fabs(d) * (HX_FAST_INTERVALS / 10.0), (double)HX_FAST_INTERVALS);
-    p.k = (int)s;
-    p.t = __builtin_amdgcn_fract(s);
-    return p;
-  }
-#ifndef HX_ABLATE
-#define HX_ABLATE 0
-#endif
-#if HX_ABLATE == 2 || HX_ABLATE == 9
-  __device__ __forceinline__ Piece fetch(const Prep& p) const { return Piece{0.6931 + p.k * 1e-9, -0.0049f, 3e-6f}; }
-#else
-  __device__ __forceinline__ Piece fetch(const Prep& p) const {
-    // exactly one 16-byte LDS access (ds_read_b128): c0 is the first double, the two fp32
-    // coefficients are the halves of the second
-    typedef double d2v __attribute__((ext_vector_type(2)));
-    const d2v v = reinterpret_cast<const d2v*>(lds)[p.k];
-    Piece c;
-    c.c0 = v.x;
-    c.c1 = __uint_as_float((unsigned)__double2loint(v.y));
-    c.c2 = __uint_as_float((unsigned)__double2hiint(v.y));
-    return c;
-  }
-#endif
-  __device__ __forceinline__ double finish(const Prep& p, const Piece& c) const {
-    return p.mx + __builtin_fma(__builtin_fma((double)c.c2, p.t, (double)c.c1), p.t, c.c0);
-  }
-  __device__ __forceinline__ double operator()(double a, double b) const {
-    const Prep p = prep(a, b);
-    return finish(p, fetch(p));
-  }
-  static __device__ __forceinline__ FastLse make(const double* p) { return FastLse{reinterpret_cast<const FastPiece*>(p)}; }
-};
-
-// The reference's table operator (hx_lse.h), phased the same way; bit-identical to lse().
-struct ExactLse3 {
-  const double* __restrict__ tab;
-  struct Prep { double mx, x; int n; bool in; };
-  struct Piece { double f0, f1; };
-  __device__ __forceinline__ Prep prep(double a, double b) const {
-    Prep p;
-    p.mx = vmax(a, b);
-    p.x = p.mx - vmin(a, b);                 // NaN for (-inf,-inf): "no lookup"
-    p.in = p.x < 10.0;
-    p.n = p.in ? (int)div_by_1em4(p.x) : 0;
-    return p;
-  }
-  __device__ __forceinline__ Piece fetch(const Prep& p) const { return Piece{tab[p.n], tab[p.n + 1]}; }
-  __device__ __forceinline__ double finish(const Prep& p, const Piece& c) const {
-    const double dx = p.x - ((double)p.n * 1e-4);
-    const double df = c.f1 - c.f0;
-    const double ret = c.f0 + df * div_by_1em4(dx);
-    return p.mx + (p.in ? ret : 0.0);
-  }
-  __device__ __forceinline__ double operator()(double a, double b) const {
-    const Prep p = prep(a, b);
-    return finish(p, fetch(p));
-  }
-  static __device__ __forceinline__ ExactLse3 make(const double* p) { return ExactLse3{p}; }
-};
-
-struct C5 { double imm, imd, idm, imi, iiw; };
-
-__device__ __forceinline__ C5 c5_neg_inf() { return C5{HX_NEG_INF, HX_NEG_INF, HX_NEG_INF, HX_NEG_INF, HX_NEG_INF}; }
-
-// value held by the previous lane (lane 0 keeps its own): one v_mov_b32_dpp per dword
-__device__ __forceinline__ double wave_shr1(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
 
 // dst lane l >= 1 receives src of lane l-1; lane 0 keeps `old` (DPP leaves lanes without a
 // source untouched when bound_ctrl is off)

@@ -1,0 +1,803 @@
+// Strip-pipelined Forward / Backward fills for general profiles (state DAGs with null
+// states, ready/wait flags, fan-in > 1 and an optional guide-alignment band):
+//   reference src/forward.cpp:68-223 (ForwardMatrix::ForwardMatrix)
+//   reference src/forward.cpp:975-1088 (BackwardMatrix::BackwardMatrix)
+//
+// Same decomposition as the chain kernels (hx_chain.hip): one workgroup per pair, its waves
+// take 64-row strips round-robin, lane <-> row, step <-> anti-diagonal, every wave on its own
+// clock.  What differs is where a cell's sources come from.  A profile state may have any
+// number of in-transitions from any earlier state, so sources are not "the lane above, one
+// step ago": they are read back from the matrix itself (L1/L2 hits: the workgroup's own
+// recent stores).  That needs two orderings and nothing else:
+//   * own strip:   a wave drains its stores (s_waitcnt vmcnt(0)) at the end of every step, so
+//                  the next step's loads see every earlier anti-diagonal of the strip;
+//   * strips above: a wave publishes, after that drain, how many columns of its strip are
+//                  complete (monotonic LDS counter); the wave below does not enter step t
+//                  before columns 0..t of the strip above are published.  Strips further up
+//                  completed those columns earlier still.
+// All waves of a workgroup share one CU and one L1, so draining + the LDS counter is a
+// workgroup-scope release/acquire; no cache maintenance is needed.
+//
+// The emission term of an IMM cell (computeLogProbAbsorb, reference src/forward.h:112-124)
+// does not depend on the DP values: it is evaluated for all cells up front by a fully parallel
+// kernel into a sixth plane in the matrix layout (or taken from the class-pair table when the
+// profiles have few distinct columns), so the dependent chain of a cell is the 12-or-so
+// transition log-sum-exps only.
+//
+// With a band (GuideAlignmentEnvelope), a strip only visits the step windows in which it has
+// in-envelope cells; everything else stays at the -inf the matrix was pre-filled with, which is
+// what the reference's cell() returns for cells it never stored (src/forward.h:68-88).
+//
+// Compiled with -ffp-contract=off (see hx_lse.h).
+#include <hip/hip_runtime.h>
+#include "hx_device.h"
+#include "hx_lse.h"
+#include "hx_common.h"
+#include "hx_policy.h"
+#include "hx_kernels.h"
+
+#ifndef HX_DAG_ABLATE
+#define HX_DAG_ABLATE 0
+#endif
+
+namespace hx {
+
+namespace {
+
+struct Side {
+  const HX_GLOBAL uint8_t* flags;
+  const HX_GLOBAL int32_t* in_off;
+  const HX_GLOBAL int32_t* in_src;
+  const HX_GLOBAL double* in_lp;
+  const HX_GLOBAL int32_t* ao_off;
+  const HX_GLOBAL int32_t* ao_dst;
+  const HX_GLOBAL double* ao_lp;
+  const HX_GLOBAL int32_t* no_off;
+  const HX_GLOBAL int32_t* no_dst;
+  const HX_GLOBAL double* no_lp;
+  const HX_GLOBAL double* ins;
+  const HX_GLOBAL double* rootsub;
+  const HX_GLOBAL int32_t* env;
+  const HX_GLOBAL int32_t* cls;
+  int n, empty, n_cls;
+};
+
+__device__ __forceinline__ Side make_side(const DevProfile& P) {
+  Side s;
+  s.flags = as_global(P.flags);
+  s.in_off = as_global(P.in_off); s.in_src = as_global(P.in_src); s.in_lp = as_global(P.in_lp);
+  s.ao_off = as_global(P.ao_off); s.ao_dst = as_global(P.ao_dst); s.ao_lp = as_global(P.ao_lp);
+  s.no_off = as_global(P.no_off); s.no_dst = as_global(P.no_dst); s.no_lp = as_global(P.no_lp);
+  s.ins = as_global((const double*)P.ins); s.rootsub = as_global((const double*)P.rootsub);
+  s.env = as_global(P.env); s.cls = as_global(P.cls);
+  s.n = P.n; s.empty = P.empty; s.n_cls = P.n_cls;
+  return s;
+}
+
+struct Mat {
+  HX_GLOBAL double* M;                 // the matrix being filled
+  const HX_GLOBAL double* etab;        // class-pair emission table, or null
+  const HX_GLOBAL double* eplane;      // per-cell emission plane (Forward layout), or null
+  int64_t plane, ss;
+  int R, Cc, max_dist;
+};
+
+__device__ __forceinline__ C5 ld5(const HX_GLOBAL double* M, int64_t plane, int64_t slot) {
+  return C5{M[slot], M[plane + slot], M[2 * plane + slot], M[3 * plane + slot], M[4 * plane + slot]};
+}
+
+__device__ __forceinline__ double emis_at(const Mat& m, const Side& x, const Side& y, int i, int j) {
+  if (m.etab) {
+    // a hand-edited profile may route an absorbing transition into a null state
+    // (reference t/testnullforward.cpp:37-39); such a pair emits nothing
+    const int cx = x.cls[i], cy = y.cls[j];
+    return (cx < 0 || cy < 0) ? HX_NEG_INF : m.etab[(int64_t)cx * y.n_cls + cy];
+  }
+  return m.eplane[cell_slot(m.ss, i, j)];
+}
+
+__device__ __forceinline__ bool in_env(const Mat& m, uint8_t xf, uint8_t yf, int xe, int ye) {
+  if ((xf | yf) & F_EDGE) return true;
+  if (m.max_dist < 0) return true;
+  int d = xe - ye;
+  d = d < 0 ? -d : d;
+  return d <= m.max_dist;
+}
+
+// one Forward cell (reference src/forward.cpp:78-203); the caller has checked the envelope
+template <class LSE>
+__device__ __forceinline__ C5 forward_cell_dag(const Mat& m, const Side& x, const Side& y, const double (*T)[6],
+                                               const LSE& L, int i, int j, uint8_t xf, uint8_t yf) {
+  const HX_GLOBAL double* M = m.M;
+  const int64_t plane = m.plane, ss = m.ss;
+  C5 r = c5_neg_inf();
+  if (i == 0 && j == 0) r.imm = 0.0;
+  const bool xnull = xf & F_NULL, ynull = yf & F_NULL;
+  const bool yok = (yf & F_READY) || y.empty;   // yState.isReady() || yEmpty
+  const bool xok = (xf & F_READY) || x.empty;
+  const int xb = x.in_off[i], xe = x.in_off[i + 1];
+  const int yb = y.in_off[j], ye = y.in_off[j + 1];
+
+  if (!xnull) {
+    if (yok) {
+      for (int t = xb; t < xe; ++t) {
+        const C5 s = ld5(M, plane, cell_slot(ss, x.in_src[t], j));
+        const double lp = x.in_lp[t];
+        double a = L(s.imm + T[0][1], s.imd + T[1][1]);
+        double b = L(s.imm + T[0][4], s.imi + T[3][4]);
+        a = L(a, s.idm + T[2][1]);
+        b = L(b, s.iiw + T[4][4]);
+        a = L(a, s.imi + T[3][1]);
+        r.imd = L(r.imd, a + lp);
+        r.iiw = L(r.iiw, b + lp);
+      }
+      r.imd += x.rootsub[i];
+      r.iiw += x.ins[i];
+    }
+  } else if (yok) {
+    for (int t = xb; t < xe; ++t) {
+      const int64_t sl = cell_slot(ss, x.in_src[t], j);
+      const double lp = x.in_lp[t];
+      r.imd = L(r.imd, M[plane + sl] + lp);
+      r.iiw = L(r.iiw, M[4 * plane + sl] + lp);
+    }
+  }
+
+  if (!ynull) {
+    if (xok) {
+      for (int t = yb; t < ye; ++t) {
+        const C5 s = ld5(M, plane, cell_slot(ss, i, y.in_src[t]));
+        const double lp = y.in_lp[t];
+        double a = L(s.imm + T[0][2], s.imd + T[1][2]);
+        const double b = L(s.imm + T[0][3], s.imi + T[3][3]);
+        a = L(a, s.idm + T[2][2]);
+        a = L(a, s.iiw + T[4][2]);
+        r.idm = L(r.idm, a + lp);
+        r.imi = L(r.imi, b + lp);
+      }
+      r.idm += y.rootsub[j];
+      r.imi += y.ins[j];
+    }
+  } else {
+    for (int t = yb; t < ye; ++t) {
+      const int64_t sl = cell_slot(ss, i, y.in_src[t]);
+      const double lp = y.in_lp[t];
+      r.idm = L(r.idm, M[2 * plane + sl] + lp);
+      r.imi = L(r.imi, M[3 * plane + sl] + lp);
+    }
+  }
+
+  if (!xnull && !ynull) {
+    for (int tx = xb; tx < xe; ++tx) {
+      const int sx = x.in_src[tx];
+      const double lpx = x.in_lp[tx];
+      for (int ty = yb; ty < ye; ++ty) {
+        const C5 s = ld5(M, plane, cell_slot(ss, sx, y.in_src[ty]));
+        double a = L(s.imm + T[0][0], s.imd + T[1][0]);
+        a = L(a, s.idm + T[2][0]);
+        a = L(a, s.imi + T[3][0]);
+        a = L(a, s.iiw + T[4][0]);
+        r.imm = L(r.imm, a + lpx + y.in_lp[ty]);
+      }
+    }
+    r.imm += emis_at(m, x, y, i, j);
+  } else if (ynull && (xf & F_EMIT_OR_START)) {
+    for (int t = yb; t < ye; ++t) r.imm = L(r.imm, M[cell_slot(ss, i, y.in_src[t])] + y.in_lp[t]);
+  } else if (yok) {
+    for (int t = xb; t < xe; ++t) r.imm = L(r.imm, M[cell_slot(ss, x.in_src[t], j)] + x.in_lp[t]);
+  }
+  return r;
+}
+
+// one Backward cell (reference src/forward.cpp:996-1086); B is stored mirrored (hx_device.h)
+template <class LSE>
+__device__ __forceinline__ C5 backward_cell_dag(const Mat& m, const Side& x, const Side& y, const double (*T)[6],
+                                                const LSE& L, int i, int j, uint8_t xf, uint8_t yf) {
+  const HX_GLOBAL double* M = m.M;
+  const int64_t plane = m.plane, ss = m.ss;
+  const int R = m.R, Cc = m.Cc;
+#define BS(a, b) bwd_slot(ss, R, Cc, (a), (b))
+  C5 r = c5_neg_inf();
+  // cells that feed END are initialised by assignment (src/forward.cpp:981-995)
+  if ((xf & F_TO_END) && (yf & F_TO_END)) {
+    const int xe = x.n - 1, ye = y.n - 1;
+    for (int tx = x.in_off[xe]; tx < x.in_off[xe + 1]; ++tx)
+      for (int ty = y.in_off[ye]; ty < y.in_off[ye + 1]; ++ty)
+        if (x.in_src[tx] == i && y.in_src[ty] == j) {
+          const double lp = x.in_lp[tx] + y.in_lp[ty];
+          r = C5{lp + T[0][5], lp + T[1][5], lp + T[2][5], lp + T[3][5], lp + T[4][5]};
+        }
+  }
+  const bool yok = (yf & F_READY) || y.empty;
+  const bool xok = (xf & F_READY) || x.empty;
+  const int xab = x.ao_off[i], xae = x.ao_off[i + 1];
+  const int yab = y.ao_off[j], yae = y.ao_off[j + 1];
+  const int xnb = x.no_off[i], xne = x.no_off[i + 1];
+  const int ynb = y.no_off[j], yne = y.no_off[j + 1];
+
+  for (int tx = xab; tx < xae; ++tx) {
+    const int dx = x.ao_dst[tx];
+    const double lpx = x.ao_lp[tx];
+    for (int ty = yab; ty < yae; ++ty) {
+      const int dy = y.ao_dst[ty];
+      const double d = lpx + y.ao_lp[ty] + emis_at(m, x, y, dx, dy) + M[BS(dx, dy)];
+      r.imm = L(r.imm, T[0][0] + d);
+      r.imd = L(r.imd, T[1][0] + d);
+      r.idm = L(r.idm, T[2][0] + d);
+      r.imi = L(r.imi, T[3][0] + d);
+      r.iiw = L(r.iiw, T[4][0] + d);
+    }
+  }
+  if (yok)
+    for (int tx = xab; tx < xae; ++tx) {
+      const int dx = x.ao_dst[tx];
+      const double lpx = x.ao_lp[tx];
+      const int64_t sl = BS(dx, j);
+      const double d1 = lpx + x.rootsub[dx] + M[plane + sl];
+      const double d2 = lpx + x.ins[dx] + M[4 * plane + sl];
+      r.imm = L(r.imm, T[0][1] + d1);
+      r.imd = L(r.imd, T[1][1] + d1);
+      r.idm = L(r.idm, T[2][1] + d1);
+      r.imi = L(r.imi, T[3][1] + d1);
+      r.imm = L(r.imm, T[0][4] + d2);
+      r.imi = L(r.imi, T[3][4] + d2);
+      r.iiw = L(r.iiw, T[4][4] + d2);
+    }
+  if (xok)
+    for (int ty = yab; ty < yae; ++ty) {
+      const int dy = y.ao_dst[ty];
+      const double lpy = y.ao_lp[ty];
+      const int64_t sl = BS(i, dy);
+      const double d1 = lpy + y.rootsub[dy] + M[2 * plane + sl];
+      const double d2 = lpy + y.ins[dy] + M[3 * plane + sl];
+      r.imm = L(r.imm, T[0][2] + d1);
+      r.imd = L(r.imd, T[1][2] + d1);
+      r.idm = L(r.idm, T[2][2] + d1);
+      r.iiw = L(r.iiw, T[4][2] + d1);
+      r.imm = L(r.imm, T[0][3] + d2);
+      r.imi = L(r.imi, T[3][3] + d2);
+    }
+  if (yok)
+    for (int tx = xnb; tx < xne; ++tx) {
+      const int dx = x.no_dst[tx];
+      if (dx >= R) continue;   // END is not stored: xyCell(END,.) is the empty cell
+      const double lpx = x.no_lp[tx];
+      const int64_t sl = BS(dx, j);
+      r.imd = L(r.imd, lpx + M[plane + sl]);
+      r.iiw = L(r.iiw, lpx + M[4 * plane + sl]);
+      r.imm = L(r.imm, lpx + M[sl]);
+    }
+  for (int ty = ynb; ty < yne; ++ty) {
+    const int dy = y.no_dst[ty];
+    if (dy >= Cc) continue;
+    const double lpy = y.no_lp[ty];
+    const int64_t sl = BS(i, dy);
+    r.idm = L(r.idm, lpy + M[2 * plane + sl]);
+    r.imi = L(r.imi, lpy + M[3 * plane + sl]);
+    if (xf & F_EMIT_OR_START) r.imm = L(r.imm, lpy + M[sl]);
+  }
+#undef BS
+  return r;
+}
+
+#define HX_DAG_MAX_WAVES 16
+
+// DIR 0: Forward, DIR 1: Backward (swept in mirrored coordinates)
+template <int DIR, class LSE, bool FAST>
+__global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_fill_dag(const DevJob* __restrict__ jobs,
+                                                                      const double* __restrict__ exact_tab,
+                                                                      const double* __restrict__ fast_tab) {
+  __shared__ volatile int prog[HX_DAG_MAX_WAVES];
+  __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : 2];
+  const int threads = blockDim.x, W = threads >> 6;
+  if (FAST)
+    for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 2; k += threads) ftab[k] = fast_tab[k];
+  if (threadIdx.x < HX_DAG_MAX_WAVES) prog[threadIdx.x] = 0;
+  __syncthreads();
+  const LSE L = LSE::make(FAST ? (const double*)ftab : exact_tab);
+  volatile HX_LDS int* progp = (volatile HX_LDS int*)prog;
+
+  const DevJob& J = jobs[blockIdx.x];
+  const Side x = make_side(J.x), y = make_side(J.y);
+  Mat m;
+  m.M = as_global(DIR ? J.bwd : J.fwd);
+  m.etab = as_global((const double*)J.emis);
+  m.eplane = as_global((const double*)J.emis_plane);
+  m.plane = J.plane; m.ss = J.strip_stride;
+  m.R = J.n_rows; m.Cc = J.n_cols; m.max_dist = J.max_dist;
+  const int R = m.R, Cc = m.Cc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_strips = (R + 63) >> 6;
+  const int prev_wave = (wave + W - 1) % W;
+  const bool banded = J.max_dist >= 0;
+  const HX_GLOBAL int32_t* win = as_global(DIR ? J.bwd_windows : J.fwd_windows);
+
+  for (int s = wave; s < n_strips; s += W) {
+    const int im = (s << 6) + lane;              // row in sweep coordinates
+    const bool rvalid = im < R;
+    const int i = rvalid ? (DIR ? R - 1 - im : im) : 0;
+    const uint8_t xf = x.flags[i];
+    const int xenv = banded ? x.env[i] : 0;
+    const int above_base = ((s - 1) / W) * Cc;   // columns the wave above published in its earlier strips
+    const int my_base = (s / W) * Cc;
+    const int64_t store_base = (int64_t)s * m.ss + (lane << 1);
+    int seen = 0;
+    // step windows [w0,w1) and [w2,w3) that hold this strip's in-envelope cells (whole sweep when unbanded)
+    int wlo[2] = {0, 0}, whi[2] = {Cc + 63, 0};
+    if (banded) {
+      wlo[0] = win[4 * s]; whi[0] = win[4 * s + 1];
+      wlo[1] = win[4 * s + 2]; whi[1] = win[4 * s + 3];
+    }
+    int published = 0;
+    for (int w = 0; w < 2; ++w) {
+      for (int t = wlo[w]; t < whi[w]; ++t) {
+        if (s > 0) {
+          const int need = above_base + (t + 1 < Cc ? t + 1 : Cc);
+          if (seen < need) {
+            do {
+              seen = __builtin_amdgcn_readfirstlane(progp[prev_wave]);
+              if (seen < need) __builtin_amdgcn_s_sleep(1);
+            } while (seen < need);
+            asm volatile("" ::: "memory");
+          }
+        }
+        const int jm = t - lane;
+        if (rvalid && jm >= 0 && jm < Cc) {
+          const int j = DIR ? Cc - 1 - jm : jm;
+          const uint8_t yf = y.flags[j];
+          if (in_env(m, xf, yf, xenv, banded ? y.env[j] : 0)) {
+            const C5 c = DIR ? backward_cell_dag(m, x, y, J.T, L, i, j, xf, yf)
+                             : forward_cell_dag(m, x, y, J.T, L, i, j, xf, yf);
+            const int64_t sl = store_base + ((int64_t)(t >> 1) << 7) + (t & 1);
+            m.M[sl] = c.imm;
+            m.M[m.plane + sl] = c.imd;
+            m.M[2 * m.plane + sl] = c.idm;
+            m.M[3 * m.plane + sl] = c.imi;
+            m.M[4 * m.plane + sl] = c.iiw;
+          }
+        }
+        // drain this step's stores: the next step (and, through the counter, the strip below) reads them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int done = t - 62;
+        done = done > Cc ? Cc : done;
+        if (done > published) {
+          published = done;
+          if (lane == 0) progp[wave] = my_base + done;
+        }
+      }
+      // columns between / after the windows hold no in-envelope cell of this strip: they count as complete
+      // once everything before them is
+      const int upto = (w == 0 && whi[1] > wlo[1]) ? wlo[1] - 63 : Cc;
+      int done = upto > Cc ? Cc : upto;
+      if (done > published) {
+        published = done;
+        if (lane == 0) progp[wave] = my_base + done;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (DIR == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
+    else *J.lp_start = J.bwd[cell_slot(m.ss, R - 1, Cc - 1)];   // B(0,0).IMM in mirrored coordinates
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Forward, second formulation.  Every cell also stores its five "outgoing sums"
+//   g0 = (+)_s cell[s] + T[s][IMD]   (s = IMM,IMD,IDM,IMI)     read by x-absorbing moves into IMD
+//   g1 = (+)_s cell[s] + T[s][IIW]   (s = IMM,IMI,IIW)         ...                       into IIW
+//   g2 = (+)_s cell[s] + T[s][IDM]   (s = IMM,IMD,IDM,IIW)     read by y-absorbing moves into IDM
+//   g3 = (+)_s cell[s] + T[s][IMI]   (s = IMM,IMI)             ...                       into IMI
+//   g4 = (+)_s cell[s] + T[s][IMM]   (all five)                read by xy-absorbing moves into IMM
+// (left-nested in the reference's order, src/forward.cpp:103-115,139-150,171-180: the reference
+// evaluates exactly these sums once per incoming transition, from the same source cell, so
+// evaluating them once at the source is bit-identical).  A destination then needs two values per
+// x- or y-transition and one per transition pair, and one log-sum-exp per value beyond the first.
+// Null destination states read the raw cell planes instead (src/forward.cpp:118-128,153-163,183-200).
+//
+// The dependent chain of a step is: one round of loads (all issued together: the first two
+// in-transitions of every state are inline in its 64-byte FwdPack, the row's pack lives in
+// registers, the column's pack is fetched one step ahead) -> accumulate -> the 13 look-ups of
+// the outgoing sums in 4 levels -> stores -> drain.
+// ---------------------------------------------------------------------------
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+struct PackRegs { double lp0, lp1, rootsub, ins; int s0, s1, in_b, meta, env, cls; };
+
+__device__ __forceinline__ PackRegs load_pack(const HX_GLOBAL FwdPack* p) {
+  const HX_GLOBAL d2v* q = (const HX_GLOBAL d2v*)p;
+  const d2v a = q[0], b = q[1], c = q[2], d = q[3];
+  PackRegs r;
+  r.lp0 = a.x; r.lp1 = a.y; r.rootsub = b.x; r.ins = b.y;
+  r.s0 = __double2loint(c.x); r.s1 = __double2hiint(c.x);
+  r.in_b = __double2loint(c.y); r.meta = __double2hiint(c.y);
+  r.env = __double2loint(d.x); r.cls = __double2hiint(d.x);
+  return r;
+}
+
+struct RowRef { int64_t base; int l; };
+__device__ __forceinline__ RowRef row_ref(int64_t ss, int r) {
+  return RowRef{(int64_t)(r >> 6) * ss + ((r & 63) << 1), r & 63};
+}
+__device__ __forceinline__ int64_t slot_at(const RowRef& r, int c) {
+  const int t = c + r.l;
+  return r.base + ((int64_t)(t >> 1) << 7) + (t & 1);
+}
+
+#define HX_DAGF_MAX_WAVES 8     // Forward pipeline: up to 8 waves (512 threads) so that a wave may use 256 VGPRs
+
+// what the next step may need from the cell a lane has just computed
+struct Fwd10 { double imm, imd, idm, imi, iiw, g0, g1, g2, g3, g4; };
+
+template <class LSE, bool FAST>
+__global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(const DevJob* __restrict__ jobs,
+                                                                               const double* __restrict__ exact_tab,
+                                                                               const double* __restrict__ fast_tab) {
+  __shared__ volatile int prog[HX_DAGF_MAX_WAVES];
+  __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : 2];
+  const int threads = blockDim.x, W = threads >> 6;
+  if (FAST)
+    for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 2; k += threads) ftab[k] = fast_tab[k];
+  if (threadIdx.x < HX_DAGF_MAX_WAVES) prog[threadIdx.x] = 0;
+  __syncthreads();
+  const LSE L = LSE::make(FAST ? (const double*)ftab : exact_tab);
+  volatile HX_LDS int* progp = (volatile HX_LDS int*)prog;
+
+  const DevJob& J = jobs[blockIdx.x];
+  const double (*T)[6] = J.T;
+  const int R = J.n_rows, Cc = J.n_cols;
+  const int64_t plane = J.plane, ss = J.strip_stride;
+  HX_GLOBAL double* M = as_global(J.fwd);
+  const int64_t aggoff = J.agg - J.fwd;          // the outgoing-sum planes, addressed relative to the matrix
+  const HX_GLOBAL double* etab = as_global((const double*)J.emis);
+  const HX_GLOBAL double* eplane = as_global((const double*)J.emis_plane);
+  const HX_GLOBAL FwdPack* xpk = as_global((const FwdPack*)J.x.fpack);
+  const HX_GLOBAL FwdPack* ypk = as_global((const FwdPack*)J.y.fpack);
+  const HX_GLOBAL int32_t* xin_src = as_global(J.x.in_src);
+  const HX_GLOBAL double* xin_lp = as_global(J.x.in_lp);
+  const HX_GLOBAL int32_t* yin_src = as_global(J.y.in_src);
+  const HX_GLOBAL double* yin_lp = as_global(J.y.in_lp);
+  const int Ky = J.y.n_cls;
+  const bool xempty = J.x.empty, yempty = J.y.empty;
+  const int max_dist = J.max_dist;
+  const bool banded = max_dist >= 0;
+  const HX_GLOBAL int32_t* win = as_global(J.fwd_windows);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_strips = (R + 63) >> 6;
+  const int prev_wave = (wave + W - 1) % W;
+  const double NI = HX_NEG_INF;
+
+  for (int s = wave; s < n_strips; s += W) {
+    const int i = (s << 6) + lane;
+    const bool rvalid = i < R;
+    const PackRegs X = load_pack(xpk + (rvalid ? i : 0));
+    const int xf = X.meta & 0xff, xdeg = X.meta >> 8;
+    const bool xnull = xf & F_NULL, xok = (xf & F_READY) || xempty, xeos = xf & F_EMIT_OR_START;
+    const RowRef own = RowRef{(int64_t)s * ss + (lane << 1), lane};
+    const RowRef X0 = row_ref(ss, X.s0), X1 = row_ref(ss, X.s1);
+    const int64_t offXa = xnull ? plane : aggoff, offXb = xnull ? 4 * plane : aggoff + plane;
+    // a source in the row directly above, inside this strip, is the previous lane's cell of the previous step:
+    // it is forwarded through registers (its store has not been issued yet, see below)
+    const bool adjx0 = lane > 0 && xdeg > 0 && X.s0 == i - 1;
+    const bool adjx1 = lane > 0 && xdeg > 1 && X.s1 == i - 1;
+    const int above_base = ((s - 1) / W) * Cc;
+    const int my_base = (s / W) * Cc;
+    int seen = 0, published = 0;
+    int wlo[2] = {0, 0}, whi[2] = {Cc + 63, 0};
+    if (banded) {
+      wlo[0] = win[4 * s]; whi[0] = win[4 * s + 1];
+      wlo[1] = win[4 * s + 2]; whi[1] = win[4 * s + 3];
+    }
+    for (int w = 0; w < 2; ++w) {
+      if (whi[w] <= wlo[w]) continue;
+      PackRegs Yn;
+      {
+        const int j0 = wlo[w] - lane;
+        Yn = load_pack(ypk + (j0 < 0 ? 0 : (j0 >= Cc ? Cc - 1 : j0)));
+      }
+      // results of the previous step: `own` this lane's cell (i, j-1), `up` the previous lane's cell (i-1, j).
+      // They are stored one step late (after the next step's loads have been issued): vector-memory
+      // operations retire in issue order, so a load issued after a store waits for that store to be
+      // acknowledged; issued before it, the load only queues behind stores that are a whole step old.
+      Fwd10 own10 = Fwd10{NI, NI, NI, NI, NI, NI, NI, NI, NI, NI};
+      double up_imm = NI, up_imd = NI, up_iiw = NI, up_g0 = NI, up_g1 = NI;
+      // (the first step's store goes to the slot that step's own cell will overwrite one step later)
+      int64_t pend_slot = own.base + ((int64_t)(wlo[w] >> 1) << 7) + (wlo[w] & 1);
+      for (int t = wlo[w]; t < whi[w]; ++t) {
+#if HX_DAG_ABLATE != 5
+        if (s > 0) {
+          const int need = above_base + (t + 1 < Cc ? t + 1 : Cc);
+          if (seen < need) {
+            do {
+              seen = __builtin_amdgcn_readfirstlane(progp[prev_wave]);
+              if (seen < need) __builtin_amdgcn_s_sleep(1);
+            } while (seen < need);
+            asm volatile("" ::: "memory");
+          }
+        }
+#endif
+        const PackRegs Y = Yn;
+        const int j = t - lane;
+        const int yf = Y.meta & 0xff, ydeg = Y.meta >> 8;
+        bool act = rvalid && j >= 0 && j < Cc;
+        if (banded) {
+          int dd = X.env - Y.env;
+          dd = dd < 0 ? -dd : dd;
+          act = act && (((xf | yf) & F_EDGE) || dd <= max_dist);
+        }
+        const bool ynull = yf & F_NULL, yok = (yf & F_READY) || yempty;
+        const int mode = (!xnull && !ynull) ? 1 : ((ynull && xeos) ? 2 : (yok ? 3 : 0));
+        const int64_t offYa = ynull ? 2 * plane : aggoff + 2 * plane, offYb = ynull ? 3 * plane : aggoff + 3 * plane;
+        const bool xgo = act && yok, ygo = act && (ynull || xok);
+        const int jc = j < 0 ? 0 : (j >= Cc ? Cc - 1 : j);       // a valid column for the addresses of idle lanes
+        const bool adjy0 = ydeg > 0 && Y.s0 == j - 1, adjy1 = ydeg > 1 && Y.s1 == j - 1;
+        const int64_t sX0j = slot_at(X0, jc), sX1j = slot_at(X1, jc);
+        const int64_t sOy0 = slot_at(own, Y.s0), sOy1 = slot_at(own, Y.s1);
+        // ---- this step's loads.  Straight-line and unconditional: absent transitions have source state 0
+        // in the pack, so every address is valid, and what an idle lane loads is discarded below.  (With
+        // conditional loads the compiler cannot count the operations in flight, and every wait for a load
+        // becomes a wait for the stores issued after it as well.)
+        // the IMM sources: pairs of transitions (both states emit), or the y / x transitions (null states)
+        const int64_t o4 = aggoff + 4 * plane;
+        const int64_t am0 = mode == 1 ? o4 + slot_at(X0, Y.s0) : (mode == 2 ? sOy0 : sX0j);
+        double x0a = M[offXa + sX0j], x0b = M[offXb + sX0j];
+        double y0a = M[offYa + sOy0], y0b = M[offYb + sOy0];
+        double m0 = M[am0];
+        double e;
+        if (etab) e = etab[(int64_t)(X.cls < 0 ? 0 : X.cls) * Ky + (Y.cls < 0 ? 0 : Y.cls)];
+        else e = eplane[slot_at(own, jc)];
+        // second transitions (about one state in eight has one): only the lanes that need them
+        double x1a = NI, x1b = NI, y1a = NI, y1b = NI, m1 = NI, m2 = NI, m3 = NI;
+        if (xgo && xdeg > 1) { x1a = M[offXa + sX1j]; x1b = M[offXb + sX1j]; }
+        if (ygo && ydeg > 1) { y1a = M[offYa + sOy1]; y1b = M[offYb + sOy1]; }
+        if (act && mode == 1) {
+          if (xdeg > 0 && ydeg > 1) m1 = M[o4 + slot_at(X0, Y.s1)];
+          if (xdeg > 1 && ydeg > 0) m2 = M[o4 + slot_at(X1, Y.s0)];
+          if (xdeg > 1 && ydeg > 1) m3 = M[o4 + slot_at(X1, Y.s1)];
+        } else if (act && mode == 2) {
+          if (ydeg > 1) m1 = M[sOy1];
+        } else if (act && mode == 3) {
+          if (xdeg > 1) m1 = M[sX1j];
+        }
+        {   // the next step's column constants
+          const int jn = j + 1;
+          Yn = load_pack(ypk + (jn < 0 ? 0 : (jn >= Cc ? Cc - 1 : jn)));
+        }
+        if (X.cls < 0 || Y.cls < 0) e = NI;
+        // ---- values forwarded from the previous step, and -inf for what does not exist ----
+        const double upA = xnull ? up_imd : up_g0, upB = xnull ? up_iiw : up_g1;
+        const double ownA = ynull ? own10.idm : own10.g2, ownB = ynull ? own10.imi : own10.g3;
+        if (adjx0) { x0a = upA; x0b = upB; }
+        if (adjx1) { x1a = upA; x1b = upB; }
+        if (adjy0) { y0a = ownA; y0b = ownB; }
+        if (adjy1) { y1a = ownA; y1b = ownB; }
+        if (mode == 2) { if (adjy0) m0 = own10.imm; if (adjy1) m1 = own10.imm; }
+        if (mode == 3) { if (adjx0) m0 = up_imm; if (adjx1) m1 = up_imm; }
+        if (!(xgo && xdeg > 0)) { x0a = NI; x0b = NI; }
+        if (!(ygo && ydeg > 0)) { y0a = NI; y0b = NI; }
+        {
+          const bool h0 = mode == 1 ? (xdeg > 0 && ydeg > 0) : (mode == 2 ? ydeg > 0 : (mode == 3 && xdeg > 0));
+          if (!h0) m0 = NI;
+        }
+
+        Fwd10 c = Fwd10{NI, NI, NI, NI, NI, NI, NI, NI, NI, NI};
+        if (act) {
+          // x-absorbing (or x-null) moves
+          double imd = x0a + X.lp0, iiw = x0b + X.lp0;
+          if (!xgo) { imd = NI; iiw = NI; }
+          if (xgo && xdeg > 1) { imd = L(imd, x1a + X.lp1); iiw = L(iiw, x1b + X.lp1); }
+          if (xgo)
+            for (int k = 2; k < xdeg; ++k) {
+              const int src = xin_src[X.in_b + k];
+              const double lp = xin_lp[X.in_b + k];
+              double va, vb;
+              if (lane > 0 && src == i - 1) { va = upA; vb = upB; }
+              else { const int64_t sl = slot_at(row_ref(ss, src), j); va = M[offXa + sl]; vb = M[offXb + sl]; }
+              imd = L(imd, va + lp);
+              iiw = L(iiw, vb + lp);
+            }
+          if (!xnull && yok) { imd += X.rootsub; iiw += X.ins; }
+          // y-absorbing (or y-null) moves
+          double idm = y0a + Y.lp0, imi = y0b + Y.lp0;
+          if (!ygo) { idm = NI; imi = NI; }
+          if (ygo && ydeg > 1) { idm = L(idm, y1a + Y.lp1); imi = L(imi, y1b + Y.lp1); }
+          if (ygo)
+            for (int k = 2; k < ydeg; ++k) {
+              const int src = yin_src[Y.in_b + k];
+              const double lp = yin_lp[Y.in_b + k];
+              double va, vb;
+              if (src == j - 1) { va = ownA; vb = ownB; }
+              else { const int64_t sl = slot_at(own, src); va = M[offYa + sl]; vb = M[offYb + sl]; }
+              idm = L(idm, va + lp);
+              imi = L(imi, vb + lp);
+            }
+          if (!ynull && xok) { idm += Y.rootsub; imi += Y.ins; }
+          // IMM
+          double imm = NI;
+          if (mode == 1) {
+            if (xdeg <= 2 && ydeg <= 2) {
+              imm = (m0 + X.lp0) + Y.lp0;
+              if (xdeg > 0 && ydeg > 1) imm = L(imm, (m1 + X.lp0) + Y.lp1);
+              if (xdeg > 1 && ydeg > 0) imm = L(imm, (m2 + X.lp1) + Y.lp0);
+              if (xdeg > 1 && ydeg > 1) imm = L(imm, (m3 + X.lp1) + Y.lp1);
+            } else {
+              const int64_t o4 = aggoff + 4 * plane;   // (a transition pair's source is at least two steps old)
+              for (int a = 0; a < xdeg; ++a) {
+                const RowRef rr = row_ref(ss, xin_src[X.in_b + a]);
+                const double lpx = xin_lp[X.in_b + a];
+                for (int b = 0; b < ydeg; ++b)
+                  imm = L(imm, (M[o4 + slot_at(rr, yin_src[Y.in_b + b])] + lpx) + yin_lp[Y.in_b + b]);
+              }
+            }
+            imm += e;
+          } else if (mode == 2) {
+            imm = m0 + Y.lp0;
+            if (ydeg > 1) imm = L(imm, m1 + Y.lp1);
+            for (int k = 2; k < ydeg; ++k) {
+              const int src = yin_src[Y.in_b + k];
+              const double v = (src == j - 1) ? own10.imm : M[slot_at(own, src)];
+              imm = L(imm, v + yin_lp[Y.in_b + k]);
+            }
+          } else if (mode == 3) {
+            imm = m0 + X.lp0;
+            if (xdeg > 1) imm = L(imm, m1 + X.lp1);
+            for (int k = 2; k < xdeg; ++k) {
+              const int src = xin_src[X.in_b + k];
+              const double v = (lane > 0 && src == i - 1) ? up_imm : M[slot_at(row_ref(ss, src), j)];
+              imm = L(imm, v + xin_lp[X.in_b + k]);
+            }
+          }
+          if (s == 0 && t == 0 && lane == 0) imm = 0.0;     // cell (0,0): lpStart() = 0 (reference src/forward.cpp:73)
+          c.imm = imm; c.imd = imd; c.idm = idm; c.imi = imi; c.iiw = iiw;
+        }
+        // ---- the previous step's cell goes to memory now, behind this step's loads (unconditionally: an
+        // idle lane writes -inf into padding or into an out-of-envelope cell, which holds -inf already) ----
+        {
+          M[pend_slot] = own10.imm;
+          M[plane + pend_slot] = own10.imd;
+          M[2 * plane + pend_slot] = own10.idm;
+          M[3 * plane + pend_slot] = own10.imi;
+          M[4 * plane + pend_slot] = own10.iiw;
+          M[aggoff + pend_slot] = own10.g0;
+          M[aggoff + plane + pend_slot] = own10.g1;
+          M[aggoff + 2 * plane + pend_slot] = own10.g2;
+          M[aggoff + 3 * plane + pend_slot] = own10.g3;
+          M[aggoff + 4 * plane + pend_slot] = own10.g4;
+        }
+        if (act) {
+          // outgoing sums, level by level (5 + 4 + 3 + 1 look-ups)
+          typename LSE::Prep p0 = L.prep(c.imm + T[0][1], c.imd + T[1][1]);
+          typename LSE::Prep p1 = L.prep(c.imm + T[0][4], c.imi + T[3][4]);
+          typename LSE::Prep p2 = L.prep(c.imm + T[0][2], c.imd + T[1][2]);
+          typename LSE::Prep p3 = L.prep(c.imm + T[0][3], c.imi + T[3][3]);
+          typename LSE::Prep p4 = L.prep(c.imm + T[0][0], c.imd + T[1][0]);
+          typename LSE::Piece c0 = L.fetch(p0), c1 = L.fetch(p1), c2 = L.fetch(p2), c3 = L.fetch(p3), c4 = L.fetch(p4);
+          double g0 = L.finish(p0, c0), g1 = L.finish(p1, c1), g2 = L.finish(p2, c2);
+          const double g3 = L.finish(p3, c3);
+          double g4 = L.finish(p4, c4);
+          p0 = L.prep(g0, c.idm + T[2][1]);
+          p1 = L.prep(g1, c.iiw + T[4][4]);
+          p2 = L.prep(g2, c.idm + T[2][2]);
+          p4 = L.prep(g4, c.idm + T[2][0]);
+          c0 = L.fetch(p0); c1 = L.fetch(p1); c2 = L.fetch(p2); c4 = L.fetch(p4);
+          g0 = L.finish(p0, c0); g1 = L.finish(p1, c1); g2 = L.finish(p2, c2); g4 = L.finish(p4, c4);
+          p0 = L.prep(g0, c.imi + T[3][1]);
+          p2 = L.prep(g2, c.iiw + T[4][2]);
+          p4 = L.prep(g4, c.imi + T[3][0]);
+          c0 = L.fetch(p0); c2 = L.fetch(p2); c4 = L.fetch(p4);
+          g0 = L.finish(p0, c0); g2 = L.finish(p2, c2); g4 = L.finish(p4, c4);
+          g4 = L(g4, c.iiw + T[4][0]);
+          c.g0 = g0; c.g1 = g1; c.g2 = g2; c.g3 = g3; c.g4 = g4;
+        }
+        // ---- rotate: this step's cell becomes `own`, and the next lane's `up` ----
+        own10 = c;
+        pend_slot = own.base + ((int64_t)(t >> 1) << 7) + (t & 1);
+        up_imm = wave_shr1(c.imm); up_imd = wave_shr1(c.imd); up_iiw = wave_shr1(c.iiw);
+        up_g0 = wave_shr1(c.g0); up_g1 = wave_shr1(c.g1);
+        // ---- publish, every 8th step: drain, then all stores issued so far (the cells of steps <= t-1)
+        // are in memory, i.e. all 64 rows have completed the columns up to t - 1 - 63
+        if ((t & 7) == 7) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          int done = t - 63;
+          done = done > Cc ? Cc : done;
+          if (done > published) {
+            published = done;
+            if (lane == 0) progp[wave] = my_base + done;
+          }
+        }
+      }
+      // flush the last cell of the window
+      {
+        M[pend_slot] = own10.imm;
+        M[plane + pend_slot] = own10.imd;
+        M[2 * plane + pend_slot] = own10.idm;
+        M[3 * plane + pend_slot] = own10.imi;
+        M[4 * plane + pend_slot] = own10.iiw;
+        M[aggoff + pend_slot] = own10.g0;
+        M[aggoff + plane + pend_slot] = own10.g1;
+        M[aggoff + 2 * plane + pend_slot] = own10.g2;
+        M[aggoff + 3 * plane + pend_slot] = own10.g3;
+        M[aggoff + 4 * plane + pend_slot] = own10.g4;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // columns between / after the windows hold no in-envelope cell of this strip
+      const int upto = (w == 0 && whi[1] > wlo[1]) ? wlo[1] - 63 : Cc;
+      const int done = upto > Cc ? Cc : upto;
+      if (done > published) {
+        published = done;
+        if (lane == 0) progp[wave] = my_base + done;
+      }
+    }
+    // (a strip without any window still has to release the strip below)
+    if (published < Cc) {
+      published = Cc;
+      if (lane == 0) progp[wave] = my_base + Cc;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
+}
+
+// emission plane: one thread per matrix slot (stores coalesced); cells outside the envelope and
+// cells of null states get 0 / -inf and are never added to a finite value
+__global__ void k_emission_plane(const DevJob* __restrict__ jobs, const double* __restrict__ tab) {
+  const DevJob& J = jobs[blockIdx.y];
+  if (!J.emis_plane) return;
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= J.plane) return;
+  const int64_t strip = slot / J.strip_stride;
+  const int64_t in = slot - strip * J.strip_stride;
+  const int l = (int)((in & 127) >> 1);
+  const int t = (int)((in >> 7) << 1) + (int)(in & 1);
+  const int i = (int)(strip << 6) + l, j = t - l;
+  double e = 0.0;
+  if (i < J.n_rows && j >= 0 && j < J.n_cols) {
+    const int cx = J.x.cls[i], cy = J.y.cls[j];
+    if (cx < 0 || cy < 0) e = HX_NEG_INF;
+    else if (in_envelope(J, i, j))
+      e = emission_rows(J, J.x.subc + (size_t)cx * J.CA, J.y.subc + (size_t)cy * J.CA, ExactLse{tab});
+  }
+  J.emis_plane[slot] = e;
+}
+
+__global__ void k_fill_neg_inf(double* __restrict__ p, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) p[k] = HX_NEG_INF;
+}
+
+}  // namespace
+
+void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, const double* tab, hipStream_t st) {
+  if (max_plane <= 0) return;
+  const int tpb = 256;
+  dim3 grid((unsigned)((max_plane + tpb - 1) / tpb), (unsigned)n_jobs);
+  hipLaunchKernelGGL(k_emission_plane, grid, dim3(tpb), 0, st, d_jobs, tab);
+}
+
+void launch_fill_neg_inf(double* p, int64_t n, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_fill_neg_inf, dim3(2048), dim3(256), 0, st, p, n);
+}
+
+static int dag_waves(int max_rows, int cap) {
+  int w = (max_rows + 63) / 64;
+  if (w < 1) w = 1;
+  if (w > cap) w = cap;
+  return w;
+}
+
+void launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+                             bool fast, hipStream_t st) {
+  const dim3 g(n_jobs), b(dag_waves(max_rows, HX_DAGF_MAX_WAVES) * 64);
+  if (fast) hipLaunchKernelGGL((k_forward_dag_pipe<FastLse, true>), g, b, 0, st, d_jobs, tab, fast_tab);
+  else hipLaunchKernelGGL((k_forward_dag_pipe<ExactLse3, false>), g, b, 0, st, d_jobs, tab, fast_tab);
+}
+
+void launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+                              bool fast, hipStream_t st) {
+  const dim3 g(n_jobs), b(dag_waves(max_rows, HX_DAG_MAX_WAVES) * 64);
+  if (fast) hipLaunchKernelGGL((k_fill_dag<1, FastLse, true>), g, b, 0, st, d_jobs, tab, fast_tab);
+  else hipLaunchKernelGGL((k_fill_dag<1, ExactLse3, false>), g, b, 0, st, d_jobs, tab, fast_tab);
+}
+
+}  // namespace hx

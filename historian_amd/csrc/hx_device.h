@@ -14,6 +14,19 @@ enum : uint8_t {
   F_TO_END = 16        // state is the source of a transition into END
 };
 
+// Per-state constants of the general-profile Forward pipeline (hx_dag.hip), one 64-byte record:
+// the first two in-transitions (reference order) are inline, further ones are read from the CSR.
+struct alignas(16) FwdPack {
+  double lp0, lp1;            // lpTrans of in-transitions 0 and 1 (0 when absent)
+  double rootsub, ins;        // rootsubx / insx of the state (-inf for null states)
+  int32_t s0, s1;             // their source states (0 when absent)
+  int32_t in_b;               // CSR position of in-transition 0
+  int32_t meta;               // flags | in-degree << 8
+  int32_t env;                // envelope coordinate (0 without a band)
+  int32_t cls;                // emission class, -1 for null states
+  int32_t pad_[2];
+};
+
 struct DevProfile {
   int32_t n;                  // number of states
   int32_t empty;              // Profile::isEmpty()
@@ -45,6 +58,7 @@ struct DevProfile {
   double* insc;               // [n_cls]
   double* rootsubc;           // [n_cls]
   const int32_t* ecls;        // [n] emission class, n_cls for null states (-> zero row of emis_pad)
+  FwdPack* fpack;             // [n]
 };
 
 struct DevJob {
@@ -72,6 +86,11 @@ struct DevJob {
   int32_t pad2_;
   double* lp_end;             // -> one double
   double* lp_start;           // -> one double
+  // general-profile strip pipeline (hx_dag.hip)
+  double* emis_plane;         // [plane] per-cell emission term in the Forward layout, or nullptr (class table used)
+  double* agg;                // [5][plane] per-cell outgoing sums of the Forward fill (hx_dag.hip), or nullptr
+  const int32_t* fwd_windows; // [n_strips][4] step windows {lo0,hi0,lo1,hi1} holding the strip's in-envelope cells
+  const int32_t* bwd_windows; // same for the mirrored (Backward) sweep; both nullptr when there is no band
 };
 
 #define HX_STRIP 64

@@ -14,6 +14,12 @@ void launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const 
                           bool fast, int leaf, bool banded, hipStream_t st);
 void launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
                            bool fast, int leaf, bool banded, hipStream_t st);
+void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, const double* tab, hipStream_t st);
+void launch_fill_neg_inf(double* p, int64_t n, hipStream_t st);
+void launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+                             bool fast, hipStream_t st);
+void launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+                              bool fast, hipStream_t st);
 void launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
 void launch_posterior_scan(const DevJob* d_jobs, int job, double lpp_threshold, PostCell* out,
                            unsigned long long cap, unsigned long long* counter, hipStream_t st);

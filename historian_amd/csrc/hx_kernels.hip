@@ -85,6 +85,20 @@ __global__ void k_scatter_prepared(const DevJob* __restrict__ jobs) {
   pk[1] = rs;
   pk[2] = ins;
   pk[3] = ok ? 0.0 : HX_NEG_INF;
+  FwdPack f;
+  const int b = P.in_off[i], deg = P.in_off[i + 1] - b;
+  f.lp0 = deg > 0 ? P.in_lp[b] : 0.0;
+  f.lp1 = deg > 1 ? P.in_lp[b + 1] : 0.0;
+  f.rootsub = rs;
+  f.ins = ins;
+  f.s0 = deg > 0 ? P.in_src[b] : 0;
+  f.s1 = deg > 1 ? P.in_src[b + 1] : 0;
+  f.in_b = b;
+  f.meta = (int)P.flags[i] | (deg << 8);
+  f.env = P.env ? P.env[i] : 0;
+  f.cls = kc;
+  f.pad_[0] = f.pad_[1] = 0;
+  P.fpack[i] = f;
 }
 
 // one thread per (x class, y class)

@@ -1,0 +1,49 @@
+"""Throughput of the general (DAG) kernels on real internal-node profiles: the gp120 family's
+internal nodes (oracle-built profiles), replicated into a batch."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from historian_amd import capi
+from oracle import c_oracle, historian_oracle as ho
+from tests import helpers as H, recon_helpers as R
+
+G = os.path.join(ROOT, "tests", "golden", "reference_data") + os.sep
+LG = os.path.join(ROOT, "tests", "golden", "models", "lg.json")
+tree, seqs, guide = R.load_family(G + "gp120.tree.nh", G + "gp120.fa", G + "gp120.guide.fa")
+res, rows = R.oracle_reconstruct(LG, tree, seqs, guide, max_distance_from_guide=20)
+model = ho.RateModel.from_file(LG); model.sub_rate = [m.tolist() for m in model.sub_rate]
+closest = ho.closest_leaves(tree)
+capi.init(0, c_oracle.table())
+root = tree.root()
+for band in (20, -1):
+    imgs = []
+    for node in range(tree.nodes()):
+        if tree.is_leaf(node): continue
+        lc, rc = tree.child[node]
+        if tree.is_leaf(lc) and tree.is_leaf(rc): continue
+        lp = ho.ProbModel(model, tree.branch_length[lc], [ho.sub_prob_matrix_ss(sr, tree.branch_length[lc]) for sr in model.sub_rate])
+        rp = ho.ProbModel(model, tree.branch_length[rc], [ho.sub_prob_matrix_ss(sr, tree.branch_length[rc]) for sr in model.sub_rate])
+        hmm = ho.PairHMM(lp, rp, model.ins_prob)
+        env = ho.GuideAlignmentEnvelope(guide, closest[lc], closest[rc], band) if band >= 0 else ho.GuideAlignmentEnvelope()
+        f = ho.ForwardMatrix(res["prof"][lc], res["prof"][rc], hmm, node, env, fill=False)
+        imgs.append(H.job_images(f))
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    sizes = [(x.n_states, y.n_states) for x, y, _, _ in imgs]
+    print("band", band, "jobs", len(imgs) * reps, "sizes", sizes)
+    for name, flags in (("exact", capi.HX_LSE_EXACT), ("fast", capi.HX_LSE_FAST)) + (() if "fwdonly" in sys.argv else (("barrier-exact", capi.HX_FORCE_GENERIC),)):
+        batch = capi.Batch(imgs * reps, flags)
+        batch.forward(); batch.sync()
+        batch.forward(); batch.sync()
+        cells = batch.total_cells()
+        fms = batch.kernel_ms(0)
+        if "fwdonly" in sys.argv:
+            print("  %-14s forward %8.3f ms %7.2f Gcell/s" % (name, fms, cells / fms / 1e6))
+            batch.close()
+            continue
+        batch.backward(); batch.sync()
+        batch.backward(); batch.sync()
+        bms = batch.kernel_ms(1)
+        print("  %-14s forward %8.3f ms %7.2f Gcell/s   backward %8.3f ms %7.2f Gcell/s (lattice cells %d)" %
+              (name, fms, cells / fms / 1e6, bms, cells / bms / 1e6, cells))
+        batch.close()
