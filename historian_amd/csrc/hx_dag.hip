@@ -6,23 +6,28 @@
 // Same decomposition as the chain kernels (hx_chain.hip): one workgroup per pair, its waves
 // take 64-row strips round-robin, lane <-> row, step <-> anti-diagonal, every wave on its own
 // clock.  What differs is where a cell's sources come from.  A profile state may have any
-// number of in-transitions from any earlier state, so sources are not "the lane above, one
-// step ago": they are read back from the matrix itself (L1/L2 hits: the workgroup's own
-// recent stores).  That needs two orderings and nothing else:
-//   * own strip:   a wave drains its stores (s_waitcnt vmcnt(0)) at the end of every step, so
-//                  the next step's loads see every earlier anti-diagonal of the strip;
-//   * strips above: a wave publishes, after that drain, how many columns of its strip are
-//                  complete (monotonic LDS counter); the wave below does not enter step t
-//                  before columns 0..t of the strip above are published.  Strips further up
-//                  completed those columns earlier still.
+// number of in-transitions from any earlier state, so a source is not always "the lane above,
+// one step ago": sources are read back from the matrix itself (L1/L2 hits: the workgroup's own
+// recent stores), ordered by
+//   * own strip:    vector-memory operations of a wave retire in issue order, so a load sees every
+//                   store the wave issued before it;
+//   * strips above: a wave publishes (monotonic LDS counter), after draining its stores, how many
+//                   columns of its strip are complete; the wave below does not enter step t before
+//                   columns 0..t of the strip above are published.  Strips further up completed
+//                   those columns earlier still.
 // All waves of a workgroup share one CU and one L1, so draining + the LDS counter is a
 // workgroup-scope release/acquire; no cache maintenance is needed.
+//
+// k_fill_dag<1>        Backward: the recursion as the reference writes it, per-step drain.
+// k_forward_dag_pipe   Forward, restructured for latency (see the comment above it): outgoing sums
+//                      stored per cell, inline transition records, register forwarding of the
+//                      previous step, stores issued behind the next step's loads.
 //
 // The emission term of an IMM cell (computeLogProbAbsorb, reference src/forward.h:112-124)
 // does not depend on the DP values: it is evaluated for all cells up front by a fully parallel
 // kernel into a sixth plane in the matrix layout (or taken from the class-pair table when the
-// profiles have few distinct columns), so the dependent chain of a cell is the 12-or-so
-// transition log-sum-exps only.
+// profiles have few distinct columns), so the dependent chain of a cell is the transition
+// log-sum-exps only.
 //
 // With a band (GuideAlignmentEnvelope), a strip only visits the step windows in which it has
 // in-envelope cells; everything else stays at the -inf the matrix was pre-filled with, which is
@@ -35,10 +40,6 @@
 #include "hx_common.h"
 #include "hx_policy.h"
 #include "hx_kernels.h"
-
-#ifndef HX_DAG_ABLATE
-#define HX_DAG_ABLATE 0
-#endif
 
 namespace hx {
 
@@ -395,24 +396,32 @@ __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_fill_dag(const DevJob
 // x- or y-transition and one per transition pair, and one log-sum-exp per value beyond the first.
 // Null destination states read the raw cell planes instead (src/forward.cpp:118-128,153-163,183-200).
 //
-// The dependent chain of a step is: one round of loads (all issued together: the first two
-// in-transitions of every state are inline in its 64-byte FwdPack, the row's pack lives in
-// registers, the column's pack is fetched one step ahead) -> accumulate -> the 13 look-ups of
-// the outgoing sums in 4 levels -> stores -> drain.
+// The dependent chain of a step is: one round of loads (all issued together: the first three
+// in-transitions of every state are inline in its 80-byte FwdPack; the row's pack lives in
+// registers, the columns' packs in a per-wave LDS ring refilled 64 columns at a time) ->
+// accumulate -> the 13 look-ups of the outgoing sums in 4 levels.  The two cells a step can need
+// from the step before -- (i-1, j) of the previous lane and (i, j-1) of the lane itself -- are
+// forwarded through registers (DPP wave_shr:1), so a cell's stores can be issued one step late,
+// behind the next step's loads: loads then never queue behind stores younger than one step.
 // ---------------------------------------------------------------------------
 typedef double d2v __attribute__((ext_vector_type(2)));
 
-struct PackRegs { double lp0, lp1, rootsub, ins; int s0, s1, in_b, meta, env, cls; };
+struct PackRegs { double lp[HX_DAG_INLINE], rootsub, ins; int s[HX_DAG_INLINE], in_b, meta, env, cls; };
+
+__device__ __forceinline__ PackRegs unpack(const d2v a, const d2v b, const d2v c, const d2v d, const d2v e) {
+  PackRegs r;
+  r.lp[0] = a.x; r.lp[1] = a.y; r.rootsub = b.x; r.ins = b.y;
+  r.s[0] = __double2loint(c.x); r.s[1] = __double2hiint(c.x);
+  r.in_b = __double2loint(c.y); r.meta = __double2hiint(c.y);
+  r.env = __double2loint(d.x); r.cls = __double2hiint(d.x);
+  r.s[2] = __double2loint(d.y);
+  r.lp[2] = e.x;
+  return r;
+}
 
 __device__ __forceinline__ PackRegs load_pack(const HX_GLOBAL FwdPack* p) {
   const HX_GLOBAL d2v* q = (const HX_GLOBAL d2v*)p;
-  const d2v a = q[0], b = q[1], c = q[2], d = q[3];
-  PackRegs r;
-  r.lp0 = a.x; r.lp1 = a.y; r.rootsub = b.x; r.ins = b.y;
-  r.s0 = __double2loint(c.x); r.s1 = __double2hiint(c.x);
-  r.in_b = __double2loint(c.y); r.meta = __double2hiint(c.y);
-  r.env = __double2loint(d.x); r.cls = __double2hiint(d.x);
-  return r;
+  return unpack(q[0], q[1], q[2], q[3], q[4]);
 }
 
 struct RowRef { int64_t base; int l; };
@@ -435,6 +444,9 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
                                                                                const double* __restrict__ fast_tab) {
   __shared__ volatile int prog[HX_DAGF_MAX_WAVES];
   __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : 2];
+  // per wave: the column constants (FwdPack) of the 128 columns around the wave's position, as four
+  // arrays of 16-byte quarters so that 64 lanes reading 64 consecutive columns do not collide on banks
+  __shared__ d2v ycols[HX_DAGF_MAX_WAVES][5][128];
   const int threads = blockDim.x, W = threads >> 6;
   if (FAST)
     for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 2; k += threads) ftab[k] = fast_tab[k];
@@ -466,6 +478,20 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
   const int n_strips = (R + 63) >> 6;
   const int prev_wave = (wave + W - 1) % W;
   const double NI = HX_NEG_INF;
+  HX_LDS d2v* ring = (HX_LDS d2v*)&ycols[wave][0][0];
+  // columns c0 .. c0+63 (clamped into the profile) -> ring; one coalesced 4 KiB read per call
+  auto stage = [&](const int c0) {
+    int c = c0 + lane;
+    c = c < 0 ? 0 : (c >= Cc ? Cc - 1 : c);
+    const HX_GLOBAL d2v* q = (const HX_GLOBAL d2v*)(ypk + c);
+    const d2v q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+    const int k = (c0 + lane) & 127;
+    ring[k] = q0; ring[128 + k] = q1; ring[256 + k] = q2; ring[384 + k] = q3; ring[512 + k] = q4;
+  };
+  auto column = [&](const int j) {
+    const int k = j & 127;
+    return unpack(ring[k], ring[128 + k], ring[256 + k], ring[384 + k], ring[512 + k]);
+  };
 
   for (int s = wave; s < n_strips; s += W) {
     const int i = (s << 6) + lane;
@@ -474,12 +500,17 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
     const int xf = X.meta & 0xff, xdeg = X.meta >> 8;
     const bool xnull = xf & F_NULL, xok = (xf & F_READY) || xempty, xeos = xf & F_EMIT_OR_START;
     const RowRef own = RowRef{(int64_t)s * ss + (lane << 1), lane};
-    const RowRef X0 = row_ref(ss, X.s0), X1 = row_ref(ss, X.s1);
+    constexpr int K = HX_DAG_INLINE;
+    RowRef XR[K];
+    bool adjx[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      XR[k] = row_ref(ss, X.s[k]);
+      // a source in the row directly above, inside this strip, is the previous lane's cell of the previous
+      // step: it is forwarded through registers (its store has not been issued yet, see below)
+      adjx[k] = lane > 0 && xdeg > k && X.s[k] == i - 1;
+    }
     const int64_t offXa = xnull ? plane : aggoff, offXb = xnull ? 4 * plane : aggoff + plane;
-    // a source in the row directly above, inside this strip, is the previous lane's cell of the previous step:
-    // it is forwarded through registers (its store has not been issued yet, see below)
-    const bool adjx0 = lane > 0 && xdeg > 0 && X.s0 == i - 1;
-    const bool adjx1 = lane > 0 && xdeg > 1 && X.s1 == i - 1;
     const int above_base = ((s - 1) / W) * Cc;
     const int my_base = (s / W) * Cc;
     int seen = 0, published = 0;
@@ -490,11 +521,8 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
     }
     for (int w = 0; w < 2; ++w) {
       if (whi[w] <= wlo[w]) continue;
-      PackRegs Yn;
-      {
-        const int j0 = wlo[w] - lane;
-        Yn = load_pack(ypk + (j0 < 0 ? 0 : (j0 >= Cc ? Cc - 1 : j0)));
-      }
+      stage(wlo[w] - 64);
+      stage(wlo[w]);
       // results of the previous step: `own` this lane's cell (i, j-1), `up` the previous lane's cell (i-1, j).
       // They are stored one step late (after the next step's loads have been issued): vector-memory
       // operations retire in issue order, so a load issued after a store waits for that store to be
@@ -504,7 +532,6 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
       // (the first step's store goes to the slot that step's own cell will overwrite one step later)
       int64_t pend_slot = own.base + ((int64_t)(wlo[w] >> 1) << 7) + (wlo[w] & 1);
       for (int t = wlo[w]; t < whi[w]; ++t) {
-#if HX_DAG_ABLATE != 5
         if (s > 0) {
           const int need = above_base + (t + 1 < Cc ? t + 1 : Cc);
           if (seen < need) {
@@ -515,9 +542,9 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
             asm volatile("" ::: "memory");
           }
         }
-#endif
-        const PackRegs Y = Yn;
+        if (t > wlo[w] && ((t - wlo[w]) & 63) == 0) stage(t);
         const int j = t - lane;
+        const PackRegs Y = column(j);
         const int yf = Y.meta & 0xff, ydeg = Y.meta >> 8;
         bool act = rvalid && j >= 0 && j < Cc;
         if (banded) {
@@ -528,100 +555,143 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
         const bool ynull = yf & F_NULL, yok = (yf & F_READY) || yempty;
         const int mode = (!xnull && !ynull) ? 1 : ((ynull && xeos) ? 2 : (yok ? 3 : 0));
         const int64_t offYa = ynull ? 2 * plane : aggoff + 2 * plane, offYb = ynull ? 3 * plane : aggoff + 3 * plane;
+        const int64_t o4 = aggoff + 4 * plane;
         const bool xgo = act && yok, ygo = act && (ynull || xok);
         const int jc = j < 0 ? 0 : (j >= Cc ? Cc - 1 : j);       // a valid column for the addresses of idle lanes
-        const bool adjy0 = ydeg > 0 && Y.s0 == j - 1, adjy1 = ydeg > 1 && Y.s1 == j - 1;
-        const int64_t sX0j = slot_at(X0, jc), sX1j = slot_at(X1, jc);
-        const int64_t sOy0 = slot_at(own, Y.s0), sOy1 = slot_at(own, Y.s1);
-        // ---- this step's loads.  Straight-line and unconditional: absent transitions have source state 0
-        // in the pack, so every address is valid, and what an idle lane loads is discarded below.  (With
-        // conditional loads the compiler cannot count the operations in flight, and every wait for a load
-        // becomes a wait for the stores issued after it as well.)
-        // the IMM sources: pairs of transitions (both states emit), or the y / x transitions (null states)
-        const int64_t o4 = aggoff + 4 * plane;
-        const int64_t am0 = mode == 1 ? o4 + slot_at(X0, Y.s0) : (mode == 2 ? sOy0 : sX0j);
-        double x0a = M[offXa + sX0j], x0b = M[offXb + sX0j];
-        double y0a = M[offYa + sOy0], y0b = M[offYb + sOy0];
-        double m0 = M[am0];
+        bool adjy[K];
+        int64_t sXj[K], sOy[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          adjy[k] = ydeg > k && Y.s[k] == j - 1;
+          sXj[k] = slot_at(XR[k], jc);
+          sOy[k] = slot_at(own, Y.s[k]);
+        }
+        // ---- this step's loads: the first transitions for every lane (absent ones have source state 0 in
+        // the pack, so the address is valid and the value is discarded below), further ones only where they
+        // exist.  xa/xb feed IMD/IIW, ya/yb feed IDM/IMI, mv[] feeds IMM: transition pairs when both states
+        // emit, else the y (mode 2) or x (mode 3) transitions.
+        double xa[K], xb[K], ya[K], yb[K], mv[K * K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) { xa[k] = NI; xb[k] = NI; ya[k] = NI; yb[k] = NI; }
+#pragma unroll
+        for (int k = 0; k < K * K; ++k) mv[k] = NI;
+        xa[0] = M[offXa + sXj[0]]; xb[0] = M[offXb + sXj[0]];
+        ya[0] = M[offYa + sOy[0]]; yb[0] = M[offYb + sOy[0]];
+        mv[0] = M[mode == 1 ? o4 + slot_at(XR[0], Y.s[0]) : (mode == 2 ? sOy[0] : sXj[0])];
         double e;
         if (etab) e = etab[(int64_t)(X.cls < 0 ? 0 : X.cls) * Ky + (Y.cls < 0 ? 0 : Y.cls)];
         else e = eplane[slot_at(own, jc)];
-        // second transitions (about one state in eight has one): only the lanes that need them
-        double x1a = NI, x1b = NI, y1a = NI, y1b = NI, m1 = NI, m2 = NI, m3 = NI;
-        if (xgo && xdeg > 1) { x1a = M[offXa + sX1j]; x1b = M[offXb + sX1j]; }
-        if (ygo && ydeg > 1) { y1a = M[offYa + sOy1]; y1b = M[offYb + sOy1]; }
-        if (act && mode == 1) {
-          if (xdeg > 0 && ydeg > 1) m1 = M[o4 + slot_at(X0, Y.s1)];
-          if (xdeg > 1 && ydeg > 0) m2 = M[o4 + slot_at(X1, Y.s0)];
-          if (xdeg > 1 && ydeg > 1) m3 = M[o4 + slot_at(X1, Y.s1)];
-        } else if (act && mode == 2) {
-          if (ydeg > 1) m1 = M[sOy1];
-        } else if (act && mode == 3) {
-          if (xdeg > 1) m1 = M[sX1j];
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+          if (xgo && xdeg > k) { xa[k] = M[offXa + sXj[k]]; xb[k] = M[offXb + sXj[k]]; }
+          if (ygo && ydeg > k) { ya[k] = M[offYa + sOy[k]]; yb[k] = M[offYb + sOy[k]]; }
         }
-        {   // the next step's column constants
-          const int jn = j + 1;
-          Yn = load_pack(ypk + (jn < 0 ? 0 : (jn >= Cc ? Cc - 1 : jn)));
+        if (act && mode == 1) {
+#pragma unroll
+          for (int a = 0; a < K; ++a)
+#pragma unroll
+            for (int b = 0; b < K; ++b)
+              if ((a | b) != 0 && xdeg > a && ydeg > b) mv[a * K + b] = M[o4 + slot_at(XR[a], Y.s[b])];
+        } else if (act && mode == 2) {
+#pragma unroll
+          for (int k = 1; k < K; ++k) if (ydeg > k) mv[k] = M[sOy[k]];
+        } else if (act && mode == 3) {
+#pragma unroll
+          for (int k = 1; k < K; ++k) if (xdeg > k) mv[k] = M[sXj[k]];
         }
         if (X.cls < 0 || Y.cls < 0) e = NI;
         // ---- values forwarded from the previous step, and -inf for what does not exist ----
         const double upA = xnull ? up_imd : up_g0, upB = xnull ? up_iiw : up_g1;
         const double ownA = ynull ? own10.idm : own10.g2, ownB = ynull ? own10.imi : own10.g3;
-        if (adjx0) { x0a = upA; x0b = upB; }
-        if (adjx1) { x1a = upA; x1b = upB; }
-        if (adjy0) { y0a = ownA; y0b = ownB; }
-        if (adjy1) { y1a = ownA; y1b = ownB; }
-        if (mode == 2) { if (adjy0) m0 = own10.imm; if (adjy1) m1 = own10.imm; }
-        if (mode == 3) { if (adjx0) m0 = up_imm; if (adjx1) m1 = up_imm; }
-        if (!(xgo && xdeg > 0)) { x0a = NI; x0b = NI; }
-        if (!(ygo && ydeg > 0)) { y0a = NI; y0b = NI; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          if (adjx[k]) { xa[k] = upA; xb[k] = upB; }
+          if (adjy[k]) { ya[k] = ownA; yb[k] = ownB; }
+          if (mode == 2 && adjy[k]) mv[k] = own10.imm;
+          if (mode == 3 && adjx[k]) mv[k] = up_imm;
+        }
+        if (!(xgo && xdeg > 0)) { xa[0] = NI; xb[0] = NI; }
+        if (!(ygo && ydeg > 0)) { ya[0] = NI; yb[0] = NI; }
         {
           const bool h0 = mode == 1 ? (xdeg > 0 && ydeg > 0) : (mode == 2 ? ydeg > 0 : (mode == 3 && xdeg > 0));
-          if (!h0) m0 = NI;
+          if (!h0) mv[0] = NI;
         }
 
         Fwd10 c = Fwd10{NI, NI, NI, NI, NI, NI, NI, NI, NI, NI};
         if (act) {
           // x-absorbing (or x-null) moves
-          double imd = x0a + X.lp0, iiw = x0b + X.lp0;
-          if (!xgo) { imd = NI; iiw = NI; }
-          if (xgo && xdeg > 1) { imd = L(imd, x1a + X.lp1); iiw = L(iiw, x1b + X.lp1); }
+          double imd = xa[0] + X.lp[0], iiw = xb[0] + X.lp[0];
+#pragma unroll
+          for (int k = 1; k < K; ++k)
+            if (xgo && xdeg > k) { imd = L(imd, xa[k] + X.lp[k]); iiw = L(iiw, xb[k] + X.lp[k]); }
+          // transitions beyond the inline ones, two at a time: their CSR entries, then their cells, then
+          // the sums (a row with many in-transitions slows its whole strip, so the loads are batched)
           if (xgo)
-            for (int k = 2; k < xdeg; ++k) {
-              const int src = xin_src[X.in_b + k];
-              const double lp = xin_lp[X.in_b + k];
-              double va, vb;
-              if (lane > 0 && src == i - 1) { va = upA; vb = upB; }
-              else { const int64_t sl = slot_at(row_ref(ss, src), j); va = M[offXa + sl]; vb = M[offXb + sl]; }
-              imd = L(imd, va + lp);
-              iiw = L(iiw, vb + lp);
+            for (int k0 = K; k0 < xdeg; k0 += 2) {
+              int src[2];
+              double lp[2], va[2], vb[2];
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+                if (k0 + u < xdeg) { src[u] = xin_src[X.in_b + k0 + u]; lp[u] = xin_lp[X.in_b + k0 + u]; }
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+                if (k0 + u < xdeg) {
+                  if (lane > 0 && src[u] == i - 1) { va[u] = upA; vb[u] = upB; }
+                  else { const int64_t sl = slot_at(row_ref(ss, src[u]), j); va[u] = M[offXa + sl]; vb[u] = M[offXb + sl]; }
+                }
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+                if (k0 + u < xdeg) { imd = L(imd, va[u] + lp[u]); iiw = L(iiw, vb[u] + lp[u]); }
             }
           if (!xnull && yok) { imd += X.rootsub; iiw += X.ins; }
           // y-absorbing (or y-null) moves
-          double idm = y0a + Y.lp0, imi = y0b + Y.lp0;
-          if (!ygo) { idm = NI; imi = NI; }
-          if (ygo && ydeg > 1) { idm = L(idm, y1a + Y.lp1); imi = L(imi, y1b + Y.lp1); }
+          double idm = ya[0] + Y.lp[0], imi = yb[0] + Y.lp[0];
+#pragma unroll
+          for (int k = 1; k < K; ++k)
+            if (ygo && ydeg > k) { idm = L(idm, ya[k] + Y.lp[k]); imi = L(imi, yb[k] + Y.lp[k]); }
           if (ygo)
-            for (int k = 2; k < ydeg; ++k) {
-              const int src = yin_src[Y.in_b + k];
-              const double lp = yin_lp[Y.in_b + k];
-              double va, vb;
-              if (src == j - 1) { va = ownA; vb = ownB; }
-              else { const int64_t sl = slot_at(own, src); va = M[offYa + sl]; vb = M[offYb + sl]; }
-              idm = L(idm, va + lp);
-              imi = L(imi, vb + lp);
+            for (int k0 = K; k0 < ydeg; k0 += 2) {
+              int src[2];
+              double lp[2], va[2], vb[2];
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+                if (k0 + u < ydeg) { src[u] = yin_src[Y.in_b + k0 + u]; lp[u] = yin_lp[Y.in_b + k0 + u]; }
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+                if (k0 + u < ydeg) {
+                  if (src[u] == j - 1) { va[u] = ownA; vb[u] = ownB; }
+                  else { const int64_t sl = slot_at(own, src[u]); va[u] = M[offYa + sl]; vb[u] = M[offYb + sl]; }
+                }
+#pragma unroll
+              for (int u = 0; u < 2; ++u)
+                if (k0 + u < ydeg) { idm = L(idm, va[u] + lp[u]); imi = L(imi, vb[u] + lp[u]); }
             }
           if (!ynull && xok) { idm += Y.rootsub; imi += Y.ins; }
           // IMM
           double imm = NI;
           if (mode == 1) {
-            if (xdeg <= 2 && ydeg <= 2) {
-              imm = (m0 + X.lp0) + Y.lp0;
-              if (xdeg > 0 && ydeg > 1) imm = L(imm, (m1 + X.lp0) + Y.lp1);
-              if (xdeg > 1 && ydeg > 0) imm = L(imm, (m2 + X.lp1) + Y.lp0);
-              if (xdeg > 1 && ydeg > 1) imm = L(imm, (m3 + X.lp1) + Y.lp1);
+            if (xdeg <= K && ydeg <= K) {
+              imm = (mv[0] + X.lp[0]) + Y.lp[0];
+#pragma unroll
+              for (int a = 0; a < K; ++a)
+#pragma unroll
+                for (int b = 0; b < K; ++b)
+                  if ((a | b) != 0 && xdeg > a && ydeg > b) imm = L(imm, (mv[a * K + b] + X.lp[a]) + Y.lp[b]);
+            } else if (ydeg <= K) {
+              // many x transitions, few y transitions: one x transition (all its pairs) per round.
+              // (a transition pair's source is at least two steps old: always in memory)
+              for (int a = 0; a < xdeg; ++a) {
+                const RowRef rr = row_ref(ss, xin_src[X.in_b + a]);
+                const double la = xin_lp[X.in_b + a];
+                double g[K];
+#pragma unroll
+                for (int b = 0; b < K; ++b)
+                  if (b < ydeg) g[b] = M[o4 + slot_at(rr, Y.s[b])];
+#pragma unroll
+                for (int b = 0; b < K; ++b)
+                  if (b < ydeg) imm = L(imm, (g[b] + la) + Y.lp[b]);
+              }
             } else {
-              const int64_t o4 = aggoff + 4 * plane;   // (a transition pair's source is at least two steps old)
               for (int a = 0; a < xdeg; ++a) {
                 const RowRef rr = row_ref(ss, xin_src[X.in_b + a]);
                 const double lpx = xin_lp[X.in_b + a];
@@ -631,17 +701,19 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
             }
             imm += e;
           } else if (mode == 2) {
-            imm = m0 + Y.lp0;
-            if (ydeg > 1) imm = L(imm, m1 + Y.lp1);
-            for (int k = 2; k < ydeg; ++k) {
+            imm = mv[0] + Y.lp[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) if (ydeg > k) imm = L(imm, mv[k] + Y.lp[k]);
+            for (int k = K; k < ydeg; ++k) {
               const int src = yin_src[Y.in_b + k];
               const double v = (src == j - 1) ? own10.imm : M[slot_at(own, src)];
               imm = L(imm, v + yin_lp[Y.in_b + k]);
             }
           } else if (mode == 3) {
-            imm = m0 + X.lp0;
-            if (xdeg > 1) imm = L(imm, m1 + X.lp1);
-            for (int k = 2; k < xdeg; ++k) {
+            imm = mv[0] + X.lp[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) if (xdeg > k) imm = L(imm, mv[k] + X.lp[k]);
+            for (int k = K; k < xdeg; ++k) {
               const int src = xin_src[X.in_b + k];
               const double v = (lane > 0 && src == i - 1) ? up_imm : M[slot_at(row_ref(ss, src), j)];
               imm = L(imm, v + xin_lp[X.in_b + k]);

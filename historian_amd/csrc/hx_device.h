@@ -14,17 +14,21 @@ enum : uint8_t {
   F_TO_END = 16        // state is the source of a transition into END
 };
 
-// Per-state constants of the general-profile Forward pipeline (hx_dag.hip), one 64-byte record:
-// the first two in-transitions (reference order) are inline, further ones are read from the CSR.
+// Per-state constants of the general-profile Forward pipeline (hx_dag.hip), one 80-byte record:
+// the first three in-transitions (reference order) are inline, further ones are read from the CSR.
+#define HX_DAG_INLINE 3
 struct alignas(16) FwdPack {
   double lp0, lp1;            // lpTrans of in-transitions 0 and 1 (0 when absent)
   double rootsub, ins;        // rootsubx / insx of the state (-inf for null states)
-  int32_t s0, s1;             // their source states (0 when absent)
+  int32_t s0, s1;             // source states of in-transitions 0 and 1 (0 when absent)
   int32_t in_b;               // CSR position of in-transition 0
   int32_t meta;               // flags | in-degree << 8
   int32_t env;                // envelope coordinate (0 without a band)
   int32_t cls;                // emission class, -1 for null states
-  int32_t pad_[2];
+  int32_t s2;                 // source state of in-transition 2
+  int32_t pad0_;
+  double lp2;                 // lpTrans of in-transition 2
+  double pad1_;
 };
 
 struct DevProfile {

@@ -93,11 +93,14 @@ __global__ void k_scatter_prepared(const DevJob* __restrict__ jobs) {
   f.ins = ins;
   f.s0 = deg > 0 ? P.in_src[b] : 0;
   f.s1 = deg > 1 ? P.in_src[b + 1] : 0;
+  f.s2 = deg > 2 ? P.in_src[b + 2] : 0;
+  f.lp2 = deg > 2 ? P.in_lp[b + 2] : 0.0;
+  f.pad0_ = 0;
+  f.pad1_ = 0.0;
   f.in_b = b;
   f.meta = (int)P.flags[i] | (deg << 8);
   f.env = P.env ? P.env[i] : 0;
   f.cls = kc;
-  f.pad_[0] = f.pad_[1] = 0;
   P.fpack[i] = f;
 }
 

@@ -29,6 +29,16 @@ for band in (20, -1):
         f = ho.ForwardMatrix(res["prof"][lc], res["prof"][rc], hmm, node, env, fill=False)
         imgs.append(H.job_images(f))
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    if "perjob" in sys.argv:
+        for k, img in enumerate(imgs):
+            b = capi.Batch([img], capi.HX_LSE_FAST)
+            b.forward(); b.sync(); b.forward(); b.sync()
+            x, y = img[0], img[1]
+            steps = (y.n_states - 1) + 63 + 72 * ((x.n_states - 1 + 63) // 64 - 1)
+            print("  job %d  %4d x %4d  fast forward %7.3f ms   %5.2f us/step over %d critical-path steps" %
+                  (k, x.n_states, y.n_states, b.kernel_ms(0), b.kernel_ms(0) * 1e3 / steps, steps))
+            b.close()
+        continue
     sizes = [(x.n_states, y.n_states) for x, y, _, _ in imgs]
     print("band", band, "jobs", len(imgs) * reps, "sizes", sizes)
     for name, flags in (("exact", capi.HX_LSE_EXACT), ("fast", capi.HX_LSE_FAST)) + (() if "fwdonly" in sys.argv else (("barrier-exact", capi.HX_FORCE_GENERIC),)):
