@@ -470,7 +470,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     mat_off[k] = mat_total;
     mat_total += 5 * J.plane;
     jo.eplane_off = -1;
-    if (!jo.table_emission && pairs > 0) {
+    if (!jo.table_emission) {   // (also for a profile without emitting states: the pipeline's loads are unconditional)
       jo.eplane_off = eplane_total;
       eplane_total += J.plane;
       if (J.plane > b->max_eplane) b->max_eplane = J.plane;

@@ -159,6 +159,33 @@ def test_dag_profiles_larger_than_one_strip():
     run_and_check(cases)
 
 
+def _max_in_degree(prof):
+    return max(len(st.in_) for st in prof.state)
+
+
+def test_dag_profiles_with_many_in_transitions_per_state():
+    # the general Forward pipeline keeps three in-transitions per state inline and walks the rest of the
+    # CSR in batches; these profiles (25-40 sampled traces) have states with 5 to 9 in-transitions on both sides
+    cases = [H.dag_case(81, n=40, samples=25), H.dag_case(83, n=60, samples=30, band=4),
+             H.dag_case(85, n=50, samples=40, band=3)]
+    for f in cases:
+        assert _max_in_degree(f.x) >= 5 and _max_in_degree(f.y) >= 5
+    run_and_check(cases)
+
+
+def test_dag_profiles_with_more_strips_than_waves():
+    # > 512 rows: the 8 waves of the general Forward pipeline take a second round of strips
+    f = H.dag_case(86, n=400, samples=3)
+    assert f.x_size > 576
+    run_and_check([f])
+
+
+def test_mixed_batch_of_leaf_and_dag_jobs():
+    cases = [H.leaf_case(7, 70, 66), H.dag_case(31), H.leaf_case(4, 0, 3), H.dag_case(43, band=3),
+             H.leaf_case(203, 200, 90, band=12)]
+    run_and_check(cases)
+
+
 def test_zero_likelihood_band_reports_minus_inf():
     # band 0 on a bad guide can leave no path: lpEnd must be -inf, not NaN (reference recon.cpp:956-975)
     f = H.dag_case(45, band=0)
@@ -214,10 +241,16 @@ def test_error_codes():
     assert e.value.code == -5
 
 
-def test_fast_mode_stays_within_tolerance_of_exact():
+@pytest.mark.parametrize("kind", ["leaf", "dag"])
+def test_fast_mode_stays_within_tolerance_of_exact(kind):
     # north_star tolerance: forward log-likelihoods within 1e-4 relative; the fast fill is far inside it
-    cases = [H.leaf_case(201, 300, 280), H.leaf_case(202, 64, 700, alphabet="arndcqeghilkmfpstwyv", jc=False),
-             H.leaf_case(203, 600, 90, band=12), H.leaf_case(204, 5, 3), H.leaf_case(205, 0, 4)]
+    if kind == "leaf":
+        cases = [H.leaf_case(201, 300, 280), H.leaf_case(202, 64, 700, alphabet="arndcqeghilkmfpstwyv", jc=False),
+                 H.leaf_case(203, 600, 90, band=12), H.leaf_case(204, 5, 3), H.leaf_case(205, 0, 4)]
+    else:
+        cases = [H.dag_case(71, n=90, samples=4), H.dag_case(72, n=150, band=6, samples=3),
+                 H.dag_case(81, n=40, samples=25), H.dag_case(51, n=10, components=2),
+                 H.dag_case(67, n=9, band=2, keep_all=True)]
     imgs = [H.job_images(f) for f in cases]
     be = capi.Batch(imgs)
     bf = capi.Batch(imgs, capi.HX_LSE_FAST)
