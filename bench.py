@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--tr", type=float, default=0.3)
     ap.add_argument("--cpu-pairs", type=int, default=10, help="pairs timed by the CPU baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--band", type=int, default=-1,
+                    help="guide-alignment band (maxDistanceFromGuide); the guide is the pair's true alignment. "
+                         "-1 = full envelope (the headline configuration)")
     ap.add_argument("--mode", choices=["exact", "fast"], default="fast",
                     help="log-sum-exp policy of the headline fill (the other mode is timed too and reported)")
     ap.add_argument("--single-mode", action="store_true", help="time only --mode")
@@ -49,8 +52,9 @@ def parse():
     return ap.parse_args()
 
 
-def synth_pair(rng, pi, length):
-    """x ~ pi; y = x with ~20% substitutions (~pi) and ~2% indels, cut/padded to `length`."""
+def synth_pair(rng, pi, length, want_guide=False):
+    """x ~ pi; y = x with ~20% substitutions (~pi) and ~2% indels, cut/padded to `length`.
+    With want_guide, also the true pairwise alignment as two boolean rows (the guide alignment)."""
     a = len(pi)
     x = rng.choice(a, size=length, p=pi)
     keep = rng.random(length) >= .02
@@ -59,9 +63,45 @@ def synth_pair(rng, pi, length):
     y = np.where(sub, rng.choice(a, size=len(y), p=pi), y)
     ins_at = np.flatnonzero(rng.random(len(y)) < .02)
     y = np.insert(y, ins_at, rng.choice(a, size=len(ins_at), p=pi))
-    if len(y) < length:
-        y = np.concatenate([y, rng.choice(a, size=length - len(y), p=pi)])
-    return x, y[:length]
+    pad = max(0, length - len(y))
+    if pad:
+        y = np.concatenate([y, rng.choice(a, size=pad, p=pi)])
+    if not want_guide:
+        return x, y[:length]
+    xrow, yrow = [], []
+    ins = set(int(k) for k in ins_at)
+    k = 0                                   # index into the kept (pre-insertion) y residues
+    for p in range(length):
+        if keep[p]:
+            if k in ins:
+                xrow.append(False); yrow.append(True)
+            xrow.append(True); yrow.append(True)
+            k += 1
+        else:
+            xrow.append(True); yrow.append(False)
+    xrow += [False] * pad
+    yrow += [True] * pad
+    # y is cut to `length` residues: later y residues leave the alignment
+    seen = 0
+    for c in range(len(yrow)):
+        if yrow[c]:
+            seen += 1
+            if seen > length:
+                yrow[c] = False
+    cols = [c for c in range(len(xrow)) if xrow[c] or yrow[c]]
+    return x, y[:length], (np.array([xrow[c] for c in cols]), np.array([yrow[c] for c in cols]))
+
+
+def envelope_coordinates(xrow, yrow):
+    """Per-state envelope coordinate of the two leaf profiles under a pairwise guide alignment
+    (reference src/alignpath.cpp:282-310 + src/forward.cpp:26-35: cumulativeMatches[rowPosToCol[pos]];
+    START has position 0, END the position of the last residue)."""
+    cm = np.concatenate([[0], np.cumsum(xrow & yrow)])
+    def coords(row):
+        pos2col = np.concatenate([[0], np.flatnonzero(row) + 1])
+        e = cm[pos2col]
+        return np.concatenate([e, e[-1:]]).astype(np.int32)
+    return coords(xrow), coords(yrow)
 
 
 def main():
@@ -95,10 +135,25 @@ def main():
     pi = pi / pi.sum()
 
     triples = []
+    env_cells = 0
+    env_cells_of = []
     for k in range(args.pairs):
         rng = np.random.default_rng(farm.pair_seed(rank, args.pairs, k))
-        xs, ys = synth_pair(rng, pi, args.length)
-        triples.append((hostmodel.leaf_profile(xs, a, c), hostmodel.leaf_profile(ys, a, c), hmm, -1))
+        if args.band < 0:
+            xs, ys = synth_pair(rng, pi, args.length)
+            triples.append((hostmodel.leaf_profile(xs, a, c), hostmodel.leaf_profile(ys, a, c), hmm, -1))
+        else:
+            xs, ys, (xrow, yrow) = synth_pair(rng, pi, args.length, want_guide=True)
+            ex, ey = envelope_coordinates(xrow, yrow)
+            triples.append((hostmodel.leaf_profile(xs, a, c, ex), hostmodel.leaf_profile(ys, a, c, ey), hmm, args.band))
+            # in-envelope cells (reference src/forward.h:92-98): within the band, or at an edge
+            # (x START row; y column of the last residue, the source of the transition into END)
+            d = np.abs(ex[:-1, None].astype(np.int64) - ey[None, :-1])
+            inside = d <= args.band
+            inside[0, :] = True
+            inside[:, -1] = True
+            env_cells_of.append(int(inside.sum()))
+            env_cells += env_cells_of[-1]
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -108,7 +163,8 @@ def main():
 
     def run_mode(mode):
         """K timed passes of the hot path in one fill mode; returns (seconds, kernel ms list, lp_end, cells)."""
-        batch = capi.Batch(triples, capi.HX_LSE_FAST if mode == "fast" else capi.HX_LSE_EXACT)
+        batch = capi.Batch(triples, (capi.HX_LSE_FAST if mode == "fast" else capi.HX_LSE_EXACT) |
+                           (capi.HX_SPARSE_ENVELOPE if args.band >= 0 else 0))
         n_cells = batch.total_cells()
         for _ in range(args.warmup):
             batch.forward(stream)
@@ -133,6 +189,8 @@ def main():
     dt_o, kernel_ms_o, lp_end_o, _ = run_mode(other) if not args.single_mode else (None, None, None, None)
 
     if rank == 0:
+        if args.band >= 0:
+            cells = env_cells          # the metric counts in-envelope cells
         total_cells = cells * world * args.steps
         value = total_cells / dt
         k_ms = float(np.mean(kernel_ms))
@@ -140,7 +198,7 @@ def main():
         if traffic is None:
             try:        # measured once with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes), see DESIGN.md
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                    traffic = json.load(f).get("%s:%d:%d" % (args.mode, args.pairs, args.length))
+                    traffic = json.load(f).get("%s:%d:%d" % (args.mode, args.pairs, args.length)) if args.band < 0 else None
             except OSError:
                 traffic = None
         achieved = cells * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9
@@ -150,8 +208,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "batch of independent 2x%d-residue protein leaf-profile pairs, %s, t=%g/%g, "
-                                   "full (unbanded) Forward DP, %s log-sum-exp" %
+                                   "%s Forward DP, %s log-sum-exp" %
                                    (args.length, args.model.upper(), args.tl, args.tr,
+                                    "full (unbanded)" if args.band < 0 else
+                                    "band-%d (guide = the pair's true alignment; in-envelope cells counted)" % args.band,
                                     "exact table (cells bit-identical to the reference recursion)" if args.mode == "exact"
                                     else "fast LDS-table (same truncation; lpEnd within 1e-9 rel., tracebacks identical)"),
                        "pairs_per_gpu": args.pairs, "cells_per_gpu_per_step": cells,
@@ -180,7 +240,7 @@ def main():
             for k in range(n_cpu):
                 x, y, h, md = triples[k]
                 r = c_oracle.forward(x, y, h, md)
-                cpu_cells += (x.n_states - 1) * (y.n_states - 1)
+                cpu_cells += env_cells_of[k] if args.band >= 0 else (x.n_states - 1) * (y.n_states - 1)
                 rel = max(rel, abs(r["lp_end"] - lp_end[k]) / abs(r["lp_end"]))
             cpu_dt = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": cpu_cells / cpu_dt, "unit": "cells/s", "cores": 1, "kind": "port",

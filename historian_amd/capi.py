@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HX_LIB_PATH") or os.path.join(_HERE, "lib", "libhistorian_hip.so")
 
 HX_LSE_TABLE_ENTRIES = 100002
-HX_LSE_EXACT, HX_LSE_FAST, HX_KEEP_BACKWARD, HX_FORCE_GENERIC = 0, 1, 2, 4
+HX_LSE_EXACT, HX_LSE_FAST, HX_KEEP_BACKWARD, HX_FORCE_GENERIC, HX_SPARSE_ENVELOPE = 0, 1, 2, 4, 8
 IMM, IMD, IDM, IMI, IIW, EEE = 0, 1, 2, 3, 4, 5
 
 _i32p = C.POINTER(C.c_int32)

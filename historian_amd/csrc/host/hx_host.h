@@ -47,6 +47,16 @@ template <class T> using vguard = std::vector<T>;
 void Abort(const char* error, ...);   // message + terminate (reference: `throw;` with no active exception)
 void Warn(const char* warning, ...);
 void Fail(const char* error, ...);    // message + exit(EXIT_FAILURE)
+
+// wall-clock accounting of the device-backed constructors (seconds, whole process); printed by hxrecon
+// when HX_TIMING is set.  Not part of the reference's interface.
+struct FillTiming {
+  double deviceInit = 0, flattenAndUpload = 0, forwardWait = 0, forwardKernel = 0, backwardWait = 0, readMatrix = 0;
+  long fills = 0, matrixReads = 0;
+  long long cells = 0;
+};
+extern FillTiming fillTiming;
+double wallSeconds();
 #define Test(assertion, ...) ((assertion) ? true : (::historian::Warn(__VA_ARGS__), false))
 #define Assert(assertion, ...) do { if (!(assertion)) ::historian::Abort("Assertion Failed: " __VA_ARGS__); } while (0)
 #define Require(assertion, ...) do { if (!(assertion)) ::historian::Fail(__VA_ARGS__); } while (0)

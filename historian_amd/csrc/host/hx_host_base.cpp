@@ -1,3 +1,4 @@
+#include <ctime>
 // util, logsumexp, fastseq, alignpath and model parts of the host mirror (see hx_host.h).
 #include "hx_host.h"
 
@@ -11,6 +12,14 @@
 #include <sstream>
 
 namespace historian {
+
+FillTiming fillTiming;
+double wallSeconds() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
 
 // ---- errors (reference src/util.cpp:26-54) --------------------------------------------------
 void Warn(const char* warning, ...) {

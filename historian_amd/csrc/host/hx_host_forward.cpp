@@ -27,12 +27,14 @@ static void hxCheck(int rc, const char* what) {
 
 static void ensureDevice() {
   if (g_deviceReady) return;
+  const double t0 = wallSeconds();
   const char* dev = getenv("HX_DEVICE");
   // the device gets the table the host built with its own libm (reference src/logsumexp.cpp:6-16)
   hxCheck(hx_init(dev ? atoi(dev) : 0, logSumExpLookupTable.lookup, HX_LSE_TABLE_ENTRIES), "hx_init");
   const char* mode = getenv("HX_FILL_MODE");   // "fast" selects the fast log-sum-exp policy for this process
   if (mode && string(mode) == "fast") g_fillMode = HX_LSE_FAST;
   g_deviceReady = true;
+  fillTiming.deviceInit += wallSeconds() - t0;
 }
 
 // POD image of a Profile for the C ABI
@@ -105,6 +107,7 @@ DPMatrix::~DPMatrix() {
 // the fill loops of src/forward.cpp:78-223: flatten, create the device job, run the Forward fill.
 void DPMatrix::createBatchAndPrepare() {
   ensureDevice();
+  const double t0 = wallSeconds();
   const size_t C = hmm.components(), A = hmm.alphabetSize();
   vguard<int> envx, envy;
   const bool banded = envelope.initialized();
@@ -145,10 +148,18 @@ void DPMatrix::createBatchAndPrepare() {
   job.y = &fy.pod;
   job.hmm = &hh;
   job.max_distance = envelope.maxDistance;
-  hxCheck(hx_batch_create(&job, 1, g_fillMode, &batch), "hx_batch_create");
+  hxCheck(hx_batch_create(&job, 1, g_fillMode | HX_SPARSE_ENVELOPE, &batch), "hx_batch_create");
   ownsBatch = true;
+  const double t1 = wallSeconds();
   hxCheck(hx_batch_forward(batch, NULL), "hx_batch_forward");
   hxCheck(hx_batch_lp_end(batch, &lpEnd), "hx_batch_lp_end");
+  const double t2 = wallSeconds();
+  float kms = 0;
+  if (hx_batch_last_kernel_ms(batch, 0, &kms) == HX_OK) fillTiming.forwardKernel += 1e-3 * kms;
+  fillTiming.flattenAndUpload += t1 - t0;
+  fillTiming.forwardWait += t2 - t1;
+  fillTiming.fills += 1;
+  fillTiming.cells += (long long)(xSize - 1) * (long long)(ySize - 1);
   hx_layout lay;
   hxCheck(hx_batch_layout(batch, 0, 0, &lay), "hx_batch_layout");
   stripStride = lay.strip_stride;
@@ -173,13 +184,17 @@ void DPMatrix::fetchPrepared() {
 
 void DPMatrix::ensureHostCells() const {
   if (haveHostCells) return;
+  const double t0 = wallSeconds();
   hostCells.resize(5 * (size_t)planeStride);
   hxCheck(hx_batch_read_matrix(batch, 0, which, hostCells.data()), "hx_batch_read_matrix");
   haveHostCells = true;
+  fillTiming.readMatrix += wallSeconds() - t0;
+  fillTiming.matrixReads += 1;
 }
 
 LogProb DPMatrix::cell(ProfileStateIndex xpos, ProfileStateIndex ypos, PairHMM::State state) const {
   if (xpos + 1 >= xSize || ypos + 1 >= ySize || state >= PairHMM::TotalStates) return NEG_INF;
+  if (!inEnvelope(xpos, ypos)) return NEG_INF;   // not stored (the batch is created with HX_SPARSE_ENVELOPE)
   ensureHostCells();
   if (which == 1) {   // the Backward matrix is stored in mirrored coordinates (hx_layout::mirrored)
     xpos = xSize - 2 - xpos;

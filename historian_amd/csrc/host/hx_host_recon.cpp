@@ -1,3 +1,5 @@
+#include <cstdlib>
+#include <cstdio>
 // Progressive reconstruction loop of the host mirror (see hx_host.h): the part of
 // Reconstructor that drives the DP (reference src/recon.cpp:864-915, 917-1052).
 #include "hx_host.h"
@@ -68,10 +70,14 @@ void Reconstructor::reconstruct(Dataset& dataset) {
 
   AlignPath path;
   map<int, Profile> prof;
+  const bool timing = getenv("HX_TIMING") != NULL;
+  double tLeaf = 0, tHmm = 0, tFwd = 0, tProf = 0, tCheck = 0;
   for (TreeNodeIndex node = 0; node < dataset.tree.nodes(); ++node) {
-    if (dataset.tree.isLeaf(node))
+    const double ta = wallSeconds();
+    if (dataset.tree.isLeaf(node)) {
       prof[node] = Profile(model.components(), model.alphabet, dataset.seqs.at(node), node);
-    else {
+      tLeaf += wallSeconds() - ta;
+    } else {
       const int lChildNode = dataset.tree.getChild(node, 0);
       const int rChildNode = dataset.tree.getChild(node, 1);
       const Profile& lProf = prof[lChildNode];
@@ -79,6 +85,8 @@ void Reconstructor::reconstruct(Dataset& dataset) {
       ProbModel lProbs(model, dataset.tree.branchLength(lChildNode));
       ProbModel rProbs(model, dataset.tree.branchLength(rChildNode));
       PairHMM hmm(lProbs, rProbs, rootProb);
+      const double tb = wallSeconds();
+      tHmm += tb - ta;
 
       ForwardMatrix* forward = NULL;
       int maxDist = maxDistanceFromGuide;
@@ -99,6 +107,8 @@ void Reconstructor::reconstruct(Dataset& dataset) {
         forward = NULL;
       }
       dataset.bandUsed[node] = maxDist;
+      const double tc = wallSeconds();
+      tFwd += tc - tb;
 
       BackwardMatrix* backward = NULL;
       if (usePosteriorsForProfile && node != dataset.tree.root()) backward = new BackwardMatrix(*forward);
@@ -115,14 +125,20 @@ void Reconstructor::reconstruct(Dataset& dataset) {
         nodeProf = forward->sampleProfile(generator, profileSamples, profileMaxStates, strategy);
 
       if (backward) delete backward;
+      const double td = wallSeconds();
+      tProf += td - tc;
       if (node == dataset.tree.root()) dataset.lpFinalFwd = forward->lpEnd;
       if (nodeProf.size()) {
         const LogProb lpTrace = nodeProf.calcSumPathAbsorbProbs(log_vector(model.cptWeight), logRootProb, NULL);
         if (node == dataset.tree.root()) dataset.lpFinalTrace = lpTrace;
       }
       delete forward;
+      tCheck += wallSeconds() - td;
     }
   }
+  if (timing)
+    fprintf(stderr, "timing: leaf profiles %.3f s, ProbModel+PairHMM %.3f s, ForwardMatrix ctor %.3f s, traceback+profile %.3f s, "
+                    "calcSumPathAbsorbProbs+delete %.3f s\n", tLeaf, tHmm, tFwd, tProf, tCheck);
   dataset.path = path;
 }
 

@@ -64,7 +64,17 @@ int main(int argc, char** argv) {
       }
     }
   ds.prepareRecon();
+  const double t0 = wallSeconds();
   recon.reconstruct(ds);
+  if (getenv("HX_TIMING")) {
+    const double total = wallSeconds() - t0;
+    const FillTiming& f = fillTiming;
+    fprintf(stderr, "timing: reconstruct %.3f s = one-off HIP/device initialisation %.3f s + %.3f s; %ld fills over %lld lattice cells: "
+                    "flatten+upload %.3f s, forward (launch..lpEnd) %.3f s of which fill kernels %.3f s, matrix D2H %.3f s in %ld reads; "
+                    "host traceback/profile building/other %.3f s\n",
+            total, f.deviceInit, total - f.deviceInit, f.fills, f.cells, f.flattenAndUpload, f.forwardWait, f.forwardKernel, f.readMatrix,
+            f.matrixReads, total - f.deviceInit - f.flattenAndUpload - f.forwardWait - f.readMatrix - f.backwardWait);
+  }
   printf("lpFinalFwd %a %.6f\n", ds.lpFinalFwd, ds.lpFinalFwd);
   printf("lpFinalTrace %a %.6f\n", ds.lpFinalTrace, ds.lpFinalTrace);
   for (const auto& nb : ds.bandUsed) printf("band %d %d\n", nb.first, nb.second);

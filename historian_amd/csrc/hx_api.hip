@@ -570,10 +570,12 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   // the reference evaluates them inside its fill loop, so the launch is inside the timed region.
   if (!(b->flags & HX_FORCE_GENERIC)) launch_emission_plane(b->d_jobs, b->n_jobs, b->max_eplane, g_tab, st);
   static const bool force_dag = getenv("HX_FORCE_DAG") != nullptr;   // tuning hook: general pipeline for chain profiles too
-  if (b->all_chain && !(b->flags & HX_FORCE_GENERIC) && !(force_dag && b->d_agg))
+  if (b->all_chain && !(b->flags & HX_FORCE_GENERIC) && !(force_dag && b->d_agg)) {
+    // with a band the strip pipelines only visit in-envelope windows; everything else is -inf
+    if (b->any_banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_fwd, b->fwd_total, st);
     launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,
                          b->all_leaf ? (b->all_ylds ? 2 : 1) : 0, b->any_banded, st);
-  else if (b->flags & HX_FORCE_GENERIC)
+  } else if (b->flags & HX_FORCE_GENERIC)
     launch_forward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
   else {
     // general profiles: the strip pipeline; with a band it only visits in-envelope windows, the rest is -inf
@@ -610,10 +612,11 @@ int hx_batch_backward(hx_batch* b, void* stream) {
     HIP_TRY(hipMemcpy(b->d_jobs, b->jobs.data(), sizeof(DevJob) * b->n_jobs, hipMemcpyHostToDevice));
   }
   HIP_TRY(hipEventRecord(b->ev[1][0], st));
-  if (b->all_leaf && !(b->flags & HX_FORCE_GENERIC))
+  if (b->all_leaf && !(b->flags & HX_FORCE_GENERIC)) {
+    if (b->any_banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_bwd, b->fwd_total, st);
     launch_backward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,
                           b->all_ylds ? 2 : 1, b->any_banded, st);
-  else if (b->flags & HX_FORCE_GENERIC)
+  } else if (b->flags & HX_FORCE_GENERIC)
     launch_backward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
   else {
     if (b->any_banded) launch_fill_neg_inf(b->d_bwd, b->fwd_total, st);
@@ -692,7 +695,7 @@ int hx_batch_read_cells(hx_batch* b, int32_t job, int32_t which, const int32_t* 
   int rc = HX_OK;
   if (hipMemcpy(d_ij, ij, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice) != hipSuccess) rc = fail(HX_ERR_HIP, "upload failed");
   if (rc == HX_OK) {
-    launch_gather_cells(matrix_of(b, job, which), J.plane, J.strip_stride, J.n_rows, J.n_cols, which, d_ij, n, d_out, b->last_stream);
+    launch_gather_cells(b->d_jobs, job, matrix_of(b, job, which), which, d_ij, n, d_out, b->last_stream);
     if (hipStreamSynchronize(b->last_stream) != hipSuccess ||
         hipMemcpy(out, d_out, sizeof(double) * 5 * n, hipMemcpyDeviceToHost) != hipSuccess)
       rc = fail(HX_ERR_HIP, "cell gather failed");

@@ -246,22 +246,30 @@ __device__ __forceinline__ C5 leaf_cell_bwd(const double (*T)[6], const LSE& L, 
 #define HX_YL_MAX_CLS 64
 #define HX_YL_MAX_EMIS 1024
 
-template <int DIR, int RPT, int W, class LSE, bool FAST, bool LEAF, bool YL, bool BANDED, int MINW = 1>
-__global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __restrict__ jobs,
-                                                                const double* __restrict__ exact_tab,
-                                                                const double* __restrict__ fast_tab) {
-  constexpr int THREADS = W * 64;
+// PPW > 1: a workgroup holds PPW pairs, W waves each, sharing the LDS log-sum-exp table.  Used for
+// banded batches: the strips of a banded pair run almost one after the other (a strip's window opens
+// when the strip above has all but finished its own), so a pair keeps one wave busy, and the GPU is
+// filled by putting many pairs, not many strips, in flight.
+template <int DIR, int RPT, int W, class LSE, bool FAST, bool LEAF, bool YL, bool BANDED, int MINW = 1, int PPW = 1>
+__global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob* __restrict__ jobs,
+                                                                      const double* __restrict__ exact_tab,
+                                                                      const double* __restrict__ fast_tab, const int n_jobs) {
+  constexpr int THREADS = W * PPW * 64;
   constexpr int SR = 64 * RPT;                      // rows per strip
-  __shared__ volatile int prog[W];
+  static_assert(PPW == 1 || !YL, "the LDS-resident y side belongs to one pair");
+  __shared__ volatile int prog[W * PPW];
   __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : 2];
   if (FAST) {
     for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 2; k += THREADS) ftab[k] = fast_tab[k];
   }
-  if (threadIdx.x < W) prog[threadIdx.x] = 0;
+  if (threadIdx.x < W * PPW) prog[threadIdx.x] = 0;
   const LSE L = LSE::make(FAST ? (const double*)ftab : exact_tab);
   const ExactLse LX{exact_tab};
 
-  const DevJob& J = jobs[blockIdx.x];
+  const int pair_in_wg = (int)(threadIdx.x >> 6) / W;
+  const int job_index = (int)blockIdx.x * PPW + pair_in_wg;
+  const bool live = job_index < n_jobs;
+  const DevJob& J = jobs[live ? job_index : 0];
   // YL: the whole y side lives in LDS (leaf-like y profile whose transitions all have
   // lpTrans 0): per column one word {emission class, not-ready bit}, per class
   // {rootsuby, insy}, and the padded class-pair emission table.  The step loop then
@@ -283,7 +291,7 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
   }
   __syncthreads();
   const int R = J.n_rows, Cc = J.n_cols;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) % W;   // wave within its pair
   const int64_t plane = J.plane, ss = J.strip_stride;
   static_assert(DIR == 0 || LEAF, "the Backward strip pipeline exists for leaf-like profiles only");
   HX_GLOBAL double* __restrict__ M = as_global(DIR ? J.bwd : J.fwd);
@@ -293,8 +301,8 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
   const HX_GLOBAL double* epad = as_global(J.emis_pad);
   const HX_GLOBAL uint8_t* yflags = as_global(J.y.flags);
   const HX_GLOBAL int32_t* yenv = as_global(J.y.env);
-  volatile HX_LDS int* progp = (volatile HX_LDS int*)prog;   // keep the LDS address space through the lambdas
-  const int n_strips = (R + SR - 1) / SR;
+  volatile HX_LDS int* progp = (volatile HX_LDS int*)prog + pair_in_wg * W;   // keep the LDS address space through the lambdas
+  const int n_strips = live ? (R + SR - 1) / SR : 0;
   const int prev_wave = (wave + W - 1) % W;
 
   for (int s = wave; s < n_strips; s += W) {
@@ -346,16 +354,43 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
     const bool store_rows = i0 < ((R + 63) & ~63);
 
     const int nsteps = Cc + SR - 1;
+    // With a band, a strip only sweeps the step windows that hold its in-envelope cells (computed on
+    // the host, hx_api.hip strip_windows; the matrix is pre-filled with -inf).  Windows are widened to
+    // even bounds: a row's two cells of steps 2m, 2m+1 are stored together.
+    int wlo[2] = {0, 0}, whi[2] = {nsteps, 0};
+    {
+      const HX_GLOBAL int32_t* win = as_global(DIR ? J.bwd_windows : J.fwd_windows);
+      if (BANDED && RPT == 1 && win) {
+        for (int w = 0; w < 2; ++w) {
+          wlo[w] = win[4 * s + 2 * w] & ~1;
+          const int h = (win[4 * s + 2 * w + 1] + 1) & ~1;
+          whi[w] = h < nsteps ? h : nsteps;
+        }
+        if (whi[1] > wlo[1] && wlo[1] <= whi[0]) { whi[0] = whi[1] > whi[0] ? whi[1] : whi[0]; wlo[1] = whi[1] = 0; }
+      }
+    }
+    int wstart = 0, published = 0;
+    // is cell (row0-1, sweep column jj) of the strip above inside the envelope?  (src/forward.h:92-98)
+    auto above_in_envelope = [&](const int jj) -> bool {
+      if (J.max_dist < 0 || row0 == 0 || jj < 0 || jj >= Cc) return true;
+      const int ia = DIR ? R - row0 : row0 - 1;          // actual x state of sweep row row0-1
+      const int ja = DIR ? Cc - 1 - jj : jj;
+      if ((J.x.flags[ia] | yflags[ja]) & F_EDGE) return true;
+      int dd = J.x.env[ia] - yenv[ja];
+      dd = dd < 0 ? -dd : dd;
+      return dd <= J.max_dist;
+    };
     // one anti-diagonal step of the strip; the lane's RPT new cells are returned in out[]
     auto step = [&](const int t, const C5 (&left)[RPT], C5 (&out)[RPT], C5& u1, C5& u2, const d4v (&Yp)[RPT],
                     const double (&ep)[RPT]) {
       if (has_above) {
-        if ((t & 63) == 0 && t < Cc) {
-          // wait until the strip above has finished (and drained) columns t .. t+63
-          const int hi = (t + 64 < Cc) ? t + 64 : Cc;
+        if (((t & 63) == 0 || t == wstart) && t < Cc) {
+          // wait until the strip above has finished (and drained) the 64-column block that holds column t
+          const int tb = t & ~63;
+          const int hi = (tb + 64 < Cc) ? tb + 64 : Cc;
           const int need = above_base + hi;
           while (progp[prev_wave] < need) __builtin_amdgcn_s_sleep(1);
-          const int jj = t + lane;
+          const int jj = tb + lane;
           bnd = c5_neg_inf();
           if (jj < Cc) {
             const int64_t sl = cell_slot(ss, row0 - 1, jj);
@@ -369,6 +404,8 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
           // consume the loads here, so that the wait for them sits in this once-per-64-steps
           // block and not at the merge point every step passes
           asm volatile("" : "+v"(bnd.imm), "+v"(bnd.imd), "+v"(bnd.idm), "+v"(bnd.imi), "+v"(bnd.iiw));
+          // with a band the strip above only wrote its in-envelope cells: anything else reads as -inf
+          if (BANDED && !above_in_envelope(jj)) bnd = c5_neg_inf();
         }
         const int sel = t & 63;
         C5 a = C5{read_lane(bnd.imm, sel), read_lane(bnd.imd, sel), read_lane(bnd.idm, sel),
@@ -428,13 +465,16 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
     // YL: per-row column word of the next step (and, for Backward, the word of the column the previous
     // step visited: in mirrored order that is actual column j+1, whose class the absorbing move needs)
     unsigned wnext[RPT], wprev1[RPT];
+    auto init_words = [&](const int t0) {
 #pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      const int j0 = 0 - (lane * RPT + k);
-      const int jm0 = j0 < 0 ? 0 : (j0 >= Cc ? Cc - 1 : j0);
-      wnext[k] = YL ? ycol[DIR ? Cc - 1 - jm0 : jm0] : 0u;
-      wprev1[k] = YL ? ycol[DIR ? Cc : 0] : 0u;
-    }
+      for (int k = 0; k < RPT; ++k) {
+        const int j0 = t0 - (lane * RPT + k);
+        const int jm0 = j0 < 0 ? 0 : (j0 >= Cc ? Cc - 1 : j0);
+        wnext[k] = YL ? ycol[DIR ? Cc - 1 - jm0 : jm0] : 0u;
+        // Backward: the word of the column visited one step earlier (actual column j+1)
+        wprev1[k] = YL ? ycol[DIR ? Cc - jm0 : 0] : 0u;
+      }
+    };
     auto prefetch = [&](const int t, d4v (&Yp)[RPT], double (&ep)[RPT]) {
       if (!LEAF) return;
 #pragma unroll
@@ -474,20 +514,47 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
     };
     d4v Ya[RPT], Yb[RPT];
     double ea[RPT], eb[RPT];
+    for (int w = 0; w < 2; ++w) {
+    if (whi[w] <= wlo[w]) continue;
+    wstart = wlo[w];
+    if (w > 0) {
+      // cells left of a window are outside the envelope: the register window restarts from -inf
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) { ca[k] = c5_neg_inf(); cb[k] = c5_neg_inf(); }
+      ua = c5_neg_inf(); ub = c5_neg_inf(); bnd = c5_neg_inf();
+    }
+    if (has_above && wstart > 0 && wstart <= Cc) {
+      // lane 0's diagonal source at the window's first step, (row0-1, wstart-1), belongs to the strip
+      // above and may well be inside the envelope: fetch it (in the steady state it is the boundary
+      // value of the previous step)
+      const int need = above_base + wstart;
+      while (progp[prev_wave] < need) __builtin_amdgcn_s_sleep(1);
+      if (lane == 0) {
+        const int64_t sl = cell_slot(ss, row0 - 1, wstart - 1);
+        ub.imm = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ub.imd = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ub.idm = __hip_atomic_load(M + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ub.imi = __hip_atomic_load(M + 3 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ub.iiw = __hip_atomic_load(M + 4 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!above_in_envelope(wstart - 1)) ub = c5_neg_inf();
+      }
+    }
+    init_words(wstart);
     if (!YL) {
-      prefetch(0, Ya, ea);
-      prefetch(1, Yb, eb);
+      prefetch(wstart, Ya, ea);
+      prefetch(wstart + 1, Yb, eb);
     }
 
     // Two steps per iteration: in the strip-skewed layout the two cells a row produces on
     // consecutive anti-diagonals are adjacent, so a lane stores RPT*16 contiguous bytes per
     // state plane every second step (a wave: RPT KiB, fully coalesced).
-    for (int t = 0; t < nsteps; t += 2) {
+    const int wend = whi[w];
+    for (int t = wstart; t < wend; t += 2) {
       C5 (&oa)[RPT] = ca;
       C5 (&ob)[RPT] = cb;
       if (YL) prefetch(t, Ya, ea);
       step(t, cb, ca, ua, ub, Ya, ea);
-      if (t + 1 < nsteps) {
+      if (t + 1 < wend) {
         if (YL) prefetch(t + 1, Yb, eb);
         step(t + 1, ca, cb, ub, ua, Yb, eb);
       }
@@ -525,18 +592,36 @@ __global__ void __launch_bounds__(W * 64, MINW) k_fill_chain(const DevJob* __res
       const int fin = (t + 2 < nsteps ? t + 2 : nsteps) - (SR - 1);
       if (fin >= Cc) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        published = Cc;
         if (lane == 0) progp[wave] = my_base + Cc;
       } else {
         const int done = fin - HX_PUBLISH_LAG;
-        if (done > 0 && ((done >> 6) != ((done - 2) >> 6))) {
+        if (done > published && ((done >> 6) != ((done - 2) >> 6))) {
           asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+          published = done;
           if (lane == 0) progp[wave] = my_base + done;
         }
       }
     }
+    // end of a window: what lies between it and the next one (or the end of the strip) holds no
+    // in-envelope cell, so those columns are complete as soon as the window's stores have drained
+    {
+      const int upto = (w == 0 && whi[1] > wlo[1]) ? wlo[1] - (SR - 1) : Cc;
+      const int done = upto > Cc ? Cc : upto;
+      if (done > published) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        published = done;
+        if (lane == 0) progp[wave] = my_base + done;
+      }
+    }
+    }
+    if (published < Cc) {          // (a strip without any window still releases the strip below)
+      published = Cc;
+      if (lane == 0) progp[wave] = my_base + Cc;
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (live && wave == 0 && lane == 0) {
     if (DIR == 0) *J.lp_end = forward_lp_end(J, LX);
     else *J.lp_start = J.bwd[cell_slot(ss, R - 1, Cc - 1)];   // B(0,0).IMM in mirrored coordinates
   }
@@ -547,7 +632,7 @@ static void launch_variant(const DevJob* d_jobs, int n_jobs, const double* tab, 
                            int leaf, bool banded, hipStream_t st) {
   const dim3 g(n_jobs), b(W * 64);
 #define HX_LAUNCH(LSE_, FAST_, LEAF_, YL_, BANDED_) \
-  hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, LSE_, FAST_, LEAF_, YL_, BANDED_, MINW>), g, b, 0, st, d_jobs, tab, fast_tab)
+  hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, LSE_, FAST_, LEAF_, YL_, BANDED_, MINW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs)
   if (leaf == 2 && !banded) {             // the headline configuration: unbanded leaf pairs, y side in LDS
     if (fast) HX_LAUNCH(FastLse, true, true, true, false); else HX_LAUNCH(ExactLse3, false, true, true, false);
   } else if (leaf == 2) {
@@ -556,11 +641,29 @@ static void launch_variant(const DevJob* d_jobs, int n_jobs, const double* tab, 
     if (fast) HX_LAUNCH(FastLse, true, true, false, true); else HX_LAUNCH(ExactLse3, false, true, false, true);
   } else if (DIR == 0) {
     if (fast)
-      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, FastLse, true, false, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, FastLse, true, false, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs);
     else
-      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, ExactLse3, false, false, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab);
+      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, ExactLse3, false, false, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs);
   }
 #undef HX_LAUNCH
+}
+
+// banded leaf-like batches: one wave per pair, PPW pairs per workgroup (see k_fill_chain, PPW); few pairs
+// per workgroup while that still leaves a workgroup for every CU
+template <int DIR, int PPW>
+static void launch_banded_leaf_ppw(const DevJob* d_jobs, int n_jobs, const double* tab, const double* fast_tab, bool fast,
+                                   hipStream_t st) {
+  const dim3 g((n_jobs + PPW - 1) / PPW), b(PPW * 64);
+  if (fast)
+    hipLaunchKernelGGL((k_fill_chain<DIR, 1, 1, FastLse, true, true, false, true, 1, PPW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs);
+  else
+    hipLaunchKernelGGL((k_fill_chain<DIR, 1, 1, ExactLse3, false, true, false, true, 1, PPW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs);
+}
+template <int DIR>
+static void launch_banded_leaf(const DevJob* d_jobs, int n_jobs, const double* tab, const double* fast_tab, bool fast,
+                               hipStream_t st) {
+  if (n_jobs <= 1024) launch_banded_leaf_ppw<DIR, 2>(d_jobs, n_jobs, tab, fast_tab, fast, st);
+  else launch_banded_leaf_ppw<DIR, 8>(d_jobs, n_jobs, tab, fast_tab, fast, st);
 }
 
 template <int DIR>
@@ -568,6 +671,10 @@ static void launch_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const d
                          bool fast, int leaf, bool banded, hipStream_t st) {
   const char* v = getenv("HX_CHAIN_VARIANT");   // tuning hook: override for long profiles
   const int vi = v ? atoi(v) : 0;
+  if (banded && leaf >= 1 && vi == 0 && n_jobs >= 64) {
+    launch_banded_leaf<DIR>(d_jobs, n_jobs, tab, fast_tab, fast, st);
+    return;
+  }
   if (max_rows <= 64)
     launch_variant<DIR, 1, 1>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, st);
   else if (max_rows <= 128)

@@ -23,7 +23,7 @@ void launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, co
 void launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
 void launch_posterior_scan(const DevJob* d_jobs, int job, double lpp_threshold, PostCell* out,
                            unsigned long long cap, unsigned long long* counter, hipStream_t st);
-void launch_gather_cells(const double* M, int64_t plane, int64_t strip_stride, int n_rows, int n_cols, int mirrored,
-                         const int* ij, int64_t n, double* out, hipStream_t st);
+void launch_gather_cells(const DevJob* d_jobs, int job, const double* M, int mirrored, const int* ij, int64_t n,
+                         double* out, hipStream_t st);
 
 }  // namespace hx

@@ -374,17 +374,18 @@ __global__ void k_posterior_scan(const DevJob* __restrict__ jobs, int job, doubl
   }
 }
 
-// gather of individual cells (traceback support)
-__global__ void k_gather_cells(const double* __restrict__ M, int64_t plane, int64_t strip_stride,
-                               int n_rows, int n_cols, int mirrored, const int* __restrict__ ij, int64_t n,
-                               double* __restrict__ out) {
+// gather of individual cells (traceback support); with a band, cells outside the envelope read as -inf
+// whatever the matrix holds there (HX_SPARSE_ENVELOPE batches do not pre-fill)
+__global__ void k_gather_cells(const DevJob* __restrict__ jobs, int job, const double* __restrict__ M, int mirrored,
+                               const int* __restrict__ ij, int64_t n, double* __restrict__ out) {
+  const DevJob& J = jobs[job];
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const int i = ij[2 * k], j = ij[2 * k + 1];
-  const bool ok = i >= 0 && j >= 0 && i < n_rows && j < n_cols;
-  const int64_t slot = !ok ? 0 : (mirrored ? bwd_slot(strip_stride, n_rows, n_cols, i, j) : cell_slot(strip_stride, i, j));
+  const bool ok = i >= 0 && j >= 0 && i < J.n_rows && j < J.n_cols && in_envelope(J, i, j);
+  const int64_t slot = !ok ? 0 : (mirrored ? bwd_slot(J.strip_stride, J.n_rows, J.n_cols, i, j) : cell_slot(J.strip_stride, i, j));
 #pragma unroll
-  for (int s = 0; s < 5; ++s) out[5 * k + s] = ok ? M[s * plane + slot] : HX_NEG_INF;
+  for (int s = 0; s < 5; ++s) out[5 * k + s] = ok ? M[s * J.plane + slot] : HX_NEG_INF;
 }
 
 // ---------------------------------------------------------------------------
@@ -428,11 +429,10 @@ void launch_posterior_scan(const DevJob* d_jobs, int job, double lpp_threshold, 
   hipLaunchKernelGGL(k_posterior_scan, dim3(1024), dim3(256), 0, st, d_jobs, job, lpp_threshold, out, cap, counter);
 }
 
-void launch_gather_cells(const double* M, int64_t plane, int64_t strip_stride, int n_rows, int n_cols, int mirrored,
-                         const int* ij, int64_t n, double* out, hipStream_t st) {
+void launch_gather_cells(const DevJob* d_jobs, int job, const double* M, int mirrored, const int* ij, int64_t n,
+                         double* out, hipStream_t st) {
   const int tpb = 256;
-  hipLaunchKernelGGL(k_gather_cells, dim3((unsigned)((n + tpb - 1) / tpb)), dim3(tpb), 0, st, M, plane,
-                     strip_stride, n_rows, n_cols, mirrored, ij, n, out);
+  hipLaunchKernelGGL(k_gather_cells, dim3((unsigned)((n + tpb - 1) / tpb)), dim3(tpb), 0, st, d_jobs, job, M, mirrored, ij, n, out);
 }
 
 }  // namespace hx

@@ -56,6 +56,11 @@ enum { HX_IMM = 0, HX_IMD = 1, HX_IDM = 2, HX_IMI = 3, HX_IIW = 4, HX_STATES = 5
                             differ from HX_LSE_EXACT by <= ~1e-9 per op               */
 #define HX_KEEP_BACKWARD 2u /* pre-allocate the Backward matrices at hx_batch_create        */
 #define HX_FORCE_GENERIC 4u /* always use the general (DAG) kernels, even for chain profiles */
+#define HX_SPARSE_ENVELOPE 8u /* banded jobs: do not pre-fill the matrices with -inf.  Cells outside the
+                                 envelope are then undefined in hx_batch_read_matrix (test the envelope, as the
+                                 reference's sparse cell storage makes its callers do, src/forward.h:68-98);
+                                 hx_batch_read_cells and hx_batch_posterior_scan still treat them as -inf.
+                                 Honoured by the chain (leaf) pipelines; general-profile batches always pre-fill. */
 
 /* POD image of a reference Profile (src/profile.h:13-76) restricted to what the
  * fills read.  Transitions are listed once; the three per-state lists hold

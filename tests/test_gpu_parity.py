@@ -105,6 +105,38 @@ def test_leaf_pairs_banded():
     run_and_check(cases, flags=capi.HX_FORCE_GENERIC)
 
 
+def test_many_banded_leaf_pairs_one_wave_each():
+    # >= 64 banded leaf pairs: one wave per pair, 16 pairs per workgroup; sizes straddle strip boundaries,
+    # the last workgroup is partly empty
+    rng = np.random.default_rng(7)
+    cases = []
+    for k in range(70):
+        lx, ly = int(rng.integers(0, 200)), int(rng.integers(0, 200))
+        cases.append(H.leaf_case(300 + k, lx, ly, band=int(rng.integers(0, 12))))
+    cases.append(H.leaf_case(400, 700, 650, band=16))
+    run_and_check(cases)
+
+
+def test_sparse_envelope_batches_agree_inside_the_envelope():
+    # HX_SPARSE_ENVELOPE: no -inf pre-fill; in-envelope cells, lpEnd/lpStart and gathered cells are unchanged
+    cases = [H.leaf_case(101, 90, 80, band=4), H.leaf_case(102, 200, 190, band=10), H.leaf_case(400, 700, 650, band=16)]
+    imgs = [H.job_images(f) for f in cases]
+    b = capi.Batch(imgs, capi.HX_KEEP_BACKWARD | capi.HX_SPARSE_ENVELOPE)
+    b.forward()
+    b.backward()
+    for k, (x, y, hmm, md) in enumerate(imgs):
+        want_f, want_b = c_oracle.forward(x, y, hmm, md), c_oracle.backward(x, y, hmm, md)
+        inside = np.isfinite(want_f["cells"]).any(axis=2) | np.isfinite(want_b["cells"]).any(axis=2)
+        H.assert_same_bits(b.read_matrix(k, 0)[inside], want_f["cells"][inside], "forward, in-envelope cells")
+        H.assert_same_bits(b.read_matrix(k, 1)[inside], want_b["cells"][inside], "backward, in-envelope cells")
+        H.assert_same_bits([b.lp_end()[k]], [want_f["lp_end"]], "lpEnd")
+        H.assert_same_bits([b.lp_start()[k]], [want_b["lp_start"]], "lpStart")
+        ij = np.array([[0, 0], [5, 5], [5, 60], [70, 3], [x.n_states - 2, y.n_states - 2]], dtype=np.int32)
+        got = b.read_cells(k, ij, 0)
+        H.assert_same_bits(got, want_f["cells"][ij[:, 0], ij[:, 1]], "gathered cells (-inf outside the envelope)")
+    b.close()
+
+
 def test_leaf_pair_with_more_rows_than_one_pass():
     # > 2048 rows: the chain kernel sweeps the matrix in two row passes
     f = H.leaf_case(104, 2150, 150)
