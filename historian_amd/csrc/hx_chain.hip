@@ -266,9 +266,10 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
   const LSE L = LSE::make(FAST ? (const double*)ftab : exact_tab);
   const ExactLse LX{exact_tab};
 
-  const int pair_in_wg = (int)(threadIdx.x >> 6) / W;
+  // (wave-uniform by construction; said explicitly so that the job record is addressed with scalar loads)
+  const int pair_in_wg = PPW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) / W;
   const int job_index = (int)blockIdx.x * PPW + pair_in_wg;
-  const bool live = job_index < n_jobs;
+  const bool live = PPW == 1 || job_index < n_jobs;   // (PPW == 1: the grid is exactly n_jobs)
   const DevJob& J = jobs[live ? job_index : 0];
   // YL: the whole y side lives in LDS (leaf-like y profile whose transitions all have
   // lpTrans 0): per column one word {emission class, not-ready bit}, per class
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
   }
   __syncthreads();
   const int R = J.n_rows, Cc = J.n_cols;
-  const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6) % W;   // wave within its pair
+  const int lane = threadIdx.x & 63, wave = PPW == 1 ? (int)(threadIdx.x >> 6) : (int)(threadIdx.x >> 6) % W;   // wave within its pair
   const int64_t plane = J.plane, ss = J.strip_stride;
   static_assert(DIR == 0 || LEAF, "the Backward strip pipeline exists for leaf-like profiles only");
   HX_GLOBAL double* __restrict__ M = as_global(DIR ? J.bwd : J.fwd);
@@ -301,6 +302,17 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
   const HX_GLOBAL double* epad = as_global(J.emis_pad);
   const HX_GLOBAL uint8_t* yflags = as_global(J.y.flags);
   const HX_GLOBAL int32_t* yenv = as_global(J.y.env);
+  // the 30 transition weights, pinned in scalar registers for the whole kernel: left to itself the
+  // compiler re-loads some of them inside the step loop (s_load + lgkmcnt(0) stalls, -3 % measured)
+  double Tk[5][6];
+#pragma unroll
+  for (int a = 0; a < 5; ++a)
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      double v = J.T[a][d];
+      asm volatile("" : "+s"(v));
+      Tk[a][d] = v;
+    }
   volatile HX_LDS int* progp = (volatile HX_LDS int*)prog + pair_in_wg * W;   // keep the LDS address space through the lambdas
   const int n_strips = live ? (R + SR - 1) / SR : 0;
   const int prev_wave = (wave + W - 1) % W;
@@ -357,10 +369,11 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
     // With a band, a strip only sweeps the step windows that hold its in-envelope cells (computed on
     // the host, hx_api.hip strip_windows; the matrix is pre-filled with -inf).  Windows are widened to
     // even bounds: a row's two cells of steps 2m, 2m+1 are stored together.
+    constexpr bool WIN = BANDED && RPT == 1;       // (without it everything below folds to one full sweep)
     int wlo[2] = {0, 0}, whi[2] = {nsteps, 0};
-    {
+    if (WIN) {
       const HX_GLOBAL int32_t* win = as_global(DIR ? J.bwd_windows : J.fwd_windows);
-      if (BANDED && RPT == 1 && win) {
+      if (win) {
         for (int w = 0; w < 2; ++w) {
           wlo[w] = win[4 * s + 2 * w] & ~1;
           const int h = (win[4 * s + 2 * w + 1] + 1) & ~1;
@@ -384,7 +397,7 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
     auto step = [&](const int t, const C5 (&left)[RPT], C5 (&out)[RPT], C5& u1, C5& u2, const d4v (&Yp)[RPT],
                     const double (&ep)[RPT]) {
       if (has_above) {
-        if (((t & 63) == 0 || t == wstart) && t < Cc) {
+        if (((t & 63) == 0 || (WIN && t == wstart)) && t < Cc) {
           // wait until the strip above has finished (and drained) the 64-column block that holds column t
           const int tb = t & ~63;
           const int hi = (tb + 64 < Cc) ? tb + 64 : Cc;
@@ -436,12 +449,12 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
           }
           const double pj = ok ? 0.0 : HX_NEG_INF;
           if (DIR == 0) {
-            nw = leaf_cell(J.T, L, XL[k], Yp[k], ep[k], pj, up, left[k], dg);
+            nw = leaf_cell(Tk, L, XL[k], Yp[k], ep[k], pj, up, left[k], dg);
             if (s == 0 && t == 0 && k == 0) {        // wave-uniform: only the very first step of strip 0
               if (lane == 0) nw.imm = 0.0;           // cell (0,0): lpStart() = 0 (reference src/forward.cpp:73)
             }
           } else {
-            nw = leaf_cell_bwd(J.T, L, XL[k], Yp[k], ep[k], pj, up, left[k], dg);
+            nw = leaf_cell_bwd(Tk, L, XL[k], Yp[k], ep[k], pj, up, left[k], dg);
             if (s == 0 && t == 0 && k == 0 && lane == 0) {
               // the cell feeding END is initialised by assignment (reference src/forward.cpp:981-995)
               const double lpe = J.x.pack[4 * (size_t)R] + J.y.pack[4 * (size_t)Cc];
@@ -514,16 +527,16 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
     };
     d4v Ya[RPT], Yb[RPT];
     double ea[RPT], eb[RPT];
-    for (int w = 0; w < 2; ++w) {
-    if (whi[w] <= wlo[w]) continue;
-    wstart = wlo[w];
-    if (w > 0) {
+    for (int w = 0; w < (WIN ? 2 : 1); ++w) {
+    if (WIN && whi[w] <= wlo[w]) continue;
+    wstart = WIN ? wlo[w] : 0;
+    if (WIN && w > 0) {
       // cells left of a window are outside the envelope: the register window restarts from -inf
 #pragma unroll
       for (int k = 0; k < RPT; ++k) { ca[k] = c5_neg_inf(); cb[k] = c5_neg_inf(); }
       ua = c5_neg_inf(); ub = c5_neg_inf(); bnd = c5_neg_inf();
     }
-    if (has_above && wstart > 0 && wstart <= Cc) {
+    if (WIN && has_above && wstart > 0 && wstart <= Cc) {
       // lane 0's diagonal source at the window's first step, (row0-1, wstart-1), belongs to the strip
       // above and may well be inside the envelope: fetch it (in the steady state it is the boundary
       // value of the previous step)
@@ -548,7 +561,7 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
     // Two steps per iteration: in the strip-skewed layout the two cells a row produces on
     // consecutive anti-diagonals are adjacent, so a lane stores RPT*16 contiguous bytes per
     // state plane every second step (a wave: RPT KiB, fully coalesced).
-    const int wend = whi[w];
+    const int wend = WIN ? whi[w] : nsteps;
     for (int t = wstart; t < wend; t += 2) {
       C5 (&oa)[RPT] = ca;
       C5 (&ob)[RPT] = cb;
@@ -592,20 +605,20 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
       const int fin = (t + 2 < nsteps ? t + 2 : nsteps) - (SR - 1);
       if (fin >= Cc) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        published = Cc;
+        if (WIN) published = Cc;
         if (lane == 0) progp[wave] = my_base + Cc;
       } else {
         const int done = fin - HX_PUBLISH_LAG;
-        if (done > published && ((done >> 6) != ((done - 2) >> 6))) {
+        if (done > (WIN ? published : 0) && ((done >> 6) != ((done - 2) >> 6))) {
           asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-          published = done;
+          if (WIN) published = done;
           if (lane == 0) progp[wave] = my_base + done;
         }
       }
     }
     // end of a window: what lies between it and the next one (or the end of the strip) holds no
     // in-envelope cell, so those columns are complete as soon as the window's stores have drained
-    {
+    if (WIN) {
       const int upto = (w == 0 && whi[1] > wlo[1]) ? wlo[1] - (SR - 1) : Cc;
       const int done = upto > Cc ? Cc : upto;
       if (done > published) {
@@ -615,7 +628,7 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
       }
     }
     }
-    if (published < Cc) {          // (a strip without any window still releases the strip below)
+    if (WIN && published < Cc) {   // (a strip without any window still releases the strip below)
       published = Cc;
       if (lane == 0) progp[wave] = my_base + Cc;
     }
