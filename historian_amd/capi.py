@@ -57,7 +57,8 @@ class HxCell(C.Structure):
 EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_create", "hx_batch_destroy",
            "hx_batch_forward", "hx_batch_backward", "hx_batch_sync", "hx_batch_lp_end", "hx_batch_lp_start",
            "hx_batch_layout", "hx_batch_read_matrix", "hx_batch_read_cells", "hx_batch_read_prepared",
-           "hx_batch_posterior_scan", "hx_batch_total_cells", "hx_batch_last_kernel_ms"]
+           "hx_batch_posterior_scan", "hx_batch_total_cells", "hx_batch_last_kernel_ms", "hx_host_alloc",
+           "hx_host_free"]
 
 
 class HxError(RuntimeError):

@@ -24,6 +24,7 @@
 #include <limits>
 #include <list>
 #include <map>
+#include <memory>
 #include <queue>
 #include <random>
 #include <set>
@@ -354,14 +355,26 @@ public:
 protected:
   vguard<LogProb> insx, insy, rootsubx, rootsuby;
   vguard<vguard<LogProb> > absorbScratch;
-  hx_batch* batch;               // device-resident job (owned by the ForwardMatrix; shared with its BackwardMatrix)
-  bool ownsBatch;
+  // device-resident batch this matrix is one job of (shared by the ForwardMatrix objects of one
+  // ForwardMatrix::fillBatch call and by their BackwardMatrix objects; destroyed with the last of them)
+  struct BatchHandle {
+    hx_batch* b;
+    int nJobs;
+    bool backwardDone;
+    BatchHandle(hx_batch* b, int nJobs) : b(b), nJobs(nJobs), backwardDone(false) {}
+    ~BatchHandle();
+  };
+  std::shared_ptr<BatchHandle> handle;
+  hx_batch* batch;               // == handle->b
+  int jobIndex;                  // this matrix's job in the batch
   int which;                     // 0 Forward, 1 Backward matrix of the batch
-  mutable vguard<double> hostCells;   // lazy copy of the device matrix (strip-skewed layout)
+  mutable double* hostCells;     // lazy copy of the device matrix (strip-skewed layout), page-locked, pooled
+  mutable size_t hostCellsCap;
   mutable bool haveHostCells;
   long long stripStride, planeStride;
 
   void createBatchAndPrepare();  // flatten inputs -> hx_batch_create; run the fill; fetch the prepared vectors
+  void attach(const std::shared_ptr<BatchHandle>& h, int job, double lpEndOfJob);   // adopt job `job` of a filled batch
   void fetchPrepared();
   void ensureHostCells() const;
   inline void initAbsorbScratch(ProfileStateIndex xpos, ProfileStateIndex ypos) {
@@ -397,6 +410,18 @@ public:
   ForwardMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, AlignRowIndex parentRowIndex,
                 const GuideAlignmentEnvelope& env, SumProduct* sumProd = NULL);
 
+  // Not in the reference: n independent Forward fills as ONE device batch (tree nodes whose children
+  // are ready, nodes of different families).  Same results as n constructor calls; the caller deletes
+  // the matrices as usual.  x, y and hmm must outlive the matrices, as for the constructor.
+  struct JobSpec {
+    const Profile* x;
+    const Profile* y;
+    const PairHMM* hmm;
+    AlignRowIndex parentRowIndex;
+    GuideAlignmentEnvelope env;
+  };
+  static vguard<ForwardMatrix*> fillBatch(const vguard<JobSpec>& jobs);
+
   Path sampleTrace(random_engine& generator);
   Path bestTrace();
   Path bestTrace(const CellCoords& end);
@@ -420,6 +445,11 @@ private:
   AlignPath traceAlignPath(const Path& path) const;
   ProfileState::SeqCoords cellSeqCoords(const CellCoords& cell) const;
   friend class BackwardMatrix;
+
+private:
+  struct Deferred {};
+  ForwardMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, AlignRowIndex parentRowIndex,
+                const GuideAlignmentEnvelope& env, Deferred);   // no fill yet (fillBatch)
 };
 
 class BackwardMatrix : public DPMatrix {
@@ -482,6 +512,10 @@ struct Reconstructor {
   double minPostProb;                    // -profminpost
   unsigned rndSeed;                      // mt19937::default_seed
   DPMatrix::random_engine generator;
+  // Not in the reference: fill every tree node whose children are ready as one device batch (the fills
+  // are independent; tracebacks and sampling still run in node order, so the results are unchanged).
+  bool batchReadyNodes;                  // default true
+  double maxBatchLatticeCells;           // upper bound on the lattice cells of one batch (device memory); default 4e8
 
   struct Dataset {
     ReconTree tree;

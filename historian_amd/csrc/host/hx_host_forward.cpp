@@ -87,7 +87,7 @@ DPMatrix::DPMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, const
       xNearStart(xSize, false), yNearEnd(ySize, false),
       insx(x.size(), NEG_INF), insy(y.size(), NEG_INF), rootsubx(x.size(), NEG_INF), rootsuby(y.size(), NEG_INF),
       absorbScratch(hmm.components(), vguard<LogProb>(hmm.alphabetSize())),
-      batch(NULL), ownsBatch(false), which(0), haveHostCells(false), stripStride(0), planeStride(0) {
+      batch(NULL), jobIndex(0), which(0), hostCells(NULL), hostCellsCap(0), haveHostCells(false), stripStride(0), planeStride(0) {
   if (env.initialized()) {
     for (ProfileStateIndex i = 1; i < xSize; ++i) xClosestLeafPos[i] = x.state[i].seqCoords.at(env.row1);
     for (ProfileStateIndex j = 1; j < ySize; ++j) yClosestLeafPos[j] = y.state[j].seqCoords.at(env.row2);
@@ -99,78 +99,174 @@ DPMatrix::DPMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, const
   for (auto yt : y.end().in) yNearEnd[y.trans[yt].src] = true;
 }
 
+// Page-locked buffers for the host copies of device matrices, recycled across matrices: pinning is not
+// free (it is what makes the D2H copy run at link rate), and consecutive tree nodes need similar sizes.
+namespace {
+struct PinnedPool {
+  std::vector<std::pair<size_t, double*> > freeList;   // (capacity in doubles, buffer)
+  double* take(size_t n, size_t& cap) {
+    size_t best = freeList.size();
+    for (size_t k = 0; k < freeList.size(); ++k)
+      if (freeList[k].first >= n && (best == freeList.size() || freeList[k].first < freeList[best].first)) best = k;
+    if (best < freeList.size()) {
+      cap = freeList[best].first;
+      double* p = freeList[best].second;
+      freeList.erase(freeList.begin() + (long)best);
+      return p;
+    }
+    if (freeList.size() >= 4) {                         // keep the pool small: drop the smallest buffer
+      size_t small = 0;
+      for (size_t k = 1; k < freeList.size(); ++k)
+        if (freeList[k].first < freeList[small].first) small = k;
+      hx_host_free(freeList[small].second);
+      freeList.erase(freeList.begin() + (long)small);
+    }
+    void* p = NULL;
+    cap = n + n / 8;
+    hxCheck(hx_host_alloc(cap * sizeof(double), &p), "hx_host_alloc");
+    return static_cast<double*>(p);
+  }
+  void give(double* p, size_t cap) { freeList.push_back(std::make_pair(cap, p)); }
+};
+PinnedPool g_pinned;
+}  // namespace
+
 DPMatrix::~DPMatrix() {
-  if (ownsBatch && batch) hx_batch_destroy(batch);
+  if (hostCells) g_pinned.give(hostCells, hostCellsCap);
+}
+
+DPMatrix::BatchHandle::~BatchHandle() {
+  if (b) hx_batch_destroy(b);
 }
 
 // Replaces the member initialisers subx/suby/insx/... of reference src/forward.cpp:20-56 and
 // the fill loops of src/forward.cpp:78-223: flatten, create the device job, run the Forward fill.
-void DPMatrix::createBatchAndPrepare() {
-  ensureDevice();
-  const double t0 = wallSeconds();
-  const size_t C = hmm.components(), A = hmm.alphabetSize();
-  vguard<int> envx, envy;
-  const bool banded = envelope.initialized();
-  if (banded) {
-    envx.resize(xSize);
-    envy.resize(ySize);
-    for (ProfileStateIndex i = 0; i < xSize; ++i) envx[i] = envelope.cumulativeMatches[envelope.row1PosToCol[xClosestLeafPos[i]]];
-    for (ProfileStateIndex j = 0; j < ySize; ++j) envy[j] = envelope.cumulativeMatches[envelope.row2PosToCol[yClosestLeafPos[j]]];
-  }
+namespace {
+// everything hx_batch_create reads for one job (must stay put until the call returns)
+struct JobImage {
   FlatProfile fx, fy;
-  fx.build(x, C, A, banded ? &envx : NULL);
-  fy.build(y, C, A, banded ? &envy : NULL);
+  vguard<int> envx, envy;
+  vguard<double> logRoot, logSubL, logSubR, logInsL, logInsR;
   hx_hmm hh;
+  hx_pair_job job;
+};
+}  // namespace
+
+static void buildJobImage(const DPMatrix& m, const vguard<SeqIdx>& xClosestLeafPos, const vguard<SeqIdx>& yClosestLeafPos,
+                          JobImage& im) {
+  const PairHMM& hmm = m.hmm;
+  const size_t C = hmm.components(), A = hmm.alphabetSize();
+  const bool banded = m.envelope.initialized();
+  if (banded) {
+    im.envx.resize(m.xSize);
+    im.envy.resize(m.ySize);
+    for (ProfileStateIndex i = 0; i < m.xSize; ++i) im.envx[i] = m.envelope.cumulativeMatches[m.envelope.row1PosToCol[xClosestLeafPos[i]]];
+    for (ProfileStateIndex j = 0; j < m.ySize; ++j) im.envy[j] = m.envelope.cumulativeMatches[m.envelope.row2PosToCol[yClosestLeafPos[j]]];
+  }
+  im.fx.build(m.x, C, A, banded ? &im.envx : NULL);
+  im.fy.build(m.y, C, A, banded ? &im.envy : NULL);
+  hx_hmm& hh = im.hh;
   hh.alph_size = (int32_t)A;
   hh.components = (int32_t)C;
   for (int s = 0; s < 5; ++s)
     for (int d = 0; d < 6; ++d) hh.lp_trans[s][d] = hmm.lpTrans((PairHMM::State)s, (PairHMM::State)d);
-  vguard<double> logRoot, logSubL, logSubR, logInsL, logInsR;
   for (size_t c = 0; c < C; ++c)
     for (size_t a = 0; a < A; ++a) {
-      logRoot.push_back(hmm.logRoot[c][a]);
-      logInsL.push_back(hmm.logl.logInsProb[c][a]);
-      logInsR.push_back(hmm.logr.logInsProb[c][a]);
+      im.logRoot.push_back(hmm.logRoot[c][a]);
+      im.logInsL.push_back(hmm.logl.logInsProb[c][a]);
+      im.logInsR.push_back(hmm.logr.logInsProb[c][a]);
       for (size_t d = 0; d < A; ++d) {
-        logSubL.push_back(log(hmm.l.subMat[c][a][d]));   // host libm log, as Profile::leftMultiply takes it
-        logSubR.push_back(log(hmm.r.subMat[c][a][d]));
+        im.logSubL.push_back(log(hmm.l.subMat[c][a][d]));   // host libm log, as Profile::leftMultiply takes it
+        im.logSubR.push_back(log(hmm.r.subMat[c][a][d]));
       }
     }
-  hh.log_root = logRoot.data();
-  hh.log_sub_l = logSubL.data();
-  hh.log_sub_r = logSubR.data();
-  hh.log_ins_l = logInsL.data();
-  hh.log_ins_r = logInsR.data();
+  hh.log_root = im.logRoot.data();
+  hh.log_sub_l = im.logSubL.data();
+  hh.log_sub_r = im.logSubR.data();
+  hh.log_ins_l = im.logInsL.data();
+  hh.log_ins_r = im.logInsR.data();
   hh.log_cptw_l = hmm.logl.logCptWeight.data();
   hh.log_cptw_r = hmm.logr.logCptWeight.data();
-  hx_pair_job job;
-  job.x = &fx.pod;
-  job.y = &fy.pod;
-  job.hmm = &hh;
-  job.max_distance = envelope.maxDistance;
-  hxCheck(hx_batch_create(&job, 1, g_fillMode | HX_SPARSE_ENVELOPE, &batch), "hx_batch_create");
-  ownsBatch = true;
+  im.job.x = &im.fx.pod;
+  im.job.y = &im.fy.pod;
+  im.job.hmm = &im.hh;
+  im.job.max_distance = m.envelope.maxDistance;
+}
+
+void DPMatrix::createBatchAndPrepare() {
+  ensureDevice();
+  const double t0 = wallSeconds();
+  JobImage im;
+  buildJobImage(*this, xClosestLeafPos, yClosestLeafPos, im);
+  hx_batch* b = NULL;
+  hxCheck(hx_batch_create(&im.job, 1, g_fillMode | HX_SPARSE_ENVELOPE, &b), "hx_batch_create");
+  std::shared_ptr<BatchHandle> h(new BatchHandle(b, 1));
   const double t1 = wallSeconds();
-  hxCheck(hx_batch_forward(batch, NULL), "hx_batch_forward");
-  hxCheck(hx_batch_lp_end(batch, &lpEnd), "hx_batch_lp_end");
+  hxCheck(hx_batch_forward(b, NULL), "hx_batch_forward");
+  double lp = NEG_INF;
+  hxCheck(hx_batch_lp_end(b, &lp), "hx_batch_lp_end");
   const double t2 = wallSeconds();
   float kms = 0;
-  if (hx_batch_last_kernel_ms(batch, 0, &kms) == HX_OK) fillTiming.forwardKernel += 1e-3 * kms;
+  if (hx_batch_last_kernel_ms(b, 0, &kms) == HX_OK) fillTiming.forwardKernel += 1e-3 * kms;
   fillTiming.flattenAndUpload += t1 - t0;
   fillTiming.forwardWait += t2 - t1;
   fillTiming.fills += 1;
   fillTiming.cells += (long long)(xSize - 1) * (long long)(ySize - 1);
+  attach(h, 0, lp);
+}
+
+void DPMatrix::attach(const std::shared_ptr<BatchHandle>& h, int job, double lpEndOfJob) {
+  handle = h;
+  batch = h->b;
+  jobIndex = job;
+  lpEnd = lpEndOfJob;
   hx_layout lay;
-  hxCheck(hx_batch_layout(batch, 0, 0, &lay), "hx_batch_layout");
+  hxCheck(hx_batch_layout(batch, jobIndex, 0, &lay), "hx_batch_layout");
   stripStride = lay.strip_stride;
   planeStride = lay.plane_stride;
   fetchPrepared();
 }
 
+// n independent fills, one device batch (not in the reference; see hx_host.h)
+vguard<ForwardMatrix*> ForwardMatrix::fillBatch(const vguard<JobSpec>& jobs) {
+  vguard<ForwardMatrix*> out;
+  if (jobs.empty()) return out;
+  ensureDevice();
+  const double t0 = wallSeconds();
+  const size_t n = jobs.size();
+  vguard<JobImage> images(n);          // sized once: hx_pair_job holds pointers into its elements
+  vguard<hx_pair_job> pods(n);
+  for (size_t k = 0; k < n; ++k) {
+    const JobSpec& js = jobs[k];
+    ForwardMatrix* f = new ForwardMatrix(*js.x, *js.y, *js.hmm, js.parentRowIndex, js.env, Deferred());
+    out.push_back(f);
+    buildJobImage(*f, f->xClosestLeafPos, f->yClosestLeafPos, images[k]);
+    pods[k] = images[k].job;
+  }
+  hx_batch* b = NULL;
+  hxCheck(hx_batch_create(pods.data(), (int32_t)n, g_fillMode | HX_SPARSE_ENVELOPE, &b), "hx_batch_create");
+  std::shared_ptr<BatchHandle> h(new BatchHandle(b, (int)n));
+  const double t1 = wallSeconds();
+  hxCheck(hx_batch_forward(b, NULL), "hx_batch_forward");
+  vguard<double> lp(n, NEG_INF);
+  hxCheck(hx_batch_lp_end(b, lp.data()), "hx_batch_lp_end");
+  const double t2 = wallSeconds();
+  float kms = 0;
+  if (hx_batch_last_kernel_ms(b, 0, &kms) == HX_OK) fillTiming.forwardKernel += 1e-3 * kms;
+  fillTiming.flattenAndUpload += t1 - t0;
+  fillTiming.forwardWait += t2 - t1;
+  for (size_t k = 0; k < n; ++k) {
+    out[k]->attach(h, (int)k, lp[k]);
+    fillTiming.fills += 1;
+    fillTiming.cells += (long long)(out[k]->xSize - 1) * (long long)(out[k]->ySize - 1);
+  }
+  return out;
+}
+
 void DPMatrix::fetchPrepared() {
   const size_t C = hmm.components(), A = hmm.alphabetSize();
   vguard<double> sx(xSize * C * A), sy(ySize * C * A);
-  hxCheck(hx_batch_read_prepared(batch, 0, sx.data(), sy.data(), insx.data(), rootsubx.data(), insy.data(), rootsuby.data()),
+  hxCheck(hx_batch_read_prepared(batch, jobIndex, sx.data(), sy.data(), insx.data(), rootsubx.data(), insy.data(), rootsuby.data()),
           "hx_batch_read_prepared");
   for (ProfileStateIndex i = 0; i < xSize; ++i)
     if (!subx.state[i].isNull())
@@ -185,8 +281,8 @@ void DPMatrix::fetchPrepared() {
 void DPMatrix::ensureHostCells() const {
   if (haveHostCells) return;
   const double t0 = wallSeconds();
-  hostCells.resize(5 * (size_t)planeStride);
-  hxCheck(hx_batch_read_matrix(batch, 0, which, hostCells.data()), "hx_batch_read_matrix");
+  hostCells = g_pinned.take(5 * (size_t)planeStride, hostCellsCap);
+  hxCheck(hx_batch_read_matrix(batch, jobIndex, which, hostCells), "hx_batch_read_matrix");
   haveHostCells = true;
   fillTiming.readMatrix += wallSeconds() - t0;
   fillTiming.matrixReads += 1;
@@ -316,6 +412,10 @@ ForwardMatrix::ForwardMatrix(const Profile& x, const Profile& y, const PairHMM& 
   Require(sumProd == NULL, "substitution counts (SumProduct) are outside this build's scope");
   createBatchAndPrepare();
 }
+
+ForwardMatrix::ForwardMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, AlignRowIndex parentRowIndex,
+                             const GuideAlignmentEnvelope& env, Deferred)
+    : DPMatrix(x, y, hmm, env), parentRowIndex(parentRowIndex), sumProd(NULL) {}
 
 ForwardMatrix::Path ForwardMatrix::sampleTrace(random_engine& generator) {
   Assert(lpEnd > NEG_INF, "Forward likelihood is zero; traceback fail");
@@ -648,8 +748,9 @@ void ForwardMatrix::slowFillTest() {}
 BackwardMatrix::BackwardMatrix(ForwardMatrix& fwd) : DPMatrix(fwd.x, fwd.y, fwd.hmm, fwd.envelope), fwd(fwd) {
   // the Forward object's device job already holds the prepared vectors; the reference recomputes them
   // (src/forward.cpp:976) -- here they are shared
+  handle = fwd.handle;
   batch = fwd.batch;
-  ownsBatch = false;
+  jobIndex = fwd.jobIndex;
   which = 1;
   stripStride = fwd.stripStride;
   planeStride = fwd.planeStride;
@@ -657,9 +758,13 @@ BackwardMatrix::BackwardMatrix(ForwardMatrix& fwd) : DPMatrix(fwd.x, fwd.y, fwd.
   suby = fwd.suby;
   insx = fwd.insx; insy = fwd.insy; rootsubx = fwd.rootsubx; rootsuby = fwd.rootsuby;
   lpEnd = 0;
-  hxCheck(hx_batch_backward(batch, NULL), "hx_batch_backward");
-  double lpStartDev = NEG_INF;
-  hxCheck(hx_batch_lp_start(batch, &lpStartDev), "hx_batch_lp_start");
+  if (!handle->backwardDone) {      // one launch fills the Backward matrices of every job of the batch
+    hxCheck(hx_batch_backward(batch, NULL), "hx_batch_backward");
+    handle->backwardDone = true;
+  }
+  vguard<double> lpStarts((size_t)handle->nJobs, NEG_INF);
+  hxCheck(hx_batch_lp_start(batch, lpStarts.data()), "hx_batch_lp_start");
+  const double lpStartDev = lpStarts[(size_t)jobIndex];
   // |a-b| <= eps * 2^exponent(max(|a|,|b|)): gsl_fcmp (reference src/forward.cpp:1091)
   const double a = lpStartDev, b = fwd.lpEnd;
   int exponent;
@@ -753,11 +858,11 @@ BackwardMatrix::Path BackwardMatrix::bestTrace(const CellCoords& traceStart) {
 std::priority_queue<BackwardMatrix::CellPostProb> BackwardMatrix::cellsAbovePostProbThreshold(double minPostProb) const {
   std::priority_queue<CellPostProb> bc;
   int64_t n = 0;
-  hxCheck(hx_batch_posterior_scan(batch, 0, minPostProb, NULL, 0, &n), "hx_batch_posterior_scan");
+  hxCheck(hx_batch_posterior_scan(batch, jobIndex, minPostProb, NULL, 0, &n), "hx_batch_posterior_scan");
   vguard<hx_cell> found((size_t)n);
   if (n > 0) {
     int64_t n2 = 0;
-    hxCheck(hx_batch_posterior_scan(batch, 0, minPostProb, found.data(), n, &n2), "hx_batch_posterior_scan");
+    hxCheck(hx_batch_posterior_scan(batch, jobIndex, minPostProb, found.data(), n, &n2), "hx_batch_posterior_scan");
     found.resize((size_t)std::min(n, n2));
   }
   std::sort(found.begin(), found.end(), [](const hx_cell& a, const hx_cell& b) {

@@ -28,7 +28,8 @@ void ReconTree::finish() {
 
 Reconstructor::Reconstructor()
     : maxDistanceFromGuide(20), profileSamples(10), profileMaxStates(0), includeBestTraceInProfile(true), keepGapsOpen(false),
-      usePosteriorsForProfile(false), reconstructRoot(true), minPostProb(.01), rndSeed(std::mt19937::default_seed) {}
+      usePosteriorsForProfile(false), reconstructRoot(true), minPostProb(.01), rndSeed(std::mt19937::default_seed),
+      batchReadyNodes(true), maxBatchLatticeCells(4e8) {}
 
 void Reconstructor::seedGenerator() { generator = DPMatrix::random_engine(rndSeed); }
 
@@ -57,7 +58,10 @@ void Reconstructor::Dataset::prepareRecon() {
     }
 }
 
-// reference src/recon.cpp:917-1052
+// reference src/recon.cpp:917-1052.  The per-node work is the reference's; what differs is when a node's
+// Forward fill is launched: as soon as both children's profiles exist, together with every other such
+// node (ForwardMatrix::fillBatch), instead of one node at a time.  Tracebacks, sampling and profile
+// building consume the shared random generator and therefore still run strictly in node order.
 void Reconstructor::reconstruct(Dataset& dataset) {
   if (!usePosteriorsForProfile) seedGenerator();
   const vguard<Vec>& rootProb = model.insProb;
@@ -68,47 +72,108 @@ void Reconstructor::reconstruct(Dataset& dataset) {
   vguard<vguard<LogProb> > logRootProb;
   for (const auto& rv : rootProb) logRootProb.push_back(log_vector(rv));
 
+  const TreeNodeIndex N = dataset.tree.nodes();
   AlignPath path;
   map<int, Profile> prof;
   const bool timing = getenv("HX_TIMING") != NULL;
   double tLeaf = 0, tHmm = 0, tFwd = 0, tProf = 0, tCheck = 0;
-  for (TreeNodeIndex node = 0; node < dataset.tree.nodes(); ++node) {
-    const double ta = wallSeconds();
-    if (dataset.tree.isLeaf(node)) {
-      prof[node] = Profile(model.components(), model.alphabet, dataset.seqs.at(node), node);
-      tLeaf += wallSeconds() - ta;
-    } else {
-      const int lChildNode = dataset.tree.getChild(node, 0);
-      const int rChildNode = dataset.tree.getChild(node, 1);
-      const Profile& lProf = prof[lChildNode];
-      const Profile& rProf = prof[rChildNode];
-      ProbModel lProbs(model, dataset.tree.branchLength(lChildNode));
-      ProbModel rProbs(model, dataset.tree.branchLength(rChildNode));
-      PairHMM hmm(lProbs, rProbs, rootProb);
-      const double tb = wallSeconds();
-      tHmm += tb - ta;
 
-      ForwardMatrix* forward = NULL;
-      int maxDist = maxDistanceFromGuide;
-      while (true) {
-        forward = new ForwardMatrix(lProf, rProf, hmm, node,
-                                    dataset.guide.empty() ? GuideAlignmentEnvelope()
-                                                          : GuideAlignmentEnvelope(dataset.guide, dataset.closestLeaf[lChildNode],
-                                                                                   dataset.closestLeaf[rChildNode], maxDist));
-        if (forward->lpEnd > NEG_INF) break;
-        if (maxDist < 0) Abort("Zero forward likelihood even in the absence of guide alignment constraints - this is not good");
-        if (maxDist * 2 > (int)alignPathColumns(dataset.guide))
-          maxDist = -1;
-        else if (maxDist == 0)
-          maxDist = 1;
-        else
-          maxDist *= 2;
-        delete forward;
-        forward = NULL;
+  // per internal node: the branch models (the matrices keep references to them), the filled matrix, the band
+  struct NodeWork {
+    ProbModel* lProbs;
+    ProbModel* rProbs;
+    PairHMM* hmm;
+    ForwardMatrix* forward;
+    int maxDist;
+    NodeWork() : lProbs(NULL), rProbs(NULL), hmm(NULL), forward(NULL), maxDist(0) {}
+  };
+  vguard<NodeWork> work(N);
+  vguard<char> done(N, 0);
+  {
+    const double ta = wallSeconds();
+    for (TreeNodeIndex node = 0; node < N; ++node)
+      if (dataset.tree.isLeaf(node)) {
+        prof[node] = Profile(model.components(), model.alphabet, dataset.seqs.at(node), node);
+        done[node] = 1;
       }
-      dataset.bandUsed[node] = maxDist;
+    tLeaf += wallSeconds() - ta;
+  }
+  auto envelopeFor = [&](TreeNodeIndex node, int maxDist) {
+    return dataset.guide.empty() ? GuideAlignmentEnvelope()
+                                 : GuideAlignmentEnvelope(dataset.guide, dataset.closestLeaf[dataset.tree.getChild(node, 0)],
+                                                          dataset.closestLeaf[dataset.tree.getChild(node, 1)], maxDist);
+  };
+
+  TreeNodeIndex next = 0;
+  while (next < N) {
+    if (dataset.tree.isLeaf(next)) { ++next; continue; }
+    // ---- launch the fills of the ready nodes (always including `next`, whose children are done) ----
+    const double tb0 = wallSeconds();
+    vguard<TreeNodeIndex> ready;
+    double cells = 0;
+    for (TreeNodeIndex node = next; node < N; ++node) {
+      if (dataset.tree.isLeaf(node) || work[node].forward) continue;
+      const int lc = dataset.tree.getChild(node, 0), rc = dataset.tree.getChild(node, 1);
+      if (!done[lc] || !done[rc]) continue;
+      const double c = (double)prof[lc].size() * (double)prof[rc].size();
+      if (!ready.empty() && (!batchReadyNodes || cells + c > maxBatchLatticeCells)) continue;
+      ready.push_back(node);
+      cells += c;
+    }
+    for (TreeNodeIndex node : ready) {
+      NodeWork& w = work[node];
+      const int lc = dataset.tree.getChild(node, 0), rc = dataset.tree.getChild(node, 1);
+      w.lProbs = new ProbModel(model, dataset.tree.branchLength(lc));
+      w.rProbs = new ProbModel(model, dataset.tree.branchLength(rc));
+      w.hmm = new PairHMM(*w.lProbs, *w.rProbs, rootProb);
+      w.maxDist = maxDistanceFromGuide;
+    }
+    const double tb1 = wallSeconds();
+    tHmm += tb1 - tb0;
+    if (ready.size() == 1) {
+      const TreeNodeIndex node = ready[0];
+      NodeWork& w = work[node];
+      w.forward = new ForwardMatrix(prof[dataset.tree.getChild(node, 0)], prof[dataset.tree.getChild(node, 1)], *w.hmm, node,
+                                    envelopeFor(node, w.maxDist));
+    } else {
+      vguard<ForwardMatrix::JobSpec> specs;
+      for (TreeNodeIndex node : ready) {
+        ForwardMatrix::JobSpec js;
+        js.x = &prof[dataset.tree.getChild(node, 0)];
+        js.y = &prof[dataset.tree.getChild(node, 1)];
+        js.hmm = work[node].hmm;
+        js.parentRowIndex = node;
+        js.env = envelopeFor(node, work[node].maxDist);
+        specs.push_back(js);
+      }
+      const vguard<ForwardMatrix*> filled = ForwardMatrix::fillBatch(specs);
+      for (size_t k = 0; k < ready.size(); ++k) work[ready[k]].forward = filled[k];
+    }
+    tFwd += wallSeconds() - tb1;
+
+    // ---- finish nodes in node order while their matrices are there ----
+    while (next < N && (dataset.tree.isLeaf(next) || work[next].forward)) {
+      const TreeNodeIndex node = next++;
+      if (dataset.tree.isLeaf(node)) continue;
+      NodeWork& w = work[node];
+      const double tc0 = wallSeconds();
+      // zero likelihood inside the band: widen and refill (reference src/recon.cpp:956-975)
+      while (!(w.forward->lpEnd > NEG_INF)) {
+        if (w.maxDist < 0) Abort("Zero forward likelihood even in the absence of guide alignment constraints - this is not good");
+        if (w.maxDist * 2 > (int)alignPathColumns(dataset.guide))
+          w.maxDist = -1;
+        else if (w.maxDist == 0)
+          w.maxDist = 1;
+        else
+          w.maxDist *= 2;
+        delete w.forward;
+        w.forward = new ForwardMatrix(prof[dataset.tree.getChild(node, 0)], prof[dataset.tree.getChild(node, 1)], *w.hmm, node,
+                                      envelopeFor(node, w.maxDist));
+      }
+      ForwardMatrix* forward = w.forward;
+      dataset.bandUsed[node] = w.maxDist;
       const double tc = wallSeconds();
-      tFwd += tc - tb;
+      tFwd += tc - tc0;
 
       BackwardMatrix* backward = NULL;
       if (usePosteriorsForProfile && node != dataset.tree.root()) backward = new BackwardMatrix(*forward);
@@ -133,11 +198,18 @@ void Reconstructor::reconstruct(Dataset& dataset) {
         if (node == dataset.tree.root()) dataset.lpFinalTrace = lpTrace;
       }
       delete forward;
+      w.forward = NULL;
+      delete w.hmm;
+      delete w.lProbs;
+      delete w.rProbs;
+      w.hmm = NULL;
+      w.lProbs = w.rProbs = NULL;
+      done[node] = 1;
       tCheck += wallSeconds() - td;
     }
   }
   if (timing)
-    fprintf(stderr, "timing: leaf profiles %.3f s, ProbModel+PairHMM %.3f s, ForwardMatrix ctor %.3f s, traceback+profile %.3f s, "
+    fprintf(stderr, "timing: leaf profiles %.3f s, ProbModel+PairHMM %.3f s, ForwardMatrix fills %.3f s, traceback+profile %.3f s, "
                     "calcSumPathAbsorbProbs+delete %.3f s\n", tLeaf, tHmm, tFwd, tProf, tCheck);
   dataset.path = path;
 }

@@ -3,7 +3,7 @@
 //   model <rate model json>
 //   seqs <fasta of ungapped leaf sequences>
 //   guide <fasta of the gapped guide alignment>      (optional)
-//   band <n> | samples <n> | maxstates <n> | seed <n> | posterior <minPostProb>   (optional)
+//   band <n> | samples <n> | maxstates <n> | seed <n> | posterior <minPostProb> | batch <0|1>   (optional)
 //   tree <N>   followed by N lines:  <parent index or -1> <branch length> <name>   (post-order, root last)
 // Output: final Forward / trace log-likelihoods as hex floats, the band used per node, and the
 // gapped reconstruction (one row per tree node on the root path).
@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
     else if (key == "samples") in >> recon.profileSamples;
     else if (key == "maxstates") in >> recon.profileMaxStates;
     else if (key == "seed") in >> recon.rndSeed;
+    else if (key == "batch") { int b; in >> b; recon.batchReadyNodes = b != 0; }
     else if (key == "posterior") { in >> recon.minPostProb; recon.usePosteriorsForProfile = true; }
     else if (key == "tree") {
       int n; in >> n;

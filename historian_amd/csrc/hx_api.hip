@@ -679,6 +679,22 @@ int hx_batch_read_matrix(hx_batch* b, int32_t job, int32_t which, double* out) {
   return HX_OK;
 }
 
+int hx_host_alloc(size_t bytes, void** out) {
+  if (!out) return fail(HX_ERR_INVALID_ARG, "out is null");
+  *out = nullptr;
+  if (bytes == 0) return HX_OK;
+  if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+    *out = nullptr;
+    return fail(HX_ERR_OUT_OF_MEMORY, "hipHostMalloc of %zu bytes failed", bytes);
+  }
+  return HX_OK;
+}
+
+int hx_host_free(void* p) {
+  if (p) HIP_TRY(hipHostFree(p));
+  return HX_OK;
+}
+
 int hx_batch_read_cells(hx_batch* b, int32_t job, int32_t which, const int32_t* ij, int64_t n, double* out) {
   if (!b || !out || !ij || n < 0 || which < 0 || which > 1) return fail(HX_ERR_INVALID_ARG, "bad arguments");
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);

@@ -188,6 +188,12 @@ int64_t hx_batch_total_cells(const hx_batch* b);
  * fill kernel (HIP events recorded around that kernel on its stream). */
 int hx_batch_last_kernel_ms(hx_batch* b, int32_t which, float* ms);
 
+/* Page-locked host memory for the destination of hx_batch_read_matrix: a device-to-host copy into
+ * pageable memory runs at a fraction of the link rate (measured 4.7 GB/s for a 55 MB matrix).
+ * Plain memory to the caller; release with hx_host_free. */
+int hx_host_alloc(size_t bytes, void** out);
+int hx_host_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

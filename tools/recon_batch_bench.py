@@ -1,0 +1,31 @@
+"""Level batching in the reconstruction driver: a balanced synthetic family through bin/hxrecon with
+`batch 1` (every ready node's fill in one device batch) and `batch 0` (one node at a time, as the
+reference does).  Usage: recon_batch_bench.py [n_leaves] [length] [model]"""
+import os, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests import recon_helpers as R
+n_leaves = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+length = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+model = sys.argv[3] if len(sys.argv) > 3 else "wag"
+MODEL = os.path.join(ROOT, "tests", "golden", "models", model + ".json")
+alphabet = "arndcqeghilkmfpstwyv"
+tree, seqs = R.balanced_family(n_leaves, length, alphabet, seed=21, branch=.05)
+exe = os.path.join(ROOT, "historian_amd", "bin", "hxrecon")
+results = {}
+with tempfile.TemporaryDirectory() as d:
+    for mode in ("fast", "exact"):
+        for batch in (1, 0):
+            job = os.path.join(d, "job_%d.txt" % batch)
+            R.write_job(job, MODEL, tree, seqs, {}, os.path.join(d, "s.fa"), os.path.join(d, "g.fa"), samples=10, batch=batch)
+            env = dict(os.environ, HX_TIMING="1")
+            if mode == "fast":
+                env["HX_FILL_MODE"] = "fast"
+            out = subprocess.run([exe, job], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=1500)
+            assert out.returncode == 0, out.stderr.decode()[-2000:]
+            results[(mode, batch)] = out.stdout
+            print("%d leaves x %d residues, %s, %s, batch %d" % (n_leaves, length, model, mode, batch))
+            for line in out.stderr.decode().strip().splitlines()[-2:]:
+                print("   ", line)
+        assert results[(mode, 1)] == results[(mode, 0)], "batched and sequential reconstructions differ"
+print("batched == sequential output: identical")
