@@ -1706,9 +1706,12 @@ def closest_leaves(tree):
 
 
 def reconstruct(model, tree, seqs, guide, max_distance_from_guide=20, profile_samples=10, max_profile_states=0,
-                seed=5489, forward_factory=None, sub_prob=sub_prob_matrix_ss):
+                seed=5489, forward_factory=None, sub_prob=sub_prob_matrix_ss, min_post_prob=None,
+                backward_factory=None):
     """seqs: dict leaf node -> (name, sequence); guide: AlignPath over leaf node rows (or {}).
     forward_factory(x, y, hmm, node, env) -> filled ForwardMatrix (default: the Python fill).
+    min_post_prob: if given, non-root profiles are posterior profiles (usePosteriorsForProfile,
+    reference src/recon.cpp:978-1013) built from backward_factory(fwd) (default: the Python fill).
     Returns dict(path, lp_final_fwd, lp_final_trace, bands, prof)."""
     if forward_factory is None:
         forward_factory = lambda x, y, hmm, node, env: ForwardMatrix(x, y, hmm, node, env)
@@ -1747,6 +1750,9 @@ def reconstruct(model, tree, seqs, guide, max_distance_from_guide=20, profile_sa
             path = fwd.best_align_path()
             node_prof = fwd.best_profile()
             lp_final_fwd = fwd.lp_end
+        elif min_post_prob is not None:
+            bwd = (backward_factory or BackwardMatrix)(fwd)
+            node_prof = bwd.post_prob_profile(min_post_prob, max_profile_states, strategy)
         else:
             node_prof = fwd.sample_profile(gen, profile_samples, max_profile_states, strategy)
         lp_trace = node_prof.calc_sum_path_absorb_probs(log_cptw, log_root, None)

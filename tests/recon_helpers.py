@@ -72,6 +72,24 @@ class ArrayForward(ho.ForwardMatrix):
         return [float(v) for v in self.arr[i, j]]
 
 
+class ArrayBackward(ho.BackwardMatrix):
+    """oracle BackwardMatrix whose cells come from the plain-C oracle fill."""
+
+    def __init__(self, fwd):
+        super().__init__(fwd, fill=False)
+        self.arr = c_oracle.backward(*H.job_images(fwd))["cells"]
+
+    def cell(self, i, j, s):
+        if i >= self.arr.shape[0] or j >= self.arr.shape[1]:
+            return H.NEG_INF
+        return float(self.arr[i, j, s])
+
+    def xy_cell(self, i, j):
+        if i >= self.arr.shape[0] or j >= self.arr.shape[1]:
+            return ho._EMPTY_CELL
+        return [float(v) for v in self.arr[i, j]]
+
+
 def load_family(tree_path, seqs_path, guide_path, max_len=None, leaves=None):
     """tree + {leaf node: (name, seq)} + guide AlignPath; optionally truncated (first max_len guide
     columns) and pruned to the first `leaves` leaves of a caterpillar for quick tests."""
@@ -116,7 +134,7 @@ def write_job(path, model_path, tree, seqs, guide, seqs_fa, guide_fa, **opts):
 def oracle_reconstruct(model_path, tree, seqs, guide, **kw):
     model = ho.RateModel.from_file(model_path)
     model.sub_rate = [m.tolist() for m in model.sub_rate]
-    res = ho.reconstruct(model, tree, seqs, guide, forward_factory=ArrayForward, **kw)
+    res = ho.reconstruct(model, tree, seqs, guide, forward_factory=ArrayForward, backward_factory=ArrayBackward, **kw)
     rows = ho.gapped_rows(tree, seqs, res["path"])
     return res, rows
 

@@ -86,3 +86,38 @@ def test_mixture_family_unbanded_exact(tmp_path):
     assert got["lpFinalFwd"] == res["lp_final_fwd"]
     assert got["lpFinalTrace"] == res["lp_final_trace"]
     assert got["rows"] == rows
+
+
+def test_posterior_profiles_with_batched_fills(tmp_path):
+    # usePosteriorsForProfile (reference src/recon.cpp:978-1013): Backward fills, threshold scan and posterior
+    # profiles, with the four leaf-pair nodes (then the two above) sharing one device batch each
+    alphabet = "acgt"
+    jc = os.path.join(ROOT, "tests", "golden", "models", "jc.json")
+    tree, seqs = R.balanced_family(8, 50, alphabet, seed=3)
+    outs = {}
+    for batch in (1, 0):
+        job = str(tmp_path / ("job%d.txt" % batch))
+        R.write_job(job, jc, tree, seqs, {}, str(tmp_path / "seqs.fa"), str(tmp_path / "guide.fa"), maxstates=0,
+                    posterior=0.01, batch=batch)
+        out = subprocess.run([HXRECON, job], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()
+        outs[batch] = out.stdout.decode()
+    assert outs[0] == outs[1]
+    got = R.parse_hxrecon(outs[1])
+    res, rows = R.oracle_reconstruct(jc, tree, seqs, {}, min_post_prob=0.01)
+    assert got["lpFinalFwd"] == res["lp_final_fwd"]
+    assert got["lpFinalTrace"] == res["lp_final_trace"]
+    assert got["rows"] == rows
+
+
+def test_batched_and_sequential_fills_give_the_same_reconstruction(tmp_path):
+    tree, seqs, guide = R.load_family(G + "gp120.tree.nh", G + "gp120.fa", G + "gp120.guide.fa", max_len=120)
+    outs = {}
+    for batch in (1, 0):
+        job = str(tmp_path / ("job%d.txt" % batch))
+        R.write_job(job, LG, tree, seqs, guide, str(tmp_path / "seqs.fa"), str(tmp_path / "guide.fa"), band=5, samples=10,
+                    maxstates=0, seed=5489, batch=batch)
+        out = subprocess.run([HXRECON, job], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()
+        outs[batch] = out.stdout.decode()
+    assert outs[0] == outs[1]
