@@ -73,3 +73,40 @@ def backward(x, y, hmm, max_distance=-1):
     rc = lib.orc_backward(jobs, _ptr(cells), C.byref(lp_start))
     assert rc == 0, rc
     return dict(cells=cells, lp_start=lp_start.value)
+
+
+# ---- guide-alignment Viterbi: oracle_quickalign.c ----------------------------
+class QAScores(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("m2m", "m2i", "m2d", "i2i", "i2m", "i2d", "d2d", "d2m", "gap_open",
+                                          "gap_extend", "no_gap")]
+
+
+def qa_scores(sc):
+    """oracle.quickalign_oracle.QuickAlignScores -> QAScores"""
+    return QAScores(sc.m2m, sc.m2i, sc.m2d, sc.i2i, sc.i2m, sc.i2d, sc.d2d, sc.d2m, sc.gap_open, sc.gap_extend, sc.no_gap)
+
+
+def quickalign(xtok, ytok, alph_size, submat, scores, diagonals=None):
+    """Dense QuickAlignMatrix fill.  Returns dict(cells [(xlen+1),(ylen+1),3], score, x_end, y_end);
+    diagonals: iterable of d = i - j in the envelope, or None for the full envelope."""
+    lib = load()
+    i32p = C.POINTER(C.c_int32)
+    lib.qa_fill.argtypes = [i32p, C.c_int32, i32p, C.c_int32, C.c_int32, _f64p, C.POINTER(QAScores),
+                            C.POINTER(C.c_uint8), _f64p, i32p, i32p]
+    lib.qa_fill.restype = C.c_double
+    xt = np.ascontiguousarray(xtok, dtype=np.int32)
+    yt = np.ascontiguousarray(ytok, dtype=np.int32)
+    sm = np.ascontiguousarray(submat, dtype=np.float64)
+    xlen, ylen = len(xt), len(yt)
+    env = None
+    if diagonals is not None:
+        env = np.zeros(xlen + ylen + 1, dtype=np.uint8)
+        for d in diagonals:
+            env[d + ylen] = 1
+    cells = np.empty((xlen + 1, ylen + 1, 3))
+    xe, ye = C.c_int32(0), C.c_int32(0)
+    sc = scores if isinstance(scores, QAScores) else qa_scores(scores)
+    score = lib.qa_fill(xt.ctypes.data_as(i32p), xlen, yt.ctypes.data_as(i32p), ylen, alph_size, _ptr(sm), C.byref(sc),
+                        env.ctypes.data_as(C.POINTER(C.c_uint8)) if env is not None else None, _ptr(cells),
+                        C.byref(xe), C.byref(ye))
+    return dict(cells=cells, score=score, x_end=xe.value, y_end=ye.value)

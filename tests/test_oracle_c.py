@@ -80,3 +80,32 @@ def test_null_state_case_of_testnullforward():
     xp.state[2].lp_absorb = []
     yp.state[1].lp_absorb = []
     check(ho.ForwardMatrix(xp, yp, hmm, 0, ho.GuideAlignmentEnvelope(), fill=False), backward=False)
+
+
+def test_quickalign_c_fill_equals_python_restatement():
+    import random
+    from oracle import quickalign_oracle as q
+    G = "tests/golden/reference_data/"
+    model = ho.RateModel.from_file(G + "testamino.json")
+    model.sub_rate = [m.tolist() for m in model.sub_rate]
+    sc = q.QuickAlignScores(model, 1.0)
+    rng = random.Random(3)
+    A = model.alphabet
+    for trial, (lx, ly, sparse) in enumerate([(33, 36, False), (60, 80, True), (120, 90, True), (5, 3, False),
+                                              (1, 1, False), (70, 70, True)]):
+        x = "".join(rng.choice(A) for _ in range(lx))
+        y = "".join((c if rng.random() > .15 else rng.choice(A)) for c in x[:ly])
+        y += "".join(rng.choice(A) for _ in range(max(0, ly - len(y))))
+        if trial == 1:
+            x = x[:20] + "x" + x[21:]          # a character outside the alphabet: emission score 0
+        env = q.DiagonalEnvelope(x, y)
+        if sparse:
+            env.init_sparse(q.KmerIndex(y, A, 3), band_size=8, kmer_threshold=1)
+        else:
+            env.init_full()
+        mx = q.QuickAlignMatrix(env, model, 1.0, scores=sc)
+        r = c_oracle.quickalign(q.tokens(x, A), q.tokens(y, A), len(A), sc.submat, sc, env.diagonals if sparse else None)
+        assert (r["score"], r["x_end"], r["y_end"]) == (mx.end, mx.x_end, mx.y_end)
+        for (i, j), c in mx.cells.items():
+            assert all(r["cells"][i, j, k] == c[k] for k in range(3))
+        assert int(np.isfinite(r["cells"]).any(axis=2).sum()) == len(mx.cells)

@@ -61,3 +61,10 @@ def test_cumlp_equals_fwdlp_on_51_cells():
             n += 1
         clp = None
     assert n == 51
+
+
+def test_testquickalign_fixture():
+    # reference Makefile:278-279: bin/testquickalign data/PF16593.pair.fa data/testamino.json 1
+    from oracle import quickalign_oracle as q
+    got = q.testquickalign_main(G + "PF16593.pair.fa", G + "testamino.json", 1)
+    assert got == open(G + "testquickalign.out.fa").read()
