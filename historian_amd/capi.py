@@ -49,6 +49,12 @@ class HxLayout(C.Structure):
                 ("mirrored", C.c_int32), ("pad_", C.c_int32)]
 
 
+class HxQuickJob(C.Structure):
+    _fields_ = [("x_tok", C.POINTER(C.c_int32)), ("y_tok", C.POINTER(C.c_int32)), ("x_len", C.c_int32),
+                ("y_len", C.c_int32), ("alph_size", C.c_int32), ("n_diagonals", C.c_int32),
+                ("submat", C.POINTER(C.c_double)), ("diagonals", C.POINTER(C.c_int32)), ("scores", C.c_double * 11)]
+
+
 class HxCell(C.Structure):
     _fields_ = [("xpos", C.c_int32), ("ypos", C.c_int32), ("state", C.c_int32), ("pad_", C.c_int32),
                 ("log_post_prob", C.c_double)]
@@ -58,7 +64,9 @@ EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_cr
            "hx_batch_forward", "hx_batch_backward", "hx_batch_sync", "hx_batch_lp_end", "hx_batch_lp_start",
            "hx_batch_layout", "hx_batch_read_matrix", "hx_batch_read_cells", "hx_batch_read_prepared",
            "hx_batch_posterior_scan", "hx_batch_total_cells", "hx_batch_last_kernel_ms", "hx_host_alloc",
-           "hx_host_free"]
+           "hx_host_free", "hx_quick_batch_create", "hx_quick_batch_destroy", "hx_quick_batch_run",
+           "hx_quick_batch_results", "hx_quick_batch_layout", "hx_quick_batch_read_matrix",
+           "hx_quick_batch_total_cells", "hx_quick_batch_last_kernel_ms"]
 
 
 class HxError(RuntimeError):
@@ -98,6 +106,15 @@ def load():
     lib.hx_batch_total_cells.argtypes = [vp]
     lib.hx_batch_total_cells.restype = C.c_int64
     lib.hx_batch_last_kernel_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
+    lib.hx_quick_batch_create.argtypes = [C.POINTER(HxQuickJob), C.c_int32, C.POINTER(vp)]
+    lib.hx_quick_batch_destroy.argtypes = [vp]
+    lib.hx_quick_batch_run.argtypes = [vp, vp]
+    lib.hx_quick_batch_results.argtypes = [vp, _f64p, _i32p, _i32p]
+    lib.hx_quick_batch_layout.argtypes = [vp, C.c_int32, C.POINTER(HxLayout)]
+    lib.hx_quick_batch_read_matrix.argtypes = [vp, C.c_int32, _f64p]
+    lib.hx_quick_batch_total_cells.argtypes = [vp]
+    lib.hx_quick_batch_total_cells.restype = C.c_int64
+    lib.hx_quick_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     _lib = lib
     return lib
 
@@ -299,3 +316,77 @@ class Batch:
         _check(load().hx_batch_posterior_scan(self._h, job, min_post_prob, out, cap, C.byref(n)))
         k = min(n.value, cap)
         return n.value, [(out[i].xpos, out[i].ypos, out[i].state, out[i].log_post_prob) for i in range(k)]
+
+
+class QuickBatch:
+    """n independent guide-alignment Viterbi fills (QuickAlignMatrix) resident on the device.
+    pairs: list of (x_tok, y_tok, alph_size, submat [A,A], scores [11], diagonals or None)."""
+
+    SCORE_NAMES = ("m2m", "m2i", "m2d", "i2i", "i2m", "i2d", "d2d", "d2m", "gap_open", "gap_extend", "no_gap")
+
+    def __init__(self, pairs):
+        self.n = len(pairs)
+        self._keep = []
+        jobs = (HxQuickJob * self.n)()
+        for k, (xt, yt, a, submat, scores, diags) in enumerate(pairs):
+            xt = np.ascontiguousarray(xt, dtype=np.int32)
+            yt = np.ascontiguousarray(yt, dtype=np.int32)
+            sm = np.ascontiguousarray(submat, dtype=np.float64)
+            dg = None if diags is None else np.ascontiguousarray(diags, dtype=np.int32)
+            self._keep.append((xt, yt, sm, dg))
+            j = jobs[k]
+            j.x_tok, j.y_tok = _p(xt, _i32p), _p(yt, _i32p)
+            j.x_len, j.y_len, j.alph_size = len(xt), len(yt), a
+            j.submat = _p(sm, _f64p)
+            j.diagonals = C.cast(None, _i32p) if dg is None else dg.ctypes.data_as(_i32p)
+            j.n_diagonals = 0 if dg is None else len(dg)
+            for s, v in enumerate(scores):
+                j.scores[s] = v
+        self._jobs = jobs
+        self._h = C.c_void_p()
+        _check(load().hx_quick_batch_create(jobs, self.n, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().hx_quick_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, stream=None):
+        _check(load().hx_quick_batch_run(self._h, C.c_void_p(stream or 0)))
+
+    def results(self):
+        score = np.empty(self.n)
+        xe, ye = np.empty(self.n, dtype=np.int32), np.empty(self.n, dtype=np.int32)
+        _check(load().hx_quick_batch_results(self._h, _p(score, _f64p), _p(xe, _i32p), _p(ye, _i32p)))
+        return score, xe, ye
+
+    def layout(self, job):
+        lay = HxLayout()
+        _check(load().hx_quick_batch_layout(self._h, job, C.byref(lay)))
+        return lay
+
+    def read_matrix(self, job):
+        """[(xlen+1), (ylen+1), 3] array indexed by the reference's (i, j): row / column 0 are -inf."""
+        lay = self.layout(job)
+        buf = np.empty(3 * lay.plane_stride)
+        _check(load().hx_quick_batch_read_matrix(self._h, job, _p(buf, _f64p)))
+        i, j = np.meshgrid(np.arange(lay.n_rows), np.arange(lay.n_cols), indexing="ij")
+        slot = slot_index(lay, i, j)
+        out = np.full((lay.n_rows + 1, lay.n_cols + 1, 3), -np.inf)
+        for s in range(3):
+            out[1:, 1:, s] = buf[s * lay.plane_stride + slot]
+        return out
+
+    def total_cells(self):
+        return int(load().hx_quick_batch_total_cells(self._h))
+
+    def kernel_ms(self):
+        ms = C.c_float()
+        _check(load().hx_quick_batch_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value

@@ -679,6 +679,182 @@ int hx_batch_read_matrix(hx_batch* b, int32_t job, int32_t which, double* out) {
   return HX_OK;
 }
 
+// ---------------------------------------------------------------------------
+// guide-alignment Viterbi batch (hx_quick.hip)
+// ---------------------------------------------------------------------------
+struct hx_quick_batch {
+  int n_jobs = 0;
+  std::vector<DevQuick> jobs;
+  std::vector<hx_layout> layouts;
+  DevQuick* d_jobs = nullptr;
+  char* d_arena = nullptr;
+  double* d_cells = nullptr;
+  int max_rows = 0;
+  bool all_full = true;
+  bool done = false;
+  int64_t total_cells = 0;
+  hipStream_t last_stream = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_batch** out) {
+  if (!out) return fail(HX_ERR_INVALID_ARG, "out is null");
+  *out = nullptr;
+  if (g_device < 0) return fail(HX_ERR_NOT_INITIALIZED, "hx_init has not been called");
+  if (!jobs || n_jobs <= 0) return fail(HX_ERR_INVALID_ARG, "no jobs");
+  HIP_TRY(hipSetDevice(g_device));
+  hx_quick_batch* b = new (std::nothrow) hx_quick_batch;
+  if (!b) return fail(HX_ERR_OUT_OF_MEMORY, "out of host memory");
+  b->n_jobs = n_jobs;
+  b->jobs.resize(n_jobs);
+  b->layouts.resize(n_jobs);
+  struct Off { size_t xtok, ytok, submat, env, best, bestj, result, xy; bool has_env; };
+  std::vector<Off> offs(n_jobs);
+  std::vector<int64_t> cell_off(n_jobs);
+  Arena ar;
+  int64_t cells_total = 0;
+  int rc = HX_OK;
+  for (int k = 0; k < n_jobs && rc == HX_OK; ++k) {
+    const hx_quick_job& q = jobs[k];
+    if (q.x_len <= 0 || q.y_len <= 0 || !q.x_tok || !q.y_tok) { rc = fail(HX_ERR_INVALID_ARG, "job %d: empty sequence", k); break; }
+    if (q.alph_size <= 0 || q.alph_size > 31 || !q.submat) { rc = fail(HX_ERR_INVALID_ARG, "job %d: alphabet size must be 1..31", k); break; }
+    for (int p = 0; p < q.x_len && rc == HX_OK; ++p)
+      if (q.x_tok[p] >= q.alph_size) rc = fail(HX_ERR_RANGE, "job %d: x token %d out of range", k, q.x_tok[p]);
+    for (int p = 0; p < q.y_len && rc == HX_OK; ++p)
+      if (q.y_tok[p] >= q.alph_size) rc = fail(HX_ERR_RANGE, "job %d: y token %d out of range", k, q.y_tok[p]);
+    if (rc != HX_OK) break;
+    Off& o = offs[k];
+    o.xtok = ar.put(q.x_tok, sizeof(int32_t) * q.x_len);
+    o.ytok = ar.put(q.y_tok, sizeof(int32_t) * q.y_len);
+    o.submat = ar.put(q.submat, sizeof(double) * q.alph_size * q.alph_size);
+    o.has_env = q.diagonals != nullptr;
+    o.env = 0;
+    if (o.has_env) {
+      std::vector<uint8_t> bits((size_t)q.x_len + q.y_len + 1, 0);
+      for (int d = 0; d < q.n_diagonals; ++d) {
+        const int64_t idx = (int64_t)q.diagonals[d] + q.y_len;
+        if (idx < 0 || idx >= (int64_t)bits.size()) { rc = fail(HX_ERR_RANGE, "job %d: diagonal %d out of range", k, q.diagonals[d]); break; }
+        bits[(size_t)idx] = 1;
+      }
+      if (rc != HX_OK) break;
+      o.env = ar.put(bits.data(), bits.size());
+      b->all_full = false;
+    }
+    o.best = ar.reserve(sizeof(double) * q.x_len);
+    o.bestj = ar.reserve(sizeof(int32_t) * q.x_len);
+    o.result = ar.reserve(sizeof(double));
+    o.xy = ar.reserve(sizeof(int32_t) * 2);
+    DevQuick& J = b->jobs[k];
+    memset(&J, 0, sizeof(J));
+    J.xlen = q.x_len; J.ylen = q.y_len; J.alph = q.alph_size;
+    J.n_strips = (q.x_len + HX_STRIP - 1) / HX_STRIP;
+    J.strip_stride = strip_stride_for(q.y_len);
+    J.plane = J.n_strips * J.strip_stride;
+    for (int s = 0; s < 11; ++s) J.sc[s] = q.scores[s];
+    hx_layout& L = b->layouts[k];
+    L.n_rows = q.x_len; L.n_cols = q.y_len; L.strip_rows = HX_STRIP; L.n_strips = J.n_strips;
+    L.strip_stride = J.strip_stride; L.plane_stride = J.plane; L.mirrored = 0; L.pad_ = 0;
+    cell_off[k] = cells_total;
+    cells_total += 3 * J.plane;
+    b->total_cells += (int64_t)q.x_len * q.y_len;
+    if (q.x_len > b->max_rows) b->max_rows = q.x_len;
+  }
+  if (rc != HX_OK) { delete b; return rc; }
+  auto cleanup = [&](int code) { hx_quick_batch_destroy(b); return code; };
+  if (hipMalloc(reinterpret_cast<void**>(&b->d_arena), ar.host.size() + 256) != hipSuccess)
+    return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %zu input bytes failed", ar.host.size()));
+  if (hipMemcpy(b->d_arena, ar.host.data(), ar.host.size(), hipMemcpyHostToDevice) != hipSuccess)
+    return cleanup(fail(HX_ERR_HIP, "input upload failed"));
+  if (hipMalloc(reinterpret_cast<void**>(&b->d_cells), sizeof(double) * (size_t)cells_total) != hipSuccess)
+    return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld matrix bytes failed", (long long)(cells_total * 8)));
+  for (int k = 0; k < n_jobs; ++k) {
+    DevQuick& J = b->jobs[k];
+    const Off& o = offs[k];
+    char* base = b->d_arena;
+    J.xtok = reinterpret_cast<int32_t*>(base + o.xtok);
+    J.ytok = reinterpret_cast<int32_t*>(base + o.ytok);
+    J.submat = reinterpret_cast<double*>(base + o.submat);
+    J.in_env = o.has_env ? reinterpret_cast<uint8_t*>(base + o.env) : nullptr;
+    J.best_score = reinterpret_cast<double*>(base + o.best);
+    J.best_j = reinterpret_cast<int32_t*>(base + o.bestj);
+    J.result = reinterpret_cast<double*>(base + o.result);
+    J.xy_end = reinterpret_cast<int32_t*>(base + o.xy);
+    J.cells = b->d_cells + cell_off[k];
+  }
+  if (hipMalloc(reinterpret_cast<void**>(&b->d_jobs), sizeof(DevQuick) * n_jobs) != hipSuccess)
+    return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of job table failed"));
+  if (hipMemcpy(b->d_jobs, b->jobs.data(), sizeof(DevQuick) * n_jobs, hipMemcpyHostToDevice) != hipSuccess)
+    return cleanup(fail(HX_ERR_HIP, "job table upload failed"));
+  for (int e = 0; e < 2; ++e)
+    if (hipEventCreate(&b->ev[e]) != hipSuccess) return cleanup(fail(HX_ERR_HIP, "hipEventCreate failed"));
+  *out = b;
+  return HX_OK;
+}
+
+int hx_quick_batch_destroy(hx_quick_batch* b) {
+  if (!b) return HX_OK;
+  (void)hipDeviceSynchronize();
+  for (int e = 0; e < 2; ++e)
+    if (b->ev[e]) (void)hipEventDestroy(b->ev[e]);
+  if (b->d_jobs) (void)hipFree(b->d_jobs);
+  if (b->d_arena) (void)hipFree(b->d_arena);
+  if (b->d_cells) (void)hipFree(b->d_cells);
+  delete b;
+  return HX_OK;
+}
+
+int hx_quick_batch_run(hx_quick_batch* b, void* stream) {
+  if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipEventRecord(b->ev[0], st));
+  launch_quickalign(b->d_jobs, b->n_jobs, b->max_rows, b->all_full, st);
+  HIP_TRY(hipEventRecord(b->ev[1], st));
+  HIP_TRY(hipGetLastError());
+  b->done = true;
+  b->last_stream = st;
+  return HX_OK;
+}
+
+int hx_quick_batch_results(hx_quick_batch* b, double* score, int32_t* x_end, int32_t* y_end) {
+  if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
+  if (!b->done) return fail(HX_ERR_STATE, "hx_quick_batch_run has not been launched");
+  HIP_TRY(hipStreamSynchronize(b->last_stream));
+  for (int k = 0; k < b->n_jobs; ++k) {
+    int32_t xy[2];
+    if (score) HIP_TRY(hipMemcpy(&score[k], b->jobs[k].result, sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(xy, b->jobs[k].xy_end, sizeof(xy), hipMemcpyDeviceToHost));
+    if (x_end) x_end[k] = xy[0];
+    if (y_end) y_end[k] = xy[1];
+  }
+  return HX_OK;
+}
+
+int hx_quick_batch_layout(const hx_quick_batch* b, int32_t job, hx_layout* out) {
+  if (!b || !out) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
+  *out = b->layouts[job];
+  return HX_OK;
+}
+
+int hx_quick_batch_read_matrix(hx_quick_batch* b, int32_t job, double* out) {
+  if (!b || !out) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
+  if (!b->done) return fail(HX_ERR_STATE, "hx_quick_batch_run has not been launched");
+  HIP_TRY(hipStreamSynchronize(b->last_stream));
+  HIP_TRY(hipMemcpy(out, b->jobs[job].cells, sizeof(double) * 3 * (size_t)b->jobs[job].plane, hipMemcpyDeviceToHost));
+  return HX_OK;
+}
+
+int64_t hx_quick_batch_total_cells(const hx_quick_batch* b) { return b ? b->total_cells : 0; }
+
+int hx_quick_batch_last_kernel_ms(hx_quick_batch* b, float* ms) {
+  if (!b || !ms) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (!b->done) return fail(HX_ERR_STATE, "hx_quick_batch_run has not been launched");
+  HIP_TRY(hipEventSynchronize(b->ev[1]));
+  HIP_TRY(hipEventElapsedTime(ms, b->ev[0], b->ev[1]));
+  return HX_OK;
+}
+
 int hx_host_alloc(size_t bytes, void** out) {
   if (!out) return fail(HX_ERR_INVALID_ARG, "out is null");
   *out = nullptr;
@@ -700,7 +876,6 @@ int hx_batch_read_cells(hx_batch* b, int32_t job, int32_t which, const int32_t* 
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
   if (which == 0 ? !b->forward_done : !b->backward_done) return fail(HX_ERR_STATE, "fill has not been launched");
   if (n == 0) return HX_OK;
-  const DevJob& J = b->jobs[job];
   int32_t* d_ij = nullptr;
   double* d_out = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ij), sizeof(int32_t) * 2 * n));

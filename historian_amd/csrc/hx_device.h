@@ -97,6 +97,22 @@ struct DevJob {
   const int32_t* bwd_windows; // same for the mirrored (Backward) sweep; both nullptr when there is no band
 };
 
+// One pair of the guide-alignment Viterbi batch (hx_quick.hip)
+struct DevQuick {
+  const int32_t* xtok;        // [xlen] tokens, -1 = outside the alphabet
+  const int32_t* ytok;        // [ylen]
+  int32_t xlen, ylen, alph, n_strips;
+  const double* submat;       // [alph][alph] log odds
+  double sc[11];              // m2m m2i m2d i2i i2m i2d d2d d2m gapOpen gapExtend noGap
+  const uint8_t* in_env;      // [xlen+ylen+1] indexed (i - j) + ylen, or nullptr = full envelope
+  double* cells;              // [3][plane]: mat, ins, del in the strip-skewed layout, row = i-1, column = j-1
+  int64_t plane, strip_stride;
+  double* best_score;         // [xlen] per-row best mat + endGapScore ...
+  int32_t* best_j;            // ... and the first column that attains it
+  double* result;             // -> Viterbi score
+  int32_t* xy_end;            // -> xEnd, yEnd
+};
+
 #define HX_STRIP 64
 #define HX_FAST_INTERVALS 4096   // quadratic pieces of the fast log-sum-exp table over [0,10)
 

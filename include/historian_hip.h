@@ -188,6 +188,35 @@ int64_t hx_batch_total_cells(const hx_batch* b);
  * fill kernel (HIP events recorded around that kernel on its stream). */
 int hx_batch_last_kernel_ms(hx_batch* b, int32_t which, float* ms);
 
+/* -- guide-alignment Viterbi (reference src/quickalign.cpp, src/diagenv.cpp) -------------------
+ * The pairwise DP that builds the guide alignment the Forward fills are banded around: a batch of
+ * independent QuickAlignMatrix fills.  Results are bit-identical to the reference (adds and maxima). */
+typedef struct hx_quick_job {
+  const int32_t* x_tok;      /* [x_len] FastSeq::unvalidatedTokens: -1 for characters outside the alphabet */
+  const int32_t* y_tok;      /* [y_len]                                                      */
+  int32_t x_len, y_len;
+  int32_t alph_size;         /* A <= 31                                                      */
+  int32_t n_diagonals;       /* 0 with diagonals == NULL: full envelope (DiagonalEnvelope::initFull) */
+  const double* submat;      /* [A][A] QuickAlignMatrix::submat (log odds, src/quickalign.cpp:26-31) */
+  const int32_t* diagonals;  /* DiagonalEnvelope::diagonals: the d = i - j the DP visits, or NULL */
+  double scores[11];         /* m2m m2i m2d i2i i2m i2d d2d d2m gapOpen gapExtend noGap (src/quickalign.cpp:33-54) */
+} hx_quick_job;
+
+typedef struct hx_quick_batch hx_quick_batch;
+
+int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_batch** out);
+int hx_quick_batch_destroy(hx_quick_batch* b);
+/* The fills (QuickAlignMatrix constructor, src/quickalign.cpp:63-99); asynchronous on `stream`. */
+int hx_quick_batch_run(hx_quick_batch* b, void* stream);
+/* QuickAlignMatrix::result, xEnd, yEnd of every pair (synchronises). */
+int hx_quick_batch_results(hx_quick_batch* b, double* score, int32_t* x_end, int32_t* y_end);
+/* Layout of pair `job`'s matrix: row = i - 1, column = j - 1 (1 <= i <= xLen, 1 <= j <= yLen), three
+ * planes mat, ins, del (hx_layout formula; mirrored = 0).  Cells outside the envelope hold -inf. */
+int hx_quick_batch_layout(const hx_quick_batch* b, int32_t job, hx_layout* out);
+int hx_quick_batch_read_matrix(hx_quick_batch* b, int32_t job, double* out /* [3 * plane_stride] */);
+int64_t hx_quick_batch_total_cells(const hx_quick_batch* b);     /* sum xLen * yLen */
+int hx_quick_batch_last_kernel_ms(hx_quick_batch* b, float* ms);
+
 /* Page-locked host memory for the destination of hx_batch_read_matrix: a device-to-host copy into
  * pageable memory runs at a fraction of the link rate (measured 4.7 GB/s for a 55 MB matrix).
  * Plain memory to the caller; release with hx_host_free. */

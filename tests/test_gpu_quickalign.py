@@ -1,0 +1,112 @@
+"""Guide-alignment Viterbi on the GPU (hx_quick.hip through the C ABI) against the oracle: every cell,
+the score and the end coordinates bit-identical; the traceback computed from the device matrix equals
+the reference's golden alignment."""
+import random
+
+import numpy as np
+import pytest
+
+from historian_amd import capi
+from oracle import c_oracle
+from oracle import historian_oracle as ho
+from oracle import quickalign_oracle as q
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+G = "tests/golden/reference_data/"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def engine():
+    capi.init(0, c_oracle.table())
+    yield
+    capi.shutdown()
+
+
+@pytest.fixture(scope="module")
+def amino():
+    model = ho.RateModel.from_file(G + "testamino.json")
+    model.sub_rate = [m.tolist() for m in model.sub_rate]
+    return model, q.QuickAlignScores(model, 1.0)
+
+
+def score_vector(sc):
+    return [getattr(sc, n) for n in capi.QuickBatch.SCORE_NAMES]
+
+
+def make_pair(rng, A, lx, ly, sub=.15):
+    x = "".join(rng.choice(A) for _ in range(lx))
+    y = "".join((c if rng.random() > sub else rng.choice(A)) for c in x[:ly])
+    y += "".join(rng.choice(A) for _ in range(max(0, ly - len(y))))
+    return x, y
+
+
+def run_and_check(pairs, A, sc):
+    """pairs: list of (x, y, diagonals or None)"""
+    jobs = [(q.tokens(x, A), q.tokens(y, A), len(A), sc.submat, score_vector(sc), d) for x, y, d in pairs]
+    b = capi.QuickBatch(jobs)
+    b.run()
+    score, xe, ye = b.results()
+    for k, (xt, yt, a, sm, sv, d) in enumerate(jobs):
+        want = c_oracle.quickalign(xt, yt, a, sm, sc, d)
+        H.assert_same_bits(b.read_matrix(k), want["cells"], "pair %d cells" % k)
+        H.assert_same_bits([score[k]], [want["score"]], "pair %d score" % k)
+        assert (int(xe[k]), int(ye[k])) == (want["x_end"], want["y_end"])
+    b.close()
+
+
+def test_reference_fixture_pair_and_its_traceback(amino):
+    model, sc = amino
+    from oracle.ref_mains import read_fasta
+    (n1, x), (n2, y) = read_fasta(G + "PF16593.pair.fa")
+    A = model.alphabet
+    jobs = [(q.tokens(x, A), q.tokens(y, A), len(A), sc.submat, score_vector(sc), None)]
+    b = capi.QuickBatch(jobs)
+    b.run()
+    score, xe, ye = b.results()
+    cells = b.read_matrix(0)
+    b.close()
+    # traceback of the reference (oracle restatement) over the DEVICE matrix
+    env = q.DiagonalEnvelope(x, y)
+    env.init_full()
+    mx = q.QuickAlignMatrix(env, model, 1.0, scores=sc, fill=False)
+    mx.cells = {(i, j): list(cells[i, j]) for i in range(1, len(x) + 1) for j in range(1, len(y) + 1)}
+    mx.end = mx.result = float(score[0])
+    mx.x_end, mx.y_end = int(xe[0]), int(ye[0])
+    got = "".join(">%s\n%s\n" % (n, g) for n, g in zip((n1, n2), mx.gapped()))
+    assert got == open(G + "testquickalign.out.fa").read()
+
+
+def test_full_envelopes_all_wave_counts(amino):
+    model, sc = amino
+    rng = random.Random(11)
+    A = model.alphabet
+    sizes = [(1, 1), (1, 40), (40, 1), (33, 36), (64, 64), (65, 63), (100, 130), (200, 150), (300, 310), (600, 520)]
+    pairs = [make_pair(rng, A, lx, ly) + (None,) for lx, ly in sizes]
+    pairs[3] = (pairs[3][0][:10] + "x" + pairs[3][0][11:], pairs[3][1], None)      # character outside the alphabet
+    for lx_max in (64, 128, 256, 512, 10 ** 9):                                    # one launch per wave-count variant
+        sub = [p for p in pairs if len(p[0]) <= lx_max]
+        run_and_check(sub, A, sc)
+
+
+def test_sparse_envelopes(amino):
+    model, sc = amino
+    rng = random.Random(12)
+    A = model.alphabet
+    pairs = []
+    for lx, ly, k, band, thr in [(60, 80, 3, 8, 1), (120, 90, 3, 8, 1), (300, 280, 4, 16, 2), (70, 70, 3, 4, 1),
+                                 (400, 150, 3, 12, 1)]:
+        x, y = make_pair(rng, A, lx, ly, sub=.1)
+        env = q.DiagonalEnvelope(x, y)
+        env.init_sparse(q.KmerIndex(y, A, k), band_size=band, kmer_threshold=thr)
+        assert len(env.diagonals) < lx + ly - 1
+        pairs.append((x, y, env.diagonals))
+    pairs.append(make_pair(rng, A, 90, 100) + (None,))      # a full envelope in the same batch
+    run_and_check(pairs, A, sc)
+
+
+def test_long_pair_two_strip_rounds(amino):
+    model, sc = amino
+    rng = random.Random(13)
+    A = model.alphabet
+    run_and_check([make_pair(rng, A, 1100, 900) + (None,)], A, sc)
