@@ -33,6 +33,8 @@
 #include <iostream>
 
 struct hx_batch;
+struct hx_quick_batch;
+struct hx_quick_job;
 
 namespace historian {
 
@@ -532,6 +534,117 @@ struct Reconstructor {
   Reconstructor();
   void seedGenerator();
   void reconstruct(Dataset& dataset);
+};
+
+namespace detail {          // shared by the device-backed classes (hx_host_forward.cpp)
+void ensureDevice();
+double* pinnedTake(size_t doubles, size_t& capacity);
+void pinnedGive(double* p, size_t capacity);
+void check(int rc, const char* what);
+}  // namespace detail
+
+// ---- src/fastseq.h (k-mers), src/diagenv.h, src/quickalign.h ---------------------------------
+// The guide-alignment pair DP.  DiagonalEnvelope keeps the reference's
+// members and methods that callers use (the storage-index bookkeeping is the reference's CPU
+// layout and has no counterpart here: the matrix lives in the device layout); QuickAlignMatrix
+// keeps the reference's interface with the fill running on the device.
+typedef unsigned long long Kmer;
+typedef vguard<UnvalidatedAlphTok> UnvalidatedTokSeq;
+UnvalidatedTokSeq unvalidatedTokens(const FastSeq& seq, const string& alphabet);
+bool kmerValid(SeqIdx k, vguard<int>::const_iterator tok);
+Kmer makeKmer(SeqIdx k, vguard<int>::const_iterator tok, AlphTok alphabetSize);
+void writeFastaSeqs(std::ostream& out, const vguard<FastSeq>& fastSeqs);
+
+struct KmerIndex {
+  const FastSeq& seq;
+  const string& alphabet;
+  const SeqIdx kmerLen;
+  map<Kmer, vguard<SeqIdx> > kmerLocations;
+  KmerIndex(const FastSeq& seq, const string& alphabet, SeqIdx kmerLen);
+};
+
+#define DEFAULT_KMER_LENGTH 6
+#define DEFAULT_KMER_THRESHOLD -1
+#define DEFAULT_BAND_SIZE 64
+
+struct DiagonalEnvelope {
+  const FastSeq *px, *py;
+  const SeqIdx xLen, yLen;
+  vguard<int> diagonals;   // sorted ascending; (i,j) is on diagonal d if i-j=d
+  bool full;               // set by initFull (lets the device skip the per-cell membership test)
+  DiagonalEnvelope(const FastSeq& x, const FastSeq& y) : px(&x), py(&y), xLen(x.length()), yLen(y.length()), full(false) {}
+  void initFull();
+  void initSparse(const KmerIndex& yKmerIndex, unsigned int bandSize = DEFAULT_BAND_SIZE,
+                  int kmerThreshold = DEFAULT_KMER_THRESHOLD, size_t cellSize = sizeof(double), size_t maxSize = 0);
+  inline int minDiagonal() const { return 1 - (int)yLen; }
+  inline int maxDiagonal() const { return (int)xLen - 1; }
+  bool contains(SeqIdx i, SeqIdx j) const;
+  static inline SeqIdx get_i(SeqIdx j, int diag) { return (SeqIdx)(diag + j); }
+  static inline int get_diag(SeqIdx i, SeqIdx j) { return (int)i - (int)j; }
+  inline bool intersects(SeqIdx j, int diag) const { const int i = diag + (int)j; return i > 0 && i <= (int)xLen; }
+  vguard<SeqIdx> forward_i(SeqIdx j) const;
+  vguard<SeqIdx> reverse_i(SeqIdx j) const;
+};
+
+class QuickAlignMatrix {
+public:
+  enum State { Start, Match, Insert, Delete };
+  const DiagonalEnvelope* penv;
+  const FastSeq *px, *py;
+  UnvalidatedTokSeq xTok, yTok;
+  SeqIdx xLen, yLen, xEnd, yEnd;
+  LogProb start, end, result;
+  const RateModel& model;
+  const double time;
+  vguard<vguard<LogProb> > submat;  // log odds-ratio
+  LogProb m2m, m2i, m2d, i2i, i2m, i2d, i2e, d2d, d2m, d2e;
+  LogProb gapOpen, gapExtend, noGap;
+
+  QuickAlignMatrix(const DiagonalEnvelope& env, const RateModel& model, double time);
+  ~QuickAlignMatrix();
+  // Not in the reference: n independent fills as one device batch (the pairs of an alignment graph)
+  static vguard<QuickAlignMatrix*> fillBatch(const vguard<const DiagonalEnvelope*>& envs, const RateModel& model, double time);
+
+  LogProb mat(SeqIdx i, SeqIdx j) const { return getCell(i, j, 0); }
+  LogProb ins(SeqIdx i, SeqIdx j) const { return getCell(i, j, 1); }
+  LogProb del(SeqIdx i, SeqIdx j) const { return getCell(i, j, 2); }
+  inline double matchEmitScore(SeqIdx i, SeqIdx j) const {
+    Assert(i > 0 && j > 0 && i <= xLen && j <= yLen, "Out of range: (i,j)=(%u,%u) (xLen,yLen)=(%u,%u)", i, j, xLen, yLen);
+    const UnvalidatedAlphTok xt = xTok[i - 1], yt = yTok[j - 1];
+    return (xt < 0 || yt < 0) ? 0 : submat[xt][yt];
+  }
+  LogProb cellScore(SeqIdx i, SeqIdx j, State state) const;
+  static const char* stateToString(State state);
+  static size_t cellSize() { return 3 * sizeof(double); }
+  bool resultIsFinite() const { return result > -std::numeric_limits<double>::infinity(); }
+  AlignPath alignPath() const;
+  AlignPath alignPath(AlignRowIndex row1, AlignRowIndex row2) const;
+  vguard<FastSeq> gappedSeq() const;   // Alignment(seqs, alignPath()).gapped()
+
+protected:
+  struct Deferred {};
+  QuickAlignMatrix(const DiagonalEnvelope& env, const RateModel& model, double time, Deferred);
+  void computeScores();
+  void fillJob(hx_quick_job& job, vguard<double>& flatSub) const;
+  LogProb getCell(SeqIdx i, SeqIdx j, unsigned int offset) const;   // -inf outside the envelope / the lattice
+  static void updateMax(LogProb& currentMax, State& currentMaxIdx, double candidateMax, State candidateMaxIdx);
+  inline LogProb startGapScore(SeqIdx i, SeqIdx j) const {
+    return (i == 1 ? noGap : (gapOpen + (i - 2) * gapExtend)) + (j == 1 ? noGap : (gapOpen + (j - 2) * gapExtend));
+  }
+  inline LogProb endGapScore(SeqIdx i, SeqIdx j) const {
+    return (i == xLen ? noGap : (gapOpen + (xLen - i - 2) * gapExtend)) + (j == yLen ? noGap : (gapOpen + (yLen - j - 2) * gapExtend));
+  }
+  struct QuickHandle {
+    hx_quick_batch* b;
+    explicit QuickHandle(hx_quick_batch* b) : b(b) {}
+    ~QuickHandle();
+  };
+  std::shared_ptr<QuickHandle> handle;
+  int jobIndex;
+  mutable double* hostCells;
+  mutable size_t hostCellsCap;
+  long long stripStride, planeStride;
+  void attach(const std::shared_ptr<QuickHandle>& h, int job, double score, int xe, int ye);
 };
 
 }  // namespace historian

@@ -135,6 +135,13 @@ DPMatrix::~DPMatrix() {
   if (hostCells) g_pinned.give(hostCells, hostCellsCap);
 }
 
+namespace detail {
+void ensureDevice() { historian::ensureDevice(); }
+double* pinnedTake(size_t doubles, size_t& capacity) { return g_pinned.take(doubles, capacity); }
+void pinnedGive(double* p, size_t capacity) { g_pinned.give(p, capacity); }
+void check(int rc, const char* what) { hxCheck(rc, what); }
+}  // namespace detail
+
 DPMatrix::BatchHandle::~BatchHandle() {
   if (b) hx_batch_destroy(b);
 }

@@ -1,0 +1,380 @@
+// Host mirror of the guide-alignment pair DP (reference src/fastseq.cpp k-mer helpers,
+// src/diagenv.cpp, src/quickalign.cpp): same names, arguments and error behaviour; the
+// QuickAlignMatrix fill runs on the device through the C ABI (hx_quick_batch_*), the traceback
+// reads the device-filled matrix.
+#include <algorithm>
+#include <cmath>
+#include <set>
+extern "C" {
+#include "../../../include/historian_hip.h"
+}
+#include "hx_host.h"
+
+namespace historian {
+
+static const double NEG_INF = -std::numeric_limits<double>::infinity();
+
+// ---- src/fastseq.cpp:142-163,255-266 ----------------------------------------------------------
+UnvalidatedTokSeq unvalidatedTokens(const FastSeq& seq, const string& alphabet) {
+  UnvalidatedTokSeq tok;
+  tok.reserve(seq.seq.size());
+  for (char c : seq.seq) tok.push_back(tokenize(c, alphabet));
+  return tok;
+}
+
+bool kmerValid(SeqIdx k, vguard<int>::const_iterator tok) {
+  for (SeqIdx j = 0; j < k; ++j)
+    if (tok[j] < 0) return false;
+  return true;
+}
+
+Kmer makeKmer(SeqIdx k, vguard<int>::const_iterator tok, AlphTok alphabetSize) {
+  Kmer kmer = 0, mul = 1;
+  for (SeqIdx j = 0; j < k; ++j) {
+    const int token = tok[k - j - 1];
+    Assert(token >= 0, "Invalid token in makeKmer");
+    kmer += mul * token;
+    mul *= alphabetSize;
+  }
+  return kmer;
+}
+
+KmerIndex::KmerIndex(const FastSeq& seq, const string& alphabet, SeqIdx kmerLen) : seq(seq), alphabet(alphabet), kmerLen(kmerLen) {
+  const UnvalidatedTokSeq tok = unvalidatedTokens(seq, alphabet);
+  const AlphTok alphabetSize = (AlphTok)alphabet.size();
+  const SeqIdx seqLen = seq.length();
+  for (SeqIdx j = 0; j + kmerLen <= seqLen; ++j)
+    if (kmerValid(kmerLen, tok.begin() + j)) kmerLocations[makeKmer(kmerLen, tok.begin() + j, alphabetSize)].push_back(j);
+}
+
+void writeFastaSeqs(std::ostream& out, const vguard<FastSeq>& fastSeqs) {
+  for (const auto& s : fastSeqs) {   // FastSeq::writeFasta (src/fastseq.cpp): name, optional comment, sequence on one line
+    out << '>' << s.name;
+    if (s.comment.size()) out << ' ' << s.comment;
+    out << '\n' << s.seq << '\n';
+  }
+}
+
+// ---- src/diagenv.cpp:104-199 ------------------------------------------------------------------
+#define MIN_KMERS_FOR_SPARSE_ENVELOPE 2
+
+void DiagonalEnvelope::initFull() {
+  diagonals.clear();
+  diagonals.reserve(xLen + yLen - 1);
+  for (int d = minDiagonal(); d <= maxDiagonal(); ++d) diagonals.push_back(d);
+  full = true;
+}
+
+void DiagonalEnvelope::initSparse(const KmerIndex& yKmerIndex, unsigned int bandSize, int kmerThreshold, size_t cellSize,
+                                  size_t maxSize) {
+  const unsigned int kmerLen = yKmerIndex.kmerLen;
+  if (kmerThreshold >= 0) {
+    const SeqIdx minLenForSparse = MIN_KMERS_FOR_SPARSE_ENVELOPE * (kmerLen + kmerThreshold);
+    if (px->length() < minLenForSparse || py->length() < minLenForSparse) {
+      initFull();
+      return;
+    }
+  } else if ((size_t)xLen * yLen * cellSize < maxSize) {   // kmerThreshold < 0: use the available memory
+    initFull();
+    return;
+  }
+  const UnvalidatedTokSeq xTok = unvalidatedTokens(*px, yKmerIndex.alphabet);
+  const AlphTok alphabetSize = (AlphTok)yKmerIndex.alphabet.size();
+  map<int, unsigned int> diagKmerCount;
+  for (SeqIdx i = 0; i + kmerLen <= xLen; ++i)
+    if (kmerValid(kmerLen, xTok.begin() + i)) {
+      const auto it = yKmerIndex.kmerLocations.find(makeKmer(kmerLen, xTok.begin() + i, alphabetSize));
+      if (it != yKmerIndex.kmerLocations.end())
+        for (auto j : it->second) ++diagKmerCount[get_diag(i, j)];
+    }
+  map<unsigned int, std::set<unsigned int> > countDistrib;
+  for (const auto& e : diagKmerCount) countDistrib[e.second].insert(e.first);
+
+  std::set<int> diags, storageDiags;
+  diags.insert(0);   // always add the zeroth diagonal to ensure at least one path exists
+  storageDiags.insert(0);
+  const unsigned int halfBandSize = bandSize / 2;
+  const size_t diagSize = std::min(xLen, yLen) * cellSize;
+  for (auto it = countDistrib.crbegin(); it != countDistrib.crend(); ++it) {
+    if (kmerThreshold >= 0 && it->first < (unsigned int)kmerThreshold) break;
+    std::set<int> moreDiags = diags, moreStorageDiags = storageDiags;
+    for (auto seedDiag : it->second) {
+      const int dMin = std::max(minDiagonal(), (int)seedDiag - (int)halfBandSize);
+      const int dMax = std::min(maxDiagonal(), (int)seedDiag + (int)halfBandSize);
+      for (int d = dMin; d <= dMax; ++d) moreDiags.insert(d);
+      for (int d = dMin - 1; d <= dMax + 1; ++d) moreStorageDiags.insert(d);
+    }
+    if (kmerThreshold < 0 && moreStorageDiags.size() * diagSize >= maxSize) break;
+    std::swap(diags, moreDiags);
+    std::swap(storageDiags, moreStorageDiags);
+  }
+  diagonals = vguard<int>(diags.begin(), diags.end());
+  full = false;
+}
+
+bool DiagonalEnvelope::contains(SeqIdx i, SeqIdx j) const {
+  const int diag = (int)i - (int)j;
+  const auto iter = std::lower_bound(diagonals.begin(), diagonals.end(), diag);
+  return iter != diagonals.end() && *iter == diag;
+}
+
+vguard<SeqIdx> DiagonalEnvelope::forward_i(SeqIdx j) const {
+  vguard<SeqIdx> i_vec;
+  i_vec.reserve(diagonals.size());
+  for (auto d : diagonals)
+    if (intersects(j, d)) i_vec.push_back(get_i(j, d));
+  return i_vec;
+}
+
+vguard<SeqIdx> DiagonalEnvelope::reverse_i(SeqIdx j) const {
+  const vguard<SeqIdx> f = forward_i(j);
+  return vguard<SeqIdx>(f.rbegin(), f.rend());
+}
+
+// ---- src/quickalign.cpp -----------------------------------------------------------------------
+QuickAlignMatrix::QuickHandle::~QuickHandle() {
+  if (b) hx_quick_batch_destroy(b);
+}
+
+QuickAlignMatrix::QuickAlignMatrix(const DiagonalEnvelope& env, const RateModel& model, double time, Deferred)
+    : penv(&env), px(env.px), py(env.py), xTok(unvalidatedTokens(*env.px, model.alphabet)),
+      yTok(unvalidatedTokens(*env.py, model.alphabet)), xLen(px->length()), yLen(py->length()), xEnd(0), yEnd(0),
+      start(NEG_INF), end(NEG_INF), result(NEG_INF), model(model), time(time), jobIndex(0), hostCells(NULL), hostCellsCap(0),
+      stripStride(0), planeStride(0) {
+  computeScores();
+}
+
+// scores: src/quickalign.cpp:25-54
+void QuickAlignMatrix::computeScores() {
+  ProbModel pm(model, time);
+  LogProbModel lpm(pm);
+  const size_t A = model.alphabetSize();
+  submat.assign(A, vguard<LogProb>(A));
+  for (AlphTok i = 0; i < A; ++i)
+    for (AlphTok j = 0; j < A; ++j) submat[i][j] = log(pm.subMat.front()[i][j]) - lpm.logInsProb.front()[j];
+  const double gapProb = pm.ins + (1 - pm.ins) * pm.del;
+  const double noGapProb = 1 - gapProb;
+  const double gapExt = 1 / ((pm.ins / gapProb) / pm.insExt + (1 - pm.ins / gapProb) / pm.delExt);
+  const double noGapExt = 1 - gapExt;
+  noGap = log(noGapProb);
+  gapOpen = log(gapProb) + log(noGapExt);
+  gapExtend = log(gapExt);
+  m2i = log(gapProb);
+  m2d = log(noGapProb * gapProb);
+  m2m = log(noGapProb * noGapProb);
+  i2i = log(gapExt);
+  i2d = log(noGapExt * gapProb);
+  i2m = log(noGapExt * noGapProb);
+  i2e = i2m;
+  d2d = log(gapExt);
+  d2m = log(noGapExt);
+  d2e = d2m;
+}
+
+void QuickAlignMatrix::fillJob(hx_quick_job& job, vguard<double>& flatSub) const {
+  const size_t A = model.alphabetSize();
+  flatSub.clear();
+  for (size_t i = 0; i < A; ++i)
+    for (size_t j = 0; j < A; ++j) flatSub.push_back(submat[i][j]);
+  job.x_tok = xTok.data();
+  job.y_tok = yTok.data();
+  job.x_len = (int32_t)xLen;
+  job.y_len = (int32_t)yLen;
+  job.alph_size = (int32_t)A;
+  job.submat = flatSub.data();
+  job.diagonals = penv->full ? NULL : penv->diagonals.data();
+  job.n_diagonals = penv->full ? 0 : (int32_t)penv->diagonals.size();
+  const double sc[11] = {m2m, m2i, m2d, i2i, i2m, i2d, d2d, d2m, gapOpen, gapExtend, noGap};
+  for (int k = 0; k < 11; ++k) job.scores[k] = sc[k];
+}
+
+void QuickAlignMatrix::attach(const std::shared_ptr<QuickHandle>& h, int job, double score, int xe, int ye) {
+  handle = h;
+  jobIndex = job;
+  start = 0;
+  end = result = score;
+  xEnd = (SeqIdx)xe;
+  yEnd = (SeqIdx)ye;
+  hx_layout lay;
+  detail::check(hx_quick_batch_layout(h->b, job, &lay), "hx_quick_batch_layout");
+  stripStride = lay.strip_stride;
+  planeStride = lay.plane_stride;
+}
+
+QuickAlignMatrix::QuickAlignMatrix(const DiagonalEnvelope& env, const RateModel& model, double time)
+    : QuickAlignMatrix(env, model, time, Deferred()) {
+  Require(xLen > 0 && yLen > 0, "Can't align an empty sequence (%s vs %s)", px->name.c_str(), py->name.c_str());
+  detail::ensureDevice();
+  hx_quick_job job;
+  vguard<double> flatSub;
+  fillJob(job, flatSub);
+  hx_quick_batch* b = NULL;
+  detail::check(hx_quick_batch_create(&job, 1, &b), "hx_quick_batch_create");
+  std::shared_ptr<QuickHandle> h(new QuickHandle(b));
+  detail::check(hx_quick_batch_run(b, NULL), "hx_quick_batch_run");
+  double score = NEG_INF;
+  int32_t xe = 0, ye = 0;
+  detail::check(hx_quick_batch_results(b, &score, &xe, &ye), "hx_quick_batch_results");
+  attach(h, 0, score, xe, ye);
+}
+
+vguard<QuickAlignMatrix*> QuickAlignMatrix::fillBatch(const vguard<const DiagonalEnvelope*>& envs, const RateModel& model,
+                                                      double time) {
+  vguard<QuickAlignMatrix*> out;
+  if (envs.empty()) return out;
+  detail::ensureDevice();
+  const size_t n = envs.size();
+  vguard<hx_quick_job> jobs(n);
+  vguard<vguard<double> > flat(n);
+  for (size_t k = 0; k < n; ++k) {
+    QuickAlignMatrix* m = new QuickAlignMatrix(*envs[k], model, time, Deferred());
+    Require(m->xLen > 0 && m->yLen > 0, "Can't align an empty sequence (%s vs %s)", m->px->name.c_str(), m->py->name.c_str());
+    out.push_back(m);
+    m->fillJob(jobs[k], flat[k]);
+  }
+  hx_quick_batch* b = NULL;
+  detail::check(hx_quick_batch_create(jobs.data(), (int32_t)n, &b), "hx_quick_batch_create");
+  std::shared_ptr<QuickHandle> h(new QuickHandle(b));
+  detail::check(hx_quick_batch_run(b, NULL), "hx_quick_batch_run");
+  vguard<double> score(n, NEG_INF);
+  vguard<int32_t> xe(n, 0), ye(n, 0);
+  detail::check(hx_quick_batch_results(b, score.data(), xe.data(), ye.data()), "hx_quick_batch_results");
+  for (size_t k = 0; k < n; ++k) out[k]->attach(h, (int)k, score[k], xe[k], ye[k]);
+  return out;
+}
+
+QuickAlignMatrix::~QuickAlignMatrix() {
+  if (hostCells) detail::pinnedGive(hostCells, hostCellsCap);
+}
+
+// reference getCell const (src/quickalign.h:30-33): `dummy` (-inf) outside the stored cells
+LogProb QuickAlignMatrix::getCell(SeqIdx i, SeqIdx j, unsigned int offset) const {
+  if (i < 1 || j < 1 || i > xLen || j > yLen) return NEG_INF;
+  if (!hostCells) {
+    hostCells = detail::pinnedTake(3 * (size_t)planeStride, hostCellsCap);
+    detail::check(hx_quick_batch_read_matrix(handle->b, jobIndex, hostCells), "hx_quick_batch_read_matrix");
+  }
+  const long long r = (long long)i - 1, c = (long long)j - 1;
+  const long long l = r & 63, t = c + l;
+  const long long slot = (r >> 6) * stripStride + ((t >> 1) << 7) + (l << 1) + (t & 1);
+  return hostCells[(size_t)offset * planeStride + slot];
+}
+
+LogProb QuickAlignMatrix::cellScore(SeqIdx i, SeqIdx j, State state) const {
+  LogProb cs = std::numeric_limits<double>::quiet_NaN();
+  switch (state) {
+    case Match: cs = mat(i, j); break;
+    case Insert: cs = ins(i, j); break;
+    case Delete: cs = del(i, j); break;
+    default: break;
+  }
+  return cs;
+}
+
+const char* QuickAlignMatrix::stateToString(State state) {
+  switch (state) {
+    case Start: return "Start";
+    case Match: return "Match";
+    case Insert: return "Insert";
+    case Delete: return "Delete";
+    default: break;
+  }
+  return "Unknown";
+}
+
+void QuickAlignMatrix::updateMax(double& currentMax, State& currentMaxIdx, double candidateMax, State candidateMaxIdx) {
+  if (candidateMax > currentMax) {
+    currentMax = candidateMax;
+    currentMaxIdx = candidateMaxIdx;
+  }
+}
+
+// src/quickalign.cpp:147-207
+AlignPath QuickAlignMatrix::alignPath() const {
+  Require(resultIsFinite(), "Can't do Viterbi traceback if final score is -infinity");
+  SeqIdx i = xEnd, j = yEnd;
+  State state = Match;
+  Assert(i > 0 && j > 0, "Traceback error at (%u,%u,End)", i, j);
+  AlignPath path;
+  path[0] = vguard<bool>(xLen - xEnd, true);
+  path[1] = vguard<bool>(xLen - xEnd, false);
+  path[0].insert(path[0].end(), yLen - yEnd, false);
+  path[1].insert(path[1].end(), yLen - yEnd, true);
+  while (state != Start) {
+    LogProb srcSc = NEG_INF;
+    LogProb emitSc = 0;
+    switch (state) {
+      case Match:
+        emitSc = matchEmitScore(i, j);
+        --i;
+        --j;
+        path[0].insert(path[0].begin(), true);
+        path[1].insert(path[1].begin(), true);
+        updateMax(srcSc, state, mat(i, j) + m2m + emitSc, Match);
+        updateMax(srcSc, state, ins(i, j) + i2m + emitSc, Insert);
+        updateMax(srcSc, state, del(i, j) + d2m + emitSc, Delete);
+        updateMax(srcSc, state, start + startGapScore(i + 1, j + 1) + emitSc, Start);
+        Assert(srcSc == mat(i + 1, j + 1), "Traceback error at (%u,%u,Match)", i + 1, j + 1);
+        break;
+      case Insert:
+        --j;
+        path[0].insert(path[0].begin(), false);
+        path[1].insert(path[1].begin(), true);
+        updateMax(srcSc, state, mat(i, j) + m2i, Match);
+        updateMax(srcSc, state, ins(i, j) + i2i, Insert);
+        Assert(srcSc == ins(i, j + 1), "Traceback error at (%u,%u,Insert)", i, j + 1);
+        break;
+      case Delete:
+        --i;
+        path[0].insert(path[0].begin(), true);
+        path[1].insert(path[1].begin(), false);
+        updateMax(srcSc, state, mat(i, j) + m2d, Match);
+        updateMax(srcSc, state, ins(i, j) + i2d, Insert);
+        updateMax(srcSc, state, del(i, j) + d2d, Delete);
+        Assert(srcSc == del(i + 1, j), "Traceback error at (%u,%u,Delete)", i + 1, j);
+        break;
+      default:
+        Abort("Traceback error");
+        break;
+    }
+  }
+  path[0].insert(path[0].begin(), i, true);
+  path[1].insert(path[1].begin(), i, false);
+  path[0].insert(path[0].begin(), j, false);
+  path[1].insert(path[1].begin(), j, true);
+  Assert(alignPathResiduesInRow(path[0]) == xLen, "Traceback error: x row has %u steps, expected %u",
+         alignPathResiduesInRow(path[0]), xLen);
+  Assert(alignPathResiduesInRow(path[1]) == yLen, "Traceback error: y row has %u steps, expected %u",
+         alignPathResiduesInRow(path[1]), yLen);
+  return path;
+}
+
+AlignPath QuickAlignMatrix::alignPath(AlignRowIndex row1, AlignRowIndex row2) const {
+  AlignPath oldPath = alignPath();
+  AlignPath newPath;
+  newPath[row1] = oldPath[0];
+  newPath[row2] = oldPath[1];
+  return newPath;
+}
+
+// Alignment(seqs, path).gapped() (src/alignpath.cpp:254-280)
+vguard<FastSeq> QuickAlignMatrix::gappedSeq() const {
+  const AlignPath path = alignPath();
+  vguard<FastSeq> gs(2);
+  const FastSeq* ug[2] = {px, py};
+  for (int row = 0; row < 2; ++row) {
+    FastSeq& g = gs[row];
+    g.name = ug[row]->name;
+    g.comment = ug[row]->comment;
+    SeqIdx pos = 0;
+    for (bool b : path.at(row))
+      if (b) {
+        Assert(ug[row]->seq.size() > pos, "Sequence position %u out of bounds for sequence %s", pos, ug[row]->name.c_str());
+        g.seq.push_back(ug[row]->seq[pos++]);
+      } else
+        g.seq.push_back(Alignment::gapChar);
+  }
+  return gs;
+}
+
+}  // namespace historian

@@ -61,3 +61,10 @@ def test_reference_golden_file_through_the_gpu_fast_mode(name):
         assert sorted(got.splitlines()) == sorted(want.splitlines())
     else:
         assert got == want
+
+
+@pytest.mark.gpu
+def test_testquickalign_golden_file_through_the_gpu():
+    # reference Makefile:278-279
+    got = run(["testquickalign", G + "PF16593.pair.fa", G + "testamino.json", 1])
+    assert got == open(G + "testquickalign.out.fa").read()
