@@ -94,7 +94,8 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
     const int my_base = (s / W) * Cc;
     const int64_t store_base = (int64_t)s * ss + (lane << 1);
     int yt_next = ytok[0];                        // token of column c = t - lane for t = 0 (clamped to column 0)
-    for (int t = 0; t < nsteps; ++t) {
+    // one anti-diagonal step of the strip: the lane's new cell (r, t - lane), -inf when there is none
+    auto step = [&](const int t) -> Q3 {
       if (has_above) {
         if ((t & 63) == 0 && t < Cc) {
           const int hi = (t + 64 < Cc) ? t + 64 : Cc;
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
       if (yt < 0) yt = J.alph;
       bool act = rvalid && c >= 0 && c < Cc;
       if (!FULL && in_env) act = act && in_env[(c < 0 || c >= Cc || !rvalid) ? 0 : (i - j + Cc)];   // (a job of a mixed batch may have the full envelope)
-      Q3 nw = q3_neg_inf();
+      Q3 nw = q3_neg_inf();                       // outside the envelope a cell reads as -inf (reference const getCell -> dummy)
       if (act) {
         double mat = dmax(dmax(u2.mat + m2m, u2.del + d2m), u2.ins + i2m);
         const double sgy = (j == 1) ? no_gap : gap_open + (double)(unsigned)(j - 2) * gap_extend;
@@ -137,30 +138,37 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
         const double egy = (j == Cc) ? no_gap : gap_open + (double)(unsigned)(Cc - j - 2) * gap_extend;
         const double ij_end = mat + (egx + egy);
         if (ij_end > best) { best = ij_end; best_j = j; }
-        const int64_t sl = store_base + ((int64_t)(t >> 1) << 7) + (t & 1);
-        M[sl] = nw.mat;
-        M[plane + sl] = nw.ins;
-        M[2 * plane + sl] = nw.del;
-      } else if (rvalid && c >= 0 && c < Cc) {
-        // outside the envelope: the cell reads as -inf (reference const getCell -> dummy)
-        const int64_t sl = store_base + ((int64_t)(t >> 1) << 7) + (t & 1);
-        M[sl] = HX_NEG_INF;
-        M[plane + sl] = HX_NEG_INF;
-        M[2 * plane + sl] = HX_NEG_INF;
       }
       own = nw;
       // rotate the row-above window: this step's `up` becomes the next step's `diag`; lane l+1's next
       // `up` is this lane's new cell (lane 0 is re-filled from the boundary block)
       u2 = u1;
       u1 = shr1_keep0(u1, nw);
-      // publish progress (columns whose stores have left the wave, see hx_chain.hip)
-      const int fin = t + 1 - 63;
+      return nw;
+    };
+    // Two steps per iteration: in the strip-skewed layout the cells a row produces on two consecutive
+    // anti-diagonals are adjacent, so a lane stores 16 contiguous bytes per plane every second step
+    // (a wave: 1 KiB, fully coalesced).  Lanes without a cell store -inf into padding.
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const int64_t plane2 = plane >> 1;
+    for (int t = 0; t < nsteps; t += 2) {
+      const Q3 ca = step(t);
+      Q3 cb = q3_neg_inf();
+      if (t + 1 < nsteps) cb = step(t + 1);
+      HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + store_base + ((int64_t)(t >> 1) << 7));
+      M2[0] = d2v{ca.mat, cb.mat};
+      M2[plane2] = d2v{ca.ins, cb.ins};
+      M2[2 * plane2] = d2v{ca.del, cb.del};
+      // publish progress: the strip's last row has finished column (t + 1) - 63; a column counts once its
+      // stores have left the wave (every iteration issues 5 vector-memory operations: everything stored
+      // HX_QA_LAG steps ago is older than the wave's 40 youngest, see hx_chain.hip)
+      const int fin = (t + 2 < nsteps ? t + 2 : nsteps) - 63;
       if (fin >= Cc) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) progp[wave] = my_base + Cc;
       } else {
         const int done = fin - HX_QA_LAG;
-        if (done > 0 && (done & 63) == 0) {
+        if (done > 0 && ((done >> 6) != ((done - 2) >> 6))) {
           asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
           if (lane == 0) progp[wave] = my_base + done;
         }
