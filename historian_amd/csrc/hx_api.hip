@@ -695,6 +695,7 @@ struct hx_quick_batch {
   int64_t total_cells = 0;
   hipStream_t last_stream = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
+  size_t res_off = 0, xy_off = 0;
 };
 
 int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_batch** out) {
@@ -708,7 +709,7 @@ int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_bat
   b->n_jobs = n_jobs;
   b->jobs.resize(n_jobs);
   b->layouts.resize(n_jobs);
-  struct Off { size_t xtok, ytok, submat, env, best, bestj, result, xy; bool has_env; };
+  struct Off { size_t xtok, ytok, submat, env, best, bestj; bool has_env; };
   std::vector<Off> offs(n_jobs);
   std::vector<int64_t> cell_off(n_jobs);
   Arena ar;
@@ -742,8 +743,6 @@ int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_bat
     }
     o.best = ar.reserve(sizeof(double) * q.x_len);
     o.bestj = ar.reserve(sizeof(int32_t) * q.x_len);
-    o.result = ar.reserve(sizeof(double));
-    o.xy = ar.reserve(sizeof(int32_t) * 2);
     DevQuick& J = b->jobs[k];
     memset(&J, 0, sizeof(J));
     J.xlen = q.x_len; J.ylen = q.y_len; J.alph = q.alph_size;
@@ -760,6 +759,9 @@ int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_bat
     if (q.x_len > b->max_rows) b->max_rows = q.x_len;
   }
   if (rc != HX_OK) { delete b; return rc; }
+  // scores and end coordinates of all pairs, contiguous: one copy back per batch
+  b->res_off = ar.reserve(sizeof(double) * n_jobs);
+  b->xy_off = ar.reserve(sizeof(int32_t) * 2 * n_jobs);
   auto cleanup = [&](int code) { hx_quick_batch_destroy(b); return code; };
   if (hipMalloc(reinterpret_cast<void**>(&b->d_arena), ar.host.size() + 256) != hipSuccess)
     return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %zu input bytes failed", ar.host.size()));
@@ -777,8 +779,8 @@ int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_bat
     J.in_env = o.has_env ? reinterpret_cast<uint8_t*>(base + o.env) : nullptr;
     J.best_score = reinterpret_cast<double*>(base + o.best);
     J.best_j = reinterpret_cast<int32_t*>(base + o.bestj);
-    J.result = reinterpret_cast<double*>(base + o.result);
-    J.xy_end = reinterpret_cast<int32_t*>(base + o.xy);
+    J.result = reinterpret_cast<double*>(base + b->res_off) + k;
+    J.xy_end = reinterpret_cast<int32_t*>(base + b->xy_off) + 2 * k;
     J.cells = b->d_cells + cell_off[k];
   }
   if (hipMalloc(reinterpret_cast<void**>(&b->d_jobs), sizeof(DevQuick) * n_jobs) != hipSuccess)
@@ -819,12 +821,12 @@ int hx_quick_batch_results(hx_quick_batch* b, double* score, int32_t* x_end, int
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
   if (!b->done) return fail(HX_ERR_STATE, "hx_quick_batch_run has not been launched");
   HIP_TRY(hipStreamSynchronize(b->last_stream));
+  if (score) HIP_TRY(hipMemcpy(score, b->d_arena + b->res_off, sizeof(double) * b->n_jobs, hipMemcpyDeviceToHost));
+  std::vector<int32_t> xy(2 * (size_t)b->n_jobs);
+  HIP_TRY(hipMemcpy(xy.data(), b->d_arena + b->xy_off, sizeof(int32_t) * xy.size(), hipMemcpyDeviceToHost));
   for (int k = 0; k < b->n_jobs; ++k) {
-    int32_t xy[2];
-    if (score) HIP_TRY(hipMemcpy(&score[k], b->jobs[k].result, sizeof(double), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(xy, b->jobs[k].xy_end, sizeof(xy), hipMemcpyDeviceToHost));
-    if (x_end) x_end[k] = xy[0];
-    if (y_end) y_end[k] = xy[1];
+    if (x_end) x_end[k] = xy[2 * k];
+    if (y_end) y_end[k] = xy[2 * k + 1];
   }
   return HX_OK;
 }
