@@ -689,7 +689,7 @@ struct hx_quick_batch {
   DevQuick* d_jobs = nullptr;
   char* d_arena = nullptr;
   double* d_cells = nullptr;
-  int max_rows = 0;
+  int max_rows = 0, max_cols = 0;
   bool all_full = true;
   bool done = false;
   int64_t total_cells = 0;
@@ -757,6 +757,8 @@ int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_bat
     cells_total += 3 * J.plane;
     b->total_cells += (int64_t)q.x_len * q.y_len;
     if (q.x_len > b->max_rows) b->max_rows = q.x_len;
+    if (q.y_len > b->max_cols) b->max_cols = q.y_len;
+    if (q.y_len > 7000) { rc = fail(HX_ERR_RANGE, "job %d: y longer than 7000 residues (per-column LDS tables)", k); break; }
   }
   if (rc != HX_OK) { delete b; return rc; }
   // scores and end coordinates of all pairs, contiguous: one copy back per batch
@@ -809,7 +811,7 @@ int hx_quick_batch_run(hx_quick_batch* b, void* stream) {
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
   hipStream_t st = static_cast<hipStream_t>(stream);
   HIP_TRY(hipEventRecord(b->ev[0], st));
-  launch_quickalign(b->d_jobs, b->n_jobs, b->max_rows, b->all_full, st);
+  launch_quickalign(b->d_jobs, b->n_jobs, b->max_rows, b->max_cols, b->all_full, st);
   HIP_TRY(hipEventRecord(b->ev[1], st));
   HIP_TRY(hipGetLastError());
   b->done = true;

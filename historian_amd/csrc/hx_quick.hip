@@ -18,6 +18,7 @@
 // a time once that wave's LDS progress counter allows.  The matrix (3 planes, strip-skewed layout
 // of hx_device.h) is written once, 24 B per cell, and kept for the traceback.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "hx_device.h"
 #include "hx_lse.h"
 #include "hx_policy.h"
@@ -43,20 +44,40 @@ __device__ __forceinline__ double lane_value(double v, int l) {
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double dmax(double a, double b) { return a < b ? b : a; }   // std::max(a, b)
+// std::max(a, b) = (a < b) ? b : a.  One v_max_f64 gives the same value for every pair of non-NaN
+// operands except max(-0.0, +0.0) (sign of zero); the scores are sums of logarithms and never -0.0.
+__device__ __forceinline__ double dmax(double a, double b) { return vmax(a, b); }
 
 #define HX_QA_LAG 16
 #define HX_QA_MAX_ALPH 31
 
 template <int W, bool FULL>
-__global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restrict__ jobs) {
+__global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restrict__ jobs, const int max_cols) {
   __shared__ volatile int prog[W];
   __shared__ double sub[(HX_QA_MAX_ALPH + 1) * (HX_QA_MAX_ALPH + 1)];   // padded with a zero row / column for invalid tokens
+  // per column (dynamic LDS, sized for the longest y of the batch): {startGap y part, endGap y part} and the
+  // row offset of the column's token into `sub`
+  extern __shared__ __attribute__((aligned(16))) double col_lds[];
   const DevQuick& J = jobs[blockIdx.x];
   const int A1 = J.alph + 1;
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  d2v* colgap = reinterpret_cast<d2v*>(col_lds);
+  int* coltok = reinterpret_cast<int*>(col_lds + 2 * (size_t)max_cols);
   for (int k = threadIdx.x; k < A1 * A1; k += W * 64) {
     const int a = k / A1, b = k - a * A1;
     sub[k] = (a < J.alph && b < J.alph) ? J.submat[a * J.alph + b] : 0.0;
+  }
+  {
+    const double gap_open = J.sc[8], gap_extend = J.sc[9], no_gap = J.sc[10];
+    const int Cc = J.ylen;
+    for (int c = threadIdx.x; c < Cc; c += W * 64) {
+      const int j = c + 1;     // startGapScore / endGapScore, y part (src/quickalign.h:57-66; SeqIdx is unsigned)
+      const double sgy = (j == 1) ? no_gap : gap_open + (double)(unsigned)(j - 2) * gap_extend;
+      const double egy = (j == Cc) ? no_gap : gap_open + (double)(unsigned)(Cc - j - 2) * gap_extend;
+      colgap[c] = d2v{sgy, egy};
+      const int yt = J.ytok[c];
+      coltok[c] = yt < 0 ? J.alph : yt;
+    }
   }
   if (threadIdx.x < W) prog[threadIdx.x] = 0;
   __syncthreads();
@@ -65,7 +86,6 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t plane = J.plane, ss = J.strip_stride;
   HX_GLOBAL double* __restrict__ M = as_global(J.cells);
-  const HX_GLOBAL int32_t* ytok = as_global(J.ytok);
   const HX_GLOBAL uint8_t* in_env = as_global(J.in_env);
   const double m2m = J.sc[0], m2i = J.sc[1], m2d = J.sc[2], i2i = J.sc[3], i2m = J.sc[4], i2d = J.sc[5], d2d = J.sc[6],
                d2m = J.sc[7], gap_open = J.sc[8], gap_extend = J.sc[9], no_gap = J.sc[10];
@@ -93,7 +113,6 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
     const int above_base = ((s - 1) / W) * Cc;
     const int my_base = (s / W) * Cc;
     const int64_t store_base = (int64_t)s * ss + (lane << 1);
-    int yt_next = ytok[0];                        // token of column c = t - lane for t = 0 (clamped to column 0)
     // one anti-diagonal step of the strip: the lane's new cell (r, t - lane), -inf when there is none
     auto step = [&](const int t) -> Q3 {
       if (has_above) {
@@ -118,25 +137,20 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
       }
       const int c = t - lane;                     // column c <-> y position j = c + 1
       const int j = c + 1;
-      int yt = yt_next;
-      {
-        const int cn = c + 1;
-        yt_next = ytok[cn < 0 ? 0 : (cn >= Cc ? Cc - 1 : cn)];
-      }
-      if (yt < 0) yt = J.alph;
+      const int cl = c < 0 ? 0 : (c >= Cc ? Cc - 1 : c);
+      const int yt = coltok[cl];
+      const d2v gy = colgap[cl];
       bool act = rvalid && c >= 0 && c < Cc;
       if (!FULL && in_env) act = act && in_env[(c < 0 || c >= Cc || !rvalid) ? 0 : (i - j + Cc)];   // (a job of a mixed batch may have the full envelope)
       Q3 nw = q3_neg_inf();                       // outside the envelope a cell reads as -inf (reference const getCell -> dummy)
       if (act) {
         double mat = dmax(dmax(u2.mat + m2m, u2.del + d2m), u2.ins + i2m);
-        const double sgy = (j == 1) ? no_gap : gap_open + (double)(unsigned)(j - 2) * gap_extend;
-        mat = dmax(mat, 0.0 + (sgx + sgy));
+        mat = dmax(mat, 0.0 + (sgx + gy.x));
         mat += sub[sub_row + yt];
         nw.mat = mat;
         nw.ins = dmax(own.ins + i2i, own.mat + m2i);
         nw.del = dmax(dmax(u1.ins + i2d, u1.del + d2d), u1.mat + m2d);
-        const double egy = (j == Cc) ? no_gap : gap_open + (double)(unsigned)(Cc - j - 2) * gap_extend;
-        const double ij_end = mat + (egx + egy);
+        const double ij_end = mat + (egx + gy.y);
         if (ij_end > best) { best = ij_end; best_j = j; }
       }
       own = nw;
@@ -149,7 +163,6 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
     // Two steps per iteration: in the strip-skewed layout the cells a row produces on two consecutive
     // anti-diagonals are adjacent, so a lane stores 16 contiguous bytes per plane every second step
     // (a wave: 1 KiB, fully coalesced).  Lanes without a cell store -inf into padding.
-    typedef double d2v __attribute__((ext_vector_type(2)));
     const int64_t plane2 = plane >> 1;
     for (int t = 0; t < nsteps; t += 2) {
       const Q3 ca = step(t);
@@ -196,19 +209,35 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
 }
 
 template <int W>
-void launch_w(const DevQuick* d_jobs, int n_jobs, bool full, hipStream_t st) {
-  if (full) hipLaunchKernelGGL((k_quickalign<W, true>), dim3(n_jobs), dim3(W * 64), 0, st, d_jobs);
-  else hipLaunchKernelGGL((k_quickalign<W, false>), dim3(n_jobs), dim3(W * 64), 0, st, d_jobs);
+void launch_w(const DevQuick* d_jobs, int n_jobs, int max_cols, bool full, hipStream_t st) {
+  const size_t lds = (size_t)max_cols * (16 + 4) + 16;
+  if (full) hipLaunchKernelGGL((k_quickalign<W, true>), dim3(n_jobs), dim3(W * 64), lds, st, d_jobs, max_cols);
+  else hipLaunchKernelGGL((k_quickalign<W, false>), dim3(n_jobs), dim3(W * 64), lds, st, d_jobs, max_cols);
 }
 
 }  // namespace
 
-void launch_quickalign(const DevQuick* d_jobs, int n_jobs, int max_rows, bool all_full, hipStream_t st) {
-  if (max_rows <= 64) launch_w<1>(d_jobs, n_jobs, all_full, st);
-  else if (max_rows <= 128) launch_w<2>(d_jobs, n_jobs, all_full, st);
-  else if (max_rows <= 256) launch_w<4>(d_jobs, n_jobs, all_full, st);
-  else if (max_rows <= 512) launch_w<8>(d_jobs, n_jobs, all_full, st);
-  else launch_w<16>(d_jobs, n_jobs, all_full, st);
+void launch_quickalign(const DevQuick* d_jobs, int n_jobs, int max_rows, int max_cols, bool all_full, hipStream_t st) {
+  const char* v = getenv("HX_QA_WAVES");   // tuning hook
+  const int forced = v ? atoi(v) : 0;
+  if (forced == 8) { launch_w<8>(d_jobs, n_jobs, max_cols, all_full, st); return; }
+  if (forced == 4) { launch_w<4>(d_jobs, n_jobs, max_cols, all_full, st); return; }
+  if (forced == 2) { launch_w<2>(d_jobs, n_jobs, max_cols, all_full, st); return; }
+  if (forced == 1) { launch_w<1>(d_jobs, n_jobs, max_cols, all_full, st); return; }
+  // Waves per pair: enough to cover the rows when the batch is small (latency of one pair), fewer when the
+  // batch alone fills the GPU -- a pair's strips start one after the other, so fewer waves per pair waste
+  // less of the sweep on the ramp (measured on 512 pairs of 2000x2000: 16 waves 0.54, 8: 0.57, 4: 0.59 of
+  // the HBM roofline; below 4 the per-column LDS tables limit the workgroups per CU).
+  int cap = 16;
+  if (n_jobs >= 384) cap = 4;
+  else if (n_jobs >= 128) cap = 8;
+  const int need = (max_rows + 63) / 64;
+  const int w = need < cap ? need : cap;
+  if (w <= 1) launch_w<1>(d_jobs, n_jobs, max_cols, all_full, st);
+  else if (w <= 2) launch_w<2>(d_jobs, n_jobs, max_cols, all_full, st);
+  else if (w <= 4) launch_w<4>(d_jobs, n_jobs, max_cols, all_full, st);
+  else if (w <= 8) launch_w<8>(d_jobs, n_jobs, max_cols, all_full, st);
+  else launch_w<16>(d_jobs, n_jobs, max_cols, all_full, st);
 }
 
 }  // namespace hx
