@@ -352,6 +352,7 @@ struct hx_batch {
   int64_t fwd_total = 0, max_eplane = 0;
   int max_states = 0, max_ca = 0, max_cls_pairs = 0, max_rows = 0, max_cls = 0;
   bool all_chain = true, all_leaf = true, all_ylds = true, any_banded = false;
+  int yl_cols = 0, yl_emis = 0;       // LDS-resident y side: columns and padded class pairs of the largest job
   int64_t total_cells = 0;
   bool forward_done = false, backward_done = false;
   hipStream_t last_stream = nullptr;
@@ -487,6 +488,8 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     b->all_leaf = b->all_leaf && J.leaf_like;
     b->any_banded = b->any_banded || pj.max_distance >= 0;
     // y side small enough for LDS (hx_chain.hip HX_YL_*) and all its transitions have lpTrans 0
+    if (jo.y.n > b->yl_cols) b->yl_cols = (jo.y.n + 3) & ~3;
+    if ((jo.x.n_cls + 1) * (jo.y.n_cls + 1) > b->yl_emis) b->yl_emis = ((jo.x.n_cls + 1) * (jo.y.n_cls + 1) + 1) & ~1;
     b->all_ylds = b->all_ylds && J.leaf_like && jo.y.lp_zero && jo.y.n <= 6144 && jo.y.n_cls + 1 <= 64 &&
                   (int64_t)(jo.x.n_cls + 1) * (jo.y.n_cls + 1) <= 1024;
   }
@@ -574,7 +577,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
     // with a band the strip pipelines only visit in-envelope windows; everything else is -inf
     if (b->any_banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_fwd, b->fwd_total, st);
     launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,
-                         b->all_leaf ? (b->all_ylds ? 2 : 1) : 0, b->any_banded, st);
+                         b->all_leaf ? (b->all_ylds ? 2 : 1) : 0, b->any_banded, b->yl_cols, b->yl_emis, st);
   } else if (b->flags & HX_FORCE_GENERIC)
     launch_forward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
   else {
@@ -615,7 +618,7 @@ int hx_batch_backward(hx_batch* b, void* stream) {
   if (b->all_leaf && !(b->flags & HX_FORCE_GENERIC)) {
     if (b->any_banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_bwd, b->fwd_total, st);
     launch_backward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,
-                          b->all_ylds ? 2 : 1, b->any_banded, st);
+                          b->all_ylds ? 2 : 1, b->any_banded, b->yl_cols, b->yl_emis, st);
   } else if (b->flags & HX_FORCE_GENERIC)
     launch_backward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
   else {

@@ -253,7 +253,7 @@ __device__ __forceinline__ C5 leaf_cell_bwd(const double (*T)[6], const LSE& L, 
 template <int DIR, int RPT, int W, class LSE, bool FAST, bool LEAF, bool YL, bool BANDED, int MINW = 1, int PPW = 1>
 __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob* __restrict__ jobs,
                                                                       const double* __restrict__ exact_tab,
-                                                                      const double* __restrict__ fast_tab, const int n_jobs) {
+                                                                      const double* __restrict__ fast_tab, const int n_jobs, const int yl_emis) {
   constexpr int THREADS = W * PPW * 64;
   constexpr int SR = 64 * RPT;                      // rows per strip
   static_assert(PPW == 1 || !YL, "the LDS-resident y side belongs to one pair");
@@ -275,9 +275,12 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
   // lpTrans 0): per column one word {emission class, not-ready bit}, per class
   // {rootsuby, insy}, and the padded class-pair emission table.  The step loop then
   // issues no vector-memory loads at all, only its write-once stores.
-  __shared__ unsigned ycol[YL ? HX_YL_MAX_COLS : 1];
+  // (column words and emission table in dynamic LDS, sized for the batch: with 2001 columns and 22x22
+  // classes a workgroup needs 78 KB in all, so two workgroups fit a CU)
+  extern __shared__ __attribute__((aligned(16))) unsigned char yl_dyn[];
+  double* elds = reinterpret_cast<double*>(yl_dyn);
+  unsigned* ycol = reinterpret_cast<unsigned*>(yl_dyn + sizeof(double) * (size_t)(YL ? yl_emis : 0));
   __shared__ __attribute__((aligned(16))) double yclass[YL ? 2 * HX_YL_MAX_CLS : 2];
-  __shared__ double elds[YL ? HX_YL_MAX_EMIS : 1];
   if (YL) {
     const int Ky1 = J.y.n_cls + 1, Kx1 = J.x.n_cls + 1;
     for (int j = threadIdx.x; j < J.y.n; j += THREADS)
@@ -642,10 +645,11 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
 
 template <int DIR, int RPT, int W, int MINW = 1>
 static void launch_variant(const DevJob* d_jobs, int n_jobs, const double* tab, const double* fast_tab, bool fast,
-                           int leaf, bool banded, hipStream_t st) {
+                           int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
   const dim3 g(n_jobs), b(W * 64);
+  const size_t dyn = leaf == 2 ? sizeof(double) * (size_t)yl_emis + sizeof(unsigned) * (size_t)yl_cols : 0;
 #define HX_LAUNCH(LSE_, FAST_, LEAF_, YL_, BANDED_) \
-  hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, LSE_, FAST_, LEAF_, YL_, BANDED_, MINW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs)
+  hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, LSE_, FAST_, LEAF_, YL_, BANDED_, MINW>), g, b, dyn, st, d_jobs, tab, fast_tab, n_jobs, yl_emis)
   if (leaf == 2 && !banded) {             // the headline configuration: unbanded leaf pairs, y side in LDS
     if (fast) HX_LAUNCH(FastLse, true, true, true, false); else HX_LAUNCH(ExactLse3, false, true, true, false);
   } else if (leaf == 2) {
@@ -654,9 +658,9 @@ static void launch_variant(const DevJob* d_jobs, int n_jobs, const double* tab, 
     if (fast) HX_LAUNCH(FastLse, true, true, false, true); else HX_LAUNCH(ExactLse3, false, true, false, true);
   } else if (DIR == 0) {
     if (fast)
-      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, FastLse, true, false, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs);
+      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, FastLse, true, false, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs, 0);
     else
-      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, ExactLse3, false, false, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs);
+      hipLaunchKernelGGL((k_fill_chain<0, RPT, W, ExactLse3, false, false, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs, 0);
   }
 #undef HX_LAUNCH
 }
@@ -668,9 +672,9 @@ static void launch_banded_leaf_ppw(const DevJob* d_jobs, int n_jobs, const doubl
                                    hipStream_t st) {
   const dim3 g((n_jobs + PPW - 1) / PPW), b(PPW * 64);
   if (fast)
-    hipLaunchKernelGGL((k_fill_chain<DIR, 1, 1, FastLse, true, true, false, true, 1, PPW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs);
+    hipLaunchKernelGGL((k_fill_chain<DIR, 1, 1, FastLse, true, true, false, true, 1, PPW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs, 0);
   else
-    hipLaunchKernelGGL((k_fill_chain<DIR, 1, 1, ExactLse3, false, true, false, true, 1, PPW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs);
+    hipLaunchKernelGGL((k_fill_chain<DIR, 1, 1, ExactLse3, false, true, false, true, 1, PPW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs, 0);
 }
 template <int DIR>
 static void launch_banded_leaf(const DevJob* d_jobs, int n_jobs, const double* tab, const double* fast_tab, bool fast,
@@ -681,7 +685,7 @@ static void launch_banded_leaf(const DevJob* d_jobs, int n_jobs, const double* t
 
 template <int DIR>
 static void launch_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                         bool fast, int leaf, bool banded, hipStream_t st) {
+                         bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
   const char* v = getenv("HX_CHAIN_VARIANT");   // tuning hook: override for long profiles
   const int vi = v ? atoi(v) : 0;
   if (banded && leaf >= 1 && vi == 0 && n_jobs >= 64) {
@@ -689,29 +693,29 @@ static void launch_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const d
     return;
   }
   if (max_rows <= 64)
-    launch_variant<DIR, 1, 1>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, st);
+    launch_variant<DIR, 1, 1>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
   else if (max_rows <= 128)
-    launch_variant<DIR, 1, 2>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, st);
+    launch_variant<DIR, 1, 2>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
   else if (max_rows <= 256)
-    launch_variant<DIR, 1, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, st);
+    launch_variant<DIR, 1, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
   else if (vi == 2 || (vi == 0 && max_rows <= 512))
-    launch_variant<DIR, 1, 8>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, st);
+    launch_variant<DIR, 1, 8>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
   else if (vi == 4)
-    launch_variant<DIR, 2, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, st);
+    launch_variant<DIR, 2, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
   else
-    launch_variant<DIR, 1, 16>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, st);   // measured fastest on 2x2000
+    launch_variant<DIR, 1, 16>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);   // measured fastest on 2x2000
 }
 
 // leaf: 0 = general chain profiles, 1 = leaf-like, 2 = leaf-like with the y side in LDS
 void launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                          bool fast, int leaf, bool banded, hipStream_t st) {
-  launch_chain<0>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, st);
+                          bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
+  launch_chain<0>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
 }
 
 // leaf-like profiles only (leaf >= 1)
 void launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                           bool fast, int leaf, bool banded, hipStream_t st) {
-  launch_chain<1>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, st);
+                           bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
+  launch_chain<1>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
 }
 
 }  // namespace hx

@@ -11,9 +11,9 @@ void launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, 
                  const double* tab, hipStream_t st);
 void launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
 void launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                          bool fast, int leaf, bool banded, hipStream_t st);
+                          bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st);
 void launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                           bool fast, int leaf, bool banded, hipStream_t st);
+                           bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st);
 void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, const double* tab, hipStream_t st);
 void launch_fill_neg_inf(double* p, int64_t n, hipStream_t st);
 void launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
