@@ -152,8 +152,16 @@ AlignPath alignPathConcat(const AlignPath& a1, const AlignPath& a2, const AlignP
 void ensureAlignPathHasRow(AlignPath&, AlignRowIndex);
 string alignPathString(const AlignPath& a);
 
+AlignPath alignPathMerge(const vguard<AlignPath>& alignments);   // synchronized merge of multiple alignments
+
 struct Alignment {
   static const char gapChar, wildcardChar;
+  vguard<FastSeq> ungapped;
+  AlignPath path;
+  Alignment() {}
+  Alignment(const vguard<FastSeq>& gapped);
+  Alignment(const vguard<FastSeq>& ungapped, const AlignPath& path);
+  vguard<FastSeq> gapped() const;
   static inline bool isGap(char c) { return c == '-' || c == '.'; }
   static inline bool isWildcard(char c) { return c == wildcardChar; }
 };
@@ -645,6 +653,57 @@ protected:
   mutable size_t hostCellsCap;
   long long stripStride, planeStride;
   void attach(const std::shared_ptr<QuickHandle>& h, int job, double score, int xe, int ye);
+};
+
+// ---- src/diagenv.h (parameters), src/span.h ---------------------------------------------------
+struct DiagEnvParams {
+  bool sparse, autoMemSize;
+  int kmerLen, kmerThreshold, bandSize;
+  size_t maxSize;
+  DiagEnvParams();
+  size_t effectiveMaxSize() const;
+};
+
+// The alignment graph of the guide alignment: which pairs are aligned, the pair farm (one device batch
+// of QuickAlignMatrix fills instead of the reference's one-at-a-time loop, same results), the maximum
+// spanning tree of the pairwise alignments and their merge.
+struct AlignGraph {
+  struct TrialEdge {
+    AlignRowIndex row1, row2;
+    TrialEdge() {}
+    TrialEdge(AlignRowIndex src, AlignRowIndex dest) : row1(src), row2(dest) {}
+  };
+  struct Edge : TrialEdge {
+    LogProb lp;
+    Edge() : lp(-std::numeric_limits<double>::infinity()) {}
+    bool operator<(const Edge& e) const { return lp < e.lp; }
+  };
+  struct Partition {
+    vguard<size_t> seqSetIdx;
+    vguard<set<size_t> > seqSet;
+    size_t nSets;
+    Partition(size_t n);
+    bool inSameSet(const TrialEdge& e) const;
+    void merge(const TrialEdge& e);
+  };
+
+  const vguard<FastSeq>& seqs;
+  const RateModel& model;
+  const double time;
+  const DiagEnvParams& diagEnvParams;
+  vguard<std::priority_queue<Edge> > edges;
+  vguard<map<AlignRowIndex, AlignPath> > edgePath;
+
+  AlignGraph(const vguard<FastSeq>& seqs, const RateModel& model, const double time, const DiagEnvParams& diagEnvParams,
+             ForwardMatrix::random_engine& generator);
+  AlignGraph(const vguard<FastSeq>& seqs, const RateModel& model, const double time, const DiagEnvParams& diagEnvParams);
+  void buildSparseRandomGraph(ForwardMatrix::random_engine& generator);
+  void buildDenseGraph();
+  void buildGraph(const list<TrialEdge>& trialEdges, const string& graphDescription);
+  list<AlignPath> minSpanTree();
+  AlignPath mstPath();
+  Alignment mstAlign();
+  vguard<FastSeq> mstGapped();
 };
 
 }  // namespace historian

@@ -4,6 +4,8 @@
 // reads the device-filled matrix.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <set>
 extern "C" {
 #include "../../../include/historian_hip.h"
@@ -169,6 +171,13 @@ void QuickAlignMatrix::computeScores() {
   d2d = log(gapExt);
   d2m = log(noGapExt);
   d2e = d2m;
+  static bool dumped = false;
+  if (!dumped && getenv("HX_DEBUG_SPAN")) {   // test hook: the inputs of the DP, exactly (tests/test_host_mirror.py)
+    dumped = true;
+    fprintf(stderr, "scores %a %a %a %a %a %a %a %a %a %a %a\n", m2m, m2i, m2d, i2i, i2m, i2d, d2d, d2m, gapOpen, gapExtend, noGap);
+    for (AlphTok i = 0; i < A; ++i)
+      for (AlphTok j = 0; j < A; ++j) fprintf(stderr, "submat %u %u %a\n", i, j, submat[i][j]);
+  }
 }
 
 void QuickAlignMatrix::fillJob(hx_quick_job& job, vguard<double>& flatSub) const {

@@ -290,3 +290,214 @@ def testquickalign_main(seq_file, model_file, time):
     for (name, _), g in zip(seqs, mx.gapped()):
         out.append(">%s\n%s\n" % (name, g))
     return "".join(out)
+
+
+# ----------------------------------------------------------------------------------------------------
+# Around the pair DP: alignment merging and the alignment graph (reference src/alignpath.cpp:9-20,
+# 93-217,232-280; src/span.cpp).  AlignPath = {row: [bool]}.
+# ----------------------------------------------------------------------------------------------------
+def is_gap(c):
+    return c in "-."
+
+
+def alignment_from_gapped(gapped):
+    """Alignment::Alignment(gapped) (src/alignpath.cpp:232-248): [(name, gapped seq)] -> (ungapped [(name, seq)], path)"""
+    cols = None
+    for name, s in gapped:
+        if cols is None:
+            cols = len(s)
+        assert cols == len(s), "Alignment is not flush"
+    ungapped, path = [], {}
+    for row, (name, s) in enumerate(gapped):
+        path[row] = [not is_gap(c) for c in s]
+        ungapped.append((name, "".join(c for c in s if not is_gap(c))))
+    return ungapped, path
+
+
+def align_path_columns(path):
+    cols = None
+    for row, p in path.items():
+        if cols is None:
+            cols = len(p)
+        assert cols == len(p), "Alignment path is not flush"
+    return cols or 0
+
+
+def gapped_from_path(ungapped, path):
+    """Alignment(ungapped, path).gapped() (src/alignpath.cpp:254-280)"""
+    out = [("", "")] * len(ungapped)
+    for row, p in path.items():
+        name, s = ungapped[row]
+        k, g = 0, []
+        for b in p:
+            if b:
+                g.append(s[k])
+                k += 1
+            else:
+                g.append("-")
+        out[row] = (name, "".join(g))
+    return out
+
+
+class AlignSeqMap:
+    """src/alignpath.cpp:93-150"""
+
+    def __init__(self, alignments):
+        self.alignments = alignments
+        self.seq_len = {}
+        self.align_cols = []
+        self.align_col_row_to_pos = {}
+        self.row_pos_align_to_col = {}
+        for align in alignments:
+            if len(align) == 0:
+                self.align_cols.append(0)
+                continue
+            self.align_cols.append(align_path_columns(align))
+            for row in sorted(align):
+                n = sum(align[row])
+                if row not in self.seq_len:
+                    self.seq_len[row] = n
+                else:
+                    assert self.seq_len[row] == n, "Incompatible number of residues for row #%d of alignment" % row
+        for n_align, align in enumerate(alignments):
+            row_pos = {row: 0 for row in align}
+            for col in range(self.align_cols[n_align]):
+                all_gaps = True
+                for row in sorted(align):
+                    if align[row][col]:
+                        pos = row_pos[row]
+                        row_pos[row] += 1
+                        self.align_col_row_to_pos.setdefault(n_align, {}).setdefault(col, {})[row] = pos
+                        self.row_pos_align_to_col.setdefault(row, {}).setdefault(pos, {})[n_align] = col
+                        all_gaps = False
+                assert not all_gaps, "Column %d of alignment %d in AlignSeqMap is empty" % (col, n_align)
+
+    def linked_columns(self, n_align, col):
+        ac, queue = {}, {n_align: col}
+        while len(queue) > len(ac):
+            for na in sorted(queue):
+                if na not in ac:
+                    c = queue[na]
+                    ac[na] = c
+                    for row, pos in sorted(self.align_col_row_to_pos[na][c].items()):
+                        for lna, lcol in sorted(self.row_pos_align_to_col[row][pos].items()):
+                            if lna in ac:
+                                assert ac[lna] == lcol, "Inconsistent alignments"
+                            queue.setdefault(lna, lcol)
+        return ac
+
+
+def align_path_merge(alignments):
+    """src/alignpath.cpp:153-203"""
+    amap = AlignSeqMap(alignments)
+    a = {row: [] for row in amap.seq_len}
+    next_col = [0] * len(alignments)
+    while True:
+        all_done = none_ready = True
+        for n in range(len(alignments)):
+            if next_col[n] < amap.align_cols[n]:
+                all_done = False
+                linked = amap.linked_columns(n, next_col[n])
+                ready = all(next_col[na] == c for na, c in sorted(linked.items()))
+                if ready:
+                    none_ready = False
+                    if linked:
+                        for row in a:
+                            a[row].append(False)
+                        for na, c in sorted(linked.items()):
+                            for row in alignments[na]:
+                                if alignments[na][row][c]:
+                                    a[row][-1] = True
+                            next_col[na] += 1
+                    else:
+                        next_col[n] += 1
+                    break
+        if none_ready and not all_done:
+            raise AssertionError("align_path_merge fail, no alignments ready")
+        if all_done:
+            break
+    align_path_columns(a)
+    return a
+
+
+def testmerge_main(files):
+    """t/testmerge.cpp; returns the FASTA the reference writes (raises where the reference aborts)"""
+    from oracle.ref_mains import read_fasta
+    name_to_row, ungapped, paths = {}, [], []
+    for f in files:
+        gapped = read_fasta(f)
+        ug, p = alignment_from_gapped(gapped)
+        path = {}
+        for n, (name, _) in enumerate(gapped):
+            if name not in name_to_row:
+                name_to_row[name] = len(ungapped)
+                ungapped.append(ug[n])
+            path[name_to_row[name]] = p[n]
+        paths.append(path)
+    merged = align_path_merge(paths)
+    return "".join(">%s\n%s\n" % ns for ns in gapped_from_path(ungapped, merged))
+
+
+class AlignGraph:
+    """src/span.cpp, all-vs-all graph (buildDenseGraph).  The reference's sparse random graph draws its
+    edges with std::uniform_int_distribution, whose output is standard-library specific (the reference's
+    own Makefile skips testspan as platform dependent); it is not restated here."""
+
+    def __init__(self, seqs, model, time, sparse_params=None, fill=None, scores=None):
+        """seqs: [(name, seq)]; sparse_params: None = full envelopes, else dict(kmer_len, band_size,
+        kmer_threshold, max_size) for DiagonalEnvelope.init_sparse; fill(env) -> QuickAlignMatrix-like."""
+        self.seqs, self.model, self.time = seqs, model, time
+        self.scores = scores or QuickAlignScores(model, time)
+        self.edges = [ho._StdMaxHeap() for _ in seqs]
+        self.edge_path = [dict() for _ in seqs]
+        n_edge = 0
+        for src in range(len(seqs) - 1):
+            for dest in range(src + 1, len(seqs)):
+                env = DiagonalEnvelope(seqs[src][1], seqs[dest][1])
+                if sparse_params:
+                    env.init_sparse(KmerIndex(seqs[dest][1], model.alphabet, sparse_params["kmer_len"]),
+                                    sparse_params["band_size"], sparse_params["kmer_threshold"], 40, sparse_params["max_size"])
+                else:
+                    env.init_full()
+                mx = fill(env) if fill else QuickAlignMatrix(env, model, time, scores=self.scores)
+                r0, r1 = mx.align_path()
+                self.edge_path[src][dest] = {src: r0, dest: r1}
+                # (lp, tie-free payload): std::priority_queue<Edge> orders by lp only
+                self.edges[src].push((mx.end, (src, dest, n_edge)))
+                self.edges[dest].push((mx.end, (src, dest, n_edge)))
+                n_edge += 1
+
+    def min_span_tree(self):
+        """src/span.cpp:122-143"""
+        n = len(self.seqs)
+        set_idx = list(range(n))
+        sets = [{i} for i in range(n)]
+        n_sets = n
+        paths = []
+        self.mst_edges = []
+
+        def same(e):
+            return set_idx[e[0]] == set_idx[e[1]]
+        while n_sets > 1:
+            best, found = None, False
+            for src in sorted(sets[0]):
+                h = self.edges[src]
+                while h.a and same(h.a[0][1]):
+                    h.pop()
+                if h.a and (not found or best[0] < h.a[0][0]):
+                    best, found = h.a[0], True
+            assert found, "Found no valid edge"
+            r1, r2 = best[1][0], best[1][1]
+            self.mst_edges.append((r1, r2, best[0]))
+            paths.append(self.edge_path[r1][r2])
+            i1, i2 = sorted((set_idx[r1], set_idx[r2]))
+            for m in sets[i2]:
+                set_idx[m] = i1
+            sets[i1] |= sets[i2]
+            sets[i2] = set()
+            n_sets -= 1
+        return paths
+
+    def mst_gapped(self):
+        merged = align_path_merge(self.min_span_tree())
+        return gapped_from_path(self.seqs, merged)

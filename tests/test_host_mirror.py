@@ -68,3 +68,70 @@ def test_testquickalign_golden_file_through_the_gpu():
     # reference Makefile:278-279
     got = run(["testquickalign", G + "PF16593.pair.fa", G + "testamino.json", 1])
     assert got == open(G + "testquickalign.out.fa").read()
+
+
+MERGE_CASES = [(["testmerge1.xy.fa", "testmerge1.xz.fa"], "testmerge1.xyz.fa"),
+               (["testmerge1.xy.fa", "testmerge1.ayz.fa"], "testmerge1.xyaz.fa"),
+               (["testmerge1.xz.fa", "testmerge1.ayz.fa"], "testmerge1.xzay.fa"),
+               (["testmerge1.axyz.fa", "testmerge1.xz.fa"], "testmerge1.axyz.fa")]
+
+
+@pytest.mark.parametrize("files,want", MERGE_CASES)
+def test_testmerge_golden_files_host_only(files, want):
+    # reference Makefile:231-235
+    assert run(["testmerge"] + [G + f for f in files]) == open(G + want).read()
+
+
+def test_testmerge_inconsistent_alignments_abort():
+    # reference Makefile:236: expected to fail with empty stdout
+    out = subprocess.run([BIN + "testmerge", G + "testmerge1.xy.fa", G + "testmerge1.xz.fa", G + "testmerge1-fail.ayz.fa"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert out.returncode != 0 and out.stdout == b""
+
+
+@pytest.mark.gpu
+def test_testspan_all_pairs_equals_the_oracle_graph():
+    # AlignGraph (src/span.cpp) with the all-vs-all graph and full envelopes: 903 pairwise fills as one device
+    # batch, maximum spanning tree, merge -- against the oracle's restatement of the same
+    from oracle import historian_oracle as ho
+    from oracle import quickalign_oracle as q
+    from oracle.ref_mains import read_fasta
+    e = dict(os.environ, HX_DEBUG_SPAN="1")
+    out = subprocess.run([BIN + "testspan", "-dense", "-kmatchoff", G + "PF16593.fa", G + "testamino.json", "1"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, check=True, timeout=300)
+    got = out.stdout.decode()
+    model = ho.RateModel.from_file(G + "testamino.json")
+    model.sub_rate = [m.tolist() for m in model.sub_rate]
+    # the DP's inputs (substitution log-odds, gap scores) exactly as the mirror computed them: this model has no
+    # "rootprob", and the mirror's Householder solve of the equilibrium differs from numpy's in the last bits
+    sc = q.QuickAlignScores(model, 1.0)
+    for line in out.stderr.decode().splitlines():
+        f = line.split()
+        if f[0] == "scores":
+            for name, v in zip(("m2m", "m2i", "m2d", "i2i", "i2m", "i2d", "d2d", "d2m", "gap_open", "gap_extend", "no_gap"), f[1:]):
+                setattr(sc, name, float.fromhex(v))
+        elif f[0] == "submat":
+            sc.submat[int(f[1])][int(f[2])] = float.fromhex(f[3])
+    ag = q.AlignGraph(read_fasta(G + "PF16593.fa"), model, 1.0, scores=sc)
+    assert got == "".join(">%s\n%s\n" % ns for ns in ag.mst_gapped())
+    # ... and the same edges, with bit-identical scores, in the same order
+    mst = [(int(f[1]), int(f[2]), float.fromhex(f[3])) for f in (l.split() for l in out.stderr.decode().splitlines()) if f[0] == "mst"]
+    assert mst == ag.mst_edges and len(mst) == len(ag.seqs) - 1
+
+
+@pytest.mark.gpu
+def test_testspan_random_graph_runs_and_is_a_valid_alignment():
+    # the reference's own Makefile skips testspan ("inconsistent platform-dependent behavior": the random graph
+    # comes from std::uniform_int_distribution); here: the output is a flush alignment of the input sequences
+    from oracle.ref_mains import read_fasta
+    got = run(["testspan", G + "PF16593.fa", G + "testamino.json", 1])
+    rows = {}
+    name = None
+    for line in got.splitlines():
+        if line.startswith(">"):
+            name = line[1:]
+        else:
+            rows[name] = rows.get(name, "") + line
+    seqs = dict(read_fasta(G + "PF16593.fa"))
+    assert set(rows) == set(seqs) and len({len(r) for r in rows.values()}) == 1
+    assert all(rows[n].replace("-", "") == seqs[n] for n in seqs)

@@ -68,3 +68,20 @@ def test_testquickalign_fixture():
     from oracle import quickalign_oracle as q
     got = q.testquickalign_main(G + "PF16593.pair.fa", G + "testamino.json", 1)
     assert got == open(G + "testquickalign.out.fa").read()
+
+
+@pytest.mark.parametrize("files,want", [(["testmerge1.xy.fa", "testmerge1.xz.fa"], "testmerge1.xyz.fa"),
+                                        (["testmerge1.xy.fa", "testmerge1.ayz.fa"], "testmerge1.xyaz.fa"),
+                                        (["testmerge1.xz.fa", "testmerge1.ayz.fa"], "testmerge1.xzay.fa"),
+                                        (["testmerge1.axyz.fa", "testmerge1.xz.fa"], "testmerge1.axyz.fa")])
+def test_testmerge_fixtures(files, want):
+    # reference Makefile:231-235
+    from oracle import quickalign_oracle as q
+    assert q.testmerge_main([G + f for f in files]) == open(G + want).read()
+
+
+def test_testmerge_inconsistent_alignments_fail():
+    # reference Makefile:236
+    from oracle import quickalign_oracle as q
+    with pytest.raises(AssertionError):
+        q.testmerge_main([G + f for f in ("testmerge1.xy.fa", "testmerge1.xz.fa", "testmerge1-fail.ayz.fa")])
