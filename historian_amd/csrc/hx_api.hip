@@ -712,7 +712,7 @@ int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_bat
   b->n_jobs = n_jobs;
   b->jobs.resize(n_jobs);
   b->layouts.resize(n_jobs);
-  struct Off { size_t xtok, ytok, submat, env, best, bestj; bool has_env; };
+  struct Off { size_t xtok, ytok, submat, env, best, bestj, cols; bool has_env; };
   std::vector<Off> offs(n_jobs);
   std::vector<int64_t> cell_off(n_jobs);
   Arena ar;
@@ -761,9 +761,11 @@ int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_bat
     b->total_cells += (int64_t)q.x_len * q.y_len;
     if (q.x_len > b->max_rows) b->max_rows = q.x_len;
     if (q.y_len > b->max_cols) b->max_cols = q.y_len;
-    if (q.y_len > 7000) { rc = fail(HX_ERR_RANGE, "job %d: y longer than 7000 residues (per-column LDS tables)", k); break; }
   }
   if (rc != HX_OK) { delete b; return rc; }
+  // per-column constants of the pairs in global memory when the longest y does not fit the kernel's LDS tables
+  for (int k = 0; k < n_jobs; ++k)
+    offs[k].cols = b->max_cols > 7000 ? ar.reserve((sizeof(double) * 2 + sizeof(int32_t)) * (size_t)jobs[k].y_len + 16) : 0;
   // scores and end coordinates of all pairs, contiguous: one copy back per batch
   b->res_off = ar.reserve(sizeof(double) * n_jobs);
   b->xy_off = ar.reserve(sizeof(int32_t) * 2 * n_jobs);
@@ -782,6 +784,7 @@ int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_bat
     J.ytok = reinterpret_cast<int32_t*>(base + o.ytok);
     J.submat = reinterpret_cast<double*>(base + o.submat);
     J.in_env = o.has_env ? reinterpret_cast<uint8_t*>(base + o.env) : nullptr;
+    J.col_scratch = b->max_cols > 7000 ? reinterpret_cast<double*>(base + o.cols) : nullptr;
     J.best_score = reinterpret_cast<double*>(base + o.best);
     J.best_j = reinterpret_cast<int32_t*>(base + o.bestj);
     J.result = reinterpret_cast<double*>(base + b->res_off) + k;

@@ -107,6 +107,7 @@ struct DevQuick {
   const uint8_t* in_env;      // [xlen+ylen+1] indexed (i - j) + ylen, or nullptr = full envelope
   double* cells;              // [3][plane]: mat, ins, del in the strip-skewed layout, row = i-1, column = j-1
   int64_t plane, strip_stride;
+  double* col_scratch;        // [2*ylen doubles + ylen ints] per-column constants when they do not fit LDS, else nullptr
   double* best_score;         // [xlen] per-row best mat + endGapScore ...
   int32_t* best_j;            // ... and the first column that attains it
   double* result;             // -> Viterbi score

@@ -51,7 +51,9 @@ __device__ __forceinline__ double dmax(double a, double b) { return vmax(a, b); 
 #define HX_QA_LAG 16
 #define HX_QA_MAX_ALPH 31
 
-template <int W, bool FULL>
+// COLG: the per-column constants do not fit LDS (y longer than HX_QA_LDS_COLS): they live in a per-pair
+// global scratch instead (L1/L2 resident; a slower path for very long sequences)
+template <int W, bool FULL, bool COLG>
 __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restrict__ jobs, const int max_cols) {
   __shared__ volatile int prog[W];
   __shared__ double sub[(HX_QA_MAX_ALPH + 1) * (HX_QA_MAX_ALPH + 1)];   // padded with a zero row / column for invalid tokens
@@ -61,8 +63,8 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
   const DevQuick& J = jobs[blockIdx.x];
   const int A1 = J.alph + 1;
   typedef double d2v __attribute__((ext_vector_type(2)));
-  d2v* colgap = reinterpret_cast<d2v*>(col_lds);
-  int* coltok = reinterpret_cast<int*>(col_lds + 2 * (size_t)max_cols);
+  d2v* colgap = COLG ? reinterpret_cast<d2v*>(J.col_scratch) : reinterpret_cast<d2v*>(col_lds);
+  int* coltok = COLG ? reinterpret_cast<int*>(J.col_scratch + 2 * (size_t)J.ylen) : reinterpret_cast<int*>(col_lds + 2 * (size_t)max_cols);
   for (int k = threadIdx.x; k < A1 * A1; k += W * 64) {
     const int a = k / A1, b = k - a * A1;
     sub[k] = (a < J.alph && b < J.alph) ? J.submat[a * J.alph + b] : 0.0;
@@ -138,8 +140,15 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
       const int c = t - lane;                     // column c <-> y position j = c + 1
       const int j = c + 1;
       const int cl = c < 0 ? 0 : (c >= Cc ? Cc - 1 : c);
-      const int yt = coltok[cl];
-      const d2v gy = colgap[cl];
+      int yt;
+      d2v gy;
+      if (COLG) {
+        yt = as_global((const int*)coltok)[cl];
+        gy = as_global((const d2v*)colgap)[cl];
+      } else {
+        yt = ((const HX_LDS int*)coltok)[cl];
+        gy = ((const HX_LDS d2v*)colgap)[cl];
+      }
       bool act = rvalid && c >= 0 && c < Cc;
       if (!FULL && in_env) act = act && in_env[(c < 0 || c >= Cc || !rvalid) ? 0 : (i - j + Cc)];   // (a job of a mixed batch may have the full envelope)
       Q3 nw = q3_neg_inf();                       // outside the envelope a cell reads as -inf (reference const getCell -> dummy)
@@ -208,11 +217,17 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
   }
 }
 
+#define HX_QA_LDS_COLS 7000
 template <int W>
 void launch_w(const DevQuick* d_jobs, int n_jobs, int max_cols, bool full, hipStream_t st) {
+  if (max_cols > HX_QA_LDS_COLS) {
+    if (full) hipLaunchKernelGGL((k_quickalign<W, true, true>), dim3(n_jobs), dim3(W * 64), 16, st, d_jobs, max_cols);
+    else hipLaunchKernelGGL((k_quickalign<W, false, true>), dim3(n_jobs), dim3(W * 64), 16, st, d_jobs, max_cols);
+    return;
+  }
   const size_t lds = (size_t)max_cols * (16 + 4) + 16;
-  if (full) hipLaunchKernelGGL((k_quickalign<W, true>), dim3(n_jobs), dim3(W * 64), lds, st, d_jobs, max_cols);
-  else hipLaunchKernelGGL((k_quickalign<W, false>), dim3(n_jobs), dim3(W * 64), lds, st, d_jobs, max_cols);
+  if (full) hipLaunchKernelGGL((k_quickalign<W, true, false>), dim3(n_jobs), dim3(W * 64), lds, st, d_jobs, max_cols);
+  else hipLaunchKernelGGL((k_quickalign<W, false, false>), dim3(n_jobs), dim3(W * 64), lds, st, d_jobs, max_cols);
 }
 
 }  // namespace

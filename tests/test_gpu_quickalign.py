@@ -110,3 +110,14 @@ def test_long_pair_two_strip_rounds(amino):
     rng = random.Random(13)
     A = model.alphabet
     run_and_check([make_pair(rng, A, 1100, 900) + (None,)], A, sc)
+
+
+def test_y_longer_than_the_lds_column_tables(amino):
+    # > 7000 columns: the per-column constants move from LDS to a global scratch
+    model, sc = amino
+    rng = random.Random(14)
+    A = model.alphabet
+    x, y = make_pair(rng, A, 150, 7300)
+    env = q.DiagonalEnvelope(x, y)
+    env.init_sparse(q.KmerIndex(y, A, 3), band_size=16, kmer_threshold=2)
+    run_and_check([(x, y, None), (x[:90], y, env.diagonals)], A, sc)
