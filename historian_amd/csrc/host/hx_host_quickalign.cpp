@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <set>
 extern "C" {
 #include "../../../include/historian_hip.h"
@@ -67,50 +68,54 @@ void DiagonalEnvelope::initFull() {
   full = true;
 }
 
+// Sparse envelope (behaviour of reference src/diagenv.cpp:113-199).  Diagonals are ranked by how many k-mers
+// of x match a k-mer of y on them; the best-supported ones seed bands of bandSize diagonals.  With a
+// non-negative kmerThreshold every diagonal with at least that many matches seeds a band; with a negative
+// one, whole tiers of equally supported diagonals are added, best tier first, while the stored diagonals
+// (bands plus one guard diagonal each side) stay below maxSize bytes.  Diagonal 0 is always present.
+// Short sequences (or a full matrix that fits maxSize) get the full envelope instead.
 void DiagonalEnvelope::initSparse(const KmerIndex& yKmerIndex, unsigned int bandSize, int kmerThreshold, size_t cellSize,
                                   size_t maxSize) {
-  const unsigned int kmerLen = yKmerIndex.kmerLen;
-  if (kmerThreshold >= 0) {
-    const SeqIdx minLenForSparse = MIN_KMERS_FOR_SPARSE_ENVELOPE * (kmerLen + kmerThreshold);
-    if (px->length() < minLenForSparse || py->length() < minLenForSparse) {
-      initFull();
-      return;
-    }
-  } else if ((size_t)xLen * yLen * cellSize < maxSize) {   // kmerThreshold < 0: use the available memory
+  const unsigned int k = yKmerIndex.kmerLen;
+  const bool byMemory = kmerThreshold < 0;
+  if (byMemory ? (size_t)xLen * yLen * cellSize < maxSize
+               : (px->length() < MIN_KMERS_FOR_SPARSE_ENVELOPE * (k + kmerThreshold) ||
+                  py->length() < MIN_KMERS_FOR_SPARSE_ENVELOPE * (k + kmerThreshold))) {
     initFull();
     return;
   }
+  // k-mer matches per diagonal
   const UnvalidatedTokSeq xTok = unvalidatedTokens(*px, yKmerIndex.alphabet);
   const AlphTok alphabetSize = (AlphTok)yKmerIndex.alphabet.size();
-  map<int, unsigned int> diagKmerCount;
-  for (SeqIdx i = 0; i + kmerLen <= xLen; ++i)
-    if (kmerValid(kmerLen, xTok.begin() + i)) {
-      const auto it = yKmerIndex.kmerLocations.find(makeKmer(kmerLen, xTok.begin() + i, alphabetSize));
-      if (it != yKmerIndex.kmerLocations.end())
-        for (auto j : it->second) ++diagKmerCount[get_diag(i, j)];
-    }
-  map<unsigned int, std::set<unsigned int> > countDistrib;
-  for (const auto& e : diagKmerCount) countDistrib[e.second].insert(e.first);
-
-  std::set<int> diags, storageDiags;
-  diags.insert(0);   // always add the zeroth diagonal to ensure at least one path exists
-  storageDiags.insert(0);
-  const unsigned int halfBandSize = bandSize / 2;
-  const size_t diagSize = std::min(xLen, yLen) * cellSize;
-  for (auto it = countDistrib.crbegin(); it != countDistrib.crend(); ++it) {
-    if (kmerThreshold >= 0 && it->first < (unsigned int)kmerThreshold) break;
-    std::set<int> moreDiags = diags, moreStorageDiags = storageDiags;
-    for (auto seedDiag : it->second) {
-      const int dMin = std::max(minDiagonal(), (int)seedDiag - (int)halfBandSize);
-      const int dMax = std::min(maxDiagonal(), (int)seedDiag + (int)halfBandSize);
-      for (int d = dMin; d <= dMax; ++d) moreDiags.insert(d);
-      for (int d = dMin - 1; d <= dMax + 1; ++d) moreStorageDiags.insert(d);
-    }
-    if (kmerThreshold < 0 && moreStorageDiags.size() * diagSize >= maxSize) break;
-    std::swap(diags, moreDiags);
-    std::swap(storageDiags, moreStorageDiags);
+  map<int, unsigned int> matchesOn;
+  for (SeqIdx i = 0; i + k <= xLen; ++i) {
+    if (!kmerValid(k, xTok.begin() + i)) continue;
+    const auto hit = yKmerIndex.kmerLocations.find(makeKmer(k, xTok.begin() + i, alphabetSize));
+    if (hit == yKmerIndex.kmerLocations.end()) continue;
+    for (SeqIdx j : hit->second) ++matchesOn[get_diag(i, j)];
   }
-  diagonals = vguard<int>(diags.begin(), diags.end());
+  // tiers of equally supported diagonals, best first
+  map<unsigned int, vguard<int>, std::greater<unsigned int> > tiers;
+  for (const auto& dm : matchesOn) tiers[dm.second].push_back(dm.first);
+
+  std::set<int> visited, stored;
+  visited.insert(0);
+  stored.insert(0);
+  const int half = (int)(bandSize / 2);
+  const size_t bytesPerDiagonal = std::min(xLen, yLen) * cellSize;
+  for (const auto& tier : tiers) {
+    if (!byMemory && tier.first < (unsigned int)kmerThreshold) break;
+    std::set<int> visitedWith = visited, storedWith = stored;
+    for (int seed : tier.second) {
+      const int lo = std::max(minDiagonal(), seed - half), hi = std::min(maxDiagonal(), seed + half);
+      for (int d = lo; d <= hi; ++d) visitedWith.insert(d);
+      for (int d = lo - 1; d <= hi + 1; ++d) storedWith.insert(d);
+    }
+    if (byMemory && storedWith.size() * bytesPerDiagonal >= maxSize) break;
+    visited.swap(visitedWith);
+    stored.swap(storedWith);
+  }
+  diagonals.assign(visited.begin(), visited.end());
   full = false;
 }
 
@@ -298,63 +303,65 @@ void QuickAlignMatrix::updateMax(double& currentMax, State& currentMaxIdx, doubl
   }
 }
 
-// src/quickalign.cpp:147-207
+// Viterbi traceback (behaviour of reference src/quickalign.cpp:147-207).  Walks back from (xEnd, yEnd, Match),
+// at every step re-deriving the cell's score from its possible sources and moving to the first source (in the
+// order Match, Insert, Delete, Start) that attains the maximum; the local alignment is then padded with the
+// unaligned ends: y's prefix, x's prefix, the aligned core, x's suffix, y's suffix.
 AlignPath QuickAlignMatrix::alignPath() const {
   Require(resultIsFinite(), "Can't do Viterbi traceback if final score is -infinity");
   SeqIdx i = xEnd, j = yEnd;
-  State state = Match;
   Assert(i > 0 && j > 0, "Traceback error at (%u,%u,End)", i, j);
-  AlignPath path;
-  path[0] = vguard<bool>(xLen - xEnd, true);
-  path[1] = vguard<bool>(xLen - xEnd, false);
-  path[0].insert(path[0].end(), yLen - yEnd, false);
-  path[1].insert(path[1].end(), yLen - yEnd, true);
+  vguard<bool> xCore, yCore;   // the aligned core, last column first
+  State state = Match;
   while (state != Start) {
-    LogProb srcSc = NEG_INF;
-    LogProb emitSc = 0;
-    switch (state) {
-      case Match:
-        emitSc = matchEmitScore(i, j);
-        --i;
-        --j;
-        path[0].insert(path[0].begin(), true);
-        path[1].insert(path[1].begin(), true);
-        updateMax(srcSc, state, mat(i, j) + m2m + emitSc, Match);
-        updateMax(srcSc, state, ins(i, j) + i2m + emitSc, Insert);
-        updateMax(srcSc, state, del(i, j) + d2m + emitSc, Delete);
-        updateMax(srcSc, state, start + startGapScore(i + 1, j + 1) + emitSc, Start);
-        Assert(srcSc == mat(i + 1, j + 1), "Traceback error at (%u,%u,Match)", i + 1, j + 1);
-        break;
-      case Insert:
-        --j;
-        path[0].insert(path[0].begin(), false);
-        path[1].insert(path[1].begin(), true);
-        updateMax(srcSc, state, mat(i, j) + m2i, Match);
-        updateMax(srcSc, state, ins(i, j) + i2i, Insert);
-        Assert(srcSc == ins(i, j + 1), "Traceback error at (%u,%u,Insert)", i, j + 1);
-        break;
-      case Delete:
-        --i;
-        path[0].insert(path[0].begin(), true);
-        path[1].insert(path[1].begin(), false);
-        updateMax(srcSc, state, mat(i, j) + m2d, Match);
-        updateMax(srcSc, state, ins(i, j) + i2d, Insert);
-        updateMax(srcSc, state, del(i, j) + d2d, Delete);
-        Assert(srcSc == del(i + 1, j), "Traceback error at (%u,%u,Delete)", i + 1, j);
-        break;
-      default:
-        Abort("Traceback error");
-        break;
-    }
+    LogProb bestScore = NEG_INF;
+    State from = state;
+    const auto consider = [&](LogProb score, State source) { updateMax(bestScore, from, score, source); };
+    if (state == Match) {
+      const LogProb emit = matchEmitScore(i, j);
+      --i;
+      --j;
+      xCore.push_back(true);
+      yCore.push_back(true);
+      consider(mat(i, j) + m2m + emit, Match);
+      consider(ins(i, j) + i2m + emit, Insert);
+      consider(del(i, j) + d2m + emit, Delete);
+      consider(start + startGapScore(i + 1, j + 1) + emit, Start);
+      Assert(bestScore == mat(i + 1, j + 1), "Traceback error at (%u,%u,Match)", i + 1, j + 1);
+    } else if (state == Insert) {
+      --j;
+      xCore.push_back(false);
+      yCore.push_back(true);
+      consider(mat(i, j) + m2i, Match);
+      consider(ins(i, j) + i2i, Insert);
+      Assert(bestScore == ins(i, j + 1), "Traceback error at (%u,%u,Insert)", i, j + 1);
+    } else if (state == Delete) {
+      --i;
+      xCore.push_back(true);
+      yCore.push_back(false);
+      consider(mat(i, j) + m2d, Match);
+      consider(ins(i, j) + i2d, Insert);
+      consider(del(i, j) + d2d, Delete);
+      Assert(bestScore == del(i + 1, j), "Traceback error at (%u,%u,Delete)", i + 1, j);
+    } else
+      Abort("Traceback error");
+    state = from;
   }
-  path[0].insert(path[0].begin(), i, true);
-  path[1].insert(path[1].begin(), i, false);
-  path[0].insert(path[0].begin(), j, false);
-  path[1].insert(path[1].begin(), j, true);
-  Assert(alignPathResiduesInRow(path[0]) == xLen, "Traceback error: x row has %u steps, expected %u",
-         alignPathResiduesInRow(path[0]), xLen);
-  Assert(alignPathResiduesInRow(path[1]) == yLen, "Traceback error: y row has %u steps, expected %u",
-         alignPathResiduesInRow(path[1]), yLen);
+  AlignPath path;
+  AlignRowPath& xRow = path[0];
+  AlignRowPath& yRow = path[1];
+  const auto pad = [&](size_t columns, bool inX) {
+    xRow.insert(xRow.end(), columns, inX);
+    yRow.insert(yRow.end(), columns, !inX);
+  };
+  pad(j, false);
+  pad(i, true);
+  xRow.insert(xRow.end(), xCore.rbegin(), xCore.rend());
+  yRow.insert(yRow.end(), yCore.rbegin(), yCore.rend());
+  pad(xLen - xEnd, true);
+  pad(yLen - yEnd, false);
+  Assert(alignPathResiduesInRow(xRow) == xLen, "Traceback error: x row has %u steps, expected %u", alignPathResiduesInRow(xRow), xLen);
+  Assert(alignPathResiduesInRow(yRow) == yLen, "Traceback error: y row has %u steps, expected %u", alignPathResiduesInRow(yRow), yLen);
   return path;
 }
 
@@ -366,24 +373,11 @@ AlignPath QuickAlignMatrix::alignPath(AlignRowIndex row1, AlignRowIndex row2) co
   return newPath;
 }
 
-// Alignment(seqs, path).gapped() (src/alignpath.cpp:254-280)
 vguard<FastSeq> QuickAlignMatrix::gappedSeq() const {
-  const AlignPath path = alignPath();
-  vguard<FastSeq> gs(2);
-  const FastSeq* ug[2] = {px, py};
-  for (int row = 0; row < 2; ++row) {
-    FastSeq& g = gs[row];
-    g.name = ug[row]->name;
-    g.comment = ug[row]->comment;
-    SeqIdx pos = 0;
-    for (bool b : path.at(row))
-      if (b) {
-        Assert(ug[row]->seq.size() > pos, "Sequence position %u out of bounds for sequence %s", pos, ug[row]->name.c_str());
-        g.seq.push_back(ug[row]->seq[pos++]);
-      } else
-        g.seq.push_back(Alignment::gapChar);
-  }
-  return gs;
+  vguard<FastSeq> pair;
+  pair.push_back(*px);
+  pair.push_back(*py);
+  return Alignment(pair, alignPath()).gapped();
 }
 
 }  // namespace historian

@@ -11,170 +11,151 @@
 
 namespace historian {
 
-// ---- src/alignpath.cpp: Alignment, AlignSeqMap, alignPathMerge ---------------------------------
-static AlignColIndex gappedSeqColumns(const vguard<FastSeq>& gapped) {
-  AlignColIndex cols = 0;
-  for (size_t row = 0; row < gapped.size(); ++row)
-    if (row == 0)
-      cols = gapped[row].length();
-    else
-      Assert(cols == gapped[row].length(), "Alignment is not flush: sequence %s has %u chars, but sequence %s has %u chars",
-             gapped[0].name.c_str(), (unsigned)cols, gapped[row].name.c_str(), gapped[row].length());
-  return cols;
-}
-
+// ---- Alignment: gapped rows <-> ungapped sequences + path (behaviour of reference src/alignpath.cpp:22-31,
+// 232-280) -----------------------------------------------------------------------------------------
 Alignment::Alignment(const vguard<FastSeq>& gapped) : ungapped(gapped.size()) {
-  (void)gappedSeqColumns(gapped);   // has the effect of checking that the alignment is flush
-  for (AlignRowIndex row = 0; row < gapped.size(); ++row) {
-    ungapped[row].name = gapped[row].name;
-    ungapped[row].comment = gapped[row].comment;
-    AlignRowPath rowPath(gapped[row].length(), false);
-    for (AlignColIndex col = 0; col < rowPath.size(); ++col)
-      if (!isGap(gapped[row].seq[col])) {
-        rowPath[col] = true;
-        ungapped[row].seq.push_back(gapped[row].seq[col]);
-      }
-    path[row] = rowPath;
+  for (size_t r = 1; r < gapped.size(); ++r)
+    Assert(gapped[0].length() == gapped[r].length(), "Alignment is not flush: sequence %s has %u chars, but sequence %s has %u chars",
+           gapped[0].name.c_str(), gapped[0].length(), gapped[r].name.c_str(), gapped[r].length());
+  for (AlignRowIndex r = 0; r < gapped.size(); ++r) {
+    FastSeq& plain = ungapped[r];
+    plain.name = gapped[r].name;
+    plain.comment = gapped[r].comment;
+    AlignRowPath& occupied = path[r];
+    occupied.reserve(gapped[r].seq.size());
+    for (char c : gapped[r].seq) {
+      occupied.push_back(!isGap(c));
+      if (!isGap(c)) plain.seq.push_back(c);
+    }
   }
 }
 
 Alignment::Alignment(const vguard<FastSeq>& ungapped, const AlignPath& path) : ungapped(ungapped), path(path) {}
 
 vguard<FastSeq> Alignment::gapped() const {
-  vguard<FastSeq> gs(ungapped.size());
-  for (auto& row_path : path) {
-    FastSeq& g = gs[row_path.first];
-    const FastSeq& ug = ungapped[row_path.first];
-    const AlignColIndex cols = row_path.second.size();
-    g.name = ug.name;
-    g.comment = ug.comment;
-    g.seq.reserve(cols);
-    SeqIdx pos = 0;
-    for (AlignColIndex col = 0; col < cols; ++col)
-      if (row_path.second[col]) {
-        Assert(ug.seq.size() > pos, "Sequence position %u out of bounds for sequence %s", (unsigned)col, ug.name.c_str());
-        g.seq.push_back(ug.seq[pos]);
-        ++pos;
-      } else
-        g.seq.push_back(gapChar);
+  vguard<FastSeq> rows(ungapped.size());
+  for (const auto& rp : path) {
+    const FastSeq& plain = ungapped[rp.first];
+    FastSeq& out = rows[rp.first];
+    out.name = plain.name;
+    out.comment = plain.comment;
+    out.seq.reserve(rp.second.size());
+    size_t used = 0;
+    for (bool occupied : rp.second) {
+      if (occupied) Assert(used < plain.seq.size(), "Sequence position %u out of bounds for sequence %s", (unsigned)used, plain.name.c_str());
+      out.seq.push_back(occupied ? plain.seq[used++] : gapChar);
+    }
   }
-  return gs;
+  return rows;
 }
 
+// ---- merging alignments that share rows (behaviour of reference src/alignpath.cpp:93-203) --------
+// Every input alignment is a list of columns; two columns of different alignments are "linked" when
+// they hold the same residue of the same row, and linked columns must come out as one merged column.
+// The merged alignment is produced by repeatedly taking, for the lowest-numbered input alignment whose
+// next column can go out (every column linked to it is also the next one of its alignment), that whole
+// linked group.  Inconsistent inputs (a cycle, or a residue aligned to two columns of one alignment)
+// abort, as in the reference.
 namespace {
-// map used by alignPathMerge
-struct AlignSeqMap {
-  typedef size_t AlignNum;
-  const vguard<AlignPath>& alignments;
-  map<AlignRowIndex, SeqIdx> seqLen;
-  vguard<AlignColIndex> alignCols;
-  map<AlignNum, map<AlignColIndex, map<AlignRowIndex, SeqIdx> > > alignColRowToPos;
-  map<AlignRowIndex, map<SeqIdx, map<AlignNum, AlignColIndex> > > rowPosAlignToCol;
-  AlignSeqMap(const vguard<AlignPath>& alignments);
-  map<AlignNum, AlignColIndex> linkedColumns(AlignNum nAlign, AlignColIndex col) const;
-};
+struct ColumnRef { size_t align; AlignColIndex col; };
 
-AlignSeqMap::AlignSeqMap(const vguard<AlignPath>& alignments) : alignments(alignments) {
-  // get row indices and sequence lengths; confirm row & sequence lengths match
-  for (auto& align : alignments) {
-    if (align.size() == 0)
-      alignCols.push_back(0);
-    else {
-      alignCols.push_back(alignPathColumns(align));
-      for (auto& row_path : align) {
-        const AlignRowIndex row = row_path.first;
-        const SeqIdx len = alignPathResiduesInRow(row_path.second);
-        if (seqLen.find(row) == seqLen.end())
-          seqLen[row] = len;
+class MergeIndex {
+public:
+  explicit MergeIndex(const vguard<AlignPath>& in) : in(in), nCols(in.size(), 0), residues(in.size()) {
+    for (size_t a = 0; a < in.size(); ++a) {
+      if (in[a].empty()) continue;
+      nCols[a] = alignPathColumns(in[a]);
+      for (const auto& rp : in[a]) {
+        const SeqIdx len = alignPathResiduesInRow(rp.second);
+        auto known = rowLength.find(rp.first);
+        if (known == rowLength.end())
+          rowLength[rp.first] = len;
         else
-          Assert(seqLen[row] == len, "Incompatible number of residues for row #%d of alignment (%d != %d)", (int)row,
-                 (int)seqLen[row], (int)len);
+          Assert(known->second == len, "Incompatible number of residues for row #%d of alignment (%d != %d)", (int)rp.first,
+                 (int)known->second, (int)len);
       }
     }
-  }
-  // build bidirectional map from (align#,column#) <==> (row#,residue#)
-  for (size_t nAlign = 0; nAlign < alignments.size(); ++nAlign) {
-    auto& align = alignments[nAlign];
-    map<AlignRowIndex, SeqIdx> rowPos;
-    for (auto& row_path : align) rowPos[row_path.first] = 0;
-    for (AlignColIndex col = 0; col < alignCols[nAlign]; ++col) {
-      bool allGaps = true;
-      for (auto& row_path : align)
-        if (row_path.second[col]) {
-          const SeqIdx pos = rowPos[row_path.first]++;
-          alignColRowToPos[nAlign][col][row_path.first] = pos;
-          rowPosAlignToCol[row_path.first][pos][nAlign] = col;
-          allGaps = false;
-        }
-      Assert(!allGaps, "Column %d of alignment %d in AlignSeqMap is empty", (int)col, (int)nAlign);
-    }
-  }
-}
-
-map<AlignSeqMap::AlignNum, AlignColIndex> AlignSeqMap::linkedColumns(AlignNum nAlign, AlignColIndex col) const {
-  map<AlignNum, AlignColIndex> ac, acQueue;
-  acQueue[nAlign] = col;
-  while (acQueue.size() > ac.size()) {
-    for (auto& nAlign_col : acQueue)
-      if (ac.find(nAlign_col.first) == ac.end()) {
-        ac.insert(nAlign_col);
-        for (auto& row_pos : alignColRowToPos.at(nAlign_col.first).at(nAlign_col.second))
-          for (auto& linked_nAlign_col : rowPosAlignToCol.at(row_pos.first).at(row_pos.second)) {
-            if (ac.find(linked_nAlign_col.first) != ac.end())
-              Assert(ac[linked_nAlign_col.first] == linked_nAlign_col.second,
-                     "Inconsistent alignments\nColumn %u of alignment %u points to position %u of sequence %u, which points "
-                     "back to column %u of alignment %u",
-                     (unsigned)col, (unsigned)nAlign, (unsigned)row_pos.second, (unsigned)row_pos.first,
-                     (unsigned)linked_nAlign_col.second, (unsigned)linked_nAlign_col.first);
-            acQueue.insert(linked_nAlign_col);
+    for (const auto& rl : rowLength) where[rl.first].assign(rl.second, vguard<ColumnRef>());
+    for (size_t a = 0; a < in.size(); ++a) {
+      residues[a].assign(nCols[a], vguard<std::pair<AlignRowIndex, SeqIdx> >());
+      map<AlignRowIndex, SeqIdx> consumed;
+      for (AlignColIndex c = 0; c < nCols[a]; ++c) {
+        for (const auto& rp : in[a])
+          if (rp.second[c]) {
+            const SeqIdx pos = consumed[rp.first]++;
+            residues[a][c].push_back(std::make_pair(rp.first, pos));
+            where[rp.first][pos].push_back(ColumnRef{a, c});
           }
+        Assert(!residues[a][c].empty(), "Column %d of alignment %d in AlignSeqMap is empty", (int)c, (int)a);
       }
+    }
   }
-  return ac;
-}
+
+  // the columns (one per alignment at most) transitively linked to column `col` of alignment `a`
+  map<size_t, AlignColIndex> group(size_t a, AlignColIndex col) const {
+    map<size_t, AlignColIndex> g;
+    vguard<ColumnRef> todo(1, ColumnRef{a, col});
+    g[a] = col;
+    while (!todo.empty()) {
+      const ColumnRef cur = todo.back();
+      todo.pop_back();
+      for (const auto& row_pos : residues[cur.align][cur.col])
+        for (const ColumnRef& other : where.at(row_pos.first)[row_pos.second]) {
+          auto seen = g.find(other.align);
+          if (seen == g.end()) {
+            g[other.align] = other.col;
+            todo.push_back(other);
+          } else
+            Assert(seen->second == other.col,
+                   "Inconsistent alignments\nColumn %u of alignment %u points to position %u of sequence %u, which points "
+                   "back to column %u of alignment %u",
+                   (unsigned)col, (unsigned)a, (unsigned)row_pos.second, (unsigned)row_pos.first, (unsigned)other.col,
+                   (unsigned)other.align);
+        }
+    }
+    return g;
+  }
+
+  const vguard<AlignPath>& in;
+  vguard<AlignColIndex> nCols;
+  map<AlignRowIndex, SeqIdx> rowLength;
+
+private:
+  vguard<vguard<vguard<std::pair<AlignRowIndex, SeqIdx> > > > residues;   // [alignment][column] -> (row, residue index)
+  map<AlignRowIndex, vguard<vguard<ColumnRef> > > where;                  // row -> residue index -> columns holding it
+};
 }  // namespace
 
 AlignPath alignPathMerge(const vguard<AlignPath>& alignments) {
-  const AlignSeqMap alignSeqMap(alignments);
-  AlignPath a;
-  for (auto& row_seqlen : alignSeqMap.seqLen) a[row_seqlen.first].clear();
-  vguard<AlignColIndex> nextCol(alignments.size(), 0);
-  bool allDone, noneReady;
-  do {
-    allDone = noneReady = true;
-    map<AlignSeqMap::AlignNum, AlignColIndex> linkedCols;
-    for (AlignSeqMap::AlignNum n = 0; n < alignments.size(); ++n)
-      if (nextCol[n] < alignSeqMap.alignCols[n]) {
-        allDone = false;
-        bool ready = true;
-        linkedCols = alignSeqMap.linkedColumns(n, nextCol[n]);
-        for (const auto& nAlign_col : linkedCols)
-          if (nextCol[nAlign_col.first] != nAlign_col.second) {
-            ready = false;
-            break;
-          }
-        if (ready) {
-          noneReady = false;
-          if (linkedCols.size()) {
-            for (auto& idx_path : a) idx_path.second.push_back(false);
-            for (const auto& nAlign_col : linkedCols) {
-              for (const auto& row_path : alignments.at(nAlign_col.first))
-                if (alignments.at(nAlign_col.first).at(row_path.first).at(nAlign_col.second)) a[row_path.first].back() = true;
-              ++nextCol[nAlign_col.first];
-            }
-          } else
-            ++nextCol[n];   // empty column
-          break;
-        }
+  const MergeIndex index(alignments);
+  AlignPath merged;
+  for (const auto& rl : index.rowLength) merged[rl.first];
+  vguard<AlignColIndex> next(alignments.size(), 0);
+  for (;;) {
+    bool pending = false, progressed = false;
+    for (size_t a = 0; a < alignments.size() && !progressed; ++a) {
+      if (next[a] >= index.nCols[a]) continue;
+      pending = true;
+      const map<size_t, AlignColIndex> g = index.group(a, next[a]);
+      bool ready = true;
+      for (const auto& ac : g) ready = ready && next[ac.first] == ac.second;
+      if (!ready) continue;
+      for (auto& rp : merged) rp.second.push_back(false);
+      for (const auto& ac : g) {
+        for (const auto& rp : alignments[ac.first])
+          if (rp.second[ac.second]) merged[rp.first].back() = true;
+        ++next[ac.first];
       }
-    if (noneReady && !allDone) {
-      for (AlignSeqMap::AlignNum n = 0; n < alignments.size(); ++n)
-        std::cerr << "Alignment #" << n << ": next column " << nextCol[n] << std::endl;
+      progressed = true;
+    }
+    if (!pending) break;
+    if (!progressed) {
+      for (size_t a = 0; a < alignments.size(); ++a) std::cerr << "Alignment #" << a << ": next column " << next[a] << std::endl;
       Abort("%s fail, no alignments ready", __func__);
     }
-  } while (!allDone);
-  (void)alignPathColumns(a);   // this will also test if alignment is flush
-  return a;
+  }
+  (void)alignPathColumns(merged);   // also checks that the result is flush
+  return merged;
 }
 
 // ---- src/diagenv.cpp:12-20,92-102 --------------------------------------------------------------
@@ -194,27 +175,27 @@ size_t DiagEnvParams::effectiveMaxSize() const {
 }
 
 // ---- src/span.cpp --------------------------------------------------------------------------------
+// Disjoint sets of sequence indices; the union keeps the smaller set index, so seqSet.front() is always the
+// component of sequence 0 (the spanning tree below grows from it).
 AlignGraph::Partition::Partition(size_t n) : seqSetIdx(n), seqSet(n), nSets(n) {
-  for (size_t i = 0; i < n; ++i) {
-    seqSetIdx[i] = i;
-    seqSet[i].insert(i);
+  for (size_t k = 0; k < n; ++k) {
+    seqSetIdx[k] = k;
+    seqSet[k].insert(k);
   }
 }
 
 bool AlignGraph::Partition::inSameSet(const AlignGraph::TrialEdge& e) const { return seqSetIdx[e.row1] == seqSetIdx[e.row2]; }
 
 void AlignGraph::Partition::merge(const AlignGraph::TrialEdge& e) {
-  if (!inSameSet(e)) {
-    size_t idx1 = seqSetIdx[e.row1];
-    size_t idx2 = seqSetIdx[e.row2];
-    if (idx1 > idx2) std::swap(idx1, idx2);
-    set<size_t>& set1 = seqSet[idx1];
-    set<size_t>& set2 = seqSet[idx2];
-    for (auto n2 : set2) seqSetIdx[n2] = idx1;
-    set1.insert(set2.begin(), set2.end());
-    set2.clear();
-    --nSets;
+  if (inSameSet(e)) return;
+  const size_t keep = std::min(seqSetIdx[e.row1], seqSetIdx[e.row2]);
+  const size_t drop = std::max(seqSetIdx[e.row1], seqSetIdx[e.row2]);
+  for (size_t member : seqSet[drop]) {
+    seqSetIdx[member] = keep;
+    seqSet[keep].insert(member);
   }
+  seqSet[drop].clear();
+  --nSets;
 }
 
 AlignGraph::AlignGraph(const vguard<FastSeq>& seqs, const RateModel& model, const double time, const DiagEnvParams& diagEnvParams,
@@ -291,25 +272,26 @@ void AlignGraph::buildGraph(const list<TrialEdge>& trialEdges, const string&) {
   }
 }
 
+// Maximum spanning tree over the pairwise alignments, grown from the component of sequence 0: every round
+// takes the best-scoring edge leaving that component (each sequence keeps its edges in a max-heap; edges that
+// have become internal are discarded lazily).  Returns the alignments of the chosen edges in selection order.
 list<AlignPath> AlignGraph::minSpanTree() {
-  list<AlignPath> paths;
-  Partition part(seqs.size());
-  while (part.nSets > 1) {
-    Edge best;
-    bool foundBest = false;
-    for (auto src : part.seqSet.front()) {
-      while (!edges[src].empty() && part.inSameSet(edges[src].top())) edges[src].pop();
-      if (!edges[src].empty() && (!foundBest || best < edges[src].top())) {
-        best = edges[src].top();
-        foundBest = true;
-      }
+  list<AlignPath> chosen;
+  Partition components(seqs.size());
+  while (components.nSets > 1) {
+    const Edge* best = NULL;
+    for (size_t member : components.seqSet.front()) {
+      std::priority_queue<Edge>& heap = edges[member];
+      while (!heap.empty() && components.inSameSet(heap.top())) heap.pop();
+      if (!heap.empty() && (best == NULL || *best < heap.top())) best = &heap.top();
     }
-    Assert(foundBest, "Found no valid edge");
-    paths.push_back(edgePath[best.row1][best.row2]);
-    part.merge(best);
-    if (getenv("HX_DEBUG_SPAN")) fprintf(stderr, "mst %d %d %a\n", (int)best.row1, (int)best.row2, best.lp);
+    Assert(best != NULL, "Found no valid edge");
+    const Edge taken = *best;
+    chosen.push_back(edgePath[taken.row1][taken.row2]);
+    components.merge(taken);
+    if (getenv("HX_DEBUG_SPAN")) fprintf(stderr, "mst %d %d %a\n", (int)taken.row1, (int)taken.row2, taken.lp);
   }
-  return paths;
+  return chosen;
 }
 
 AlignPath AlignGraph::mstPath() {

@@ -1,32 +1,40 @@
-// Mirror of the reference's t/testmerge.cpp: testmerge <align1> <align2> ...  (host only)
+// Merges alignments that share sequences (same command line and output as the reference's testmerge):
+//   testmerge <alignment.fa> <alignment.fa> ...
+// Rows are identified by sequence name across the files; the merged alignment goes to stdout as FASTA.
+// Host only.
 #include <cstdlib>
 #include <iostream>
 #include "../hx_host.h"
 using namespace historian;
 
+namespace {
+struct RowRegistry {
+  map<string, AlignRowIndex> rowOf;
+  vguard<FastSeq> sequences;
+  AlignRowIndex lookup(const FastSeq& ungapped) {
+    const auto known = rowOf.find(ungapped.name);
+    if (known != rowOf.end()) return known->second;
+    const AlignRowIndex row = sequences.size();
+    rowOf[ungapped.name] = row;
+    sequences.push_back(ungapped);
+    return row;
+  }
+};
+}  // namespace
+
 int main(int argc, char** argv) {
   if (argc < 3) {
     std::cout << "Usage: " << argv[0] << " <align1> <align2> ...\n";
-    exit(EXIT_FAILURE);
+    return EXIT_FAILURE;
   }
-  map<string, AlignRowIndex> nameToRowIndex;
-  vguard<FastSeq> ungapped;
-  vguard<AlignPath> paths;
-  for (int n = 1; n < argc; ++n) {
-    vguard<FastSeq> gapped = readFastSeqs(argv[n]);
-    Alignment align(gapped);
-    AlignPath path;
-    for (size_t k = 0; k < gapped.size(); ++k) {
-      if (nameToRowIndex.find(gapped[k].name) == nameToRowIndex.end()) {
-        nameToRowIndex[gapped[k].name] = ungapped.size();
-        ungapped.push_back(align.ungapped[k]);
-      }
-      path[nameToRowIndex[gapped[k].name]] = align.path[k];
-    }
-    paths.push_back(path);
+  RowRegistry rows;
+  vguard<AlignPath> inputs;
+  for (int f = 1; f < argc; ++f) {
+    const Alignment file(readFastSeqs(argv[f]));
+    AlignPath renumbered;
+    for (size_t k = 0; k < file.ungapped.size(); ++k) renumbered[rows.lookup(file.ungapped[k])] = file.path.at(k);
+    inputs.push_back(renumbered);
   }
-  const AlignPath path = alignPathMerge(paths);
-  const Alignment align(ungapped, path);
-  writeFastaSeqs(std::cout, align.gapped());
-  exit(EXIT_SUCCESS);
+  writeFastaSeqs(std::cout, Alignment(rows.sequences, alignPathMerge(inputs)).gapped());
+  return EXIT_SUCCESS;
 }

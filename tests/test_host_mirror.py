@@ -89,15 +89,12 @@ def test_testmerge_inconsistent_alignments_abort():
     assert out.returncode != 0 and out.stdout == b""
 
 
-@pytest.mark.gpu
-def test_testspan_all_pairs_equals_the_oracle_graph():
-    # AlignGraph (src/span.cpp) with the all-vs-all graph and full envelopes: 903 pairwise fills as one device
-    # batch, maximum spanning tree, merge -- against the oracle's restatement of the same
+def _span_against_oracle(extra_args, sparse_params):
     from oracle import historian_oracle as ho
     from oracle import quickalign_oracle as q
     from oracle.ref_mains import read_fasta
     e = dict(os.environ, HX_DEBUG_SPAN="1")
-    out = subprocess.run([BIN + "testspan", "-dense", "-kmatchoff", G + "PF16593.fa", G + "testamino.json", "1"],
+    out = subprocess.run([BIN + "testspan", "-dense"] + extra_args + [G + "PF16593.fa", G + "testamino.json", "1"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, check=True, timeout=300)
     got = out.stdout.decode()
     model = ho.RateModel.from_file(G + "testamino.json")
@@ -112,11 +109,32 @@ def test_testspan_all_pairs_equals_the_oracle_graph():
                 setattr(sc, name, float.fromhex(v))
         elif f[0] == "submat":
             sc.submat[int(f[1])][int(f[2])] = float.fromhex(f[3])
-    ag = q.AlignGraph(read_fasta(G + "PF16593.fa"), model, 1.0, scores=sc)
+    ag = q.AlignGraph(read_fasta(G + "PF16593.fa"), model, 1.0, sparse_params=sparse_params, scores=sc)
     assert got == "".join(">%s\n%s\n" % ns for ns in ag.mst_gapped())
     # ... and the same edges, with bit-identical scores, in the same order
     mst = [(int(f[1]), int(f[2]), float.fromhex(f[3])) for f in (l.split() for l in out.stderr.decode().splitlines()) if f[0] == "mst"]
     assert mst == ag.mst_edges and len(mst) == len(ag.seqs) - 1
+    return ag
+
+
+@pytest.mark.gpu
+def test_testspan_all_pairs_equals_the_oracle_graph():
+    # AlignGraph (src/span.cpp) with the all-vs-all graph and full envelopes: 903 pairwise fills as one device
+    # batch, maximum spanning tree, merge -- against the oracle's restatement of the same
+    _span_against_oracle(["-kmatchoff"], None)
+
+
+@pytest.mark.gpu
+def test_testspan_all_pairs_sparse_envelopes():
+    # k-mer seeded DiagonalEnvelope::initSparse (3-mers, threshold 1, band 8) in the mirror and in the oracle
+    from oracle import quickalign_oracle as q
+    from oracle.ref_mains import read_fasta
+    ag = _span_against_oracle(["-kmatch", "3", "-kmatchn", "1", "-kmatchband", "8"],
+                              dict(kmer_len=3, band_size=8, kmer_threshold=1, max_size=0))
+    seqs = read_fasta(G + "PF16593.fa")
+    env = q.DiagonalEnvelope(seqs[0][1], seqs[1][1])
+    env.init_sparse(q.KmerIndex(seqs[1][1], ag.model.alphabet, 3), 8, 1, 40, 0)
+    assert len(env.diagonals) < len(seqs[0][1]) + len(seqs[1][1]) - 1     # the envelopes really are sparse
 
 
 @pytest.mark.gpu
