@@ -27,6 +27,7 @@ thread_local char g_err[512] = "";
 int g_device = -1;
 double* g_tab = nullptr;      // device copy of the host-built log_sum_exp table
 double* g_fast_tab = nullptr; // device copy of the cubic table of the fast fill mode
+double* g_pair_tab = nullptr; // {lookup[n], lookup[n+1]-lookup[n]} pairs, 16-byte aligned (exact fill mode)
 
 // Quadratic pieces of T(d) = log(1 + exp(-d)) on [0,10): piece k covers [k h, (k+1) h),
 // h = 10/N, as c0 + c1 t + c2 t^2 with t = (d - k h)/h, interpolating T at the three Chebyshev
@@ -377,6 +378,16 @@ int hx_init(int device_ordinal, const double* lse_table, size_t n_entries) {
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_tab), n_entries * sizeof(double)));
   HIP_TRY(hipMemcpy(g_tab, lse_table, n_entries * sizeof(double), hipMemcpyHostToDevice));
   {
+    std::vector<double> pairs(2 * n_entries, 0.0);
+    for (size_t n = 0; n < n_entries; ++n) {
+      pairs[2 * n] = lse_table[n];
+      pairs[2 * n + 1] = n + 1 < n_entries ? lse_table[n + 1] - lse_table[n] : 0.0;
+    }
+    if (g_pair_tab) { (void)hipFree(g_pair_tab); g_pair_tab = nullptr; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_pair_tab), pairs.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(g_pair_tab, pairs.data(), pairs.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  {
     std::vector<double> ft;
     build_fast_table(ft);
     if (g_fast_tab) { (void)hipFree(g_fast_tab); g_fast_tab = nullptr; }
@@ -390,6 +401,7 @@ int hx_init(int device_ordinal, const double* lse_table, size_t n_entries) {
 int hx_shutdown(void) {
   if (g_tab) { (void)hipFree(g_tab); g_tab = nullptr; }
   if (g_fast_tab) { (void)hipFree(g_fast_tab); g_fast_tab = nullptr; }
+  if (g_pair_tab) { (void)hipFree(g_pair_tab); g_pair_tab = nullptr; }
   g_device = -1;
   return HX_OK;
 }
@@ -576,7 +588,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   if (b->all_chain && !(b->flags & HX_FORCE_GENERIC) && !(force_dag && b->d_agg)) {
     // with a band the strip pipelines only visit in-envelope windows; everything else is -inf
     if (b->any_banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_fwd, b->fwd_total, st);
-    launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,
+    launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, (b->flags & HX_LSE_FAST) ? g_fast_tab : g_pair_tab, (b->flags & HX_LSE_FAST) != 0,
                          b->all_leaf ? (b->all_ylds ? 2 : 1) : 0, b->any_banded, b->yl_cols, b->yl_emis, st);
   } else if (b->flags & HX_FORCE_GENERIC)
     launch_forward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
@@ -586,7 +598,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
       launch_fill_neg_inf(b->d_fwd, b->fwd_total, st);
       launch_fill_neg_inf(b->d_agg, b->fwd_total, st);
     }
-    launch_forward_dag_pipe(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0, st);
+    launch_forward_dag_pipe(b->d_jobs, b->n_jobs, b->max_rows, g_tab, (b->flags & HX_LSE_FAST) ? g_fast_tab : g_pair_tab, (b->flags & HX_LSE_FAST) != 0, st);
   }
   HIP_TRY(hipEventRecord(b->ev[0][1], st));
   HIP_TRY(hipGetLastError());
@@ -617,13 +629,13 @@ int hx_batch_backward(hx_batch* b, void* stream) {
   HIP_TRY(hipEventRecord(b->ev[1][0], st));
   if (b->all_leaf && !(b->flags & HX_FORCE_GENERIC)) {
     if (b->any_banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_bwd, b->fwd_total, st);
-    launch_backward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0,
+    launch_backward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, (b->flags & HX_LSE_FAST) ? g_fast_tab : g_pair_tab, (b->flags & HX_LSE_FAST) != 0,
                           b->all_ylds ? 2 : 1, b->any_banded, b->yl_cols, b->yl_emis, st);
   } else if (b->flags & HX_FORCE_GENERIC)
     launch_backward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
   else {
     if (b->any_banded) launch_fill_neg_inf(b->d_bwd, b->fwd_total, st);
-    launch_backward_dag_pipe(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_fast_tab, (b->flags & HX_LSE_FAST) != 0, st);
+    launch_backward_dag_pipe(b->d_jobs, b->n_jobs, b->max_rows, g_tab, (b->flags & HX_LSE_FAST) ? g_fast_tab : g_pair_tab, (b->flags & HX_LSE_FAST) != 0, st);
   }
   HIP_TRY(hipEventRecord(b->ev[1][1], st));
   HIP_TRY(hipGetLastError());

@@ -242,6 +242,7 @@ __device__ __forceinline__ C5 leaf_cell_bwd(const double (*T)[6], const LSE& L, 
 // block-loads 64 columns of it at a time (L1-bypassing loads) once the producer's
 // progress counter (LDS, monotonic) says those columns are complete and drained.
 #define HX_PUBLISH_LAG 16
+#define HX_EXACT_LDS 15000      // table entries (d < 1.5) the exact chain kernel keeps in LDS: 117 KB (the y side may need 33 KB more)
 #define HX_YL_MAX_COLS 6144
 #define HX_YL_MAX_CLS 64
 #define HX_YL_MAX_EMIS 1024
@@ -258,12 +259,17 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
   constexpr int SR = 64 * RPT;                      // rows per strip
   static_assert(PPW == 1 || !YL, "the LDS-resident y side belongs to one pair");
   __shared__ volatile int prog[W * PPW];
-  __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : 2];
+  // FAST: the 4096-piece table.  Exact, one pair per workgroup: the head of the reference's table (differences
+  // below HX_EXACT_LDS * 1e-4), see ExactLse3.
+  constexpr int XH = (!FAST && PPW == 1) ? HX_EXACT_LDS : 0;
+  __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : XH + 2];
   if (FAST) {
     for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 2; k += THREADS) ftab[k] = fast_tab[k];
+  } else {
+    for (int k = threadIdx.x; k < XH + 2; k += THREADS) ftab[k] = exact_tab[k];
   }
   if (threadIdx.x < W * PPW) prog[threadIdx.x] = 0;
-  const LSE L = LSE::make(FAST ? (const double*)ftab : exact_tab);
+  const LSE L = FAST ? LSE::make((const double*)ftab) : LSE::make(fast_tab /* exact mode: the pair table */, ftab, XH);
   const ExactLse LX{exact_tab};
 
   // (wave-uniform by construction; said explicitly so that the job record is addressed with scalar loads)

@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_fill_dag(const DevJob
     for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 2; k += threads) ftab[k] = fast_tab[k];
   if (threadIdx.x < HX_DAG_MAX_WAVES) prog[threadIdx.x] = 0;
   __syncthreads();
-  const LSE L = LSE::make(FAST ? (const double*)ftab : exact_tab);
+  const LSE L = LSE::make(FAST ? (const double*)ftab : fast_tab)   /* exact mode: fast_tab is the pair table */;
   volatile HX_LDS int* progp = (volatile HX_LDS int*)prog;
 
   const DevJob& J = jobs[blockIdx.x];
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
     for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 2; k += threads) ftab[k] = fast_tab[k];
   if (threadIdx.x < HX_DAGF_MAX_WAVES) prog[threadIdx.x] = 0;
   __syncthreads();
-  const LSE L = LSE::make(FAST ? (const double*)ftab : exact_tab);
+  const LSE L = LSE::make(FAST ? (const double*)ftab : fast_tab)   /* exact mode: fast_tab is the pair table */;
   volatile HX_LDS int* progp = (volatile HX_LDS int*)prog;
 
   const DevJob& J = jobs[blockIdx.x];

@@ -83,13 +83,23 @@ struct FastLse {
     return finish(p, fetch(p));
   }
   static __device__ __forceinline__ FastLse make(const double* p) { return FastLse{reinterpret_cast<const FastPiece*>(p)}; }
+  static __device__ __forceinline__ FastLse make(const double* p, const double*, int) { return make(p); }
 };
 
 // The reference's table operator (hx_lse.h), phased the same way; bit-identical to lse().
 struct ExactLse3 {
+  // 16-byte aligned pairs {lookup[n], lookup[n+1] - lookup[n]} (built by hx_init from the host's table: the
+  // difference is the same IEEE subtraction the reference performs at every look-up), so that a look-up is one
+  // naturally aligned 16-byte gather.
   const double* __restrict__ tab;
+  // Optionally the head of the table, lookup[0 .. n_lds], also sits in LDS.  The exact fill is bound by the
+  // L1's miss handling (about 0.5 gather-lanes per clock and CU: PMC, tools/pmc_exact.sh), and the small
+  // differences are by far the most frequent (15 % of all look-ups fall below 0.5, a third hit no entry at
+  // all because the difference is >= 10): whatever LDS serves, the L1 does not see.
+  const double* lds;
+  int n_lds;
   struct Prep { double mx, x; int n; bool in; };
-  struct Piece { double f0, f1; };
+  struct Piece { double f0, df; };
   __device__ __forceinline__ Prep prep(double a, double b) const {
     Prep p;
     p.mx = vmax(a, b);
@@ -98,18 +108,27 @@ struct ExactLse3 {
     p.n = p.in ? (int)div_by_1em4(p.x) : 0;
     return p;
   }
-  __device__ __forceinline__ Piece fetch(const Prep& p) const { return Piece{tab[p.n], tab[p.n + 1]}; }
+  __device__ __forceinline__ Piece fetch(const Prep& p) const {
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    if (p.n < n_lds) {
+      const HX_LDS double* l = (const HX_LDS double*)lds;
+      const double f0 = l[p.n], f1 = l[p.n + 1];
+      return Piece{f0, f1 - f0};
+    }
+    const d2v v = reinterpret_cast<const d2v*>(tab)[p.n];
+    return Piece{v.x, v.y};
+  }
   __device__ __forceinline__ double finish(const Prep& p, const Piece& c) const {
     const double dx = p.x - ((double)p.n * 1e-4);
-    const double df = c.f1 - c.f0;
-    const double ret = c.f0 + df * div_by_1em4(dx);
+    const double ret = c.f0 + c.df * div_by_1em4(dx);
     return p.mx + (p.in ? ret : 0.0);
   }
   __device__ __forceinline__ double operator()(double a, double b) const {
     const Prep p = prep(a, b);
     return finish(p, fetch(p));
   }
-  static __device__ __forceinline__ ExactLse3 make(const double* p) { return ExactLse3{p}; }
+  static __device__ __forceinline__ ExactLse3 make(const double* p) { return ExactLse3{p, nullptr, 0}; }
+  static __device__ __forceinline__ ExactLse3 make(const double* p, const double* lds_head, int n) { return ExactLse3{p, lds_head, n}; }
 };
 
 struct C5 { double imm, imd, idm, imi, iiw; };
