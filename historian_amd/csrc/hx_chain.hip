@@ -262,7 +262,9 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
   // FAST: the 4096-piece table.  Exact, one pair per workgroup: the head of the reference's table (differences
   // below HX_EXACT_LDS * 1e-4), see ExactLse3.  (Not for the one-wave-per-pair launches of banded batches: there
   // 117 KB of LDS per workgroup would leave two waves per CU; measured 16.4 -> 24.9 ms.)
-  constexpr int XH = (!FAST && PPW == 1) ? HX_EXACT_LDS : 0;
+  // Only with 16 waves per pair, where one workgroup fills the CU's register file anyway: for smaller pairs the
+  // LDS would cap the workgroups per CU.
+  constexpr int XH = (!FAST && PPW == 1 && W == 16) ? HX_EXACT_LDS : 0;
   __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : XH + 2];
   if (FAST) {
     for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 2; k += THREADS) ftab[k] = fast_tab[k];
