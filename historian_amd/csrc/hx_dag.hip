@@ -619,106 +619,82 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
 
         Fwd10 c = Fwd10{NI, NI, NI, NI, NI, NI, NI, NI, NI, NI};
         if (act) {
-          // x-absorbing (or x-null) moves
-          double imd = xa[0] + X.lp[0], iiw = xb[0] + X.lp[0];
+          // ---- the inline transitions (their cells were loaded with the step's other sources) ----
+          double imd = xa[0] + X.lp[0], iiw = xb[0] + X.lp[0];      // x-absorbing (or x-null) moves
 #pragma unroll
           for (int k = 1; k < K; ++k)
             if (xgo && xdeg > k) { imd = L(imd, xa[k] + X.lp[k]); iiw = L(iiw, xb[k] + X.lp[k]); }
-          // transitions beyond the inline ones, two at a time: their CSR entries, then their cells, then
-          // the sums (a row with many in-transitions slows its whole strip, so the loads are batched)
-          if (xgo)
-            for (int k0 = K; k0 < xdeg; k0 += 2) {
-              int src[2];
-              double lp[2], va[2], vb[2];
-#pragma unroll
-              for (int u = 0; u < 2; ++u)
-                if (k0 + u < xdeg) { src[u] = xin_src[X.in_b + k0 + u]; lp[u] = xin_lp[X.in_b + k0 + u]; }
-#pragma unroll
-              for (int u = 0; u < 2; ++u)
-                if (k0 + u < xdeg) {
-                  if (lane > 0 && src[u] == i - 1) { va[u] = upA; vb[u] = upB; }
-                  else { const int64_t sl = slot_at(row_ref(ss, src[u]), j); va[u] = M[offXa + sl]; vb[u] = M[offXb + sl]; }
-                }
-#pragma unroll
-              for (int u = 0; u < 2; ++u)
-                if (k0 + u < xdeg) { imd = L(imd, va[u] + lp[u]); iiw = L(iiw, vb[u] + lp[u]); }
-            }
-          if (!xnull && yok) { imd += X.rootsub; iiw += X.ins; }
-          // y-absorbing (or y-null) moves
-          double idm = ya[0] + Y.lp[0], imi = yb[0] + Y.lp[0];
+          double idm = ya[0] + Y.lp[0], imi = yb[0] + Y.lp[0];      // y-absorbing (or y-null) moves
 #pragma unroll
           for (int k = 1; k < K; ++k)
             if (ygo && ydeg > k) { idm = L(idm, ya[k] + Y.lp[k]); imi = L(imi, yb[k] + Y.lp[k]); }
-          if (ygo)
-            for (int k0 = K; k0 < ydeg; k0 += 2) {
-              int src[2];
-              double lp[2], va[2], vb[2];
-#pragma unroll
-              for (int u = 0; u < 2; ++u)
-                if (k0 + u < ydeg) { src[u] = yin_src[Y.in_b + k0 + u]; lp[u] = yin_lp[Y.in_b + k0 + u]; }
-#pragma unroll
-              for (int u = 0; u < 2; ++u)
-                if (k0 + u < ydeg) {
-                  if (src[u] == j - 1) { va[u] = ownA; vb[u] = ownB; }
-                  else { const int64_t sl = slot_at(own, src[u]); va[u] = M[offYa + sl]; vb[u] = M[offYb + sl]; }
-                }
-#pragma unroll
-              for (int u = 0; u < 2; ++u)
-                if (k0 + u < ydeg) { idm = L(idm, va[u] + lp[u]); imi = L(imi, vb[u] + lp[u]); }
-            }
-          if (!ynull && xok) { idm += Y.rootsub; imi += Y.ins; }
-          // IMM
           double imm = NI;
-          if (mode == 1) {
-            if (xdeg <= K && ydeg <= K) {
-              imm = (mv[0] + X.lp[0]) + Y.lp[0];
+          const bool pairs_inline = mode == 1 && ydeg <= K;         // else (both emit, > K y transitions): generic loop below
+          if (pairs_inline) {
+            imm = (mv[0] + X.lp[0]) + Y.lp[0];
 #pragma unroll
-              for (int a = 0; a < K; ++a)
+            for (int a = 0; a < K; ++a)
 #pragma unroll
-                for (int b = 0; b < K; ++b)
-                  if ((a | b) != 0 && xdeg > a && ydeg > b) imm = L(imm, (mv[a * K + b] + X.lp[a]) + Y.lp[b]);
-            } else if (ydeg <= K) {
-              // many x transitions, few y transitions: one x transition (all its pairs) per round.
-              // (a transition pair's source is at least two steps old: always in memory)
-              for (int a = 0; a < xdeg; ++a) {
-                const RowRef rr = row_ref(ss, xin_src[X.in_b + a]);
-                const double la = xin_lp[X.in_b + a];
-                double g[K];
-#pragma unroll
-                for (int b = 0; b < K; ++b)
-                  if (b < ydeg) g[b] = M[o4 + slot_at(rr, Y.s[b])];
-#pragma unroll
-                for (int b = 0; b < K; ++b)
-                  if (b < ydeg) imm = L(imm, (g[b] + la) + Y.lp[b]);
-              }
-            } else {
-              for (int a = 0; a < xdeg; ++a) {
-                const RowRef rr = row_ref(ss, xin_src[X.in_b + a]);
-                const double lpx = xin_lp[X.in_b + a];
-                for (int b = 0; b < ydeg; ++b)
-                  imm = L(imm, (M[o4 + slot_at(rr, yin_src[Y.in_b + b])] + lpx) + yin_lp[Y.in_b + b]);
-              }
-            }
-            imm += e;
+              for (int b = 0; b < K; ++b)
+                if ((a | b) != 0 && xdeg > a && ydeg > b) imm = L(imm, (mv[a * K + b] + X.lp[a]) + Y.lp[b]);
           } else if (mode == 2) {
             imm = mv[0] + Y.lp[0];
 #pragma unroll
             for (int k = 1; k < K; ++k) if (ydeg > k) imm = L(imm, mv[k] + Y.lp[k]);
-            for (int k = K; k < ydeg; ++k) {
-              const int src = yin_src[Y.in_b + k];
-              const double v = (src == j - 1) ? own10.imm : M[slot_at(own, src)];
-              imm = L(imm, v + yin_lp[Y.in_b + k]);
-            }
           } else if (mode == 3) {
             imm = mv[0] + X.lp[0];
 #pragma unroll
             for (int k = 1; k < K; ++k) if (xdeg > k) imm = L(imm, mv[k] + X.lp[k]);
-            for (int k = K; k < xdeg; ++k) {
-              const int src = xin_src[X.in_b + k];
-              const double v = (lane > 0 && src == i - 1) ? up_imm : M[slot_at(row_ref(ss, src), j)];
-              imm = L(imm, v + xin_lp[X.in_b + k]);
+          }
+          // ---- transitions beyond the inline ones.  Rare, but a row that has them has them at every step and
+          // sets the pace of its strip (and through the pipeline of its pair): one round per transition reads its
+          // CSR entry once and fetches everything that hangs on it -- the two sums of the x (or y) part and, in
+          // the same round, its IMM sources -- before any of the dependent look-ups.
+          for (int a = K; a < xdeg; ++a) {
+            const int src = xin_src[X.in_b + a];
+            const double lp = xin_lp[X.in_b + a];
+            const bool adj = lane > 0 && src == i - 1;              // the previous lane's cell of the previous step
+            const RowRef rr = row_ref(ss, src);
+            const int64_t sl = slot_at(rr, j);
+            double va = upA, vb = upB, vm = up_imm, g[K];
+            if (xgo && !adj) { va = M[offXa + sl]; vb = M[offXb + sl]; }
+            if (mode == 3 && !adj) vm = M[sl];
+            if (pairs_inline) {                                      // (a pair's source is >= 2 steps old: in memory)
+#pragma unroll
+              for (int b = 0; b < K; ++b)
+                if (b < ydeg) g[b] = M[o4 + slot_at(rr, Y.s[b])];
+            }
+            if (xgo) { imd = L(imd, va + lp); iiw = L(iiw, vb + lp); }
+            if (mode == 3) imm = L(imm, vm + lp);
+            if (pairs_inline) {
+#pragma unroll
+              for (int b = 0; b < K; ++b)
+                if (b < ydeg) imm = L(imm, (g[b] + lp) + Y.lp[b]);
             }
           }
+          for (int b = K; b < ydeg; ++b) {
+            const int src = yin_src[Y.in_b + b];
+            const double lp = yin_lp[Y.in_b + b];
+            const bool adj = src == j - 1;                          // the lane's own cell of the previous step
+            const int64_t sl = slot_at(own, src);
+            double va = ownA, vb = ownB, vm = own10.imm;
+            if (ygo && !adj) { va = M[offYa + sl]; vb = M[offYb + sl]; }
+            if (mode == 2 && !adj) vm = M[sl];
+            if (ygo) { idm = L(idm, va + lp); imi = L(imi, vb + lp); }
+            if (mode == 2) imm = L(imm, vm + lp);
+          }
+          if (mode == 1 && !pairs_inline) {
+            // both states emit and y has more than K in-transitions: all pairs in the reference's order
+            for (int a = 0; a < xdeg; ++a) {
+              const RowRef rr = row_ref(ss, xin_src[X.in_b + a]);
+              const double lpx = xin_lp[X.in_b + a];
+              for (int b = 0; b < ydeg; ++b)
+                imm = L(imm, (M[o4 + slot_at(rr, yin_src[Y.in_b + b])] + lpx) + yin_lp[Y.in_b + b]);
+            }
+          }
+          if (!xnull && yok) { imd += X.rootsub; iiw += X.ins; }
+          if (!ynull && xok) { idm += Y.rootsub; imi += Y.ins; }
+          if (mode == 1) imm += e;
           if (s == 0 && t == 0 && lane == 0) imm = 0.0;     // cell (0,0): lpStart() = 0 (reference src/forward.cpp:73)
           c.imm = imm; c.imd = imd; c.idm = idm; c.imi = imi; c.iiw = iiw;
         }
