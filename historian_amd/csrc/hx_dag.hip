@@ -435,6 +435,16 @@ __device__ __forceinline__ int64_t slot_at(const RowRef& r, int c) {
 
 #define HX_DAGF_MAX_WAVES 8     // Forward pipeline: up to 8 waves (512 threads) so that a wave may use 256 VGPRs
 
+// Trace builds (-DHX_DAG_TRACE): per-strip cycle sums of the phases of a step, printed by lane 0 at the end of
+// every strip (tools/dag_trace.sh).  The explicit waits a trace build adds perturb the schedule a little.
+#ifdef HX_DAG_TRACE
+#define HX_TR(k) do { const long long now_ = (long long)__builtin_readcyclecounter(); tr_sum[k] += now_ - tr_last; tr_last = now_; } while (0)
+#define HX_TR_WAIT_LOADS() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define HX_TR(k) do { } while (0)
+#define HX_TR_WAIT_LOADS() do { } while (0)
+#endif
+
 // what the next step may need from the cell a lane has just computed
 struct Fwd10 { double imm, imd, idm, imi, iiw, g0, g1, g2, g3, g4; };
 
@@ -514,6 +524,11 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
     const int above_base = ((s - 1) / W) * Cc;
     const int my_base = (s / W) * Cc;
     int seen = 0, published = 0;
+#ifdef HX_DAG_TRACE
+    long long tr_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tr_last = (long long)__builtin_readcyclecounter();
+    int tr_steps = 0;
+#endif
     int wlo[2] = {0, 0}, whi[2] = {Cc + 63, 0};
     if (banded) {
       wlo[0] = win[4 * s]; whi[0] = win[4 * s + 1];
@@ -542,6 +557,7 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
             asm volatile("" ::: "memory");
           }
         }
+        HX_TR(0);      // progress wait
         if (t > wlo[w] && ((t - wlo[w]) & 63) == 0) stage(t);
         const int j = t - lane;
         const PackRegs Y = column(j);
@@ -600,6 +616,9 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
           for (int k = 1; k < K; ++k) if (xdeg > k) mv[k] = M[sXj[k]];
         }
         if (X.cls < 0 || Y.cls < 0) e = NI;
+        HX_TR(1);      // column record, addresses, load issue
+        HX_TR_WAIT_LOADS();
+        HX_TR(2);      // waiting for the loads
         // ---- values forwarded from the previous step, and -inf for what does not exist ----
         const double upA = xnull ? up_imd : up_g0, upB = xnull ? up_iiw : up_g1;
         const double ownA = ynull ? own10.idm : own10.g2, ownB = ynull ? own10.imi : own10.g3;
@@ -698,6 +717,7 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
           if (s == 0 && t == 0 && lane == 0) imm = 0.0;     // cell (0,0): lpStart() = 0 (reference src/forward.cpp:73)
           c.imm = imm; c.imd = imd; c.idm = idm; c.imi = imi; c.iiw = iiw;
         }
+        HX_TR(3);      // accumulate (inline transitions and tails)
         // ---- the previous step's cell goes to memory now, behind this step's loads (unconditionally: an
         // idle lane writes -inf into padding or into an out-of-envelope cell, which holds -inf already) ----
         {
@@ -737,6 +757,7 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
           g4 = L(g4, c.iiw + T[4][0]);
           c.g0 = g0; c.g1 = g1; c.g2 = g2; c.g3 = g3; c.g4 = g4;
         }
+        HX_TR(4);      // stores issued, outgoing sums
         // ---- rotate: this step's cell becomes `own`, and the next lane's `up` ----
         own10 = c;
         pend_slot = own.base + ((int64_t)(t >> 1) << 7) + (t & 1);
@@ -753,6 +774,10 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
             if (lane == 0) progp[wave] = my_base + done;
           }
         }
+        HX_TR(5);      // rotate, drain + publish
+#ifdef HX_DAG_TRACE
+        ++tr_steps;
+#endif
       }
       // flush the last cell of the window
       {
@@ -776,6 +801,11 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
         if (lane == 0) progp[wave] = my_base + done;
       }
     }
+#ifdef HX_DAG_TRACE
+    if (lane == 0 && tr_steps > 0)
+      printf("trace job %d strip %d steps %d wait %lld issue %lld loads %lld accumulate %lld sums %lld rotate %lld\\n", (int)blockIdx.x, s, tr_steps,
+             tr_sum[0] / tr_steps, tr_sum[1] / tr_steps, tr_sum[2] / tr_steps, tr_sum[3] / tr_steps, tr_sum[4] / tr_steps, tr_sum[5] / tr_steps);
+#endif
     // (a strip without any window still has to release the strip below)
     if (published < Cc) {
       published = Cc;
