@@ -63,7 +63,7 @@ class HxCell(C.Structure):
 EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_create", "hx_batch_destroy",
            "hx_batch_forward", "hx_batch_backward", "hx_batch_sync", "hx_batch_lp_end", "hx_batch_lp_start",
            "hx_batch_layout", "hx_batch_read_matrix", "hx_batch_read_cells", "hx_batch_read_prepared",
-           "hx_batch_posterior_scan", "hx_batch_total_cells", "hx_batch_last_kernel_ms", "hx_host_alloc",
+           "hx_batch_posterior_scan", "hx_batch_best_trace", "hx_batch_total_cells", "hx_batch_last_kernel_ms", "hx_host_alloc",
            "hx_host_free", "hx_quick_batch_create", "hx_quick_batch_destroy", "hx_quick_batch_run",
            "hx_quick_batch_results", "hx_quick_batch_layout", "hx_quick_batch_read_matrix",
            "hx_quick_batch_total_cells", "hx_quick_batch_last_kernel_ms"]
@@ -103,6 +103,7 @@ def load():
     lib.hx_batch_read_prepared.argtypes = [vp, C.c_int32] + [_f64p] * 6
     lib.hx_batch_posterior_scan.argtypes = [vp, C.c_int32, C.c_double, C.POINTER(HxCell), C.c_int64,
                                             C.POINTER(C.c_int64)]
+    lib.hx_batch_best_trace.argtypes = [vp, vp, C.c_int64, _i32p]
     lib.hx_batch_total_cells.argtypes = [vp]
     lib.hx_batch_total_cells.restype = C.c_int64
     lib.hx_batch_last_kernel_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
@@ -316,6 +317,27 @@ class Batch:
         _check(load().hx_batch_posterior_scan(self._h, job, min_post_prob, out, cap, C.byref(n)))
         k = min(n.value, cap)
         return n.value, [(out[i].xpos, out[i].ypos, out[i].state, out[i].log_post_prob) for i in range(k)]
+
+    def best_trace(self, cap=None, raw=False):
+        """ForwardMatrix::bestTrace() of every job, found on the device: a list (one entry per job) of
+        [(xpos, ypos, state), ...] from the start cell to the END cell; None where lpEnd is -inf.
+        raw=True returns the arrays (cells [n, cap, 3], n_cells [n]) instead."""
+        if cap is None:
+            cap = max(self.layout(k).n_rows + self.layout(k).n_cols for k in range(self.n)) + 4
+        cells = np.zeros((self.n, cap, 3), dtype=np.int32)
+        n_cells = np.zeros(self.n, dtype=np.int32)
+        _check(load().hx_batch_best_trace(self._h, cells.ctypes.data_as(C.c_void_p), cap, _p(n_cells, _i32p)))
+        if raw:
+            return cells, n_cells
+        out = []
+        for k in range(self.n):
+            if n_cells[k] == -1:
+                out.append(None)
+            elif n_cells[k] < 0:
+                raise HxError(int(n_cells[k]), "traceback failure in job %d" % k)
+            else:
+                out.append([tuple(int(v) for v in c) for c in cells[k, :n_cells[k]]])
+        return out
 
 
 class QuickBatch:

@@ -55,7 +55,8 @@ void Fail(const char* error, ...);    // message + exit(EXIT_FAILURE)
 // when HX_TIMING is set.  Not part of the reference's interface.
 struct FillTiming {
   double deviceInit = 0, flattenAndUpload = 0, forwardWait = 0, forwardKernel = 0, backwardWait = 0, readMatrix = 0;
-  long fills = 0, matrixReads = 0;
+  double deviceTrace = 0, cellGather = 0;
+  long fills = 0, matrixReads = 0, deviceTraces = 0, cellGathers = 0;
   long long cells = 0;
 };
 extern FillTiming fillTiming;
@@ -360,6 +361,10 @@ public:
 
   // log-sum-exp policy of the device fills: 0 = exact (bit-identical to the reference, default), 1 = fast
   static void setFillMode(unsigned hxFlags);
+  // device-side best-path traceback (default on; HX_HOST_TRACEBACK=1 in the environment or false here keeps the
+  // reference's host loop over a host copy of the matrix - same paths either way)
+  static void setDeviceTraceback(bool on);
+  static bool deviceTraceback();
   static unsigned fillMode();
 
 protected:
@@ -371,7 +376,12 @@ protected:
     hx_batch* b;
     int nJobs;
     bool backwardDone;
-    BatchHandle(hx_batch* b, int nJobs) : b(b), nJobs(nJobs), backwardDone(false) {}
+    // ForwardMatrix::bestTrace of every job, found on the device on first use (hx_batch_best_trace)
+    bool bestTracesDone;
+    long long bestTraceCap;
+    vguard<int32_t> bestTraceCells;         // [nJobs][bestTraceCap] hx_trace_cell = {xpos, ypos, state}
+    vguard<int32_t> bestTraceLen;           // [nJobs]
+    BatchHandle(hx_batch* b, int nJobs) : b(b), nJobs(nJobs), backwardDone(false), bestTracesDone(false), bestTraceCap(0) {}
     ~BatchHandle();
   };
   std::shared_ptr<BatchHandle> handle;
@@ -381,6 +391,10 @@ protected:
   mutable double* hostCells;     // lazy copy of the device matrix (strip-skewed layout), page-locked, pooled
   mutable size_t hostCellsCap;
   mutable bool haveHostCells;
+  // cells gathered from the device without copying the matrix (hx_batch_read_cells): used while the full
+  // host copy does not exist, so that a best-path profile never moves 40 B/cell over PCIe
+  mutable map<std::pair<ProfileStateIndex, ProfileStateIndex>, XYCell> sparseCells;
+  void prefetchCells(const set<CellCoords>& cells) const;
   long long stripStride, planeStride;
 
   void createBatchAndPrepare();  // flatten inputs -> hx_batch_create; run the fill; fetch the prepared vectors

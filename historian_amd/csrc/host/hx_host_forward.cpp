@@ -19,6 +19,12 @@ static unsigned g_fillMode = HX_LSE_EXACT;
 static bool g_deviceReady = false;
 
 void DPMatrix::setFillMode(unsigned hxFlags) { g_fillMode = hxFlags & HX_LSE_FAST; }
+static int g_deviceTraceback = -1;
+void DPMatrix::setDeviceTraceback(bool on) { g_deviceTraceback = on ? 1 : 0; }
+bool DPMatrix::deviceTraceback() {
+  if (g_deviceTraceback < 0) g_deviceTraceback = getenv("HX_HOST_TRACEBACK") ? 0 : 1;
+  return g_deviceTraceback != 0;
+}
 unsigned DPMatrix::fillMode() { return g_fillMode; }
 
 static void hxCheck(int rc, const char* what) {
@@ -295,9 +301,37 @@ void DPMatrix::ensureHostCells() const {
   fillTiming.matrixReads += 1;
 }
 
+void DPMatrix::prefetchCells(const set<CellCoords>& cells) const {
+  vguard<int32_t> ij;
+  vguard<std::pair<ProfileStateIndex, ProfileStateIndex> > keys;
+  for (const auto& c : cells) {
+    if (c.xpos + 1 >= xSize || c.ypos + 1 >= ySize) continue;
+    const std::pair<ProfileStateIndex, ProfileStateIndex> key(c.xpos, c.ypos);
+    if (sparseCells.count(key) || (!keys.empty() && keys.back() == key)) continue;   // the set is ordered by (x, y, state)
+    keys.push_back(key);
+    ij.push_back((int32_t)c.xpos);
+    ij.push_back((int32_t)c.ypos);
+  }
+  if (keys.empty()) return;
+  const double t0 = wallSeconds();
+  vguard<double> vals(5 * keys.size());
+  hxCheck(hx_batch_read_cells(batch, jobIndex, which, ij.data(), (int64_t)keys.size(), vals.data()), "hx_batch_read_cells");
+  for (size_t k = 0; k < keys.size(); ++k) {
+    XYCell xy;
+    for (int s = 0; s < PairHMM::TotalStates; ++s) xy.lp[s] = vals[5 * k + s];
+    sparseCells[keys[k]] = xy;
+  }
+  fillTiming.cellGather += wallSeconds() - t0;
+  fillTiming.cellGathers += 1;
+}
+
 LogProb DPMatrix::cell(ProfileStateIndex xpos, ProfileStateIndex ypos, PairHMM::State state) const {
   if (xpos + 1 >= xSize || ypos + 1 >= ySize || state >= PairHMM::TotalStates) return NEG_INF;
   if (!inEnvelope(xpos, ypos)) return NEG_INF;   // not stored (the batch is created with HX_SPARSE_ENVELOPE)
+  if (!haveHostCells && !sparseCells.empty()) {
+    const auto it = sparseCells.find(std::make_pair(xpos, ypos));
+    if (it != sparseCells.end()) return it->second.lp[state];
+  }
   ensureHostCells();
   if (which == 1) {   // the Backward matrix is stored in mirrored coordinates (hx_layout::mirrored)
     xpos = xSize - 2 - xpos;
@@ -441,7 +475,31 @@ ForwardMatrix::Path ForwardMatrix::sampleTrace(random_engine& generator) {
 
 ForwardMatrix::Path ForwardMatrix::bestTrace() {
   Assert(lpEnd > NEG_INF, "Forward likelihood is zero; traceback fail");
-  return bestTrace(endCell);
+  if (haveHostCells || !batch || !handle || !deviceTraceback()) return bestTrace(endCell);
+  // the matrix is still device-resident: walk it there (one wavefront per job, all jobs of the batch at once)
+  BatchHandle& h = *handle;
+  if (!h.bestTracesDone) {
+    const double t0 = wallSeconds();
+    long long cap = 0;
+    for (int k = 0; k < h.nJobs; ++k) {
+      hx_layout lay;
+      hxCheck(hx_batch_layout(h.b, k, 0, &lay), "hx_batch_layout");
+      cap = std::max(cap, (long long)lay.n_rows + lay.n_cols + 4);
+    }
+    h.bestTraceCap = cap;
+    h.bestTraceCells.resize(3 * (size_t)cap * h.nJobs);
+    h.bestTraceLen.assign(h.nJobs, 0);
+    hxCheck(hx_batch_best_trace(h.b, reinterpret_cast<hx_trace_cell*>(h.bestTraceCells.data()), cap, h.bestTraceLen.data()), "hx_batch_best_trace");
+    h.bestTracesDone = true;
+    fillTiming.deviceTrace += wallSeconds() - t0;
+    fillTiming.deviceTraces += 1;
+  }
+  const int len = h.bestTraceLen[jobIndex];
+  Assert(len > 0, "traceback failure");
+  Path path;
+  const hx_trace_cell* tc = reinterpret_cast<const hx_trace_cell*>(h.bestTraceCells.data()) + (size_t)h.bestTraceCap * jobIndex;
+  for (int k = 0; k < len; ++k) path.push_back(CellCoords(tc[k].xpos, tc[k].ypos, (PairHMM::State)tc[k].state));
+  return path;
 }
 
 ForwardMatrix::Path ForwardMatrix::bestTrace(const CellCoords& end) {
@@ -608,6 +666,7 @@ Profile ForwardMatrix::makeProfile(const set<CellCoords>& cells, ProfilingStrate
   prof.meta["node"] = std::to_string(parentRowIndex);
   Assert(cells.find(startCell) != cells.end(), "Missing SSS");
   Assert(cells.find(endCell) != cells.end(), "Missing EEE");
+  if (!haveHostCells && batch) prefetchCells(cells);   // the fwdLogProb annotations below read these cells
 
   map<CellCoords, ProfileStateIndex> profStateIndex;
   map<CellCoords, int> outgoingTransitionCount;

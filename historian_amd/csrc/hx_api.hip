@@ -918,6 +918,47 @@ int hx_batch_read_cells(hx_batch* b, int32_t job, int32_t which, const int32_t* 
   return rc;
 }
 
+// Device-side ForwardMatrix::bestTrace for every job of the batch (hx_trace.hip).
+int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t* n_cells) {
+  if (!b || !cells || !n_cells || cap < 1) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (!b->forward_done) return fail(HX_ERR_STATE, "hx_batch_best_trace needs a previous hx_batch_forward");
+  const int n = b->n_jobs;
+  int32_t* d_paths = nullptr;
+  int32_t* d_n = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d_paths), sizeof(int32_t) * 3 * (size_t)cap * n) != hipSuccess)
+    return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %zu path bytes failed", sizeof(int32_t) * 3 * (size_t)cap * n);
+  if (hipMalloc(reinterpret_cast<void**>(&d_n), sizeof(int32_t) * n) != hipSuccess) {
+    (void)hipFree(d_paths);
+    return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+  }
+  int rc = HX_OK;
+  // the per-cell emission plane is only filled by the strip pipelines (hx_batch_forward)
+  launch_best_trace(b->d_jobs, n, d_paths, cap, d_n, g_tab, !(b->flags & HX_FORCE_GENERIC), b->last_stream);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(b->last_stream) != hipSuccess ||
+      hipMemcpy(n_cells, d_n, sizeof(int32_t) * n, hipMemcpyDeviceToHost) != hipSuccess)
+    rc = fail(HX_ERR_HIP, "best-trace kernel failed: %s", hipGetErrorString(hipGetLastError()));
+  std::vector<int32_t> tmp;
+  for (int k = 0; rc == HX_OK && k < n; ++k) {
+    if (n_cells[k] == -3) { rc = fail(HX_ERR_RANGE, "path of job %d does not fit %lld cells", k, (long long)cap); break; }
+    if (n_cells[k] <= 0) continue;
+    const size_t m = (size_t)n_cells[k];
+    tmp.resize(3 * m);
+    if (hipMemcpy(tmp.data(), d_paths + 3 * (size_t)cap * k, sizeof(int32_t) * 3 * m, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(HX_ERR_HIP, "path download failed");
+      break;
+    }
+    // the kernel walks from the END cell backwards; the reference's Path starts at the start cell
+    hx_trace_cell* out = cells + (size_t)cap * k;
+    for (size_t c = 0; c < m; ++c) {
+      const int32_t* t = &tmp[3 * (m - 1 - c)];
+      out[c].xpos = t[0]; out[c].ypos = t[1]; out[c].state = t[2];
+    }
+  }
+  (void)hipFree(d_paths);
+  (void)hipFree(d_n);
+  return rc;
+}
+
 int hx_batch_read_prepared(hx_batch* b, int32_t job, double* subx, double* suby, double* insx, double* rootsubx,
                            double* insy, double* rootsuby) {
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");

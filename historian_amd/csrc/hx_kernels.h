@@ -26,6 +26,9 @@ void launch_posterior_scan(const DevJob* d_jobs, int job, double lpp_threshold, 
 void launch_gather_cells(const DevJob* d_jobs, int job, const double* M, int mirrored, const int* ij, int64_t n,
                          double* out, hipStream_t st);
 
+void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, const double* tab,
+                       bool plane_valid, hipStream_t st);
+
 void launch_quickalign(const DevQuick* d_jobs, int n_jobs, int max_rows, int max_cols, bool all_full, hipStream_t st);
 
 }  // namespace hx

@@ -1,0 +1,130 @@
+// Device-side argmax traceback through a filled Forward matrix.
+//
+// Restates ForwardMatrix::bestTrace (reference src/forward.cpp:278-302) with its helpers
+// sourceTransitionsWithoutEmitOrAbsorb (:326-398), lpCellEmitOrAbsorb (:404-440), sourceCells (:309-314)
+// and bestCell (:245-255), so that a host that only needs the best path of every pair never copies the
+// 40 B/cell matrices over PCIe.  Only additions and comparisons are involved: the path is the one the
+// reference's code finds in the same matrix, ties included (bestCell keeps the first maximum in
+// CellCoords order x, y, state).
+//
+// One wavefront per pair.  A step enumerates the source cells of the current cell — (in-transitions of
+// the x state) x (in-transitions of the y state) x (pair-HMM source states) — one candidate per lane,
+// 64 at a time, and reduces them with a wave-wide arg-max.  Steps are dependent (each needs the cell the
+// previous one chose), so a pair runs at memory latency; the batch supplies the parallelism.
+#include <hip/hip_runtime.h>
+#include "hx_common.h"
+#include "hx_kernels.h"
+
+namespace hx {
+
+namespace {
+
+constexpr unsigned long long NO_KEY = ~0ull;
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+  const int lo = __shfl_xor((int)(unsigned)(v & 0xffffffffull), m, 64);
+  const int hi = __shfl_xor((int)(unsigned)(v >> 32), m, 64);
+  return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+// a stored Forward cell, or -inf outside the storage (reference DPMatrix::cell, src/forward.h:74-88)
+__device__ __forceinline__ double forward_cell(const DevJob& J, int i, int j, int s) {
+  if (i < 0 || j < 0 || i >= J.n_rows || j >= J.n_cols) return HX_NEG_INF;
+  if (J.max_dist >= 0 && !in_envelope(J, i, j)) return HX_NEG_INF;
+  return J.fwd[(int64_t)s * J.plane + cell_slot(J.strip_stride, i, j)];
+}
+
+}  // namespace
+
+// paths: [n_jobs][cap][3] int32 (x, y, state), written from the END cell backwards; n_cells[job] = number of
+// cells written, or -1 when lpEnd = -inf (the reference asserts), -2 when a cell had no source transitions
+// (the reference's "traceback failure"), -3 when cap was too small.
+__global__ __launch_bounds__(64) void k_best_trace(const DevJob* __restrict__ jobs, int32_t* __restrict__ paths, int64_t cap,
+                                                   int32_t* __restrict__ n_cells, const double* __restrict__ tab, int plane_valid) {
+  const DevJob& J = jobs[blockIdx.x];
+  const int lane = threadIdx.x;
+  int32_t* out = paths + (int64_t)blockIdx.x * cap * 3;
+  const int Nx = J.x.n, Ny = J.y.n;
+  if (!(*J.lp_end > HX_NEG_INF)) {
+    if (lane == 0) n_cells[blockIdx.x] = -1;
+    return;
+  }
+  int dx = Nx - 1, dy = Ny - 1, ds = 5;
+  int64_t n = 0;
+  int status = 0;
+  if (cap < 1) status = -3;
+  else if (lane == 0) { out[0] = dx; out[1] = dy; out[2] = ds; }
+  n = 1;
+  while (status == 0 && (dx > 0 || dy > 0)) {
+    const uint8_t xf = J.x.flags[dx], yf = J.y.flags[dy];
+    const bool x_null = xf & F_NULL, y_null = yf & F_NULL;
+    const bool x_ready = (xf & F_READY) || J.x.empty, y_ready = (yf & F_READY) || J.y.empty;
+    // which of the three factors a source cell may differ in (src/forward.cpp:326-398)
+    bool move_x = false, move_y = false, hmm = false, any = false;
+    double lp_abs = 0.;   // lpCellEmitOrAbsorb of the destination
+    if (ds == 1 || ds == 4) {            // IMD, IIW
+      move_x = true;
+      if (x_null) any = y_ready && dx < Nx - 1;
+      else { any = y_ready; hmm = true; lp_abs = ds == 1 ? J.x.rootsub[dx] : J.x.ins[dx]; }
+    } else if (ds == 2 || ds == 3) {     // IDM, IMI
+      move_y = true;
+      if (y_null) any = dy < Ny - 1;
+      else { any = x_ready; hmm = true; lp_abs = ds == 2 ? J.y.rootsub[dy] : J.y.ins[dy]; }
+    } else if (ds == 0) {                // IMM
+      if (y_null && (xf & F_EMIT_OR_START)) { move_y = true; any = dy < Ny - 1; }
+      else if (x_null) { move_x = true; any = y_ready && dx < Nx - 1; }
+      else if (!y_null) {
+        move_x = move_y = hmm = any = true;
+        if (J.emis) {
+          const int cx = J.x.cls[dx], cy = J.y.cls[dy];
+          lp_abs = (cx < 0 || cy < 0) ? HX_NEG_INF : J.emis[(size_t)cx * J.y.n_cls + cy];
+        } else if (plane_valid)
+          lp_abs = J.emis_plane[cell_slot(J.strip_stride, dx, dy)];
+        else
+          lp_abs = emission(J, dx, dy, tab);
+      }
+    } else {                             // EEE: only the end cell
+      move_x = move_y = hmm = any = true;
+    }
+    const int xb = J.x.in_off[dx], yb = J.y.in_off[dy];
+    const int nx = move_x ? J.x.in_off[dx + 1] - xb : 1;
+    const int ny = move_y ? J.y.in_off[dy + 1] - yb : 1;
+    const int ns = hmm ? 5 : 1;
+    const int total = any ? nx * ny * ns : 0;
+    if (total == 0) { status = -2; break; }
+    double best = HX_NEG_INF;
+    unsigned long long bkey = NO_KEY;
+    for (int c = lane; c < total; c += 64) {
+      const int si = c % ns, r = c / ns, yi = r % ny, xi = r / ny;
+      const int sx = move_x ? J.x.in_src[xb + xi] : dx;
+      const int sy = move_y ? J.y.in_src[yb + yi] : dy;
+      const double xlp = move_x ? J.x.in_lp[xb + xi] : 0.;
+      const double ylp = move_y ? J.y.in_lp[yb + yi] : 0.;
+      const int s = hmm ? si : ds;
+      const double h = hmm ? J.T[si][ds] : 0.;
+      // sourceTransitions then sourceCells: ((hmm + x) + y) + emit, then + cell (absent terms are +0.0, exact)
+      const double v = (((h + xlp) + ylp) + lp_abs) + forward_cell(J, sx, sy, s);
+      const unsigned long long key = ((unsigned long long)(unsigned)sx << 32) | ((unsigned long long)(unsigned)sy << 3) | (unsigned)s;
+      if (v > best || (v == best && v > HX_NEG_INF && key < bkey)) { best = v; bkey = key; }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const double ov = __shfl_xor(best, m, 64);
+      const unsigned long long ok = shfl_xor_u64(bkey, m);
+      if (ov > best || (ov == best && ok < bkey)) { best = ov; bkey = ok; }
+    }
+    if (bkey == NO_KEY) { dx = 0; dy = 0; ds = 5; }   // bestCell's default-constructed CellCoords (src/forward.h:32)
+    else { dx = (int)(bkey >> 32); dy = (int)((bkey & 0xffffffffull) >> 3); ds = (int)(bkey & 7); }
+    if (n >= cap) { status = -3; break; }
+    if (lane == 0) { out[3 * n] = dx; out[3 * n + 1] = dy; out[3 * n + 2] = ds; }
+    ++n;
+  }
+  if (lane == 0) n_cells[blockIdx.x] = status < 0 ? status : (int32_t)n;
+}
+
+void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, const double* tab,
+                       bool plane_valid, hipStream_t st) {
+  hipLaunchKernelGGL(k_best_trace, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_paths, cap, d_n_cells, tab, plane_valid ? 1 : 0);
+}
+
+}  // namespace hx

@@ -181,6 +181,19 @@ int hx_batch_read_prepared(hx_batch* b, int32_t job, double* subx, double* suby,
 int hx_batch_posterior_scan(hx_batch* b, int32_t job, double min_post_prob,
                             hx_cell* out, int64_t cap, int64_t* n_out);
 
+/* Device-side ForwardMatrix::bestTrace() (src/forward.cpp:278-302, with sourceCells :309-398 and
+ * bestCell :245-255) for EVERY job of the batch: the arg-max path from the END cell back to the start
+ * cell, found in the device-resident Forward matrix, so that a caller who needs only best paths never
+ * copies 40 B/cell over PCIe.  cells is [n_jobs][cap]; job k's path is written in the reference's Path
+ * order (start cell first, (Nx-1,Ny-1,EEE) last) and n_cells[k] gets its length (<= Nx+Ny), or -1 when
+ * the job's lpEnd is -inf (the reference asserts), or -2 when a cell had no source transitions (the
+ * reference's "traceback failure").  Returns HX_ERR_RANGE when cap was too small.  Additions and
+ * comparisons only: the path is bit-identical to the reference's traceback through the same matrix. */
+typedef struct hx_trace_cell {
+  int32_t xpos, ypos, state;   /* state: 0..4 = IMM,IMD,IDM,IMI,IIW, 5 = EEE */
+} hx_trace_cell;
+int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t* n_cells);
+
 /* Total in-envelope-or-not lattice cells of the batch, sum (Nx-1)(Ny-1). */
 int64_t hx_batch_total_cells(const hx_batch* b);
 

@@ -121,3 +121,31 @@ def test_batched_and_sequential_fills_give_the_same_reconstruction(tmp_path):
         assert out.returncode == 0, out.stderr.decode()
         outs[batch] = out.stdout.decode()
     assert outs[0] == outs[1]
+
+
+def test_best_path_profiles_never_copy_a_matrix(tmp_path):
+    # profsamples 0: every node's profile is its best path (what the reference's -fast preset amounts to).  The
+    # tracebacks run on the device (hx_batch_best_trace) and the profile annotations come from a cell gather, so no
+    # Forward matrix crosses PCIe - and the alignment is still the oracle's, with host or device tracebacks.
+    import re
+    tree, seqs, guide = R.load_family(G + "gp120.tree.nh", G + "gp120.fa", G + "gp120.guide.fa", max_len=200)
+    job = str(tmp_path / "job.txt")
+    R.write_job(job, LG, tree, seqs, guide, str(tmp_path / "seqs.fa"), str(tmp_path / "guide.fa"), band=10,
+                samples=0, maxstates=0, seed=5489)
+    res, rows = R.oracle_reconstruct(LG, tree, seqs, guide, max_distance_from_guide=10, profile_samples=0)
+    outs = {}
+    for host_traceback in (False, True):
+        env = dict(os.environ, HX_TIMING="1")
+        if host_traceback:
+            env["HX_HOST_TRACEBACK"] = "1"
+        out = subprocess.run([HXRECON, job], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()
+        got = R.parse_hxrecon(out.stdout.decode())
+        assert got["lpFinalFwd"] == res["lp_final_fwd"]
+        assert got["lpFinalTrace"] == res["lp_final_trace"]
+        assert got["rows"] == rows
+        outs[host_traceback] = out.stdout.decode()
+        reads = int(re.search(r"matrix D2H [0-9.]+ s in (\d+) reads", out.stderr.decode()).group(1))
+        traces = int(re.search(r"tracebacks [0-9.]+ s in (\d+) calls", out.stderr.decode()).group(1))
+        assert (reads > 0) == host_traceback and (traces > 0) == (not host_traceback)
+    assert outs[False] == outs[True]
