@@ -44,8 +44,10 @@ def parse():
     ap.add_argument("--band", type=int, default=-1,
                     help="guide-alignment band (maxDistanceFromGuide); the guide is the pair's true alignment. "
                          "-1 = full envelope (the headline configuration)")
-    ap.add_argument("--mode", choices=["exact", "fast"], default="fast",
-                    help="log-sum-exp policy of the headline fill (the other mode is timed too and reported)")
+    ap.add_argument("--mode", choices=["exact", "fast", "linear"], default="linear",
+                    help="arithmetic of the headline fill: linear = scaled probabilities (HX_LSE_LINEAR; on banded "
+                         "batches it is the fast policy), fast = LDS-table log-sum-exp, exact = the reference's table, "
+                         "bit for bit.  The other policies are timed too and reported")
     ap.add_argument("--single-mode", action="store_true", help="time only --mode")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a PMC run (default: profiles/traffic.json entry for this workload)")
@@ -163,7 +165,7 @@ def main():
 
     def run_mode(mode):
         """K timed passes of the hot path in one fill mode; returns (seconds, kernel ms list, lp_end, cells)."""
-        batch = capi.Batch(triples, (capi.HX_LSE_FAST if mode == "fast" else capi.HX_LSE_EXACT) |
+        batch = capi.Batch(triples, {"exact": capi.HX_LSE_EXACT, "fast": capi.HX_LSE_FAST, "linear": capi.HX_LSE_LINEAR}[mode] |
                            (capi.HX_SPARSE_ENVELOPE if args.band >= 0 else 0))
         n_cells = batch.total_cells()
         for _ in range(args.warmup):
@@ -185,8 +187,10 @@ def main():
         return dt, k_ms, lp, n_cells
 
     dt, kernel_ms, lp_end, cells = run_mode(args.mode)
-    other = "exact" if args.mode == "fast" else "fast"
+    other = "exact" if args.mode != "exact" else "fast"
     dt_o, kernel_ms_o, lp_end_o, _ = run_mode(other) if not args.single_mode else (None, None, None, None)
+    linear = args.mode == "linear" and args.band < 0      # the scaled-probability kernel (hx_linear.hip) ran
+    dt_t, kernel_ms_t, lp_end_t, _ = run_mode("fast") if (linear and not args.single_mode) else (None, None, None, None)
 
     if rank == 0:
         if args.band >= 0:
@@ -213,12 +217,16 @@ def main():
                                     "full (unbanded)" if args.band < 0 else
                                     "band-%d (guide = the pair's true alignment; in-envelope cells counted)" % args.band,
                                     "exact table (cells bit-identical to the reference recursion)" if args.mode == "exact"
-                                    else "fast LDS-table (same truncation; lpEnd within 1e-9 rel., tracebacks identical)"),
+                                    else ("scaled-probability recursion (fp64 sums of probabilities with a per-cell exponent, "
+                                          "log-probabilities at the store; lpEnd within 1e-5 rel. of the reference's table "
+                                          "arithmetic, north_star allows 1e-4) in place of" if linear else
+                                          "fast LDS-table (same truncation; lpEnd within 1e-9 rel., tracebacks identical)")),
                        "pairs_per_gpu": args.pairs, "cells_per_gpu_per_step": cells,
                        "parallelism": "pairs farmed across %d rank(s); RCCL broadcast of model constants only" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "hx::k_fill_chain<0,...>", "kernel_ms": k_ms, "bytes_per_cell": BYTES_PER_CELL},
+                         "kernel": "hx::k_forward_leaf_linear<W>" if linear else "hx::k_fill_chain<0,...>",
+                         "kernel_ms": k_ms, "bytes_per_cell": BYTES_PER_CELL},
             "fill_mode": args.mode,
             "lp_end_pair0": float(lp_end[0]),
         }
@@ -230,6 +238,14 @@ def main():
                                  "roofline_frac": ach_o / HBM_PEAK_GBS,
                                  "lp_end_max_rel_diff_between_modes":
                                      float(np.max(np.abs(lp_end - lp_end_o) / np.abs(lp_end_o)))}
+        if dt_t is not None:
+            k_t = float(np.mean(kernel_ms_t))
+            out["table_mode"] = {"fill_mode": "fast (HX_LSE_FAST: LDS-table log-sum-exp with the reference's truncation)",
+                                 "value": cells * world * args.steps / dt_t, "unit": "cells/s",
+                                 "ms_per_step": dt_t / args.steps * 1e3, "kernel_ms": k_t,
+                                 "roofline_frac": cells * BYTES_PER_CELL / (k_t * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "lp_end_max_rel_diff_to_exact":
+                                     float(np.max(np.abs(lp_end_t - lp_end_o) / np.abs(lp_end_o)))}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import c_oracle           # the checker, timed as the CPU baseline ("port")
             c_oracle.load()
@@ -248,6 +264,7 @@ def main():
                                              "(dense-array restatement of the reference fill), 1 thread, %.1f s"
                                              % (n_cpu, cpu_dt)}
             out["lp_end_max_rel_err_vs_cpu"] = rel
+            assert rel <= 1e-4, "Forward log-likelihoods outside north_star's tolerance of the CPU path: %g" % rel
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("HX_LIB_PATH") or os.path.join(_HERE, "lib", "libhisto
 
 HX_LSE_TABLE_ENTRIES = 100002
 HX_LSE_EXACT, HX_LSE_FAST, HX_KEEP_BACKWARD, HX_FORCE_GENERIC, HX_SPARSE_ENVELOPE = 0, 1, 2, 4, 8
+HX_LSE_LINEAR = 17      # HX_LSE_FAST + scaled-probability Forward fill where it applies (include/historian_hip.h)
 IMM, IMD, IDM, IMI, IIW, EEE = 0, 1, 2, 3, 4, 5
 
 _i32p = C.POINTER(C.c_int32)

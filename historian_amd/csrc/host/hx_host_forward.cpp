@@ -18,7 +18,7 @@ static const double NEG_INF = -std::numeric_limits<double>::infinity();
 static unsigned g_fillMode = HX_LSE_EXACT;
 static bool g_deviceReady = false;
 
-void DPMatrix::setFillMode(unsigned hxFlags) { g_fillMode = hxFlags & HX_LSE_FAST; }
+void DPMatrix::setFillMode(unsigned hxFlags) { g_fillMode = hxFlags & HX_LSE_LINEAR; }
 static int g_deviceTraceback = -1;
 void DPMatrix::setDeviceTraceback(bool on) { g_deviceTraceback = on ? 1 : 0; }
 bool DPMatrix::deviceTraceback() {
@@ -39,6 +39,7 @@ static void ensureDevice() {
   hxCheck(hx_init(dev ? atoi(dev) : 0, logSumExpLookupTable.lookup, HX_LSE_TABLE_ENTRIES), "hx_init");
   const char* mode = getenv("HX_FILL_MODE");   // "fast" selects the fast log-sum-exp policy for this process
   if (mode && string(mode) == "fast") g_fillMode = HX_LSE_FAST;
+  if (mode && string(mode) == "linear") g_fillMode = HX_LSE_LINEAR;
   g_deviceReady = true;
   fillTiming.deviceInit += wallSeconds() - t0;
 }

@@ -27,6 +27,7 @@ thread_local char g_err[512] = "";
 int g_device = -1;
 double* g_tab = nullptr;      // device copy of the host-built log_sum_exp table
 double* g_fast_tab = nullptr; // device copy of the cubic table of the fast fill mode
+double* g_log_tab = nullptr;  // {c, -log c} entries of the scaled-linear Forward fill's logarithm (hx_linear.hip)
 double* g_pair_tab = nullptr; // {lookup[n], lookup[n+1]-lookup[n]} pairs, 16-byte aligned (exact fill mode)
 
 // Quadratic pieces of T(d) = log(1 + exp(-d)) on [0,10): piece k covers [k h, (k+1) h),
@@ -384,12 +385,20 @@ int hx_init(int device_ordinal, const double* lse_table, size_t n_entries) {
       pairs[2 * n + 1] = n + 1 < n_entries ? lse_table[n + 1] - lse_table[n] : 0.0;
     }
     if (g_pair_tab) { (void)hipFree(g_pair_tab); g_pair_tab = nullptr; }
+  if (g_log_tab) { (void)hipFree(g_log_tab); g_log_tab = nullptr; }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_pair_tab), pairs.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(g_pair_tab, pairs.data(), pairs.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   {
     std::vector<double> ft;
     build_fast_table(ft);
+    {
+      std::vector<double> lt((size_t)log_table_doubles());
+      build_log_table(lt.data());
+      if (g_log_tab) { (void)hipFree(g_log_tab); g_log_tab = nullptr; }
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_log_tab), lt.size() * sizeof(double)));
+      HIP_TRY(hipMemcpy(g_log_tab, lt.data(), lt.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if (g_fast_tab) { (void)hipFree(g_fast_tab); g_fast_tab = nullptr; }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_fast_tab), ft.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(g_fast_tab, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -588,6 +597,11 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   if (b->all_chain && !(b->flags & HX_FORCE_GENERIC) && !(force_dag && b->d_agg)) {
     // with a band the strip pipelines only visit in-envelope windows; everything else is -inf
     if (b->any_banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_fwd, b->fwd_total, st);
+    // HX_LSE_LINEAR on unbanded leaf pairs whose y side fits LDS (the headline workload): the recursion runs on
+    // scaled probabilities instead of table log-sum-exps (hx_linear.hip)
+    if ((b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && b->all_leaf && b->all_ylds && !b->any_banded)
+      launch_forward_leaf_linear(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_log_tab, b->yl_cols, b->yl_emis, st);
+    else
     launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, (b->flags & HX_LSE_FAST) ? g_fast_tab : g_pair_tab, (b->flags & HX_LSE_FAST) != 0,
                          b->all_leaf ? (b->all_ylds ? 2 : 1) : 0, b->any_banded, b->yl_cols, b->yl_emis, st);
   } else if (b->flags & HX_FORCE_GENERIC)

@@ -26,6 +26,12 @@ void launch_posterior_scan(const DevJob* d_jobs, int job, double lpp_threshold, 
 void launch_gather_cells(const DevJob* d_jobs, int job, const double* M, int mirrored, const int* ij, int64_t n,
                          double* out, hipStream_t st);
 
+// scaled-linear Forward fill of leaf-like pairs (hx_linear.hip); log_tab from build_log_table
+int log_table_doubles();
+void build_log_table(double* out /* [log_table_doubles()] */);
+void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* log_tab,
+                                int yl_cols, int yl_emis, hipStream_t st);
+
 void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, const double* tab,
                        bool plane_valid, hipStream_t st);
 

@@ -1,0 +1,449 @@
+// Forward fill of leaf-like pairs in SCALED LINEAR space (the HX_LSE_FAST policy of the headline path).
+//
+// The reference (src/forward.cpp:68-223) works on log-probabilities and combines them with a table-driven
+// log-sum-exp: 18 table look-ups per cell for a pair of leaf profiles.  The same recursion on the probabilities
+// themselves is 18 multiply-adds.  This kernel keeps every cell as five fp64 mantissas plus ONE integer
+// exponent per cell (p_state = m_state * 2^e), so nothing under- or overflows however long the sequences are,
+// runs the recursion with fused multiply-adds, and converts each finished cell to the reference's storage format
+// - five log-probabilities, 40 B/cell, same strip-skewed layout - with an fp64 table-plus-polynomial logarithm
+// (256 intervals, |error| < 1e-14) just before the store.  Nothing is approximated beyond fp64 rounding: the
+// results differ from the reference's by the reference's OWN table-interpolation error (~1e-9 per look-up), which
+// is what HX_LSE_FAST allows (the bit-exact policy is ExactLse3 in hx_chain.hip).
+//
+// Pipeline structure is that of k_fill_chain (hx_chain.hip): one workgroup per pair, 64-row strips dealt to the
+// waves round-robin, lane <-> row, step <-> anti-diagonal, up/diag neighbours by DPP wave_shr:1, the strip above's
+// last row block-loaded from the matrix behind a lagged LDS progress counter, the whole y side in LDS, two steps
+// per iteration so that a lane stores 16 contiguous bytes per state plane.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include "hx_device.h"
+#include "hx_lse.h"
+#include "hx_common.h"
+#include "hx_policy.h"
+#include "hx_kernels.h"
+
+namespace hx {
+
+namespace {
+
+#define HXL_PUBLISH_LAG 16
+#define HX_YL_MAX_CLS_LINEAR 64   // (hx_api.hip admits y sides of at most 63 emission classes to the LDS-resident path)
+#define HXL_EMIN (-(1 << 28))      // exponent of an all-zero cell: loses every max()
+#define HXL_RENORM_MASK 6          // mantissas are renormalised on steps with (t & 6) == 0: every 8th step
+
+struct L5 { double imm, imd, idm, imi, iiw; int e; };
+
+__device__ __forceinline__ L5 l5_zero() { return L5{0., 0., 0., 0., 0., HXL_EMIN}; }
+
+__device__ __forceinline__ int dpp_shr1_keep0(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ double dpp_shr1_keep0(double old, double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ L5 dpp_shr1_keep0(const L5& o, const L5& c) {
+  return L5{dpp_shr1_keep0(o.imm, c.imm), dpp_shr1_keep0(o.imd, c.imd), dpp_shr1_keep0(o.idm, c.idm),
+            dpp_shr1_keep0(o.imi, c.imi), dpp_shr1_keep0(o.iiw, c.iiw), dpp_shr1_keep0(o.e, c.e)};
+}
+// lane l receives v of lane l+1 (lane 63 keeps its own)
+__device__ __forceinline__ int dpp_shl1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ double dpp_shl1(double v) {
+  return __hiloint2double(dpp_shl1(__double2hiint(v)), dpp_shl1(__double2loint(v)));
+}
+// lane l >= 1 receives c of lane l-1; lane 0 receives its own o
+__device__ __forceinline__ L5 dpp_shr1_old(const L5& o, const L5& c) {
+  return L5{dpp_shr1_keep0(o.imm, c.imm), dpp_shr1_keep0(o.imd, c.imd), dpp_shr1_keep0(o.idm, c.idm),
+            dpp_shr1_keep0(o.imi, c.imi), dpp_shr1_keep0(o.iiw, c.iiw), dpp_shr1_keep0(o.e, c.e)};
+}
+
+// log(m * 2^e) for m >= 0: frexp, one 16-byte LDS entry {c, -log(c)} with c ~ 1/centre of the mantissa's
+// interval (512 intervals over [0.5, 1)), and log1p(f*c - 1) by a cubic (|f*c - 1| <= 2^-10: truncation error
+// < 2.3e-13, below the spacing of fp64 numbers at the magnitude of these log-probabilities).  The table is indexed
+// by the two low exponent bits and nine mantissa bits of the frexp mantissa, so that m == 0 (mantissa 0.0) lands on
+// entry 0 = {0, -inf} and comes out as -inf without a compare: real entries are 1024..1535.
+#define HXL_LOG_ENTRIES 1536
+__device__ __forceinline__ double log_scaled(double m, int e, const HX_LDS double* ltab) {
+  typedef double d2v __attribute__((ext_vector_type(2)));
+#if HX_ABLATE == 22      // no logarithm
+  return m + (double)e;
+#endif
+  const double f = __builtin_amdgcn_frexp_mant(m);           // [0.5, 1), or 0
+  const int k = __builtin_amdgcn_frexp_exp(m);
+  const unsigned byte_off = ((unsigned)__double2hiint(f) >> 7) & 0x7FF0u;
+  const d2v ce = *(const HX_LDS d2v*)((const HX_LDS char*)ltab + byte_off);
+  const double r = __builtin_fma(f, ce.x, -1.0);
+  double p = __builtin_fma(r, 1.0 / 3.0, -0.5);
+  p = __builtin_fma(p, r, 1.0);
+  const double lf = __builtin_fma(p, r, ce.y);
+  return __builtin_fma((double)(e + k), 0.693147180559945309417, lf);
+}
+
+// a stored log cell -> mantissas with a common exponent (only on the wrap-around link, see the kernel)
+__device__ __forceinline__ L5 from_logs(double a, double b, double c, double d, double g) {
+  const double mx = vmax(vmax(vmax(a, b), vmax(c, d)), g);
+  if (!(mx > HX_NEG_INF)) return l5_zero();
+  const double n = __builtin_rint(mx * 1.44269504088896340736);
+  const double hi = n * 0.693147180369123816490, lo = n * 1.90821492927058770002e-10;   // ln2 in two parts
+  L5 r;
+  r.imm = exp((a - hi) - lo);
+  r.imd = exp((b - hi) - lo);
+  r.idm = exp((c - hi) - lo);
+  r.imi = exp((d - hi) - lo);
+  r.iiw = exp((g - hi) - lo);
+  r.e = (int)n;
+  return r;
+}
+
+// LDS plan of a workgroup (byte offsets into the dynamic allocation, computed by plan_lds on the host).  The
+// logarithm table's entries 1..1023 are never addressed: the y side is put into that hole when it fits.
+struct LdsPlan { int elds, ycol, ring, yclass, flags, total; };
+
+#define HXL_RING 64                // columns of the strip above's last row in flight between two waves
+#define HXL_STAGE 128              // wave 0's staging ring on the wrap-around link: two 64-column blocks
+
+template <int W>
+__global__ void __launch_bounds__(W * 64, 4)   // four waves per SIMD: 128 vector registers
+k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const double* __restrict__ log_tab,
+                      const LdsPlan plan) {
+  constexpr int THREADS = W * 64;
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  double* ltab = reinterpret_cast<double*>(lds);
+  double* elds = reinterpret_cast<double*>(lds + plan.elds);
+  unsigned* ycol = reinterpret_cast<unsigned*>(lds + plan.ycol);
+  double* yclass = reinterpret_cast<double*>(lds + plan.yclass);
+  volatile int* prog = reinterpret_cast<volatile int*>(lds + plan.flags);   // [W] columns written to the wave's ring (+ base)
+  volatile int* cons = prog + W;                                             // [W] columns the wave has taken from the ring above
+  volatile int* drain = cons + W;                                            // [1] wrap-around link: columns of wave W-1's strip that are in memory
+  const DevJob& J = jobs[blockIdx.x];
+  // (the table first: the y side may sit in its hole)
+  for (int k = threadIdx.x; k < 2; k += THREADS) ltab[k] = log_tab[k];
+  for (int k = 2048 + threadIdx.x; k < 2 * HXL_LOG_ENTRIES; k += THREADS) ltab[k] = log_tab[k];
+  if (threadIdx.x < 2 * W + 1) prog[threadIdx.x] = 0;
+  {
+    // the y side, in linear space: per column {emission class, not ready ? 0xFFFF : 0}, per class
+    // {exp(rootsuby), exp(insy)}, and exp() of the padded class-pair emission table
+    const int Ky1 = J.y.n_cls + 1, Kx1 = J.x.n_cls + 1;
+    // (64 words of padding on either side: a lane whose column is outside the lattice reads the edge column's word)
+    for (int jp = threadIdx.x; jp < J.n_cols + 128; jp += THREADS) {
+      const int j = jp < 64 ? 0 : (jp - 64 >= J.n_cols ? J.n_cols - 1 : jp - 64);
+      ycol[jp] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0xFFFF0000u : 0u);
+    }
+    for (int c = threadIdx.x; c < Ky1; c += THREADS) {
+      const bool real = c < J.y.n_cls;
+      const int rep = real ? J.y.cls_rep[c] : 0;
+      yclass[2 * c] = real ? exp(J.y.pack[4 * (size_t)rep + 1]) : 0.;
+      yclass[2 * c + 1] = real ? exp(J.y.pack[4 * (size_t)rep + 2]) : 0.;
+    }
+    for (int e = threadIdx.x; e < Kx1 * Ky1; e += THREADS) elds[e] = exp(J.emis_pad[e]);
+  }
+  __syncthreads();
+  const int R = J.n_rows, Cc = J.n_cols;
+  const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6);
+  const int64_t plane = J.plane, ss = J.strip_stride;
+  HX_GLOBAL double* __restrict__ M = as_global(J.fwd);
+  const HX_GLOBAL d4v* xpack = (const HX_GLOBAL d4v*)as_global(J.x.pack);
+  // the 18 transition probabilities (src/pairhmm.cpp:17-43), pinned in scalar registers
+  double P[5][5];
+#pragma unroll
+  for (int a = 0; a < 5; ++a)
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+      const bool used = d == 0 || (d == 1 && a != 4) || (d == 2 && a != 3) || (d == 3 && (a == 0 || a == 3)) ||
+                        (d == 4 && (a == 0 || a == 3 || a == 4));
+      if (!used) { P[a][d] = 0.; continue; }
+      const double pv = exp(J.T[a][d]);            // (wave-uniform, but computed by the vector unit)
+      double v = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(pv)), __builtin_amdgcn_readfirstlane(__double2loint(pv)));
+      asm volatile("" : "+s"(v));
+      P[a][d] = v;
+    }
+  volatile HX_LDS int* progp = (volatile HX_LDS int*)prog;
+  volatile HX_LDS int* consp = (volatile HX_LDS int*)cons;
+  volatile HX_LDS int* drainp = (volatile HX_LDS int*)drain;
+  const HX_LDS double* lt = (const HX_LDS double*)ltab;
+  HX_LDS d2v* ring_mine = (HX_LDS d2v*)(lds + plan.ring) + (size_t)wave * (HXL_RING * 3);
+  const int n_strips = (R + 63) / 64;
+  const int prev_wave = (wave + W - 1) % W, next_wave = (wave + 1) % W;
+  // Strips are dealt round-robin, so with more strips than waves the last wave feeds the first one's NEXT strip, which
+  // starts a whole sweep later: that link cannot be a bounded ring (the waves would wait for each other in a circle).
+  // It goes through the matrix instead - wave W-1 publishes how many columns of its last row have reached memory, wave 0
+  // block-loads them 64 at a time, converts them back to mantissas + exponent and stages them in a ring of its own.
+  HX_LDS d2v* staging = (HX_LDS d2v*)(lds + plan.ring) + (size_t)W * (HXL_RING * 3);   // [HXL_STAGE] entries
+  const HX_LDS d2v* ring_prev = (const HX_LDS d2v*)(lds + plan.ring) + (size_t)prev_wave * (HXL_RING * 3);
+
+  for (int s = wave; s < n_strips; s += W) {
+    const int row0 = s * 64;
+    const int i0 = row0 + lane;
+    const bool row_valid = i0 < R;
+    // x-side constants of the lane's row, in linear space; an absent row computes zeros
+    double fx, f_imd, f_iiw;
+    int x_wait;                                    // x state not ready: 2^29, else 0
+    unsigned eoff;
+    {
+      const int ic = row_valid ? i0 : 0;
+      const d4v p = xpack[ic];
+      fx = row_valid ? exp(p.x) : 0.;
+      f_imd = row_valid ? exp(p.x + p.y) : 0.;
+      f_iiw = row_valid ? exp(p.x + p.z) : 0.;
+      x_wait = (row_valid && !(p.w < 0.0)) ? 0 : (1 << 29);
+      eoff = (unsigned)J.x.ecls[ic] * (unsigned)(J.y.n_cls + 1);
+    }
+    L5 ca = l5_zero(), cb = l5_zero(), ua = l5_zero(), ub = l5_zero();
+    const bool has_above = s > 0, has_below = s + 1 < n_strips;
+    const bool wrap_in = has_above && wave == 0;             // the strip above went through memory (W > 1: s >= W)
+    const bool wrap_out = has_below && wave == W - 1;        // this strip's last row is read back from memory
+    const bool ring_out = has_below && !wrap_out;
+    // column sequence numbers: column j of strip s is number (s / W) * Cc + j of its wave's ring
+    const int above_base = ((s - 1) / W) * Cc;
+    const int my_base = (s / W) * Cc;
+    const int64_t store_base2 = (int64_t)s * ss + (lane << 1);
+    const int nsteps = Cc + 63;
+
+    // The strip above's last row arrives through that wave's LDS ring, one cell {5 mantissas, exponent} per
+    // column: the producer's lane 63 writes it the moment it is computed, lane 0 of this wave needs it 64 + a few
+    // steps later.  The DPP shift that hands every lane its upper neighbour's new cell (wave_shr:1) leaves lane 0
+    // untouched - with the ring entry as its `old` operand, lane 0 receives the boundary cell in the same instruction.
+    auto wait_for = [&](const int cols) {          // columns of the strip above that must have been written
+      const int need = above_base + (cols < Cc ? cols : Cc);
+      while (progp[prev_wave] < need) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");               // the ring reads below stay below
+    };
+    const HX_LDS d2v* ring_above = wrap_in ? (const HX_LDS d2v*)staging : ring_prev;
+    const int ring_base = wrap_in ? 0 : above_base;
+    const int ring_mask = wrap_in ? HXL_STAGE - 1 : HXL_RING - 1;
+    auto ring_entry = [&](const int col) -> L5 {   // (uniform address: a broadcast read)
+      const HX_LDS d2v* q = ring_above + (size_t)((ring_base + col) & ring_mask) * 3;
+      const d2v a = q[0], b = q[1], c = q[2];
+      return L5{a.x, a.y, b.x, b.y, c.x, __double2loint(c.y)};
+    };
+    // wrap-around link: stage columns [c0, c0 + 64) of the strip above's last row
+    auto stage_block = [&](const int c0) {
+      const int hi = (c0 + 64 < Cc) ? c0 + 64 : Cc;
+      const int need = above_base + hi;
+      while (drainp[0] < need) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      const int jj = c0 + lane;
+      if (jj < Cc) {
+        const int64_t sl = cell_slot(ss, row0 - 1, jj);
+        // agent-scope relaxed loads: served by L2, never by a stale L1 line
+        const double a = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double b = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double c = __hip_atomic_load(M + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double d = __hip_atomic_load(M + 3 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double g = __hip_atomic_load(M + 4 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const L5 v = from_logs(a, b, c, d, g);
+        HX_LDS d2v* q = staging + (size_t)(jj & (HXL_STAGE - 1)) * 3;
+        q[0] = d2v{v.imm, v.imd};
+        q[1] = d2v{v.idm, v.imi};
+        q[2] = d2v{v.iiw, __hiloint2double(0, v.e)};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (same wave reads them back: LDS operations complete in order)
+    };
+    if (has_above) {
+      if (wrap_in) stage_block(0); else wait_for(8);
+      const L5 b0 = ring_entry(0);
+      if (lane == 0) ua = b0;                      // (row0-1, 0) for step 0
+    }
+    // one anti-diagonal step: the lane's new cell from left (own previous), u1 = (i-1, j), u2 = (i-1, j-1)
+    auto step = [&](const int t, const L5& left, L5& out, L5& u1, L5& u2, const unsigned w) {
+      L5 nb = l5_zero();                           // (row0-1, t+1): lane 0's upper neighbour of the next step
+      if (has_above && t + 1 < Cc) {
+        if (wrap_in) {
+          if ((t & 63) == 63) stage_block(t + 1);
+        } else if ((t & 7) == 7) {
+          if (lane == 0) consp[wave] = above_base + t;     // the ring's slots up to column t may be reused
+          wait_for(t + 9);
+        }
+        nb = ring_entry(t + 1);
+      }
+      // y-side constants of column j = t - lane (cells outside the lattice only feed cells outside it)
+      const unsigned c = w & 0xFFFFu;
+      const d2v rc = reinterpret_cast<const d2v*>(yclass)[c];
+      const int y_wait = (int)((w >> 16) << 13);   // y state not ready: 2^29, else 0
+      const double em = elds[eoff + c];
+      // the five sums of src/forward.cpp:103-115,139-150,171-180 on probabilities
+      double s_imd = u1.imm * P[0][1];
+      double s_iiw = u1.imm * P[0][4];
+      double s_idm = left.imm * P[0][2];
+      double s_imi = left.imm * P[0][3];
+      double s_imm = u2.imm * P[0][0];
+      s_imd = __builtin_fma(u1.imd, P[1][1], s_imd);
+      s_iiw = __builtin_fma(u1.imi, P[3][4], s_iiw);
+      s_idm = __builtin_fma(left.imd, P[1][2], s_idm);
+      s_imi = __builtin_fma(left.imi, P[3][3], s_imi);
+      s_imm = __builtin_fma(u2.imd, P[1][0], s_imm);
+      s_imd = __builtin_fma(u1.idm, P[2][1], s_imd);
+      s_iiw = __builtin_fma(u1.iiw, P[4][4], s_iiw);
+      s_idm = __builtin_fma(left.idm, P[2][2], s_idm);
+      s_imm = __builtin_fma(u2.idm, P[2][0], s_imm);
+      s_imd = __builtin_fma(u1.imi, P[3][1], s_imd);
+      s_idm = __builtin_fma(left.iiw, P[4][2], s_idm);
+      s_imm = __builtin_fma(u2.imi, P[3][0], s_imm);
+      s_imm = __builtin_fma(u2.iiw, P[4][0], s_imm);
+      // common exponent of the new cell, and the three groups brought to it; a state that may not be entered
+      // (y or x state not ready: src/forward.cpp:97,133) is shifted out of the fp64 range, i.e. to zero
+      int E = left.e > u1.e ? left.e : u1.e;
+      E = E > u2.e ? E : u2.e;
+      const int du = (u1.e - E) - y_wait, dl = (left.e - E) - x_wait, dd = u2.e - E;
+      out.imd = __builtin_ldexp(s_imd * f_imd, du);
+      out.iiw = __builtin_ldexp(s_iiw * f_iiw, du);
+      out.idm = __builtin_ldexp(s_idm * rc.x, dl);
+      out.imi = __builtin_ldexp(s_imi * rc.y, dl);
+      out.imm = __builtin_ldexp(s_imm * (fx * em), dd);
+      out.e = E;
+      if (s == 0 && t == 0) {                      // wave-uniform: cell (0,0), lpStart() = 0 (src/forward.cpp:73)
+        if (lane == 0) { out.imm = 1.0; out.e = 0; }
+      }
+      if ((t & HXL_RENORM_MASK) == 0) {            // wave-uniform
+        const double mx = vmax(vmax(vmax(out.imm, out.imd), vmax(out.idm, out.imi)), out.iiw);
+        const int k = __builtin_amdgcn_frexp_exp(mx);
+        out.imm = __builtin_ldexp(out.imm, -k);
+        out.imd = __builtin_ldexp(out.imd, -k);
+        out.idm = __builtin_ldexp(out.idm, -k);
+        out.imi = __builtin_ldexp(out.imi, -k);
+        out.iiw = __builtin_ldexp(out.iiw, -k);
+        out.e = mx > 0. ? out.e + k : HXL_EMIN;
+      }
+      // the strip's last row goes to the wave below through the ring (lane 63, column t - 63)
+      if (ring_out && t >= 63 && t - 63 < Cc) {
+        const int col = t - 63;
+        if ((col & 7) == 0) {
+          // flow control: the slots of the next eight columns must have been consumed
+          const int need = my_base + col + 8 - HXL_RING;
+          while (consp[next_wave] < need) __builtin_amdgcn_s_sleep(1);
+          asm volatile("" ::: "memory");
+        }
+        if (lane == 63) {
+          HX_LDS d2v* q = ring_mine + (size_t)((my_base + col) & (HXL_RING - 1)) * 3;
+          q[0] = d2v{out.imm, out.imd};
+          q[1] = d2v{out.idm, out.imi};
+          q[2] = d2v{out.iiw, __hiloint2double(0, out.e)};
+        }
+        if ((col & 7) == 7 || col == Cc - 1) {
+          asm volatile("" ::: "memory");           // data before flag
+          if (lane == 63) progp[wave] = my_base + col + 1;   // (LDS operations of a wave complete in order)
+        }
+      }
+      u2 = dpp_shr1_old(nb, out);
+    };
+
+    // column words, fetched one step ahead (ycol is padded by 64 words on either side)
+    unsigned wnext = ycol[64 - lane];
+    auto next_word = [&](const int t) -> unsigned {
+      const unsigned w = wnext;
+      wnext = ycol[t + 65 - lane];
+      return w;
+    };
+
+    for (int t = 0; t < nsteps; t += 2) {
+      step(t, cb, ca, ua, ub, next_word(t));
+      const double l0 = log_scaled(ca.imm, ca.e, lt), l1 = log_scaled(ca.imd, ca.e, lt),
+                   l2 = log_scaled(ca.idm, ca.e, lt), l3 = log_scaled(ca.imi, ca.e, lt),
+                   l4 = log_scaled(ca.iiw, ca.e, lt);
+      double h0 = HX_NEG_INF, h1 = HX_NEG_INF, h2 = HX_NEG_INF, h3 = HX_NEG_INF, h4 = HX_NEG_INF;
+      if (t + 1 < nsteps) {
+        step(t + 1, ca, cb, ub, ua, next_word(t + 1));
+        h0 = log_scaled(cb.imm, cb.e, lt); h1 = log_scaled(cb.imd, cb.e, lt);
+        h2 = log_scaled(cb.idm, cb.e, lt); h3 = log_scaled(cb.imi, cb.e, lt);
+        h4 = log_scaled(cb.iiw, cb.e, lt);
+      }
+      {
+        // t64 = j + (i & 63) = t: both cells of the step pair are adjacent in the strip-skewed layout
+        const int64_t sl = store_base2 + ((int64_t)(t >> 1) << 7);
+        HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
+        const int64_t plane2 = plane >> 1;
+#if HX_ABLATE == 21      // no stores (keeps the values alive)
+        if (l0 + l1 + l2 + l3 + l4 + h0 + h1 + h2 + h3 + h4 == 12345.678) M2[0] = d2v{l0, h0};
+#elif HX_ABLATE == 23    // plain stores
+        M2[0] = d2v{l0, h0};
+        M2[plane2] = d2v{l1, h1};
+        M2[2 * plane2] = d2v{l2, h2};
+        M2[3 * plane2] = d2v{l3, h3};
+        M2[4 * plane2] = d2v{l4, h4};
+#else
+        // write-once data that this kernel never reads again (the wrap-around link reads 1/64 of it, from L2 or
+        // memory): non-temporal stores, measured 17.4 -> 15.8 ms on the headline workload
+        __builtin_nontemporal_store(d2v{l0, h0}, &M2[0]);
+        __builtin_nontemporal_store(d2v{l1, h1}, &M2[plane2]);
+        __builtin_nontemporal_store(d2v{l2, h2}, &M2[2 * plane2]);
+        __builtin_nontemporal_store(d2v{l3, h3}, &M2[3 * plane2]);
+        __builtin_nontemporal_store(d2v{l4, h4}, &M2[4 * plane2]);
+#endif
+      }
+      if (wrap_out) {
+        // wrap-around link: a column counts once its stores have left the wave.  Vector-memory operations retire in
+        // issue order and every iteration issues five stores (and nothing else), so everything stored
+        // HXL_PUBLISH_LAG steps = 8 iterations ago is older than the wave's 40 youngest operations.
+        const int fin = (t + 2 < nsteps ? t + 2 : nsteps) - 63;
+        if (fin >= Cc) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) drainp[0] = my_base + Cc;
+        } else {
+          const int done = fin - HXL_PUBLISH_LAG;
+          if (done > 0 && ((done >> 6) != ((done - 2) >> 6))) {
+            asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+            if (lane == 0) drainp[0] = my_base + done;
+          }
+        }
+      }
+    }
+    if (has_above && !wrap_in && lane == 0) consp[wave] = above_base + Cc;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wave == 0 && lane == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
+}
+
+}  // namespace
+
+// see log_scaled: entry 0 = {0, -inf}; entries 1024 + k, k < 512: {c, -log(c)} with c = 1 / (centre of interval k of [0.5, 1))
+int log_table_doubles() { return 2 * HXL_LOG_ENTRIES; }
+void build_log_table(double* out) {
+  for (int k = 0; k < 2 * HXL_LOG_ENTRIES; ++k) out[k] = 0.;
+  out[1] = -HUGE_VAL;
+  for (int k = 0; k < 512; ++k) {
+    const double centre = 0.5 * (1.0 + (k + 0.5) / 512.0);
+    const double c = 1.0 / centre;
+    out[2 * (1024 + k)] = c;
+    out[2 * (1024 + k) + 1] = -log(c);
+  }
+}
+
+static LdsPlan plan_lds(int W, int yl_cols, int yl_emis) {
+  LdsPlan p;
+  const int table = 16 * HXL_LOG_ENTRIES, hole = 16 * 1024;
+  const int elds = 8 * yl_emis, ycol = 4 * (yl_cols + 128);
+  int end = table;
+  if (16 + elds + ycol <= hole) { p.elds = 16; p.ycol = 16 + elds; }
+  else { p.elds = end; p.ycol = end + elds; end += (elds + ycol + 15) & ~15; }
+  p.ring = end; end += (W * HXL_RING + HXL_STAGE) * 48;     // one ring per wave + wave 0's staging ring
+  p.yclass = end; end += 16 * HX_YL_MAX_CLS_LINEAR;
+  p.flags = end; end += 4 * (2 * W + 1);
+  p.total = (end + 15) & ~15;
+  return p;
+}
+
+void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* log_tab,
+                                int yl_cols, int yl_emis, hipStream_t st) {
+  const dim3 g(n_jobs);
+#define HXL_LAUNCH(W_) do { const LdsPlan p = plan_lds(W_, yl_cols, yl_emis); \
+    hipLaunchKernelGGL((k_forward_leaf_linear<W_>), g, dim3(W_ * 64), p.total, st, d_jobs, tab, log_tab, p); } while (0)
+  const char* v = getenv("HX_LINEAR_WAVES");     // tuning / test hook: waves per pair (any count works for any size)
+  const int forced = v ? atoi(v) : 0;
+  if (forced == 1) HXL_LAUNCH(1);
+  else if (forced == 2) HXL_LAUNCH(2);
+  else if (forced == 4) HXL_LAUNCH(4);
+  else if (forced == 8) HXL_LAUNCH(8);
+  else if (forced == 16) HXL_LAUNCH(16);
+  else if (max_rows <= 64) HXL_LAUNCH(1);
+  else if (max_rows <= 128) HXL_LAUNCH(2);
+  else if (max_rows <= 256) HXL_LAUNCH(4);
+  // more pairs than compute units: eight waves per pair, two pairs per CU (less pipeline fill per pair)
+  else if (max_rows <= 512 || n_jobs > 256) HXL_LAUNCH(8);
+  else HXL_LAUNCH(16);
+#undef HXL_LAUNCH
+}
+
+}  // namespace hx

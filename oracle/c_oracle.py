@@ -49,9 +49,12 @@ def _ptr(a):
     return a.ctypes.data_as(_f64p)
 
 
-def forward(x, y, hmm, max_distance=-1):
-    """Returns dict(cells [R][Cc][5], lp_end, subx, suby, insx, rootsubx, insy, rootsuby)."""
+def forward(x, y, hmm, max_distance=-1, true_math=False):
+    """Returns dict(cells [R][Cc][5], lp_end, subx, suby, insx, rootsubx, insy, rootsuby).
+    true_math: the cell recursion sums probabilities with libm's log1p/exp instead of the reference's table
+    operator (a second yardstick for the scaled-linear HIP kernel; everything else stays the reference's)."""
     lib = load()
+    lib.orc_set_true_math(1 if true_math else 0)
     jobs = capi.make_jobs([(x, y, hmm, max_distance)])
     R, Cc, ca = x.n_states - 1, y.n_states - 1, hmm.alph_size * hmm.components
     cells = np.empty((R, Cc, 5))
@@ -60,6 +63,7 @@ def forward(x, y, hmm, max_distance=-1):
     insx, rsx, insy, rsy = (np.empty(x.n_states), np.empty(x.n_states), np.empty(y.n_states), np.empty(y.n_states))
     rc = lib.orc_forward(jobs, _ptr(cells), C.byref(lp_end), _ptr(subx), _ptr(suby), _ptr(insx), _ptr(rsx),
                          _ptr(insy), _ptr(rsy))
+    lib.orc_set_true_math(0)
     assert rc == 0, rc
     return dict(cells=cells, lp_end=lp_end.value, subx=subx, suby=suby, insx=insx, rootsubx=rsx, insy=insy,
                 rootsuby=rsy)

@@ -64,6 +64,22 @@ static inline double lse(double a, double b) {
 
 double orc_log_sum_exp(double a, double b) { return lse(a, b); }
 
+/* Test switch for the Forward recursion only (not the profile preparation, emission terms or lpEnd, which keep
+ * the reference's operator): log(exp(a) + exp(b)) evaluated with libm and without the reference's table or its
+ * truncation of differences >= 10.  The scaled-linear HIP kernel (hx_linear.hip) computes the recursion on
+ * probabilities, i.e. in this arithmetic; the tests bound its distance to this as well as to the reference's. */
+static int g_true_math;
+void orc_set_true_math(int on) { g_true_math = on; }
+static inline double cell_lse(double a, double b) {
+  double max, diff;
+  if (!g_true_math) return lse(a, b);
+  if (a == b) { max = a; diff = 0; }
+  else if (a < b) { max = b; diff = b - a; }
+  else { max = a; diff = a - b; }
+  if (isnan(diff) || isinf(diff)) return max;
+  return max + log1p(exp(-diff));
+}
+
 typedef struct {
   int n;
   int empty;
@@ -178,6 +194,7 @@ int orc_forward(const hx_pair_job* job, double* cells, double* lp_end_out,
       double* c = CELL(i, j);
       c[0] = c[1] = c[2] = c[3] = c[4] = NEG_INF;
     }
+#define lse(a, b) cell_lse(a, b)
   CELL(0, 0)[0] = 0;
   for (i = 0; i < R; ++i) {
     const int xnull = x->is_null[i];
@@ -240,6 +257,7 @@ int orc_forward(const hx_pair_job* job, double* cells, double* lp_end_out,
       dest[0] = imm; dest[1] = imd; dest[2] = idm; dest[3] = imi; dest[4] = iiw;
     }
   }
+#undef lse
   lp_end = NEG_INF;
   for (kx = x->in_off[R]; kx < x->in_off[R + 1]; ++kx)
     for (ky = y->in_off[Cc]; ky < y->in_off[Cc + 1]; ++ky) {

@@ -50,6 +50,20 @@ def test_protein_2x2000_pair():
         H.assert_same_bits(got[k], want["cells"][i, j], "cell (%d,%d)" % (i, j))
     # every cell of the exact fill, bit for bit
     H.assert_same_bits(r["be"].read_matrix(0), want["cells"], "2x2000 forward cells")
+    # HX_LSE_LINEAR runs this pair on scaled probabilities (hx_linear.hip): exact arithmetic up to fp64 rounding, so it
+    # differs from the reference by the reference's own truncation of log-sum-exp terms below e^-10
+    bl = capi.Batch([r["img"]], capi.HX_LSE_LINEAR)
+    bl.forward()
+    lp_lin = float(bl.lp_end()[0])
+    assert abs(lp_lin - want["lp_end"]) <= 1e-4 * abs(want["lp_end"])   # north_star tolerance
+    assert abs(lp_lin - want["lp_end"]) <= 1e-5 * abs(want["lp_end"])   # what it actually achieves
+    true = c_oracle.forward(*r["img"], true_math=True)                  # the oracle's recursion in libm arithmetic
+    assert abs(lp_lin - true["lp_end"]) <= 1e-12 * abs(true["lp_end"])
+    lin = bl.read_matrix(0)
+    assert np.array_equal(np.isneginf(lin), np.isneginf(true["cells"]))
+    fin = np.isfinite(lin)
+    assert np.max(np.abs(lin[fin] - true["cells"][fin])) < 1e-8
+    bl.close()
     r["be"].close()
     r["bf"].close()
 

@@ -302,3 +302,45 @@ def test_fast_mode_stays_within_tolerance_of_exact(kind):
         assert abs(se[k] - sf[k]) <= 1e-9 * abs(se[k])
     be.close()
     bf.close()
+
+
+@pytest.mark.parametrize("waves", [0, 1, 2, 8])
+def test_linear_mode_on_unbanded_leaf_pairs_runs_on_scaled_probabilities(waves, monkeypatch):
+    # HX_LSE_LINEAR on unbanded leaf pairs (the headline workload) takes the scaled-linear kernel (hx_linear.hip):
+    # the recursion on probabilities with a per-cell exponent, converted to log-probabilities at the store.
+    # Every workgroup shape (1, 2, 4, 8, 16 waves; more strips than waves), DNA / protein / mixture models,
+    # empty sequences.  Two yardsticks:
+    #  * the oracle with the cell recursion in libm arithmetic (log1p(exp()) instead of the reference's table and
+    #    its truncation of differences >= 10; profile preparation, emission terms and lpEnd as in the reference):
+    #    same -inf pattern, finite cells within 1e-9, lpEnd within 1e-12 relative - the kernel is exact up to fp64
+    #    rounding;
+    #  * the reference's own arithmetic (the bit-exact fill): lpEnd within 1e-5 relative, 10x inside north_star's
+    #    1e-4 - what remains is the reference's truncation error (each dropped term is < e^-10 of its sum).
+    # waves != 0 forces the waves per pair (HX_LINEAR_WAVES): with fewer waves than 64-row strips the last wave's
+    # rows reach the first wave's next strip through the matrix instead of an LDS ring (hx_linear.hip)
+    if waves:
+        monkeypatch.setenv("HX_LINEAR_WAVES", str(waves))
+    aa = "arndcqeghilkmfpstwyv"
+    groups = [[H.leaf_case(301, 40, 45), H.leaf_case(312, 1, 1), H.leaf_case(305, 63, 64, alphabet=aa, jc=False, tl=.3, tr=.2)],
+              [H.leaf_case(306, 100, 130), H.leaf_case(307, 127, 20, alphabet=aa, components=2, jc=False)],
+              [H.leaf_case(308, 250, 200, alphabet=aa, jc=False)],
+              [H.leaf_case(309, 500, 300)],
+              [H.leaf_case(310, 1100, 700, alphabet=aa, jc=False, tl=.2, tr=.3), H.leaf_case(311, 700, 1500)]]
+    for cases in groups:
+        imgs = [H.job_images(f) for f in cases]
+        be = capi.Batch(imgs)
+        bf = capi.Batch(imgs, capi.HX_LSE_LINEAR)
+        be.forward()
+        bf.forward()
+        le, lf = be.lp_end(), bf.lp_end()
+        for k, (x, y, hmm, md) in enumerate(imgs):
+            want = c_oracle.forward(x, y, hmm, md, true_math=True)
+            mf = bf.read_matrix(k, 0)
+            assert not np.isnan(mf).any()
+            assert np.array_equal(np.isneginf(want["cells"]), np.isneginf(mf)), "job %d: -inf pattern" % k
+            fin = np.isfinite(mf)
+            assert np.max(np.abs(want["cells"][fin] - mf[fin]), initial=0.) < 1e-9, "job %d" % k
+            assert abs(want["lp_end"] - lf[k]) <= 1e-12 * abs(lf[k])
+            assert abs(le[k] - lf[k]) <= 1e-5 * abs(le[k])
+        be.close()
+        bf.close()

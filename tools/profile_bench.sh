@@ -17,9 +17,11 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
     for f in glob.glob("gpurun_out/$tag/pmc_%s/*/*counter_collection.csv"%c):
         agg=collections.defaultdict(lambda: [0.0,0])
         for r in csv.DictReader(open(f)):
-            if "k_fill_chain<0" in r["Kernel_Name"] and r["Counter_Name"]==c:
-                key="fast" if "FastLse" in r["Kernel_Name"] else "exact"
-                agg[key][0]+=float(r["Counter_Value"]); agg[key][1]+=1
+            if r["Counter_Name"]!=c: continue
+            if "k_forward_leaf_linear" in r["Kernel_Name"]: key="linear"
+            elif "k_fill_chain<0" in r["Kernel_Name"]: key="fast" if "FastLse" in r["Kernel_Name"] else "exact"
+            else: continue
+            agg[key][0]+=float(r["Counter_Value"]); agg[key][1]+=1
         for k,(v,n) in agg.items(): res[c+":"+k]=v/n
 print(json.dumps(res))
 open("gpurun_out/$tag/pmc_summary.json","w").write(json.dumps(res,indent=1))
