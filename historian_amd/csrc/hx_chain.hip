@@ -603,11 +603,12 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
         const int64_t plane2 = plane >> 1;
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-          M2[k] = d2v{oa[k].imm, ob[k].imm};
-          M2[plane2 + k] = d2v{oa[k].imd, ob[k].imd};
-          M2[2 * plane2 + k] = d2v{oa[k].idm, ob[k].idm};
-          M2[3 * plane2 + k] = d2v{oa[k].imi, ob[k].imi};
-          M2[4 * plane2 + k] = d2v{oa[k].iiw, ob[k].iiw};
+          // write-once data: non-temporal stores (the 1/64 of it that the strip below reads back comes from L2 or memory)
+          __builtin_nontemporal_store(d2v{oa[k].imm, ob[k].imm}, &M2[k]);
+          __builtin_nontemporal_store(d2v{oa[k].imd, ob[k].imd}, &M2[plane2 + k]);
+          __builtin_nontemporal_store(d2v{oa[k].idm, ob[k].idm}, &M2[2 * plane2 + k]);
+          __builtin_nontemporal_store(d2v{oa[k].imi, ob[k].imi}, &M2[3 * plane2 + k]);
+          __builtin_nontemporal_store(d2v{oa[k].iiw, ob[k].iiw}, &M2[4 * plane2 + k]);
         }
       }
       // publish progress.  The strip's last row has finished column (t + 1) - (SR - 1); a

@@ -98,7 +98,7 @@ __device__ __forceinline__ L5 from_logs(double a, double b, double c, double d, 
 
 // LDS plan of a workgroup (byte offsets into the dynamic allocation, computed by plan_lds on the host).  The
 // logarithm table's entries 1..1023 are never addressed: the y side is put into that hole when it fits.
-struct LdsPlan { int elds, ycol, ring, yclass, flags, total; };
+struct LdsPlan { int elds, ycol, ring, yclass, flags, zero, total; };
 
 #define HXL_RING 64                // columns of the strip above's last row in flight between two waves
 #define HXL_STAGE 128              // wave 0's staging ring on the wrap-around link: two 64-column blocks
@@ -122,12 +122,16 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
   for (int k = threadIdx.x; k < 2; k += THREADS) ltab[k] = log_tab[k];
   for (int k = 2048 + threadIdx.x; k < 2 * HXL_LOG_ENTRIES; k += THREADS) ltab[k] = log_tab[k];
   if (threadIdx.x < 2 * W + 1) prog[threadIdx.x] = 0;
+  if (threadIdx.x == 0) {
+    d2v* z = reinterpret_cast<d2v*>(lds + plan.zero);
+    z[0] = d2v{0., 0.}; z[1] = d2v{0., 0.}; z[2] = d2v{0., __hiloint2double(0, HXL_EMIN)};
+  }
   {
     // the y side, in linear space: per column {emission class, not ready ? 0xFFFF : 0}, per class
     // {exp(rootsuby), exp(insy)}, and exp() of the padded class-pair emission table
     const int Ky1 = J.y.n_cls + 1, Kx1 = J.x.n_cls + 1;
     // (64 words of padding on either side: a lane whose column is outside the lattice reads the edge column's word)
-    for (int jp = threadIdx.x; jp < J.n_cols + 128; jp += THREADS) {
+    for (int jp = threadIdx.x; jp < J.n_cols + 130; jp += THREADS) {
       const int j = jp < 64 ? 0 : (jp - 64 >= J.n_cols ? J.n_cols - 1 : jp - 64);
       ycol[jp] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0xFFFF0000u : 0u);
     }
@@ -199,7 +203,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     const int above_base = ((s - 1) / W) * Cc;
     const int my_base = (s / W) * Cc;
     const int64_t store_base2 = (int64_t)s * ss + (lane << 1);
-    const int nsteps = Cc + 63;
+    const int nsteps = (Cc + 64) & ~1;             // Cc + 63 anti-diagonals, rounded up to whole step pairs
 
     // The strip above's last row arrives through that wave's LDS ring, one cell {5 mantissas, exponent} per
     // column: the producer's lane 63 writes it the moment it is computed, lane 0 of this wave needs it 64 + a few
@@ -210,9 +214,10 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
       while (progp[prev_wave] < need) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");               // the ring reads below stay below
     };
-    const HX_LDS d2v* ring_above = wrap_in ? (const HX_LDS d2v*)staging : ring_prev;
-    const int ring_base = wrap_in ? 0 : above_base;
-    const int ring_mask = wrap_in ? HXL_STAGE - 1 : HXL_RING - 1;
+    // (strip 0 reads an all-zero entry: the ring read below is unconditional)
+    const HX_LDS d2v* ring_above = !has_above ? (const HX_LDS d2v*)(lds + plan.zero) : wrap_in ? (const HX_LDS d2v*)staging : ring_prev;
+    const int ring_base = (wrap_in || !has_above) ? 0 : above_base;
+    const int ring_mask = !has_above ? 0 : wrap_in ? HXL_STAGE - 1 : HXL_RING - 1;
     auto ring_entry = [&](const int col) -> L5 {   // (uniform address: a broadcast read)
       const HX_LDS d2v* q = ring_above + (size_t)((ring_base + col) & ring_mask) * 3;
       const d2v a = q[0], b = q[1], c = q[2];
@@ -248,15 +253,13 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     }
     // one anti-diagonal step: the lane's new cell from left (own previous), u1 = (i-1, j), u2 = (i-1, j-1)
     auto step = [&](const int t, const L5& left, L5& out, L5& u1, L5& u2, const unsigned w) {
-      L5 nb = l5_zero();                           // (row0-1, t+1): lane 0's upper neighbour of the next step
-      if (has_above && t + 1 < Cc) {
+      if ((t & 7) == 7 && has_above && t + 1 < Cc) {
         if (wrap_in) {
           if ((t & 63) == 63) stage_block(t + 1);
-        } else if ((t & 7) == 7) {
+        } else {
           if (lane == 0) consp[wave] = above_base + t;     // the ring's slots up to column t may be reused
           wait_for(t + 9);
         }
-        nb = ring_entry(t + 1);
       }
       // y-side constants of column j = t - lane (cells outside the lattice only feed cells outside it)
       const unsigned c = w & 0xFFFFu;
@@ -282,21 +285,25 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
       s_idm = __builtin_fma(left.iiw, P[4][2], s_idm);
       s_imm = __builtin_fma(u2.imi, P[3][0], s_imm);
       s_imm = __builtin_fma(u2.iiw, P[4][0], s_imm);
+      const int e_diag = u2.e;
+      // (row0-1, t+1), lane 0's upper neighbour of the next step, into the registers the diagonal cell has just
+      // vacated.  Unconditional: past the last column it returns a stale entry, which only feeds cells outside the lattice.
+      u2 = ring_entry(t + 1);
       // common exponent of the new cell, and the three groups brought to it; a state that may not be entered
       // (y or x state not ready: src/forward.cpp:97,133) is shifted out of the fp64 range, i.e. to zero
       int E = left.e > u1.e ? left.e : u1.e;
-      E = E > u2.e ? E : u2.e;
-      const int du = (u1.e - E) - y_wait, dl = (left.e - E) - x_wait, dd = u2.e - E;
+      E = E > e_diag ? E : e_diag;
+      const int du = (u1.e - E) - y_wait, dl = (left.e - E) - x_wait, dd = e_diag - E;
       out.imd = __builtin_ldexp(s_imd * f_imd, du);
       out.iiw = __builtin_ldexp(s_iiw * f_iiw, du);
       out.idm = __builtin_ldexp(s_idm * rc.x, dl);
       out.imi = __builtin_ldexp(s_imi * rc.y, dl);
       out.imm = __builtin_ldexp(s_imm * (fx * em), dd);
       out.e = E;
-      if (s == 0 && t == 0) {                      // wave-uniform: cell (0,0), lpStart() = 0 (src/forward.cpp:73)
-        if (lane == 0) { out.imm = 1.0; out.e = 0; }
-      }
       if ((t & HXL_RENORM_MASK) == 0) {            // wave-uniform
+        if (s == 0 && t == 0) {                    // cell (0,0): lpStart() = 0 (src/forward.cpp:73)
+          if (lane == 0) { out.imm = 1.0; out.e = 0; }
+        }
         const double mx = vmax(vmax(vmax(out.imm, out.imd), vmax(out.idm, out.imi)), out.iiw);
         const int k = __builtin_amdgcn_frexp_exp(mx);
         out.imm = __builtin_ldexp(out.imm, -k);
@@ -326,7 +333,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
           if (lane == 63) progp[wave] = my_base + col + 1;   // (LDS operations of a wave complete in order)
         }
       }
-      u2 = dpp_shr1_old(nb, out);
+      u2 = dpp_shr1_old(u2, out);
     };
 
     // column words, fetched one step ahead (ycol is padded by 64 words on either side)
@@ -342,13 +349,10 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
       const double l0 = log_scaled(ca.imm, ca.e, lt), l1 = log_scaled(ca.imd, ca.e, lt),
                    l2 = log_scaled(ca.idm, ca.e, lt), l3 = log_scaled(ca.imi, ca.e, lt),
                    l4 = log_scaled(ca.iiw, ca.e, lt);
-      double h0 = HX_NEG_INF, h1 = HX_NEG_INF, h2 = HX_NEG_INF, h3 = HX_NEG_INF, h4 = HX_NEG_INF;
-      if (t + 1 < nsteps) {
-        step(t + 1, ca, cb, ub, ua, next_word(t + 1));
-        h0 = log_scaled(cb.imm, cb.e, lt); h1 = log_scaled(cb.imd, cb.e, lt);
-        h2 = log_scaled(cb.idm, cb.e, lt); h3 = log_scaled(cb.imi, cb.e, lt);
-        h4 = log_scaled(cb.iiw, cb.e, lt);
-      }
+      step(t + 1, ca, cb, ub, ua, next_word(t + 1));
+      const double h0 = log_scaled(cb.imm, cb.e, lt), h1 = log_scaled(cb.imd, cb.e, lt),
+                   h2 = log_scaled(cb.idm, cb.e, lt), h3 = log_scaled(cb.imi, cb.e, lt),
+                   h4 = log_scaled(cb.iiw, cb.e, lt);
       {
         // t64 = j + (i & 63) = t: both cells of the step pair are adjacent in the strip-skewed layout
         const int64_t sl = store_base2 + ((int64_t)(t >> 1) << 7);
@@ -414,13 +418,14 @@ void build_log_table(double* out) {
 static LdsPlan plan_lds(int W, int yl_cols, int yl_emis) {
   LdsPlan p;
   const int table = 16 * HXL_LOG_ENTRIES, hole = 16 * 1024;
-  const int elds = 8 * yl_emis, ycol = 4 * (yl_cols + 128);
+  const int elds = 8 * yl_emis, ycol = 4 * (yl_cols + 132);
   int end = table;
   if (16 + elds + ycol <= hole) { p.elds = 16; p.ycol = 16 + elds; }
   else { p.elds = end; p.ycol = end + elds; end += (elds + ycol + 15) & ~15; }
   p.ring = end; end += (W * HXL_RING + HXL_STAGE) * 48;     // one ring per wave + wave 0's staging ring
   p.yclass = end; end += 16 * HX_YL_MAX_CLS_LINEAR;
-  p.flags = end; end += 4 * (2 * W + 1);
+  p.flags = end; end += (4 * (2 * W + 1) + 15) & ~15;
+  p.zero = end; end += 48;                          // an all-zero ring entry: what strip 0 reads as its row above
   p.total = (end + 15) & ~15;
   return p;
 }

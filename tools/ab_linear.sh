@@ -1,0 +1,6 @@
+# A/B of two builds of the library on the same box: historian_amd/lib_prev (older hx_linear.hip) vs historian_amd/lib
+for i in 1 2; do
+for a in lib_prev lib; do
+HX_LIB_PATH=$GRAFT_REPO_ROOT/historian_amd/$a/libhistorian_hip.so timeout -k 10 100 python bench.py --no-cpu-baseline --single-mode --steps 5 > gpurun_out/ab_$a.log 2>&1
+echo $a $(grep -o "\"kernel_ms\": [0-9.]*" gpurun_out/ab_$a.log)
+done; done
