@@ -45,8 +45,8 @@ def parse():
                     help="guide-alignment band (maxDistanceFromGuide); the guide is the pair's true alignment. "
                          "-1 = full envelope (the headline configuration)")
     ap.add_argument("--mode", choices=["exact", "fast", "linear"], default="linear",
-                    help="arithmetic of the headline fill: linear = scaled probabilities (HX_LSE_LINEAR; on banded "
-                         "batches it is the fast policy), fast = LDS-table log-sum-exp, exact = the reference's table, "
+                    help="arithmetic of the headline fill: linear = scaled probabilities (HX_LSE_LINEAR), "
+                         "fast = LDS-table log-sum-exp, exact = the reference's table, "
                          "bit for bit.  The other policies are timed too and reported")
     ap.add_argument("--single-mode", action="store_true", help="time only --mode")
     ap.add_argument("--traffic", type=float, default=None,
@@ -189,7 +189,7 @@ def main():
     dt, kernel_ms, lp_end, cells = run_mode(args.mode)
     other = "exact" if args.mode != "exact" else "fast"
     dt_o, kernel_ms_o, lp_end_o, _ = run_mode(other) if not args.single_mode else (None, None, None, None)
-    linear = args.mode == "linear" and args.band < 0      # the scaled-probability kernel (hx_linear.hip) ran
+    linear = args.mode == "linear"                        # the scaled-probability kernel (hx_linear.hip) ran
     dt_t, kernel_ms_t, lp_end_t, _ = run_mode("fast") if (linear and not args.single_mode) else (None, None, None, None)
 
     if rank == 0:
@@ -225,7 +225,7 @@ def main():
                        "parallelism": "pairs farmed across %d rank(s); RCCL broadcast of model constants only" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "hx::k_forward_leaf_linear<W>" if linear else "hx::k_fill_chain<0,...>",
+                         "kernel": "hx::k_forward_leaf_linear<W,BANDED>" if linear else "hx::k_fill_chain<0,...>",
                          "kernel_ms": k_ms, "bytes_per_cell": BYTES_PER_CELL},
             "fill_mode": args.mode,
             "lp_end_pair0": float(lp_end[0]),

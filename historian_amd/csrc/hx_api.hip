@@ -597,10 +597,10 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   if (b->all_chain && !(b->flags & HX_FORCE_GENERIC) && !(force_dag && b->d_agg)) {
     // with a band the strip pipelines only visit in-envelope windows; everything else is -inf
     if (b->any_banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_fwd, b->fwd_total, st);
-    // HX_LSE_LINEAR on unbanded leaf pairs whose y side fits LDS (the headline workload): the recursion runs on
+    // HX_LSE_LINEAR on leaf pairs whose y side fits LDS (the headline workload, and its banded variant): the recursion runs on
     // scaled probabilities instead of table log-sum-exps (hx_linear.hip)
-    if ((b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && b->all_leaf && b->all_ylds && !b->any_banded)
-      launch_forward_leaf_linear(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_log_tab, b->yl_cols, b->yl_emis, st);
+    if ((b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && b->all_leaf && b->all_ylds && b->max_cls < 255)
+      launch_forward_leaf_linear(b->d_jobs, b->n_jobs, b->max_rows, b->any_banded, g_tab, g_log_tab, b->yl_cols, b->yl_emis, st);
     else
     launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, (b->flags & HX_LSE_FAST) ? g_fast_tab : g_pair_tab, (b->flags & HX_LSE_FAST) != 0,
                          b->all_leaf ? (b->all_ylds ? 2 : 1) : 0, b->any_banded, b->yl_cols, b->yl_emis, st);

@@ -103,10 +103,14 @@ struct LdsPlan { int elds, ycol, ring, yclass, flags, zero, total; };
 #define HXL_RING 64                // columns of the strip above's last row in flight between two waves
 #define HXL_STAGE 128              // wave 0's staging ring on the wrap-around link: two 64-column blocks
 
-template <int W>
+// BANDED (W == 1): one wavefront per pair, as k_fill_chain does for banded leaf batches - the strips of a banded pair
+// run one after the other anyway.  A strip sweeps only the step windows that hold its in-envelope cells (hx_api.hip
+// strip_windows), cells outside the envelope are shifted to zero, and every strip boundary is the wrap-around link.
+template <int W, bool BANDED>
 __global__ void __launch_bounds__(W * 64, 4)   // four waves per SIMD: 128 vector registers
 k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const double* __restrict__ log_tab,
                       const LdsPlan plan) {
+  static_assert(!BANDED || W == 1, "banded batches run one wavefront per pair");
   constexpr int THREADS = W * 64;
   typedef double d2v __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -133,7 +137,11 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     // (64 words of padding on either side: a lane whose column is outside the lattice reads the edge column's word)
     for (int jp = threadIdx.x; jp < J.n_cols + 130; jp += THREADS) {
       const int j = jp < 64 ? 0 : (jp - 64 >= J.n_cols ? J.n_cols - 1 : jp - 64);
-      ycol[jp] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0xFFFF0000u : 0u);
+      if (BANDED)   // {class : 8, not ready : 1, always in envelope : 1, envelope coordinate : 22}
+        ycol[jp] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0x100u : 0u) |
+                   ((J.y.flags[j] & F_EDGE) ? 0x200u : 0u) | (J.max_dist >= 0 ? (unsigned)J.y.env[j] << 10 : 0u);
+      else
+        ycol[jp] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0xFFFF0000u : 0u);
     }
     for (int c = threadIdx.x; c < Ky1; c += THREADS) {
       const bool real = c < J.y.n_cls;
@@ -145,6 +153,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
   }
   __syncthreads();
   const int R = J.n_rows, Cc = J.n_cols;
+  const int max_dist = J.max_dist;
   const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6);
   const int64_t plane = J.plane, ss = J.strip_stride;
   HX_GLOBAL double* __restrict__ M = as_global(J.fwd);
@@ -185,6 +194,8 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     double fx, f_imd, f_iiw;
     int x_wait;                                    // x state not ready: 2^29, else 0
     unsigned eoff;
+    int env_x = 0;
+    bool edge_x = true;
     {
       const int ic = row_valid ? i0 : 0;
       const d4v p = xpack[ic];
@@ -193,6 +204,10 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
       f_iiw = row_valid ? exp(p.x + p.z) : 0.;
       x_wait = (row_valid && !(p.w < 0.0)) ? 0 : (1 << 29);
       eoff = (unsigned)J.x.ecls[ic] * (unsigned)(J.y.n_cls + 1);
+      if (BANDED) {
+        env_x = J.max_dist >= 0 ? J.x.env[ic] : 0;
+        edge_x = (J.x.flags[ic] & F_EDGE) != 0 || J.max_dist < 0;
+      }
     }
     L5 ca = l5_zero(), cb = l5_zero(), ua = l5_zero(), ub = l5_zero();
     const bool has_above = s > 0, has_below = s + 1 < n_strips;
@@ -238,7 +253,13 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
         const double c = __hip_atomic_load(M + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double d = __hip_atomic_load(M + 3 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double g = __hip_atomic_load(M + 4 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const L5 v = from_logs(a, b, c, d, g);
+        L5 v = from_logs(a, b, c, d, g);
+        if (BANDED && max_dist >= 0) {
+          // the strip above only wrote its in-envelope cells (HX_SPARSE_ENVELOPE: anything else is undefined)
+          int dist = J.x.env[row0 - 1] - J.y.env[jj];
+          dist = dist < 0 ? -dist : dist;
+          if (!(((J.x.flags[row0 - 1] | J.y.flags[jj]) & F_EDGE) || dist <= max_dist)) v = l5_zero();
+        }
         HX_LDS d2v* q = staging + (size_t)(jj & (HXL_STAGE - 1)) * 3;
         q[0] = d2v{v.imm, v.imd};
         q[1] = d2v{v.idm, v.imi};
@@ -246,11 +267,21 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (same wave reads them back: LDS operations complete in order)
     };
-    if (has_above) {
-      if (wrap_in) stage_block(0); else wait_for(8);
-      const L5 b0 = ring_entry(0);
-      if (lane == 0) ua = b0;                      // (row0-1, 0) for step 0
-    }
+    // lane 0's upper and diagonal neighbours at the first step t0 of a sweep: (row0-1, t0) and (row0-1, t0-1)
+    auto open_sweep = [&](const int t0) {
+      if (!has_above) return;
+      if (wrap_in) {
+        if (t0 > 0 && (t0 & 63) == 0) stage_block(t0 - 64);     // (the block of column t0-1)
+        if (t0 < Cc) stage_block(t0 & ~63);
+      } else {
+        wait_for(8);
+      }
+      const L5 b0 = ring_entry(t0), bd = ring_entry(t0 > 0 ? t0 - 1 : 0);
+      if (lane == 0) {
+        ua = b0;
+        if (BANDED && t0 > 0) ub = bd;
+      }
+    };
     // one anti-diagonal step: the lane's new cell from left (own previous), u1 = (i-1, j), u2 = (i-1, j-1)
     auto step = [&](const int t, const L5& left, L5& out, L5& u1, L5& u2, const unsigned w) {
       if ((t & 7) == 7 && has_above && t + 1 < Cc) {
@@ -262,9 +293,9 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
         }
       }
       // y-side constants of column j = t - lane (cells outside the lattice only feed cells outside it)
-      const unsigned c = w & 0xFFFFu;
+      const unsigned c = BANDED ? (w & 0xFFu) : (w & 0xFFFFu);
       const d2v rc = reinterpret_cast<const d2v*>(yclass)[c];
-      const int y_wait = (int)((w >> 16) << 13);   // y state not ready: 2^29, else 0
+      const int y_wait = BANDED ? (int)((w & 0x100u) << 21) : (int)((w >> 16) << 13);   // y state not ready: 2^29, else 0
       const double em = elds[eoff + c];
       // the five sums of src/forward.cpp:103-115,139-150,171-180 on probabilities
       double s_imd = u1.imm * P[0][1];
@@ -293,7 +324,14 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
       // (y or x state not ready: src/forward.cpp:97,133) is shifted out of the fp64 range, i.e. to zero
       int E = left.e > u1.e ? left.e : u1.e;
       E = E > e_diag ? E : e_diag;
-      const int du = (u1.e - E) - y_wait, dl = (left.e - E) - x_wait, dd = e_diag - E;
+      int du = (u1.e - E) - y_wait, dl = (left.e - E) - x_wait, dd = e_diag - E;
+      if (BANDED) {
+        // a cell outside the envelope (src/forward.h:92-98) is shifted to zero as a whole
+        int dist = env_x - (int)(w >> 10);
+        dist = dist < 0 ? -dist : dist;
+        const int out_of_env = (edge_x || (w & 0x200u) || dist <= max_dist) ? 0 : (1 << 29);
+        du -= out_of_env; dl -= out_of_env; dd -= out_of_env;
+      }
       out.imd = __builtin_ldexp(s_imd * f_imd, du);
       out.iiw = __builtin_ldexp(s_iiw * f_iiw, du);
       out.idm = __builtin_ldexp(s_idm * rc.x, dl);
@@ -337,14 +375,34 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     };
 
     // column words, fetched one step ahead (ycol is padded by 64 words on either side)
-    unsigned wnext = ycol[64 - lane];
+    unsigned wnext = 0;
     auto next_word = [&](const int t) -> unsigned {
       const unsigned w = wnext;
       wnext = ycol[t + 65 - lane];
       return w;
     };
 
-    for (int t = 0; t < nsteps; t += 2) {
+    // With a band, the strip sweeps only the (up to two) step windows that hold its in-envelope cells, widened to whole
+    // step pairs; cells left of a window are outside the envelope, so the register window restarts from zero.
+    int wlo[2] = {0, 0}, whi[2] = {nsteps, 0};
+    if (BANDED) {
+      const HX_GLOBAL int32_t* win = as_global(J.fwd_windows);
+      if (win) {
+        for (int w = 0; w < 2; ++w) {
+          wlo[w] = win[4 * s + 2 * w] & ~1;
+          const int h = (win[4 * s + 2 * w + 1] + 1) & ~1;
+          whi[w] = h < nsteps ? h : nsteps;
+        }
+        if (whi[1] > wlo[1] && wlo[1] <= whi[0]) { whi[0] = whi[1] > whi[0] ? whi[1] : whi[0]; wlo[1] = whi[1] = 0; }
+      }
+    }
+    for (int wi = 0; wi < (BANDED ? 2 : 1); ++wi) {
+    if (BANDED && whi[wi] <= wlo[wi]) continue;
+    const int wstart = BANDED ? wlo[wi] : 0, wend = BANDED ? whi[wi] : nsteps;
+    if (BANDED) { ca = l5_zero(); cb = l5_zero(); ua = l5_zero(); ub = l5_zero(); }
+    open_sweep(wstart);
+    wnext = ycol[wstart + 64 - lane];
+    for (int t = wstart; t < wend; t += 2) {
       step(t, cb, ca, ua, ub, next_word(t));
       const double l0 = log_scaled(ca.imm, ca.e, lt), l1 = log_scaled(ca.imd, ca.e, lt),
                    l2 = log_scaled(ca.idm, ca.e, lt), l3 = log_scaled(ca.imi, ca.e, lt),
@@ -376,7 +434,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
         __builtin_nontemporal_store(d2v{l4, h4}, &M2[4 * plane2]);
 #endif
       }
-      if (wrap_out) {
+      if (wrap_out && !BANDED) {
         // wrap-around link: a column counts once its stores have left the wave.  Vector-memory operations retire in
         // issue order and every iteration issues five stores (and nothing else), so everything stored
         // HXL_PUBLISH_LAG steps = 8 iterations ago is older than the wave's 40 youngest operations.
@@ -392,6 +450,12 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
           }
         }
       }
+    }
+    }
+    if (BANDED && wrap_out) {
+      // (the windows need not reach the strip's last step: everything this strip will ever write is out)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) drainp[0] = my_base + Cc;
     }
     if (has_above && !wrap_in && lane == 0) consp[wave] = above_base + Cc;
   }
@@ -430,24 +494,25 @@ static LdsPlan plan_lds(int W, int yl_cols, int yl_emis) {
   return p;
 }
 
-void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* log_tab,
+void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
                                 int yl_cols, int yl_emis, hipStream_t st) {
   const dim3 g(n_jobs);
-#define HXL_LAUNCH(W_) do { const LdsPlan p = plan_lds(W_, yl_cols, yl_emis); \
-    hipLaunchKernelGGL((k_forward_leaf_linear<W_>), g, dim3(W_ * 64), p.total, st, d_jobs, tab, log_tab, p); } while (0)
+#define HXL_LAUNCH(W_, B_) do { const LdsPlan p = plan_lds(W_, yl_cols, yl_emis); \
+    hipLaunchKernelGGL((k_forward_leaf_linear<W_, B_>), g, dim3(W_ * 64), p.total, st, d_jobs, tab, log_tab, p); } while (0)
+  if (banded) { HXL_LAUNCH(1, true); return; }    // one wavefront per pair
   const char* v = getenv("HX_LINEAR_WAVES");     // tuning / test hook: waves per pair (any count works for any size)
   const int forced = v ? atoi(v) : 0;
-  if (forced == 1) HXL_LAUNCH(1);
-  else if (forced == 2) HXL_LAUNCH(2);
-  else if (forced == 4) HXL_LAUNCH(4);
-  else if (forced == 8) HXL_LAUNCH(8);
-  else if (forced == 16) HXL_LAUNCH(16);
-  else if (max_rows <= 64) HXL_LAUNCH(1);
-  else if (max_rows <= 128) HXL_LAUNCH(2);
-  else if (max_rows <= 256) HXL_LAUNCH(4);
+  if (forced == 1) HXL_LAUNCH(1, false);
+  else if (forced == 2) HXL_LAUNCH(2, false);
+  else if (forced == 4) HXL_LAUNCH(4, false);
+  else if (forced == 8) HXL_LAUNCH(8, false);
+  else if (forced == 16) HXL_LAUNCH(16, false);
+  else if (max_rows <= 64) HXL_LAUNCH(1, false);
+  else if (max_rows <= 128) HXL_LAUNCH(2, false);
+  else if (max_rows <= 256) HXL_LAUNCH(4, false);
   // more pairs than compute units: eight waves per pair, two pairs per CU (less pipeline fill per pair)
-  else if (max_rows <= 512 || n_jobs > 256) HXL_LAUNCH(8);
-  else HXL_LAUNCH(16);
+  else if (max_rows <= 512 || n_jobs > 256) HXL_LAUNCH(8, false);
+  else HXL_LAUNCH(16, false);
 #undef HXL_LAUNCH
 }
 

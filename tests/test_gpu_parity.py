@@ -344,3 +344,34 @@ def test_linear_mode_on_unbanded_leaf_pairs_runs_on_scaled_probabilities(waves, 
             assert abs(le[k] - lf[k]) <= 1e-5 * abs(le[k])
         be.close()
         bf.close()
+
+
+def test_linear_mode_on_banded_leaf_pairs():
+    # HX_LSE_LINEAR with a band: one wavefront per pair sweeping the strips' step windows (hx_linear.hip, BANDED),
+    # default and sparse-envelope storage, several strips, a band too narrow for any path (lpEnd = -inf), and an
+    # unbanded pair in the same batch.  Same two yardsticks as the unbanded test.
+    aa = "arndcqeghilkmfpstwyv"
+    cases = [H.leaf_case(401, 70, 66, band=5), H.leaf_case(402, 200, 90, band=12), H.leaf_case(403, 130, 150, band=3),
+             H.leaf_case(404, 300, 330, alphabet=aa, jc=False, band=20), H.leaf_case(405, 40, 45, band=0),
+             H.leaf_case(406, 150, 100), H.leaf_case(407, 500, 520, band=8)]
+    imgs = [H.job_images(f) for f in cases]
+    for flags in (0, capi.HX_SPARSE_ENVELOPE):
+        be = capi.Batch(imgs, flags)
+        bf = capi.Batch(imgs, capi.HX_LSE_LINEAR | flags)
+        be.forward()
+        bf.forward()
+        le, lf = be.lp_end(), bf.lp_end()
+        for k, (x, y, hmm, md) in enumerate(imgs):
+            want = c_oracle.forward(x, y, hmm, md, true_math=True)
+            mf = bf.read_matrix(k, 0)
+            inside = np.isfinite(want["cells"])         # (sparse storage leaves cells outside the envelope undefined)
+            if not flags:
+                assert np.array_equal(np.isneginf(want["cells"]), np.isneginf(mf)), "job %d: -inf pattern" % k
+            assert np.max(np.abs(want["cells"][inside] - mf[inside]), initial=0.) < 1e-9, "job %d" % k
+            if np.isfinite(want["lp_end"]):
+                assert abs(want["lp_end"] - lf[k]) <= 1e-12 * abs(lf[k])
+                assert abs(le[k] - lf[k]) <= 1e-5 * abs(le[k])
+            else:
+                assert lf[k] == want["lp_end"] == le[k]
+        be.close()
+        bf.close()
