@@ -163,6 +163,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    traces = {}
+
     def run_mode(mode):
         """K timed passes of the hot path in one fill mode; returns (seconds, kernel ms list, lp_end, cells)."""
         batch = capi.Batch(triples, {"exact": capi.HX_LSE_EXACT, "fast": capi.HX_LSE_FAST, "linear": capi.HX_LSE_LINEAR}[mode] |
@@ -182,6 +184,11 @@ def main():
         dt = time.perf_counter() - t0
         dt = farm.max_over_ranks(dt, world, dev)
         lp = batch.lp_end()
+        # outside the timed region: the device-side best-path traceback of every pair (hx_batch_best_trace); the first
+        # few paths are compared with the CPU oracle's below
+        tcells, tlen = batch.best_trace(raw=True)
+        n_keep = max(1, min(args.cpu_pairs, args.pairs))
+        traces[mode] = [[tuple(int(v) for v in c) for c in tcells[k, :tlen[k]]] for k in range(n_keep)]
         batch.close()
         assert np.all(np.isfinite(lp)), "non-finite Forward log-likelihood"
         return dt, k_ms, lp, n_cells
@@ -250,20 +257,29 @@ def main():
             from oracle import c_oracle           # the checker, timed as the CPU baseline ("port")
             c_oracle.load()
             n_cpu = max(1, min(args.cpu_pairs, args.pairs))
+            from oracle import trace_oracle
+            cpu_dt = 0.0
             t1 = time.perf_counter()
             cpu_cells = 0
             rel = 0.0
+            same = {}
             for k in range(n_cpu):
                 x, y, h, md = triples[k]
                 r = c_oracle.forward(x, y, h, md)
                 cpu_cells += env_cells_of[k] if args.band >= 0 else (x.n_states - 1) * (y.n_states - 1)
                 rel = max(rel, abs(r["lp_end"] - lp_end[k]) / abs(r["lp_end"]))
-            cpu_dt = time.perf_counter() - t1
+                # traceback identity: the reference's bestTrace over the CPU matrix vs the device's paths
+                cpu_dt += time.perf_counter() - t1
+                path = trace_oracle.best_trace(x, y, h, md, r)
+                for m in traces:
+                    same[m] = same.get(m, 0) + (traces[m][k] == path)
+                t1 = time.perf_counter()
             out["cpu_baseline"] = {"value": cpu_cells / cpu_dt, "unit": "cells/s", "cores": 1, "kind": "port",
                                    "sample": "first %d pair(s) of the same batch, oracle/oracle_fill.c "
                                              "(dense-array restatement of the reference fill), 1 thread, %.1f s"
                                              % (n_cpu, cpu_dt)}
             out["lp_end_max_rel_err_vs_cpu"] = rel
+            out["best_trace_identical_to_cpu"] = {m: "%d of %d pairs" % (same.get(m, 0), n_cpu) for m in traces}
             assert rel <= 1e-4, "Forward log-likelihoods outside north_star's tolerance of the CPU path: %g" % rel
         print(json.dumps(out))
     if world > 1:

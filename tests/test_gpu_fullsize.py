@@ -50,6 +50,12 @@ def test_protein_2x2000_pair():
         H.assert_same_bits(got[k], want["cells"][i, j], "cell (%d,%d)" % (i, j))
     # every cell of the exact fill, bit for bit
     H.assert_same_bits(r["be"].read_matrix(0), want["cells"], "2x2000 forward cells")
+    # the device-side best-path traceback through the exact matrix is the reference's path (oracle/trace_oracle.py
+    # restates bestTrace over the CPU matrix); the fast fill's matrix gives the same path here
+    from oracle import trace_oracle
+    path = trace_oracle.best_trace(*r["img"], want)
+    assert r["be"].best_trace()[0] == path
+    assert r["bf"].best_trace()[0] == path
     # HX_LSE_LINEAR runs this pair on scaled probabilities (hx_linear.hip): exact arithmetic up to fp64 rounding, so it
     # differs from the reference by the reference's own truncation of log-sum-exp terms below e^-10
     bl = capi.Batch([r["img"]], capi.HX_LSE_LINEAR)

@@ -109,3 +109,15 @@ def test_quickalign_c_fill_equals_python_restatement():
         for (i, j), c in mx.cells.items():
             assert all(r["cells"][i, j, k] == c[k] for k in range(3))
         assert int(np.isfinite(r["cells"]).any(axis=2).sum()) == len(mx.cells)
+
+
+def test_pod_image_traceback_equals_the_object_based_restatement():
+    # oracle/trace_oracle.py (used by bench.py and the full-size GPU tests) against historian_oracle's best_trace
+    from oracle import trace_oracle
+    for f in [H.leaf_case(7, 70, 66), H.leaf_case(3, 0, 5), H.leaf_case(203, 90, 60, band=6), H.dag_case(31), H.dag_case(43, band=3),
+              H.dag_case(61, n=9, keep_all=True), H.dag_case(81, n=30, samples=20)]:
+        x, y, hmm, md = H.job_images(f)
+        fwd = c_oracle.forward(x, y, hmm, md)
+        f.fill()
+        if f.lp_end > H.NEG_INF:
+            assert trace_oracle.best_trace(x, y, hmm, md, fwd) == [tuple(c) for c in f.best_trace()]
