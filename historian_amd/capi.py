@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("HX_LIB_PATH") or os.path.join(_HERE, "lib", "libhisto
 
 HX_LSE_TABLE_ENTRIES = 100002
 HX_LSE_EXACT, HX_LSE_FAST, HX_KEEP_BACKWARD, HX_FORCE_GENERIC, HX_SPARSE_ENVELOPE = 0, 1, 2, 4, 8
+HX_BAND_COMPRESSED = 32   # banded jobs keep only the swept step windows (include/historian_hip.h)
 HX_LSE_LINEAR = 17      # HX_LSE_FAST + scaled-probability Forward fill where it applies (include/historian_hip.h)
 IMM, IMD, IDM, IMI, IIW, EEE = 0, 1, 2, 3, 4, 5
 
@@ -47,7 +48,7 @@ class HxPairJob(C.Structure):
 class HxLayout(C.Structure):
     _fields_ = [("n_rows", C.c_int32), ("n_cols", C.c_int32), ("strip_rows", C.c_int32),
                 ("n_strips", C.c_int32), ("strip_stride", C.c_int64), ("plane_stride", C.c_int64),
-                ("mirrored", C.c_int32), ("pad_", C.c_int32)]
+                ("mirrored", C.c_int32), ("compressed", C.c_int32)]
 
 
 class HxQuickJob(C.Structure):
@@ -64,7 +65,7 @@ class HxCell(C.Structure):
 EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_create", "hx_batch_destroy",
            "hx_batch_forward", "hx_batch_backward", "hx_batch_sync", "hx_batch_lp_end", "hx_batch_lp_start",
            "hx_batch_layout", "hx_batch_read_matrix", "hx_batch_read_cells", "hx_batch_read_prepared",
-           "hx_batch_posterior_scan", "hx_batch_best_trace", "hx_batch_total_cells", "hx_batch_last_kernel_ms", "hx_host_alloc",
+           "hx_batch_posterior_scan", "hx_batch_best_trace", "hx_batch_strip_windows", "hx_batch_total_cells", "hx_batch_last_kernel_ms", "hx_host_alloc",
            "hx_host_free", "hx_quick_batch_create", "hx_quick_batch_destroy", "hx_quick_batch_run",
            "hx_quick_batch_results", "hx_quick_batch_layout", "hx_quick_batch_read_matrix",
            "hx_quick_batch_total_cells", "hx_quick_batch_last_kernel_ms"]
@@ -105,6 +106,7 @@ def load():
     lib.hx_batch_posterior_scan.argtypes = [vp, C.c_int32, C.c_double, C.POINTER(HxCell), C.c_int64,
                                             C.POINTER(C.c_int64)]
     lib.hx_batch_best_trace.argtypes = [vp, vp, C.c_int64, _i32p]
+    lib.hx_batch_strip_windows.argtypes = [vp, C.c_int32, _i32p, C.POINTER(C.c_int64)]
     lib.hx_batch_total_cells.argtypes = [vp]
     lib.hx_batch_total_cells.restype = C.c_int64
     lib.hx_batch_last_kernel_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
@@ -291,10 +293,36 @@ class Batch:
         l = self.layout(job, which)
         buf = np.empty(5 * l.plane_stride)
         _check(load().hx_batch_read_matrix(self._h, job, which, _p(buf, _f64p)))
+        if l.compressed:
+            return self._dense_from_compressed(job, l, buf)
         ii, jj = np.meshgrid(np.arange(l.n_rows), np.arange(l.n_cols), indexing="ij")
         slot = slot_index(l, ii, jj)
         planes = buf.reshape(5, l.plane_stride)
         return np.stack([planes[s][slot] for s in range(5)], axis=-1)
+
+    def strip_windows(self, job):
+        l = self.layout(job)
+        win = np.zeros((l.n_strips, 4), dtype=np.int32)
+        bases = np.zeros((l.n_strips, 2), dtype=np.int64)
+        _check(load().hx_batch_strip_windows(self._h, job, _p(win, _i32p), bases.ctypes.data_as(C.POINTER(C.c_int64))))
+        return win, bases
+
+    def _dense_from_compressed(self, job, l, buf):
+        """HX_BAND_COMPRESSED: cells that are not stored read as -inf (hx_layout.compressed)."""
+        win, bases = self.strip_windows(job)
+        planes = buf.reshape(5, l.plane_stride)
+        out = np.full((l.n_rows, l.n_cols, 5), -np.inf)
+        sr = l.strip_rows
+        ii, jj = np.meshgrid(np.arange(l.n_rows), np.arange(l.n_cols), indexing="ij")
+        strip, lane = ii // sr, ii % sr
+        t = jj + lane
+        for w in range(2):
+            lo, hi, base = win[strip, 2 * w], win[strip, 2 * w + 1], bases[strip, w]
+            inside = (t >= lo) & (t < hi)
+            slot = base + ((t - lo) // 2) * (2 * sr) + lane * 2 + t % 2
+            for s in range(5):
+                out[..., s][inside] = planes[s][slot[inside]]
+        return out
 
     def read_cells(self, job, ij, which=0):
         ij = np.ascontiguousarray(ij, dtype=np.int32).reshape(-1, 2)

@@ -276,7 +276,9 @@ void bind_profile(DevProfile& d, const ProfOff& o, char* base) {
 struct JobOff {
   ProfOff x, y;
   size_t log_root, log_sub_l, log_sub_r, log_ins_l, log_ins_r, log_cptw_l, log_cptw_r, emis, emis_pad, scalars;
-  size_t fwd_windows, bwd_windows;
+  size_t fwd_windows, bwd_windows, strip_base;
+  bool compressed;
+  int64_t compact_plane;
   int64_t eplane_off;     // into hx_batch::d_eplane, or -1
   bool table_emission;
 };
@@ -353,7 +355,7 @@ struct hx_batch {
   double* d_agg = nullptr;          // outgoing-sum planes of the general-profile Forward pipeline (same size as d_fwd)
   int64_t fwd_total = 0, max_eplane = 0;
   int max_states = 0, max_ca = 0, max_cls_pairs = 0, max_rows = 0, max_cls = 0;
-  bool all_chain = true, all_leaf = true, all_ylds = true, any_banded = false;
+  bool all_chain = true, all_leaf = true, all_ylds = true, any_banded = false, any_compressed = false;
   int yl_cols = 0, yl_emis = 0;       // LDS-resident y side: columns and padded class pairs of the largest job
   int64_t total_cells = 0;
   bool forward_done = false, backward_done = false;
@@ -460,7 +462,9 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     jo.emis = jo.table_emission ? ar.reserve(sizeof(double) * pairs) : 0;
     jo.emis_pad = jo.table_emission ? ar.reserve(sizeof(double) * (jo.x.n_cls + 1) * (jo.y.n_cls + 1)) : 0;
     jo.scalars = ar.reserve(sizeof(double) * 2);
-    jo.fwd_windows = jo.bwd_windows = 0;
+    jo.fwd_windows = jo.bwd_windows = jo.strip_base = 0;
+    jo.compressed = false;
+    jo.compact_plane = 0;
     if (need_env) {
       const int R = jo.x.n - 1, Cc = jo.y.n - 1;
       // (copies: put() may reallocate the staging image the pointers would point into)
@@ -468,8 +472,38 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
       const std::vector<uint8_t> yf(ar.host.data() + jo.y.flags, ar.host.data() + jo.y.flags + jo.y.n);
       const std::vector<int32_t> wf = strip_windows(xf.data(), pj.x->env_pos, yf.data(), pj.y->env_pos, R, Cc, pj.max_distance, false);
       const std::vector<int32_t> wb = strip_windows(xf.data(), pj.x->env_pos, yf.data(), pj.y->env_pos, R, Cc, pj.max_distance, true);
-      jo.fwd_windows = ar.put(wf.data(), sizeof(int32_t) * wf.size());
       jo.bwd_windows = ar.put(wb.data(), sizeof(int32_t) * wb.size());
+      if (flags & HX_BAND_COMPRESSED) {
+        // Band-compressed storage: a strip keeps only the step windows it sweeps.  The windows are put into the
+        // form the fill uses them in (whole step pairs, clipped, merged when they touch - k_forward_leaf_linear),
+        // which that kernel's own widening leaves unchanged, and every window gets its offset in the state plane.
+        std::vector<int32_t> we(wf);
+        const int n_strips = (R + HX_STRIP - 1) / HX_STRIP, nsteps = (Cc + HX_STRIP) & ~1;
+        std::vector<int64_t> sb(2 * (size_t)n_strips, 0);
+        int64_t off = 0;
+        for (int s = 0; s < n_strips; ++s) {
+          int32_t* o = &we[4 * (size_t)s];
+          int lo[2], hi[2];
+          for (int w = 0; w < 2; ++w) {
+            lo[w] = o[2 * w] & ~1;
+            const int h = (o[2 * w + 1] + 1) & ~1;
+            hi[w] = h < nsteps ? h : nsteps;
+            if (hi[w] < lo[w]) hi[w] = lo[w];
+          }
+          if (hi[1] > lo[1] && lo[1] <= hi[0]) { hi[0] = std::max(hi[0], hi[1]); lo[1] = hi[1] = 0; }
+          for (int w = 0; w < 2; ++w) {
+            o[2 * w] = lo[w]; o[2 * w + 1] = hi[w];
+            sb[2 * (size_t)s + w] = off;
+            off += (int64_t)((hi[w] - lo[w]) >> 1) * (2 * HX_STRIP);
+          }
+        }
+        jo.fwd_windows = ar.put(we.data(), sizeof(int32_t) * we.size());
+        jo.strip_base = ar.put(sb.data(), sizeof(int64_t) * sb.size());
+        jo.compressed = true;
+        jo.compact_plane = (off + 1) & ~(int64_t)1;
+      } else {
+        jo.fwd_windows = ar.put(wf.data(), sizeof(int32_t) * wf.size());
+      }
     }
 
     DevJob& J = b->jobs[k];
@@ -482,13 +516,14 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     J.n_cols = jo.y.n - 1;
     J.n_strips = (J.n_rows + HX_STRIP - 1) / HX_STRIP;
     J.strip_stride = strip_stride_for(J.n_cols);
-    J.plane = J.n_strips * J.strip_stride;
+    J.plane = jo.compressed ? jo.compact_plane : J.n_strips * J.strip_stride;
     J.chain = jo.x.chain && jo.y.chain;
     J.leaf_like = J.chain && jo.x.interior_emit && jo.y.interior_emit && jo.table_emission;
     hx_layout& L = b->layouts[k];
     L.n_rows = J.n_rows; L.n_cols = J.n_cols; L.strip_rows = HX_STRIP; L.n_strips = J.n_strips;
     L.strip_stride = J.strip_stride; L.plane_stride = J.plane;
-    L.mirrored = 0; L.pad_ = 0;
+    L.mirrored = 0; L.compressed = jo.compressed ? 1 : 0;
+    b->any_compressed = b->any_compressed || jo.compressed;
     mat_off[k] = mat_total;
     mat_total += 5 * J.plane;
     jo.eplane_off = -1;
@@ -514,6 +549,10 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     b->all_ylds = b->all_ylds && J.leaf_like && jo.y.lp_zero && jo.y.n <= 6144 && jo.y.n_cls + 1 <= 64 &&
                   (int64_t)(jo.x.n_cls + 1) * (jo.y.n_cls + 1) <= 1024;
   }
+  if (rc == HX_OK && (flags & HX_BAND_COMPRESSED) &&
+      !((flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && b->all_leaf && b->all_ylds && b->max_cls < 255 && !(flags & (HX_KEEP_BACKWARD | HX_FORCE_GENERIC))))
+    rc = fail(HX_ERR_INVALID_ARG, "HX_BAND_COMPRESSED is implemented by the scaled-probability Forward fill only: it needs HX_LSE_LINEAR and "
+                                  "a batch of leaf-profile pairs, without HX_KEEP_BACKWARD / HX_FORCE_GENERIC");
   if (rc != HX_OK) { delete b; return rc; }
 
   auto cleanup = [&](int code) { hx_batch_destroy(b); return code; };
@@ -553,6 +592,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     J.agg = b->d_agg ? b->d_agg + mat_off[k] : nullptr;
     J.fwd_windows = J.max_dist >= 0 ? reinterpret_cast<int32_t*>(base + jo.fwd_windows) : nullptr;
     J.bwd_windows = J.max_dist >= 0 ? reinterpret_cast<int32_t*>(base + jo.bwd_windows) : nullptr;
+    J.strip_base = jo.compressed ? reinterpret_cast<int64_t*>(base + jo.strip_base) : nullptr;
     J.lp_end = reinterpret_cast<double*>(base + jo.scalars);
     J.lp_start = J.lp_end + 1;
     J.fwd = b->d_fwd + mat_off[k];
@@ -596,7 +636,8 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   static const bool force_dag = getenv("HX_FORCE_DAG") != nullptr;   // tuning hook: general pipeline for chain profiles too
   if (b->all_chain && !(b->flags & HX_FORCE_GENERIC) && !(force_dag && b->d_agg)) {
     // with a band the strip pipelines only visit in-envelope windows; everything else is -inf
-    if (b->any_banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_fwd, b->fwd_total, st);
+    // (band-compressed matrices hold nothing but the swept windows, which the fill writes completely)
+    if (b->any_banded && !(b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED))) launch_fill_neg_inf(b->d_fwd, b->fwd_total, st);
     // HX_LSE_LINEAR on leaf pairs whose y side fits LDS (the headline workload, and its banded variant): the recursion runs on
     // scaled probabilities instead of table log-sum-exps (hx_linear.hip)
     if ((b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && b->all_leaf && b->all_ylds && b->max_cls < 255)
@@ -625,6 +666,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
 int hx_batch_backward(hx_batch* b, void* stream) {
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
   if (!b->forward_done) return fail(HX_ERR_STATE, "hx_batch_backward needs a previous hx_batch_forward");
+  if (b->any_compressed) return fail(HX_ERR_STATE, "the Backward fill does not support HX_BAND_COMPRESSED batches");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (!b->d_bwd) {
     // not pre-allocated with HX_KEEP_BACKWARD: allocate the Backward matrices now and re-publish the job table
@@ -690,6 +732,16 @@ int hx_batch_layout(const hx_batch* b, int32_t job, int32_t which, hx_layout* ou
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
   *out = b->layouts[job];
   out->mirrored = which;      // the Backward matrix is stored in mirrored coordinates
+  return HX_OK;
+}
+
+int hx_batch_strip_windows(const hx_batch* b, int32_t job, int32_t* windows, int64_t* bases) {
+  if (!b || !windows || !bases) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
+  const DevJob& J = b->jobs[job];
+  if (!J.strip_base) return fail(HX_ERR_STATE, "job %d is not stored band-compressed", job);
+  HIP_TRY(hipMemcpy(windows, J.fwd_windows, sizeof(int32_t) * 4 * J.n_strips, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(bases, J.strip_base, sizeof(int64_t) * 2 * J.n_strips, hipMemcpyDeviceToHost));
   return HX_OK;
 }
 
@@ -781,7 +833,7 @@ int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_bat
     for (int s = 0; s < 11; ++s) J.sc[s] = q.scores[s];
     hx_layout& L = b->layouts[k];
     L.n_rows = q.x_len; L.n_cols = q.y_len; L.strip_rows = HX_STRIP; L.n_strips = J.n_strips;
-    L.strip_stride = J.strip_stride; L.plane_stride = J.plane; L.mirrored = 0; L.pad_ = 0;
+    L.strip_stride = J.strip_stride; L.plane_stride = J.plane; L.mirrored = 0; L.compressed = 0;
     cell_off[k] = cells_total;
     cells_total += 3 * J.plane;
     b->total_cells += (int64_t)q.x_len * q.y_len;

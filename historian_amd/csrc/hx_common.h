@@ -46,6 +46,17 @@ __device__ __forceinline__ bool in_envelope(const DevJob& J, int i, int j) {
   return d <= J.max_dist;
 }
 
+// Slot of Forward cell (i, j) inside a state plane, or -1 when a band-compressed job (HX_BAND_COMPRESSED) does not store
+// it: such a job keeps, per 64-row strip, only the step windows the fill sweeps (DevJob::fwd_windows / strip_base).
+__device__ __forceinline__ int64_t stored_slot(const DevJob& J, int i, int j) {
+  if (!J.strip_base) return cell_slot(J.strip_stride, i, j);
+  const int s = i >> 6, l = i & (HX_STRIP - 1), t = j + l;
+  const int32_t* w = J.fwd_windows + 4 * s;
+  if (t >= w[0] && t < w[1]) return J.strip_base[2 * s] + ((int64_t)((t - w[0]) >> 1) << 7) + (l << 1) + (t & 1);
+  if (t >= w[2] && t < w[3]) return J.strip_base[2 * s + 1] + ((int64_t)((t - w[2]) >> 1) << 7) + (l << 1) + (t & 1);
+  return -1;
+}
+
 struct Cell5 { double v[5]; };
 
 __device__ __forceinline__ Cell5 load_cell(const double* __restrict__ m, int64_t plane, int64_t slot) {
@@ -62,7 +73,9 @@ __device__ inline double forward_lp_end(const DevJob& J, const LSE& L) {
   const int xe = J.x.n - 1, ye = J.y.n - 1;
   for (int tx = J.x.in_off[xe]; tx < J.x.in_off[xe + 1]; ++tx)
     for (int ty = J.y.in_off[ye]; ty < J.y.in_off[ye + 1]; ++ty) {
-      const Cell5 s = load_cell(J.fwd, J.plane, cell_slot(J.strip_stride, J.x.in_src[tx], J.y.in_src[ty]));
+      const int64_t slot = stored_slot(J, J.x.in_src[tx], J.y.in_src[ty]);
+      if (slot < 0) continue;                      // (band-compressed storage: not stored = -inf, contributes nothing)
+      const Cell5 s = load_cell(J.fwd, J.plane, slot);
       double a = L(s.v[0] + J.T[0][5], s.v[1] + J.T[1][5]);
       a = L(a, s.v[2] + J.T[2][5]);
       a = L(a, s.v[3] + J.T[3][5]);

@@ -95,6 +95,8 @@ struct DevJob {
   double* agg;                // [5][plane] per-cell outgoing sums of the Forward fill (hx_dag.hip), or nullptr
   const int32_t* fwd_windows; // [n_strips][4] step windows {lo0,hi0,lo1,hi1} holding the strip's in-envelope cells
   const int32_t* bwd_windows; // same for the mirrored (Backward) sweep; both nullptr when there is no band
+  const int64_t* strip_base;  // [n_strips][2] band-compressed storage (HX_BAND_COMPRESSED): offset of each Forward window in a
+                              // state plane; fwd_windows then holds the windows exactly as swept.  nullptr: dense planes
 };
 
 // One pair of the guide-alignment Viterbi batch (hx_quick.hip)

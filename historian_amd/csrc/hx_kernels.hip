@@ -383,9 +383,9 @@ __global__ void k_gather_cells(const DevJob* __restrict__ jobs, int job, const d
   if (k >= n) return;
   const int i = ij[2 * k], j = ij[2 * k + 1];
   const bool ok = i >= 0 && j >= 0 && i < J.n_rows && j < J.n_cols && in_envelope(J, i, j);
-  const int64_t slot = !ok ? 0 : (mirrored ? bwd_slot(J.strip_stride, J.n_rows, J.n_cols, i, j) : cell_slot(J.strip_stride, i, j));
+  const int64_t slot = !ok ? 0 : (mirrored ? bwd_slot(J.strip_stride, J.n_rows, J.n_cols, i, j) : stored_slot(J, i, j));
 #pragma unroll
-  for (int s = 0; s < 5; ++s) out[5 * k + s] = ok ? M[s * J.plane + slot] : HX_NEG_INF;
+  for (int s = 0; s < 5; ++s) out[5 * k + s] = (ok && slot >= 0) ? M[s * J.plane + slot] : HX_NEG_INF;
 }
 
 // ---------------------------------------------------------------------------

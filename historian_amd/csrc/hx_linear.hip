@@ -217,7 +217,8 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     // column sequence numbers: column j of strip s is number (s / W) * Cc + j of its wave's ring
     const int above_base = ((s - 1) / W) * Cc;
     const int my_base = (s / W) * Cc;
-    const int64_t store_base2 = (int64_t)s * ss + (lane << 1);
+    int64_t store_base2 = (int64_t)s * ss + (lane << 1);
+    int store_t0 = 0;                              // (band-compressed storage: a window's cells are stored from its own offset)
     const int nsteps = (Cc + 64) & ~1;             // Cc + 63 anti-diagonals, rounded up to whole step pairs
 
     // The strip above's last row arrives through that wave's LDS ring, one cell {5 mantissas, exponent} per
@@ -245,8 +246,12 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
       while (drainp[0] < need) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
       const int jj = c0 + lane;
-      if (jj < Cc) {
-        const int64_t sl = cell_slot(ss, row0 - 1, jj);
+      const int64_t sl = jj < Cc ? (BANDED ? stored_slot(J, row0 - 1, jj) : cell_slot(ss, row0 - 1, jj)) : -1;
+      if (jj < Cc && sl < 0) {                     // band-compressed storage: not stored = outside the envelope
+        HX_LDS d2v* q = staging + (size_t)(jj & (HXL_STAGE - 1)) * 3;
+        q[0] = d2v{0., 0.}; q[1] = d2v{0., 0.}; q[2] = d2v{0., __hiloint2double(0, HXL_EMIN)};
+      }
+      if (sl >= 0) {
         // agent-scope relaxed loads: served by L2, never by a stale L1 line
         const double a = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double b = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -400,6 +405,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     if (BANDED && whi[wi] <= wlo[wi]) continue;
     const int wstart = BANDED ? wlo[wi] : 0, wend = BANDED ? whi[wi] : nsteps;
     if (BANDED) { ca = l5_zero(); cb = l5_zero(); ua = l5_zero(); ub = l5_zero(); }
+    if (BANDED && J.strip_base) { store_base2 = J.strip_base[2 * s + wi] + (lane << 1); store_t0 = wstart; }
     open_sweep(wstart);
     wnext = ycol[wstart + 64 - lane];
     for (int t = wstart; t < wend; t += 2) {
@@ -413,7 +419,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
                    h4 = log_scaled(cb.iiw, cb.e, lt);
       {
         // t64 = j + (i & 63) = t: both cells of the step pair are adjacent in the strip-skewed layout
-        const int64_t sl = store_base2 + ((int64_t)(t >> 1) << 7);
+        const int64_t sl = store_base2 + ((int64_t)((t - store_t0) >> 1) << 7);
         HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
         const int64_t plane2 = plane >> 1;
 #if HX_ABLATE == 21      // no stores (keeps the values alive)

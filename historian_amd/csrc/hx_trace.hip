@@ -31,7 +31,8 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 __device__ __forceinline__ double forward_cell(const DevJob& J, int i, int j, int s) {
   if (i < 0 || j < 0 || i >= J.n_rows || j >= J.n_cols) return HX_NEG_INF;
   if (J.max_dist >= 0 && !in_envelope(J, i, j)) return HX_NEG_INF;
-  return J.fwd[(int64_t)s * J.plane + cell_slot(J.strip_stride, i, j)];
+  const int64_t slot = stored_slot(J, i, j);
+  return slot < 0 ? HX_NEG_INF : J.fwd[(int64_t)s * J.plane + slot];
 }
 
 }  // namespace

@@ -69,6 +69,14 @@ enum { HX_IMM = 0, HX_IMD = 1, HX_IDM = 2, HX_IMI = 3, HX_IIW = 4, HX_STATES = 5
                                  hx_batch_read_cells and hx_batch_posterior_scan still treat them as -inf.
                                  Honoured by the chain (leaf) pipelines; general-profile batches always pre-fill. */
 
+#define HX_BAND_COMPRESSED 32u /* banded jobs: keep only the cells the fill sweeps - per 64-row strip the (at most two)
+                                 step windows that hold its in-envelope cells - instead of dense planes: a 2x2000 pair
+                                 with band 20 takes ~15 MB instead of 169 MB, so thousands of pairs fit one batch (the
+                                 reference's sparse cell map, src/forward.h:22,68, is the same idea).  hx_layout::compressed
+                                 is set and hx_batch_strip_windows describes the planes; hx_batch_read_cells,
+                                 hx_batch_best_trace and lpEnd work as usual.  Implemented by the scaled-probability
+                                 Forward fill: needs HX_LSE_LINEAR and leaf-profile pairs; no Backward fill.           */
+
 /* POD image of a reference Profile (src/profile.h:13-76) restricted to what the
  * fills read.  Transitions are listed once; the three per-state lists hold
  * transition indices in the reference's vector order (ProfileState::in, absorbOut,
@@ -132,7 +140,11 @@ typedef struct hx_layout {
   int64_t plane_stride;      /* doubles per state plane = n_strips * strip_stride      */
   int32_t mirrored;          /* 1 for the Backward matrix: apply the formula to
                                 (n_rows-1-i, n_cols-1-j) -- its fill sweeps from the far corner */
-  int32_t pad_;
+  int32_t compressed;        /* 1: HX_BAND_COMPRESSED job.  strip_stride is unused; with the windows {lo0,hi0,lo1,hi1}
+                                and offsets {base0,base1} of strip i / strip_rows from hx_batch_strip_windows,
+                                  slot(i,j) = base_w + ((t - lo_w) / 2) * (2 * strip_rows) + l * 2 + t % 2
+                                for the window w with lo_w <= t < hi_w; a cell in neither window is not stored
+                                (it is outside the envelope and reads as -inf).                                  */
 } hx_layout;
 
 typedef struct hx_cell {
@@ -200,6 +212,9 @@ typedef struct hx_trace_cell {
   int32_t xpos, ypos, state;   /* state: 0..4 = IMM,IMD,IDM,IMI,IIW, 5 = EEE */
 } hx_trace_cell;
 int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t* n_cells);
+
+/* HX_BAND_COMPRESSED jobs: the step windows [n_strips][4] and their plane offsets [n_strips][2] (see hx_layout). */
+int hx_batch_strip_windows(const hx_batch* b, int32_t job, int32_t* windows, int64_t* bases);
 
 /* Total in-envelope-or-not lattice cells of the batch, sum (Nx-1)(Ny-1). */
 int64_t hx_batch_total_cells(const hx_batch* b);

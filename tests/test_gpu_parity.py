@@ -355,8 +355,8 @@ def test_linear_mode_on_banded_leaf_pairs():
              H.leaf_case(404, 300, 330, alphabet=aa, jc=False, band=20), H.leaf_case(405, 40, 45, band=0),
              H.leaf_case(406, 150, 100), H.leaf_case(407, 500, 520, band=8)]
     imgs = [H.job_images(f) for f in cases]
-    for flags in (0, capi.HX_SPARSE_ENVELOPE):
-        be = capi.Batch(imgs, flags)
+    for flags in (0, capi.HX_SPARSE_ENVELOPE, capi.HX_BAND_COMPRESSED):
+        be = capi.Batch(imgs, flags & ~capi.HX_BAND_COMPRESSED)
         bf = capi.Batch(imgs, capi.HX_LSE_LINEAR | flags)
         be.forward()
         bf.forward()
@@ -365,7 +365,7 @@ def test_linear_mode_on_banded_leaf_pairs():
             want = c_oracle.forward(x, y, hmm, md, true_math=True)
             mf = bf.read_matrix(k, 0)
             inside = np.isfinite(want["cells"])         # (sparse storage leaves cells outside the envelope undefined)
-            if not flags:
+            if flags != capi.HX_SPARSE_ENVELOPE:        # (band-compressed storage: cells that are not stored read as -inf)
                 assert np.array_equal(np.isneginf(want["cells"]), np.isneginf(mf)), "job %d: -inf pattern" % k
             assert np.max(np.abs(want["cells"][inside] - mf[inside]), initial=0.) < 1e-9, "job %d" % k
             if np.isfinite(want["lp_end"]):
@@ -373,5 +373,18 @@ def test_linear_mode_on_banded_leaf_pairs():
                 assert abs(le[k] - lf[k]) <= 1e-5 * abs(le[k])
             else:
                 assert lf[k] == want["lp_end"] == le[k]
+        if flags == capi.HX_BAND_COMPRESSED:
+            # a banded 2x500 pair takes a fraction of its dense planes; gathers and the device traceback see the same cells
+            lay = bf.layout(6)
+            assert lay.compressed == 1 and lay.plane_stride < 0.5 * be.layout(6).plane_stride
+            assert bf.layout(5).compressed == 0          # the unbanded job of the batch stays dense
+            ij = np.array([[0, 0], [3, 500], [250, 251], [250, 400], [499, 519], [500, 520], [64, 60], [63, 70]])
+            H.assert_same_bits(bf.read_cells(6, ij), bf.read_matrix(6, 0)[ij[:, 0], ij[:, 1]], "gather from compressed planes")
+            bd = capi.Batch(imgs, capi.HX_LSE_LINEAR)
+            bd.forward()
+            assert bf.best_trace() == bd.best_trace()
+            bd.close()
         be.close()
         bf.close()
+    with pytest.raises(capi.HxError):                    # only the scaled-probability fill writes compressed planes
+        capi.Batch(imgs, capi.HX_BAND_COMPRESSED)
