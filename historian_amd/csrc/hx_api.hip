@@ -276,7 +276,7 @@ void bind_profile(DevProfile& d, const ProfOff& o, char* base) {
 struct JobOff {
   ProfOff x, y;
   size_t log_root, log_sub_l, log_sub_r, log_ins_l, log_ins_r, log_cptw_l, log_cptw_r, emis, emis_pad, scalars;
-  size_t fwd_windows, bwd_windows, strip_base;
+  size_t fwd_windows, bwd_windows, strip_base, yword;
   bool compressed;
   int64_t compact_plane;
   int64_t eplane_off;     // into hx_batch::d_eplane, or -1
@@ -462,9 +462,26 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     jo.emis = jo.table_emission ? ar.reserve(sizeof(double) * pairs) : 0;
     jo.emis_pad = jo.table_emission ? ar.reserve(sizeof(double) * (jo.x.n_cls + 1) * (jo.y.n_cls + 1)) : 0;
     jo.scalars = ar.reserve(sizeof(double) * 2);
-    jo.fwd_windows = jo.bwd_windows = jo.strip_base = 0;
+    jo.fwd_windows = jo.bwd_windows = jo.strip_base = jo.yword = 0;
     jo.compressed = false;
     jo.compact_plane = 0;
+    if ((flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && jo.y.n_cls < 255 && jo.y.n >= 2) {
+      // per-column words of the banded scaled-probability fill (hx_linear.hip): {emission class : 8, not ready : 1,
+      // always in envelope : 1, envelope coordinate : 22}, with 64 words of padding on either side (the edge columns').
+      // Built for every job: a banded batch may hold unbanded jobs too.
+      const int Cc = jo.y.n - 1;
+      const std::vector<uint8_t> yf(ar.host.data() + jo.y.flags, ar.host.data() + jo.y.flags + jo.y.n);
+      const std::vector<int32_t> ecls(reinterpret_cast<const int32_t*>(ar.host.data() + jo.y.ecls),
+                                      reinterpret_cast<const int32_t*>(ar.host.data() + jo.y.ecls) + jo.y.n);
+      std::vector<uint32_t> yw((size_t)Cc + 136);
+      for (int jp = 0; jp < Cc + 136; ++jp) {
+        const int j = jp < 64 ? 0 : (jp - 64 >= Cc ? Cc - 1 : jp - 64);
+        const bool ready = (yf[j] & F_READY) || jo.y.empty;
+        const uint32_t env = (need_env && pj.y->env_pos) ? (uint32_t)pj.y->env_pos[j] : 0u;
+        yw[jp] = (uint32_t)ecls[j] | (ready ? 0u : 0x100u) | ((yf[j] & F_EDGE) ? 0x200u : 0u) | (env << 10);
+      }
+      jo.yword = ar.put(yw.data(), sizeof(uint32_t) * yw.size());
+    }
     if (need_env) {
       const int R = jo.x.n - 1, Cc = jo.y.n - 1;
       // (copies: put() may reallocate the staging image the pointers would point into)
@@ -593,6 +610,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     J.fwd_windows = J.max_dist >= 0 ? reinterpret_cast<int32_t*>(base + jo.fwd_windows) : nullptr;
     J.bwd_windows = J.max_dist >= 0 ? reinterpret_cast<int32_t*>(base + jo.bwd_windows) : nullptr;
     J.strip_base = jo.compressed ? reinterpret_cast<int64_t*>(base + jo.strip_base) : nullptr;
+    J.yword = jo.yword ? reinterpret_cast<uint32_t*>(base + jo.yword) : nullptr;
     J.lp_end = reinterpret_cast<double*>(base + jo.scalars);
     J.lp_start = J.lp_end + 1;
     J.fwd = b->d_fwd + mat_off[k];

@@ -98,7 +98,11 @@ __device__ __forceinline__ L5 from_logs(double a, double b, double c, double d, 
 
 // LDS plan of a workgroup (byte offsets into the dynamic allocation, computed by plan_lds on the host).  The
 // logarithm table's entries 1..1023 are never addressed: the y side is put into that hole when it fits.
-struct LdsPlan { int elds, ycol, ring, yclass, flags, zero, total; };
+// A pair's LDS is two blocks: A = {emission table, [column words], class constants, counters, zero entry} and
+// B = {rings, staging ring}; offsets inside a block are the same for every pair of the workgroup, pair 0's blocks may sit
+// in the table's hole.
+struct LdsPlan { int elds, ycol, yclass, flags, zero;   // inside block A
+                 int a0, b0, a1, stride, total; };    // block A / B of pair 0; block A of pair 1 (B follows A); bytes per further pair
 
 #define HXL_RING 64                // columns of the strip above's last row in flight between two waves
 #define HXL_STAGE 128              // wave 0's staging ring on the wrap-around link: two 64-column blocks
@@ -106,28 +110,39 @@ struct LdsPlan { int elds, ycol, ring, yclass, flags, zero, total; };
 // BANDED (W == 1): one wavefront per pair, as k_fill_chain does for banded leaf batches - the strips of a banded pair
 // run one after the other anyway.  A strip sweeps only the step windows that hold its in-envelope cells (hx_api.hip
 // strip_windows), cells outside the envelope are shifted to zero, and every strip boundary is the wrap-around link.
-template <int W, bool BANDED>
-__global__ void __launch_bounds__(W * 64, 4)   // four waves per SIMD: 128 vector registers
+// PPW > 1 (banded): PPW pairs per workgroup share the logarithm table; their column words come from memory
+// (DevJob::yword), so that a pair needs 11 KB of LDS and twelve pairs fit a CU.
+template <int W, bool BANDED, int PPW>
+__global__ void __launch_bounds__(W * PPW * 64, 4)   // four waves per SIMD: 128 vector registers
 k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const double* __restrict__ log_tab,
-                      const LdsPlan plan) {
+                      const LdsPlan plan, const int n_jobs) {
   static_assert(!BANDED || W == 1, "banded batches run one wavefront per pair");
-  constexpr int THREADS = W * 64;
+  static_assert(PPW == 1 || BANDED, "several pairs per workgroup: banded batches only");
+  constexpr int THREADS = W * PPW * 64, PT = W * 64;       // threads of the workgroup / of a pair
+  constexpr int RING_ENTRIES = BANDED ? 0 : W * HXL_RING;  // (a banded pair is one wave: every strip boundary is the wrap-around link)
   typedef double d2v __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   double* ltab = reinterpret_cast<double*>(lds);
-  double* elds = reinterpret_cast<double*>(lds + plan.elds);
-  unsigned* ycol = reinterpret_cast<unsigned*>(lds + plan.ycol);
-  double* yclass = reinterpret_cast<double*>(lds + plan.yclass);
-  volatile int* prog = reinterpret_cast<volatile int*>(lds + plan.flags);   // [W] columns written to the wave's ring (+ base)
+  const int pair = PPW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tid = (int)threadIdx.x - pair * PT;              // thread within its pair
+  const int job = (int)blockIdx.x * PPW + pair;
+  const bool live = PPW == 1 || job < n_jobs;
+  const DevJob& J = jobs[live ? job : 0];
+  unsigned char* blk_a = lds + (pair == 0 ? plan.a0 : plan.a1 + (pair - 1) * plan.stride);
+  unsigned char* blk_b = pair == 0 ? lds + plan.b0 : blk_a + (plan.stride - (RING_ENTRIES + HXL_STAGE) * 48);
+  double* elds = reinterpret_cast<double*>(blk_a + plan.elds);
+  unsigned* ycol = reinterpret_cast<unsigned*>(blk_a + plan.ycol);
+  double* yclass = reinterpret_cast<double*>(blk_a + plan.yclass);
+  volatile int* prog = reinterpret_cast<volatile int*>(blk_a + plan.flags);   // [W] columns written to the wave's ring (+ base)
   volatile int* cons = prog + W;                                             // [W] columns the wave has taken from the ring above
   volatile int* drain = cons + W;                                            // [1] wrap-around link: columns of wave W-1's strip that are in memory
-  const DevJob& J = jobs[blockIdx.x];
+  constexpr bool lds_words = !BANDED;                        // column words in LDS, or (banded) read from memory: DevJob::yword
   // (the table first: the y side may sit in its hole)
   for (int k = threadIdx.x; k < 2; k += THREADS) ltab[k] = log_tab[k];
   for (int k = 2048 + threadIdx.x; k < 2 * HXL_LOG_ENTRIES; k += THREADS) ltab[k] = log_tab[k];
-  if (threadIdx.x < 2 * W + 1) prog[threadIdx.x] = 0;
-  if (threadIdx.x == 0) {
-    d2v* z = reinterpret_cast<d2v*>(lds + plan.zero);
+  if (tid < 2 * W + 1) prog[tid] = 0;
+  if (tid == 0) {
+    d2v* z = reinterpret_cast<d2v*>(blk_a + plan.zero);
     z[0] = d2v{0., 0.}; z[1] = d2v{0., 0.}; z[2] = d2v{0., __hiloint2double(0, HXL_EMIN)};
   }
   {
@@ -135,7 +150,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     // {exp(rootsuby), exp(insy)}, and exp() of the padded class-pair emission table
     const int Ky1 = J.y.n_cls + 1, Kx1 = J.x.n_cls + 1;
     // (64 words of padding on either side: a lane whose column is outside the lattice reads the edge column's word)
-    for (int jp = threadIdx.x; jp < J.n_cols + 130; jp += THREADS) {
+    for (int jp = tid; jp < (lds_words ? J.n_cols + 130 : 0); jp += PT) {
       const int j = jp < 64 ? 0 : (jp - 64 >= J.n_cols ? J.n_cols - 1 : jp - 64);
       if (BANDED)   // {class : 8, not ready : 1, always in envelope : 1, envelope coordinate : 22}
         ycol[jp] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0x100u : 0u) |
@@ -143,18 +158,18 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
       else
         ycol[jp] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0xFFFF0000u : 0u);
     }
-    for (int c = threadIdx.x; c < Ky1; c += THREADS) {
+    for (int c = tid; c < Ky1; c += PT) {
       const bool real = c < J.y.n_cls;
       const int rep = real ? J.y.cls_rep[c] : 0;
       yclass[2 * c] = real ? exp(J.y.pack[4 * (size_t)rep + 1]) : 0.;
       yclass[2 * c + 1] = real ? exp(J.y.pack[4 * (size_t)rep + 2]) : 0.;
     }
-    for (int e = threadIdx.x; e < Kx1 * Ky1; e += THREADS) elds[e] = exp(J.emis_pad[e]);
+    for (int e = tid; e < Kx1 * Ky1; e += PT) elds[e] = exp(J.emis_pad[e]);
   }
   __syncthreads();
   const int R = J.n_rows, Cc = J.n_cols;
   const int max_dist = J.max_dist;
-  const int lane = threadIdx.x & 63, wave = (int)(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave = PPW == 1 ? (int)(threadIdx.x >> 6) : 0;   // wave within its pair
   const int64_t plane = J.plane, ss = J.strip_stride;
   HX_GLOBAL double* __restrict__ M = as_global(J.fwd);
   const HX_GLOBAL d4v* xpack = (const HX_GLOBAL d4v*)as_global(J.x.pack);
@@ -176,15 +191,15 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
   volatile HX_LDS int* consp = (volatile HX_LDS int*)cons;
   volatile HX_LDS int* drainp = (volatile HX_LDS int*)drain;
   const HX_LDS double* lt = (const HX_LDS double*)ltab;
-  HX_LDS d2v* ring_mine = (HX_LDS d2v*)(lds + plan.ring) + (size_t)wave * (HXL_RING * 3);
-  const int n_strips = (R + 63) / 64;
+  HX_LDS d2v* ring_mine = (HX_LDS d2v*)blk_b + (size_t)wave * (HXL_RING * 3);
+  const int n_strips = live ? (R + 63) / 64 : 0;
   const int prev_wave = (wave + W - 1) % W, next_wave = (wave + 1) % W;
   // Strips are dealt round-robin, so with more strips than waves the last wave feeds the first one's NEXT strip, which
   // starts a whole sweep later: that link cannot be a bounded ring (the waves would wait for each other in a circle).
   // It goes through the matrix instead - wave W-1 publishes how many columns of its last row have reached memory, wave 0
   // block-loads them 64 at a time, converts them back to mantissas + exponent and stages them in a ring of its own.
-  HX_LDS d2v* staging = (HX_LDS d2v*)(lds + plan.ring) + (size_t)W * (HXL_RING * 3);   // [HXL_STAGE] entries
-  const HX_LDS d2v* ring_prev = (const HX_LDS d2v*)(lds + plan.ring) + (size_t)prev_wave * (HXL_RING * 3);
+  HX_LDS d2v* staging = (HX_LDS d2v*)blk_b + (size_t)RING_ENTRIES * 3;   // [HXL_STAGE] entries
+  const HX_LDS d2v* ring_prev = (const HX_LDS d2v*)blk_b + (size_t)prev_wave * (HXL_RING * 3);
 
   for (int s = wave; s < n_strips; s += W) {
     const int row0 = s * 64;
@@ -231,7 +246,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
       asm volatile("" ::: "memory");               // the ring reads below stay below
     };
     // (strip 0 reads an all-zero entry: the ring read below is unconditional)
-    const HX_LDS d2v* ring_above = !has_above ? (const HX_LDS d2v*)(lds + plan.zero) : wrap_in ? (const HX_LDS d2v*)staging : ring_prev;
+    const HX_LDS d2v* ring_above = !has_above ? (const HX_LDS d2v*)(blk_a + plan.zero) : wrap_in ? (const HX_LDS d2v*)staging : ring_prev;
     const int ring_base = (wrap_in || !has_above) ? 0 : above_base;
     const int ring_mask = !has_above ? 0 : wrap_in ? HXL_STAGE - 1 : HXL_RING - 1;
     auto ring_entry = [&](const int col) -> L5 {   // (uniform address: a broadcast read)
@@ -380,10 +395,18 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     };
 
     // column words, fetched one step ahead (ycol is padded by 64 words on either side)
-    unsigned wnext = 0;
+    // Words from memory (banded, DevJob::yword) are fetched four steps ahead: vector-memory operations retire in issue
+    // order, so a load issued behind a step pair's stores returns only when those have left; two iterations hide that.
+    unsigned wnext = 0, wq1 = 0, wq2 = 0, wq3 = 0;
+    const HX_GLOBAL unsigned* ywords = (const HX_GLOBAL unsigned*)as_global(J.yword);
+    auto first_words = [&](const int t0) {
+      if (lds_words) { wnext = ycol[t0 + 64 - lane]; return; }
+      wnext = ywords[t0 + 64 - lane]; wq1 = ywords[t0 + 65 - lane]; wq2 = ywords[t0 + 66 - lane]; wq3 = ywords[t0 + 67 - lane];
+    };
     auto next_word = [&](const int t) -> unsigned {
       const unsigned w = wnext;
-      wnext = ycol[t + 65 - lane];
+      if (lds_words) wnext = ycol[t + 65 - lane];
+      else { wnext = wq1; wq1 = wq2; wq2 = wq3; wq3 = ywords[t + 68 - lane]; }
       return w;
     };
 
@@ -407,7 +430,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     if (BANDED) { ca = l5_zero(); cb = l5_zero(); ua = l5_zero(); ub = l5_zero(); }
     if (BANDED && J.strip_base) { store_base2 = J.strip_base[2 * s + wi] + (lane << 1); store_t0 = wstart; }
     open_sweep(wstart);
-    wnext = ycol[wstart + 64 - lane];
+    first_words(wstart);
     for (int t = wstart; t < wend; t += 2) {
       step(t, cb, ca, ua, ub, next_word(t));
       const double l0 = log_scaled(ca.imm, ca.e, lt), l1 = log_scaled(ca.imd, ca.e, lt),
@@ -467,7 +490,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (wave == 0 && lane == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
+  if (live && wave == 0 && lane == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
 }
 
 }  // namespace
@@ -485,40 +508,56 @@ void build_log_table(double* out) {
   }
 }
 
-static LdsPlan plan_lds(int W, int yl_cols, int yl_emis) {
+static LdsPlan plan_lds(int W, int PPW, bool banded, int yl_cols, int yl_emis) {
+  const bool lds_words = !banded;
   LdsPlan p;
   const int table = 16 * HXL_LOG_ENTRIES, hole = 16 * 1024;
-  const int elds = 8 * yl_emis, ycol = 4 * (yl_cols + 132);
+  int a = 0;
+  p.elds = a; a += (8 * yl_emis + 15) & ~15;
+  p.ycol = a; a += lds_words ? (4 * (yl_cols + 132) + 15) & ~15 : 0;
+  p.yclass = a; a += 16 * HX_YL_MAX_CLS_LINEAR;
+  p.flags = a; a += (4 * (2 * W + 1) + 15) & ~15;
+  p.zero = a; a += 48;                           // an all-zero ring entry: what strip 0 reads as its row above
+  const int b = ((banded ? 0 : W * HXL_RING) + HXL_STAGE) * 48;   // one ring per wave + wave 0's staging ring
   int end = table;
-  if (16 + elds + ycol <= hole) { p.elds = 16; p.ycol = 16 + elds; }
-  else { p.elds = end; p.ycol = end + elds; end += (elds + ycol + 15) & ~15; }
-  p.ring = end; end += (W * HXL_RING + HXL_STAGE) * 48;     // one ring per wave + wave 0's staging ring
-  p.yclass = end; end += 16 * HX_YL_MAX_CLS_LINEAR;
-  p.flags = end; end += (4 * (2 * W + 1) + 15) & ~15;
-  p.zero = end; end += 48;                          // an all-zero ring entry: what strip 0 reads as its row above
+  // pair 0: as much as fits goes into the hole of the table (entries 1..1023 are never addressed)
+  if (16 + a + b <= hole) { p.a0 = 16; p.b0 = 16 + a; }
+  else if (16 + a <= hole) { p.a0 = 16; p.b0 = end; end += b; }
+  else { p.a0 = end; p.b0 = end + a; end += a + b; }
+  p.a1 = end;
+  p.stride = a + b;
+  end += (PPW - 1) * p.stride;
   p.total = (end + 15) & ~15;
   return p;
 }
 
 void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
                                 int yl_cols, int yl_emis, hipStream_t st) {
-  const dim3 g(n_jobs);
-#define HXL_LAUNCH(W_, B_) do { const LdsPlan p = plan_lds(W_, yl_cols, yl_emis); \
-    hipLaunchKernelGGL((k_forward_leaf_linear<W_, B_>), g, dim3(W_ * 64), p.total, st, d_jobs, tab, log_tab, p); } while (0)
-  if (banded) { HXL_LAUNCH(1, true); return; }    // one wavefront per pair
+#define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis); \
+    hipLaunchKernelGGL((k_forward_leaf_linear<W_, B_, PPW_>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
+                       d_jobs, tab, log_tab, p, n_jobs); } while (0)
+  if (banded) {
+    // one wavefront per pair; with more pairs than fit the CUs one by one (LDS: four workgroups of one pair), six pairs
+    // per workgroup share the logarithm table: twelve waves per CU
+    const char* v = getenv("HX_LINEAR_PPW");     // tuning / test hook
+    const int forced = v ? atoi(v) : 0;
+    if (forced == 6 || (forced == 0 && n_jobs > 1024)) HXL_LAUNCH(1, true, 6);
+    else HXL_LAUNCH(1, true, 1);
+    return;
+  }
   const char* v = getenv("HX_LINEAR_WAVES");     // tuning / test hook: waves per pair (any count works for any size)
   const int forced = v ? atoi(v) : 0;
-  if (forced == 1) HXL_LAUNCH(1, false);
-  else if (forced == 2) HXL_LAUNCH(2, false);
-  else if (forced == 4) HXL_LAUNCH(4, false);
-  else if (forced == 8) HXL_LAUNCH(8, false);
-  else if (forced == 16) HXL_LAUNCH(16, false);
-  else if (max_rows <= 64) HXL_LAUNCH(1, false);
-  else if (max_rows <= 128) HXL_LAUNCH(2, false);
-  else if (max_rows <= 256) HXL_LAUNCH(4, false);
+  if (forced == 1) HXL_LAUNCH(1, false, 1);
+  else if (forced == 2) HXL_LAUNCH(2, false, 1);
+  else if (forced == 4) HXL_LAUNCH(4, false, 1);
+  else if (forced == 8) HXL_LAUNCH(8, false, 1);
+  else if (forced == 16) HXL_LAUNCH(16, false, 1);
+  else if (max_rows <= 64) HXL_LAUNCH(1, false, 1);
+  else if (max_rows <= 128) HXL_LAUNCH(2, false, 1);
+  else if (max_rows <= 256) HXL_LAUNCH(4, false, 1);
   // more pairs than compute units: eight waves per pair, two pairs per CU (less pipeline fill per pair)
-  else if (max_rows <= 512 || n_jobs > 256) HXL_LAUNCH(8, false);
-  else HXL_LAUNCH(16, false);
+  else if (max_rows <= 512 || n_jobs > 256) HXL_LAUNCH(8, false, 1);
+  else HXL_LAUNCH(16, false, 1);
 #undef HXL_LAUNCH
 }
 

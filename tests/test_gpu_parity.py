@@ -346,10 +346,14 @@ def test_linear_mode_on_unbanded_leaf_pairs_runs_on_scaled_probabilities(waves, 
         bf.close()
 
 
-def test_linear_mode_on_banded_leaf_pairs():
+@pytest.mark.parametrize("ppw", [0, 6])
+def test_linear_mode_on_banded_leaf_pairs(ppw, monkeypatch):
     # HX_LSE_LINEAR with a band: one wavefront per pair sweeping the strips' step windows (hx_linear.hip, BANDED),
     # default and sparse-envelope storage, several strips, a band too narrow for any path (lpEnd = -inf), and an
-    # unbanded pair in the same batch.  Same two yardsticks as the unbanded test.
+    # unbanded pair in the same batch.  Same two yardsticks as the unbanded test.  ppw = 6 forces the large-batch launch:
+    # six pairs per workgroup sharing the logarithm table (the second workgroup of this batch has five idle waves).
+    if ppw:
+        monkeypatch.setenv("HX_LINEAR_PPW", str(ppw))
     aa = "arndcqeghilkmfpstwyv"
     cases = [H.leaf_case(401, 70, 66, band=5), H.leaf_case(402, 200, 90, band=12), H.leaf_case(403, 130, 150, band=3),
              H.leaf_case(404, 300, 330, alphabet=aa, jc=False, band=20), H.leaf_case(405, 40, 45, band=0),
