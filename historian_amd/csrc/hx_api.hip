@@ -473,8 +473,8 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
       const std::vector<uint8_t> yf(ar.host.data() + jo.y.flags, ar.host.data() + jo.y.flags + jo.y.n);
       const std::vector<int32_t> ecls(reinterpret_cast<const int32_t*>(ar.host.data() + jo.y.ecls),
                                       reinterpret_cast<const int32_t*>(ar.host.data() + jo.y.ecls) + jo.y.n);
-      std::vector<uint32_t> yw((size_t)Cc + 136);
-      for (int jp = 0; jp < Cc + 136; ++jp) {
+      std::vector<uint32_t> yw((size_t)Cc + 328);     // (the kernel refills its word ring 64 words at a time, up to 256 ahead)
+      for (int jp = 0; jp < Cc + 328; ++jp) {
         const int j = jp < 64 ? 0 : (jp - 64 >= Cc ? Cc - 1 : jp - 64);
         const bool ready = (yf[j] & F_READY) || jo.y.empty;
         const uint32_t env = (need_env && pj.y->env_pos) ? (uint32_t)pj.y->env_pos[j] : 0u;
@@ -659,7 +659,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
     // HX_LSE_LINEAR on leaf pairs whose y side fits LDS (the headline workload, and its banded variant): the recursion runs on
     // scaled probabilities instead of table log-sum-exps (hx_linear.hip)
     if ((b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && b->all_leaf && b->all_ylds && b->max_cls < 255)
-      launch_forward_leaf_linear(b->d_jobs, b->n_jobs, b->max_rows, b->any_banded, g_tab, g_log_tab, b->yl_cols, b->yl_emis, st);
+      launch_forward_leaf_linear(b->d_jobs, b->n_jobs, b->max_rows, b->any_banded, g_tab, g_log_tab, b->yl_cols, b->yl_emis, b->max_cls + 1, st);
     else
     launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, (b->flags & HX_LSE_FAST) ? g_fast_tab : g_pair_tab, (b->flags & HX_LSE_FAST) != 0,
                          b->all_leaf ? (b->all_ylds ? 2 : 1) : 0, b->any_banded, b->yl_cols, b->yl_emis, st);

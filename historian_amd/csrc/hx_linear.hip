@@ -136,7 +136,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
   volatile int* prog = reinterpret_cast<volatile int*>(blk_a + plan.flags);   // [W] columns written to the wave's ring (+ base)
   volatile int* cons = prog + W;                                             // [W] columns the wave has taken from the ring above
   volatile int* drain = cons + W;                                            // [1] wrap-around link: columns of wave W-1's strip that are in memory
-  constexpr bool lds_words = !BANDED;                        // column words in LDS, or (banded) read from memory: DevJob::yword
+  constexpr bool lds_words = !BANDED;                        // all column words in LDS, or (banded) a ring refilled from DevJob::yword
   // (the table first: the y side may sit in its hole)
   for (int k = threadIdx.x; k < 2; k += THREADS) ltab[k] = log_tab[k];
   for (int k = 2048 + threadIdx.x; k < 2 * HXL_LOG_ENTRIES; k += THREADS) ltab[k] = log_tab[k];
@@ -150,7 +150,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     // {exp(rootsuby), exp(insy)}, and exp() of the padded class-pair emission table
     const int Ky1 = J.y.n_cls + 1, Kx1 = J.x.n_cls + 1;
     // (64 words of padding on either side: a lane whose column is outside the lattice reads the edge column's word)
-    for (int jp = tid; jp < (lds_words ? J.n_cols + 130 : 0); jp += PT) {
+    for (int jp = tid; jp < (lds_words ? J.n_cols + 130 : 0); jp += PT) {   // (banded: see refill_words)
       const int j = jp < 64 ? 0 : (jp - 64 >= J.n_cols ? J.n_cols - 1 : jp - 64);
       if (BANDED)   // {class : 8, not ready : 1, always in envelope : 1, envelope coordinate : 22}
         ycol[jp] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0x100u : 0u) |
@@ -302,8 +302,30 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
         if (BANDED && t0 > 0) ub = bd;
       }
     };
+    // Column words, fetched one step ahead.  Unbanded: the pair's whole y side is in LDS (ycol, padded by 64 words on either
+    // side).  Banded: a 256-word LDS ring refilled from memory (DevJob::yword) every 64 steps - a vector-memory load
+    // inside the step loop would make every step wait for the stores before it (they retire in issue order).
+    unsigned wnext = 0;
+    const HX_GLOBAL unsigned* ywords = (const HX_GLOBAL unsigned*)as_global(J.yword);
+    auto refill_words = [&](const int i0) {             // word indices [i0, i0 + 64)
+      const unsigned v = ywords[i0 + lane];
+      ycol[(i0 + lane) & 255] = v;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
+    auto first_words = [&](const int t0) {
+      if (lds_words) { wnext = ycol[t0 + 64 - lane]; return; }
+      // the steps [t0, next multiple of 64) read word indices t + 64 - lane: within [(t0 & ~63) + 1, (t0 & ~63) + 128)
+      refill_words(t0 & ~63); refill_words((t0 & ~63) + 64); refill_words((t0 & ~63) + 128);
+      wnext = ycol[(t0 + 64 - lane) & 255];
+    };
+    auto next_word = [&](const int t) -> unsigned {
+      const unsigned w = wnext;
+      wnext = lds_words ? ycol[t + 65 - lane] : ycol[(t + 65 - lane) & 255];
+      return w;
+    };
     // one anti-diagonal step: the lane's new cell from left (own previous), u1 = (i-1, j), u2 = (i-1, j-1)
     auto step = [&](const int t, const L5& left, L5& out, L5& u1, L5& u2, const unsigned w) {
+      if (!lds_words && (t & 63) == 62) refill_words(t + 2 + 128);   // (steps from t+2 on read up to index t+2+127)
       if ((t & 7) == 7 && has_above && t + 1 < Cc) {
         if (wrap_in) {
           if ((t & 63) == 63) stage_block(t + 1);
@@ -395,21 +417,6 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     };
 
     // column words, fetched one step ahead (ycol is padded by 64 words on either side)
-    // Words from memory (banded, DevJob::yword) are fetched four steps ahead: vector-memory operations retire in issue
-    // order, so a load issued behind a step pair's stores returns only when those have left; two iterations hide that.
-    unsigned wnext = 0, wq1 = 0, wq2 = 0, wq3 = 0;
-    const HX_GLOBAL unsigned* ywords = (const HX_GLOBAL unsigned*)as_global(J.yword);
-    auto first_words = [&](const int t0) {
-      if (lds_words) { wnext = ycol[t0 + 64 - lane]; return; }
-      wnext = ywords[t0 + 64 - lane]; wq1 = ywords[t0 + 65 - lane]; wq2 = ywords[t0 + 66 - lane]; wq3 = ywords[t0 + 67 - lane];
-    };
-    auto next_word = [&](const int t) -> unsigned {
-      const unsigned w = wnext;
-      if (lds_words) wnext = ycol[t + 65 - lane];
-      else { wnext = wq1; wq1 = wq2; wq2 = wq3; wq3 = ywords[t + 68 - lane]; }
-      return w;
-    };
-
     // With a band, the strip sweeps only the (up to two) step windows that hold its in-envelope cells, widened to whole
     // step pairs; cells left of a window are outside the envelope, so the register window restarts from zero.
     int wlo[2] = {0, 0}, whi[2] = {nsteps, 0};
@@ -431,7 +438,8 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     if (BANDED && J.strip_base) { store_base2 = J.strip_base[2 * s + wi] + (lane << 1); store_t0 = wstart; }
     open_sweep(wstart);
     first_words(wstart);
-    for (int t = wstart; t < wend; t += 2) {
+    // a pair of steps: in the strip-skewed layout its two cells per row are adjacent, 16 bytes per lane and state plane
+    auto step_pair = [&](const int t) {
       step(t, cb, ca, ua, ub, next_word(t));
       const double l0 = log_scaled(ca.imm, ca.e, lt), l1 = log_scaled(ca.imd, ca.e, lt),
                    l2 = log_scaled(ca.idm, ca.e, lt), l3 = log_scaled(ca.imi, ca.e, lt),
@@ -441,7 +449,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
                    h2 = log_scaled(cb.idm, cb.e, lt), h3 = log_scaled(cb.imi, cb.e, lt),
                    h4 = log_scaled(cb.iiw, cb.e, lt);
       {
-        // t64 = j + (i & 63) = t: both cells of the step pair are adjacent in the strip-skewed layout
+        // t64 = j + (i & 63) = t
         const int64_t sl = store_base2 + ((int64_t)((t - store_t0) >> 1) << 7);
         HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
         const int64_t plane2 = plane >> 1;
@@ -479,7 +487,8 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
           }
         }
       }
-    }
+    };
+    for (int t = wstart; t < wend; t += 2) step_pair(t);
     }
     if (BANDED && wrap_out) {
       // (the windows need not reach the strip's last step: everything this strip will ever write is out)
@@ -508,14 +517,13 @@ void build_log_table(double* out) {
   }
 }
 
-static LdsPlan plan_lds(int W, int PPW, bool banded, int yl_cols, int yl_emis) {
-  const bool lds_words = !banded;
+static LdsPlan plan_lds(int W, int PPW, bool banded, int yl_cols, int yl_emis, int yl_cls) {
   LdsPlan p;
   const int table = 16 * HXL_LOG_ENTRIES, hole = 16 * 1024;
   int a = 0;
   p.elds = a; a += (8 * yl_emis + 15) & ~15;
-  p.ycol = a; a += lds_words ? (4 * (yl_cols + 132) + 15) & ~15 : 0;
-  p.yclass = a; a += 16 * HX_YL_MAX_CLS_LINEAR;
+  p.ycol = a; a += banded ? 4 * 256 : (4 * (yl_cols + 132) + 15) & ~15;   // (banded: a ring of 256 words)
+  p.yclass = a; a += 16 * yl_cls;
   p.flags = a; a += (4 * (2 * W + 1) + 15) & ~15;
   p.zero = a; a += 48;                           // an all-zero ring entry: what strip 0 reads as its row above
   const int b = ((banded ? 0 : W * HXL_RING) + HXL_STAGE) * 48;   // one ring per wave + wave 0's staging ring
@@ -532,8 +540,8 @@ static LdsPlan plan_lds(int W, int PPW, bool banded, int yl_cols, int yl_emis) {
 }
 
 void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
-                                int yl_cols, int yl_emis, hipStream_t st) {
-#define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis); \
+                                int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
+#define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis, yl_cls); \
     hipLaunchKernelGGL((k_forward_leaf_linear<W_, B_, PPW_>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
                        d_jobs, tab, log_tab, p, n_jobs); } while (0)
   if (banded) {
@@ -541,8 +549,12 @@ void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, 
     // per workgroup share the logarithm table: twelve waves per CU
     const char* v = getenv("HX_LINEAR_PPW");     // tuning / test hook
     const int forced = v ? atoi(v) : 0;
-    if (forced == 6 || (forced == 0 && n_jobs > 1024)) HXL_LAUNCH(1, true, 6);
-    else HXL_LAUNCH(1, true, 1);
+    if (forced > 1 || (forced == 0 && n_jobs > 1024)) {
+      // two workgroups per CU (160 KB of LDS; a workgroup of exactly 80 KB was measured NOT to fit twice)
+      if (plan_lds(1, 6, true, yl_cols, yl_emis, yl_cls).total <= 76 * 1024) HXL_LAUNCH(1, true, 6);
+      else if (plan_lds(1, 5, true, yl_cols, yl_emis, yl_cls).total <= 76 * 1024) HXL_LAUNCH(1, true, 5);
+      else HXL_LAUNCH(1, true, 4);
+    } else HXL_LAUNCH(1, true, 1);
     return;
   }
   const char* v = getenv("HX_LINEAR_WAVES");     // tuning / test hook: waves per pair (any count works for any size)
