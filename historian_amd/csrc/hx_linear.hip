@@ -225,7 +225,11 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
       }
     }
     L5 ca = l5_zero(), cb = l5_zero(), ua = l5_zero(), ub = l5_zero();
+#if HX_ABLATE == 24      // no exchange between strips at all (wrong results): what the synchronisation machinery costs
+    const bool has_above = false, has_below = false;
+#else
     const bool has_above = s > 0, has_below = s + 1 < n_strips;
+#endif
     const bool wrap_in = has_above && wave == 0;             // the strip above went through memory (W > 1: s >= W)
     const bool wrap_out = has_below && wave == W - 1;        // this strip's last row is read back from memory
     const bool ring_out = has_below && !wrap_out;
