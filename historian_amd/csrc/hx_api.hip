@@ -703,6 +703,9 @@ int hx_batch_backward(hx_batch* b, void* stream) {
   HIP_TRY(hipEventRecord(b->ev[1][0], st));
   if (b->all_leaf && !(b->flags & HX_FORCE_GENERIC)) {
     if (b->any_banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_bwd, b->fwd_total, st);
+    if ((b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && b->all_ylds && !b->any_banded)
+      launch_backward_leaf_linear(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_log_tab, b->yl_cols, b->yl_emis, b->max_cls + 1, st);
+    else
     launch_backward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, (b->flags & HX_LSE_FAST) ? g_fast_tab : g_pair_tab, (b->flags & HX_LSE_FAST) != 0,
                           b->all_ylds ? 2 : 1, b->any_banded, b->yl_cols, b->yl_emis, st);
   } else if (b->flags & HX_FORCE_GENERIC)

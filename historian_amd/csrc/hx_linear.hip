@@ -112,12 +112,16 @@ struct LdsPlan { int elds, ycol, yclass, flags, zero;   // inside block A
 // strip_windows), cells outside the envelope are shifted to zero, and every strip boundary is the wrap-around link.
 // PPW > 1 (banded): PPW pairs per workgroup share the logarithm table; their column words come from memory
 // (DevJob::yword), so that a pair needs 11 KB of LDS and twelve pairs fit a CU.
-template <int W, bool BANDED, int PPW>
+// DIR = 1: the Backward fill (reference src/forward.cpp:975-1088 for leaf-like profiles) - the same pipeline in mirrored
+// coordinates (sweep row i' = R-1-i, sweep column j' = Cc-1-j, as k_fill_chain<1> and the stored layout), with the Backward
+// recursion: B(i,j,s) = sum over the destination cells (i+1,j+1), (i+1,j), (i,j+1) of P[s][dest state] x emission x B(dest).
+template <int W, bool BANDED, int PPW, int DIR>
 __global__ void __launch_bounds__(W * PPW * 64, 4)   // four waves per SIMD: 128 vector registers
 k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const double* __restrict__ log_tab,
                       const LdsPlan plan, const int n_jobs) {
   static_assert(!BANDED || W == 1, "banded batches run one wavefront per pair");
   static_assert(PPW == 1 || BANDED, "several pairs per workgroup: banded batches only");
+  static_assert(DIR == 0 || !BANDED, "the scaled-probability Backward fill exists for unbanded batches");
   constexpr int THREADS = W * PPW * 64, PT = W * 64;       // threads of the workgroup / of a pair
   constexpr int RING_ENTRIES = BANDED ? 0 : W * HXL_RING;  // (a banded pair is one wave: every strip boundary is the wrap-around link)
   typedef double d2v __attribute__((ext_vector_type(2)));
@@ -155,8 +159,14 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
       if (BANDED)   // {class : 8, not ready : 1, always in envelope : 1, envelope coordinate : 22}
         ycol[jp] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0x100u : 0u) |
                    ((J.y.flags[j] & F_EDGE) ? 0x200u : 0u) | (J.max_dist >= 0 ? (unsigned)J.y.env[j] << 10 : 0u);
-      else
+      else if (DIR == 0)
         ycol[jp] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0xFFFF0000u : 0u);
+      else {
+        // sweep column j is y state jc = Cc-1-j: its own readiness, and the emission class of the state jc+1 that an
+        // absorbing move leads to
+        const int jc = J.n_cols - 1 - j;
+        ycol[jp] = (unsigned)J.y.ecls[jc + 1] | (J.y.pack[4 * (size_t)jc + 3] < 0.0 ? 0xFFFF0000u : 0u);
+      }
     }
     for (int c = tid; c < Ky1; c += PT) {
       const bool real = c < J.y.n_cls;
@@ -171,7 +181,7 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
   const int max_dist = J.max_dist;
   const int lane = threadIdx.x & 63, wave = PPW == 1 ? (int)(threadIdx.x >> 6) : 0;   // wave within its pair
   const int64_t plane = J.plane, ss = J.strip_stride;
-  HX_GLOBAL double* __restrict__ M = as_global(J.fwd);
+  HX_GLOBAL double* __restrict__ M = as_global(DIR ? J.bwd : J.fwd);
   const HX_GLOBAL d4v* xpack = (const HX_GLOBAL d4v*)as_global(J.x.pack);
   // the 18 transition probabilities (src/pairhmm.cpp:17-43), pinned in scalar registers
   double P[5][5];
@@ -212,13 +222,16 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
     int env_x = 0;
     bool edge_x = true;
     {
-      const int ic = row_valid ? i0 : 0;
+      const int ic = row_valid ? (DIR ? R - 1 - i0 : i0) : 0;      // the row's x state
       const d4v p = xpack[ic];
-      fx = row_valid ? exp(p.x) : 0.;
-      f_imd = row_valid ? exp(p.x + p.y) : 0.;
-      f_iiw = row_valid ? exp(p.x + p.z) : 0.;
+      // Forward: the state's own in-transition, rootsubx, insx.  Backward: those of state ic+1, which an absorbing
+      // move leads to; the readiness test is the row's own state's in both directions.
+      const d4v q = DIR ? xpack[ic + 1] : p;
+      fx = row_valid ? exp(q.x) : 0.;
+      f_imd = row_valid ? exp(q.x + q.y) : 0.;
+      f_iiw = row_valid ? exp(q.x + q.z) : 0.;
       x_wait = (row_valid && !(p.w < 0.0)) ? 0 : (1 << 29);
-      eoff = (unsigned)J.x.ecls[ic] * (unsigned)(J.y.n_cls + 1);
+      eoff = (unsigned)J.x.ecls[DIR ? ic + 1 : ic] * (unsigned)(J.y.n_cls + 1);
       if (BANDED) {
         env_x = J.max_dist >= 0 ? J.x.env[ic] : 0;
         edge_x = (J.x.flags[ic] & F_EDGE) != 0 || J.max_dist < 0;
@@ -343,50 +356,81 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
       const d2v rc = reinterpret_cast<const d2v*>(yclass)[c];
       const int y_wait = BANDED ? (int)((w & 0x100u) << 21) : (int)((w >> 16) << 13);   // y state not ready: 2^29, else 0
       const double em = elds[eoff + c];
+      int E;
+      if (DIR == 0) {
       // the five sums of src/forward.cpp:103-115,139-150,171-180 on probabilities
-      double s_imd = u1.imm * P[0][1];
-      double s_iiw = u1.imm * P[0][4];
-      double s_idm = left.imm * P[0][2];
-      double s_imi = left.imm * P[0][3];
-      double s_imm = u2.imm * P[0][0];
-      s_imd = __builtin_fma(u1.imd, P[1][1], s_imd);
-      s_iiw = __builtin_fma(u1.imi, P[3][4], s_iiw);
-      s_idm = __builtin_fma(left.imd, P[1][2], s_idm);
-      s_imi = __builtin_fma(left.imi, P[3][3], s_imi);
-      s_imm = __builtin_fma(u2.imd, P[1][0], s_imm);
-      s_imd = __builtin_fma(u1.idm, P[2][1], s_imd);
-      s_iiw = __builtin_fma(u1.iiw, P[4][4], s_iiw);
-      s_idm = __builtin_fma(left.idm, P[2][2], s_idm);
-      s_imm = __builtin_fma(u2.idm, P[2][0], s_imm);
-      s_imd = __builtin_fma(u1.imi, P[3][1], s_imd);
-      s_idm = __builtin_fma(left.iiw, P[4][2], s_idm);
-      s_imm = __builtin_fma(u2.imi, P[3][0], s_imm);
-      s_imm = __builtin_fma(u2.iiw, P[4][0], s_imm);
-      const int e_diag = u2.e;
-      // (row0-1, t+1), lane 0's upper neighbour of the next step, into the registers the diagonal cell has just
-      // vacated.  Unconditional: past the last column it returns a stale entry, which only feeds cells outside the lattice.
-      u2 = ring_entry(t + 1);
-      // common exponent of the new cell, and the three groups brought to it; a state that may not be entered
-      // (y or x state not ready: src/forward.cpp:97,133) is shifted out of the fp64 range, i.e. to zero
-      int E = left.e > u1.e ? left.e : u1.e;
-      E = E > e_diag ? E : e_diag;
-      int du = (u1.e - E) - y_wait, dl = (left.e - E) - x_wait, dd = e_diag - E;
-      if (BANDED) {
-        // a cell outside the envelope (src/forward.h:92-98) is shifted to zero as a whole
-        int dist = env_x - (int)(w >> 10);
-        dist = dist < 0 ? -dist : dist;
-        const int out_of_env = (edge_x || (w & 0x200u) || dist <= max_dist) ? 0 : (1 << 29);
-        du -= out_of_env; dl -= out_of_env; dd -= out_of_env;
+        double s_imd = u1.imm * P[0][1];
+        double s_iiw = u1.imm * P[0][4];
+        double s_idm = left.imm * P[0][2];
+        double s_imi = left.imm * P[0][3];
+        double s_imm = u2.imm * P[0][0];
+        s_imd = __builtin_fma(u1.imd, P[1][1], s_imd);
+        s_iiw = __builtin_fma(u1.imi, P[3][4], s_iiw);
+        s_idm = __builtin_fma(left.imd, P[1][2], s_idm);
+        s_imi = __builtin_fma(left.imi, P[3][3], s_imi);
+        s_imm = __builtin_fma(u2.imd, P[1][0], s_imm);
+        s_imd = __builtin_fma(u1.idm, P[2][1], s_imd);
+        s_iiw = __builtin_fma(u1.iiw, P[4][4], s_iiw);
+        s_idm = __builtin_fma(left.idm, P[2][2], s_idm);
+        s_imm = __builtin_fma(u2.idm, P[2][0], s_imm);
+        s_imd = __builtin_fma(u1.imi, P[3][1], s_imd);
+        s_idm = __builtin_fma(left.iiw, P[4][2], s_idm);
+        s_imm = __builtin_fma(u2.imi, P[3][0], s_imm);
+        s_imm = __builtin_fma(u2.iiw, P[4][0], s_imm);
+        const int e_diag = u2.e;
+        // (row0-1, t+1), lane 0's upper neighbour of the next step, into the registers the diagonal cell has just
+        // vacated.  Unconditional: past the last column it returns a stale entry, which only feeds cells outside the lattice.
+        u2 = ring_entry(t + 1);
+        // common exponent of the new cell, and the three groups brought to it; a state that may not be entered
+        // (y or x state not ready: src/forward.cpp:97,133) is shifted out of the fp64 range, i.e. to zero
+        E = left.e > u1.e ? left.e : u1.e;
+        E = E > e_diag ? E : e_diag;
+        int du = (u1.e - E) - y_wait, dl = (left.e - E) - x_wait, dd = e_diag - E;
+        if (BANDED) {
+          // a cell outside the envelope (src/forward.h:92-98) is shifted to zero as a whole
+          int dist = env_x - (int)(w >> 10);
+          dist = dist < 0 ? -dist : dist;
+          const int out_of_env = (edge_x || (w & 0x200u) || dist <= max_dist) ? 0 : (1 << 29);
+          du -= out_of_env; dl -= out_of_env; dd -= out_of_env;
+        }
+        out.imd = __builtin_ldexp(s_imd * f_imd, du);
+        out.iiw = __builtin_ldexp(s_iiw * f_iiw, du);
+        out.idm = __builtin_ldexp(s_idm * rc.x, dl);
+        out.imi = __builtin_ldexp(s_imi * rc.y, dl);
+        out.imm = __builtin_ldexp(s_imm * (fx * em), dd);
+      } else {
+        // Backward (src/forward.cpp:1018-1065 for leaf-like profiles): the five destination terms - the xy-absorbing move
+        // into (i+1,j+1), the x-absorbing moves into (i+1,j) as IMD / IIW, the y-absorbing moves into (i,j+1) as IDM / IMI -
+        // brought to the cell's exponent (a move that may not be made is shifted out of range), then 18 multiply-adds
+        const int e_diag = u2.e;
+        const double tD = u2.imm * (fx * em);
+        const double t1x = u1.imd * f_imd, t2x = u1.iiw * f_iiw;
+        const double t1y = left.idm * rc.x, t2y = left.imi * rc.y;
+        u2 = ring_entry(t + 1);
+        E = left.e > u1.e ? left.e : u1.e;
+        E = E > e_diag ? E : e_diag;
+        const int du = (u1.e - E) - y_wait, dl = (left.e - E) - x_wait, dd = e_diag - E;
+        const double D = __builtin_ldexp(tD, dd);
+        const double d1x = __builtin_ldexp(t1x, du), d2x = __builtin_ldexp(t2x, du);
+        const double d1y = __builtin_ldexp(t1y, dl), d2y = __builtin_ldexp(t2y, dl);
+        out.imm = __builtin_fma(P[0][3], d2y, __builtin_fma(P[0][2], d1y, __builtin_fma(P[0][4], d2x, __builtin_fma(P[0][1], d1x, P[0][0] * D))));
+        out.imd = __builtin_fma(P[1][2], d1y, __builtin_fma(P[1][1], d1x, P[1][0] * D));
+        out.idm = __builtin_fma(P[2][2], d1y, __builtin_fma(P[2][1], d1x, P[2][0] * D));
+        out.imi = __builtin_fma(P[3][3], d2y, __builtin_fma(P[3][4], d2x, __builtin_fma(P[3][1], d1x, P[3][0] * D)));
+        out.iiw = __builtin_fma(P[4][2], d1y, __builtin_fma(P[4][4], d2x, P[4][0] * D));
       }
-      out.imd = __builtin_ldexp(s_imd * f_imd, du);
-      out.iiw = __builtin_ldexp(s_iiw * f_iiw, du);
-      out.idm = __builtin_ldexp(s_idm * rc.x, dl);
-      out.imi = __builtin_ldexp(s_imi * rc.y, dl);
-      out.imm = __builtin_ldexp(s_imm * (fx * em), dd);
       out.e = E;
       if ((t & HXL_RENORM_MASK) == 0) {            // wave-uniform
-        if (s == 0 && t == 0) {                    // cell (0,0): lpStart() = 0 (src/forward.cpp:73)
-          if (lane == 0) { out.imm = 1.0; out.e = 0; }
+        if (s == 0 && t == 0) {
+          if (DIR == 0) {                          // cell (0,0): lpStart() = 0 (src/forward.cpp:73)
+            if (lane == 0) { out.imm = 1.0; out.e = 0; }
+          } else if (lane == 0) {
+            // the cell feeding END is initialised by assignment (src/forward.cpp:981-995)
+            const double lpe = J.x.pack[4 * (size_t)R] + J.y.pack[4 * (size_t)Cc];
+            out.imm = exp(lpe + J.T[0][5]); out.imd = exp(lpe + J.T[1][5]); out.idm = exp(lpe + J.T[2][5]);
+            out.imi = exp(lpe + J.T[3][5]); out.iiw = exp(lpe + J.T[4][5]);
+            out.e = 0;
+          }
         }
         const double mx = vmax(vmax(vmax(out.imm, out.imd), vmax(out.idm, out.imi)), out.iiw);
         const int k = __builtin_amdgcn_frexp_exp(mx);
@@ -503,7 +547,10 @@ k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict_
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (live && wave == 0 && lane == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
+  if (live && wave == 0 && lane == 0) {
+    if (DIR == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
+    else *J.lp_start = J.bwd[cell_slot(ss, R - 1, Cc - 1)];   // B(0,0).IMM in mirrored coordinates
+  }
 }
 
 }  // namespace
@@ -546,7 +593,7 @@ static LdsPlan plan_lds(int W, int PPW, bool banded, int yl_cols, int yl_emis, i
 void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
                                 int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
 #define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis, yl_cls); \
-    hipLaunchKernelGGL((k_forward_leaf_linear<W_, B_, PPW_>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
+    hipLaunchKernelGGL((k_forward_leaf_linear<W_, B_, PPW_, 0>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
                        d_jobs, tab, log_tab, p, n_jobs); } while (0)
   if (banded) {
     // one wavefront per pair; with more pairs than fit the CUs one by one (LDS: four workgroups of one pair), six pairs
@@ -574,6 +621,24 @@ void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, 
   // more pairs than compute units: eight waves per pair, two pairs per CU (less pipeline fill per pair)
   else if (max_rows <= 512 || n_jobs > 256) HXL_LAUNCH(8, false, 1);
   else HXL_LAUNCH(16, false, 1);
+#undef HXL_LAUNCH
+}
+
+// Backward fill of unbanded leaf batches on scaled probabilities (the same kernel, DIR = 1)
+void launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* log_tab,
+                                 int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
+#define HXL_LAUNCH(W_) do { const LdsPlan p = plan_lds(W_, 1, false, yl_cols, yl_emis, yl_cls); \
+    hipLaunchKernelGGL((k_forward_leaf_linear<W_, false, 1, 1>), dim3(n_jobs), dim3(W_ * 64), p.total, st, d_jobs, tab, log_tab, p, n_jobs); } while (0)
+  const char* v = getenv("HX_LINEAR_WAVES");
+  const int forced = v ? atoi(v) : 0;
+  if (forced == 1) HXL_LAUNCH(1);
+  else if (forced == 2) HXL_LAUNCH(2);
+  else if (forced == 8) HXL_LAUNCH(8);
+  else if (max_rows <= 64) HXL_LAUNCH(1);
+  else if (max_rows <= 128) HXL_LAUNCH(2);
+  else if (max_rows <= 256) HXL_LAUNCH(4);
+  else if (max_rows <= 512 || n_jobs > 256) HXL_LAUNCH(8);
+  else HXL_LAUNCH(16);
 #undef HXL_LAUNCH
 }
 

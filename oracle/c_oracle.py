@@ -69,12 +69,14 @@ def forward(x, y, hmm, max_distance=-1, true_math=False):
                 rootsuby=rsy)
 
 
-def backward(x, y, hmm, max_distance=-1):
+def backward(x, y, hmm, max_distance=-1, true_math=False):
     lib = load()
+    lib.orc_set_true_math(1 if true_math else 0)
     jobs = capi.make_jobs([(x, y, hmm, max_distance)])
     cells = np.empty((x.n_states - 1, y.n_states - 1, 5))
     lp_start = C.c_double()
     rc = lib.orc_backward(jobs, _ptr(cells), C.byref(lp_start))
+    lib.orc_set_true_math(0)
     assert rc == 0, rc
     return dict(cells=cells, lp_start=lp_start.value)
 

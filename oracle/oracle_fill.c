@@ -301,6 +301,7 @@ int orc_backward(const hx_pair_job* job, double* cells, double* lp_start_out) {
         double* c = CELL(TSRC(x, kx), TSRC(y, ky));
         for (s = 0; s < 5; ++s) c[s] = TLP(x, kx) + TLP(y, ky) + T[s][5];
       }
+#define lse(a, b) cell_lse(a, b)
   for (i = R - 1; i >= 0; --i)
     for (j = Cc - 1; j >= 0; --j) {
       double* src;
@@ -364,6 +365,7 @@ int orc_backward(const hx_pair_job* job, double* cells, double* lp_start_out) {
       }
       src[0] = imm; src[1] = imd; src[2] = idm; src[3] = imi; src[4] = iiw;
     }
+#undef lse
   *lp_start_out = CELL(0, 0)[0];
   side_free(&X);
   side_free(&Y);

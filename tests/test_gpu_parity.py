@@ -392,3 +392,40 @@ def test_linear_mode_on_banded_leaf_pairs(ppw, monkeypatch):
         bf.close()
     with pytest.raises(capi.HxError):                    # only the scaled-probability fill writes compressed planes
         capi.Batch(imgs, capi.HX_BAND_COMPRESSED)
+
+
+@pytest.mark.parametrize("waves", [0, 2])
+def test_linear_mode_backward_fill_on_unbanded_leaf_pairs(waves, monkeypatch):
+    # The Backward fill on scaled probabilities (k_forward_leaf_linear<.., DIR = 1>): every workgroup shape, the wrap-around
+    # link (waves = 2 with up to 24 strips), protein and mixture models.  Yardsticks as for Forward: the oracle's Backward
+    # recursion in libm arithmetic (cells < 1e-9, lpStart < 1e-12 rel.) and the reference arithmetic (lpStart < 1e-5 rel.).
+    # Without the reference's truncation Forward and Backward agree to rounding: lpStart == lpEnd to 1e-11 relative
+    # (the table arithmetic only manages 1e-7).
+    if waves:
+        monkeypatch.setenv("HX_LINEAR_WAVES", str(waves))
+    aa = "arndcqeghilkmfpstwyv"
+    groups = [[H.leaf_case(501, 40, 45), H.leaf_case(502, 1, 1), H.leaf_case(503, 63, 64, alphabet=aa, jc=False, tl=.3, tr=.2)],
+              [H.leaf_case(504, 100, 130), H.leaf_case(505, 127, 20, alphabet=aa, components=2, jc=False)],
+              [H.leaf_case(506, 250, 200, alphabet=aa, jc=False)],
+              [H.leaf_case(507, 500, 300)],
+              [H.leaf_case(508, 1100, 700, alphabet=aa, jc=False, tl=.2, tr=.3), H.leaf_case(509, 700, 1500)]]
+    for cases in groups:
+        imgs = [H.job_images(f) for f in cases]
+        be = capi.Batch(imgs)
+        bf = capi.Batch(imgs, capi.HX_LSE_LINEAR)
+        for b in (be, bf):
+            b.forward()
+            b.backward()
+        se, sf, lf = be.lp_start(), bf.lp_start(), bf.lp_end()
+        for k, (x, y, hmm, md) in enumerate(imgs):
+            want = c_oracle.backward(x, y, hmm, md, true_math=True)
+            mf = bf.read_matrix(k, 1)
+            assert not np.isnan(mf).any()
+            assert np.array_equal(np.isneginf(want["cells"]), np.isneginf(mf)), "job %d: -inf pattern" % k
+            fin = np.isfinite(mf)
+            assert np.max(np.abs(want["cells"][fin] - mf[fin]), initial=0.) < 1e-9, "job %d" % k
+            assert abs(want["lp_start"] - sf[k]) <= 1e-12 * abs(sf[k])
+            assert abs(se[k] - sf[k]) <= 1e-5 * abs(se[k])
+            assert abs(sf[k] - lf[k]) <= 1e-11 * abs(lf[k])
+        be.close()
+        bf.close()

@@ -13,8 +13,8 @@ for k in range(P):
     rng = np.random.default_rng(1000 + k)
     xs, ys = bench.synth_pair(rng, pi, 2000)
     tr.append((hostmodel.leaf_profile(xs, 20), hostmodel.leaf_profile(ys, 20), hmm, -1))
-for mode in ("fast", "exact"):
-    b = capi.Batch(tr, (capi.HX_LSE_FAST if mode == "fast" else 0) | capi.HX_KEEP_BACKWARD)
+for mode in ("linear", "fast", "exact"):
+    b = capi.Batch(tr, {"linear": capi.HX_LSE_LINEAR, "fast": capi.HX_LSE_FAST, "exact": 0}[mode] | capi.HX_KEEP_BACKWARD)
     b.forward(); b.backward(); b.sync()
     b.forward(); b.backward(); b.sync()
     cells = b.total_cells()
