@@ -361,6 +361,10 @@ struct hx_batch {
   bool forward_done = false, backward_done = false;
   hipStream_t last_stream = nullptr;
   hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  int32_t* d_trace = nullptr;        // hx_batch_best_trace: path buffers, kept between calls
+  int64_t* d_trace_n = nullptr;
+  void* h_trace = nullptr;
+  int64_t trace_cap = 0;
   bool ev_valid[2] = {false, false};
 };
 
@@ -639,6 +643,9 @@ int hx_batch_destroy(hx_batch* b) {
   if (b->d_bwd) (void)hipFree(b->d_bwd);
   if (b->d_eplane) (void)hipFree(b->d_eplane);
   if (b->d_agg) (void)hipFree(b->d_agg);
+  if (b->d_trace) (void)hipFree(b->d_trace);
+  if (b->d_trace_n) (void)hipFree(b->d_trace_n);
+  if (b->h_trace) (void)hipHostFree(b->h_trace);
   delete b;
   return HX_OK;
 }
@@ -1010,40 +1017,47 @@ int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t*
   if (!b || !cells || !n_cells || cap < 1) return fail(HX_ERR_INVALID_ARG, "bad arguments");
   if (!b->forward_done) return fail(HX_ERR_STATE, "hx_batch_best_trace needs a previous hx_batch_forward");
   const int n = b->n_jobs;
-  int32_t* d_paths = nullptr;
-  int32_t* d_n = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&d_paths), sizeof(int32_t) * 3 * (size_t)cap * n) != hipSuccess)
-    return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %zu path bytes failed", sizeof(int32_t) * 3 * (size_t)cap * n);
-  if (hipMalloc(reinterpret_cast<void**>(&d_n), sizeof(int32_t) * n) != hipSuccess) {
-    (void)hipFree(d_paths);
-    return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+  // device buffers and the page-locked staging buffer are kept with the batch (a host mirror asks once per fill batch,
+  // a benchmark many times)
+  if (cap > b->trace_cap) {
+    if (b->d_trace) (void)hipFree(b->d_trace);
+    if (b->d_trace_n) (void)hipFree(b->d_trace_n);
+    if (b->h_trace) (void)hipHostFree(b->h_trace);
+    b->d_trace = nullptr; b->d_trace_n = nullptr; b->h_trace = nullptr; b->trace_cap = 0;
+    // [n][cap][3] as walked (END cell first) + the same amount for the compacted, start-first copy; [2n] lengths + offsets
+    if (hipMalloc(reinterpret_cast<void**>(&b->d_trace), sizeof(int32_t) * 6 * (size_t)cap * n) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&b->d_trace_n), sizeof(int64_t) * 2 * (size_t)n) != hipSuccess ||
+        hipHostMalloc(&b->h_trace, sizeof(int32_t) * 3 * (size_t)cap * n, hipHostMallocDefault) != hipSuccess)
+      return fail(HX_ERR_OUT_OF_MEMORY, "allocating %zu path bytes failed", sizeof(int32_t) * 9 * (size_t)cap * n);
+    b->trace_cap = cap;
   }
-  int rc = HX_OK;
+  int32_t* d_paths = b->d_trace;
+  int32_t* d_out = b->d_trace + 3 * (size_t)cap * n;
+  int32_t* d_n = reinterpret_cast<int32_t*>(b->d_trace_n);
+  int64_t* d_off = b->d_trace_n + n;
+  hipStream_t st = b->last_stream;
   // the per-cell emission plane is only filled by the strip pipelines (hx_batch_forward)
-  launch_best_trace(b->d_jobs, n, d_paths, cap, d_n, g_tab, !(b->flags & HX_FORCE_GENERIC), b->last_stream);
-  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(b->last_stream) != hipSuccess ||
+  launch_best_trace(b->d_jobs, n, d_paths, cap, d_n, g_tab, !(b->flags & HX_FORCE_GENERIC), st);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
       hipMemcpy(n_cells, d_n, sizeof(int32_t) * n, hipMemcpyDeviceToHost) != hipSuccess)
-    rc = fail(HX_ERR_HIP, "best-trace kernel failed: %s", hipGetErrorString(hipGetLastError()));
-  std::vector<int32_t> tmp;
-  for (int k = 0; rc == HX_OK && k < n; ++k) {
-    if (n_cells[k] == -3) { rc = fail(HX_ERR_RANGE, "path of job %d does not fit %lld cells", k, (long long)cap); break; }
-    if (n_cells[k] <= 0) continue;
-    const size_t m = (size_t)n_cells[k];
-    tmp.resize(3 * m);
-    if (hipMemcpy(tmp.data(), d_paths + 3 * (size_t)cap * k, sizeof(int32_t) * 3 * m, hipMemcpyDeviceToHost) != hipSuccess) {
-      rc = fail(HX_ERR_HIP, "path download failed");
-      break;
-    }
-    // the kernel walks from the END cell backwards; the reference's Path starts at the start cell
-    hx_trace_cell* out = cells + (size_t)cap * k;
-    for (size_t c = 0; c < m; ++c) {
-      const int32_t* t = &tmp[3 * (m - 1 - c)];
-      out[c].xpos = t[0]; out[c].ypos = t[1]; out[c].state = t[2];
-    }
+    return fail(HX_ERR_HIP, "best-trace kernel failed: %s", hipGetErrorString(hipGetLastError()));
+  std::vector<int64_t> off((size_t)n + 1, 0);
+  for (int k = 0; k < n; ++k) {
+    if (n_cells[k] == -3) return fail(HX_ERR_RANGE, "path of job %d does not fit %lld cells", k, (long long)cap);
+    off[k + 1] = off[k] + (n_cells[k] > 0 ? n_cells[k] : 0);
   }
-  (void)hipFree(d_paths);
-  (void)hipFree(d_n);
-  return rc;
+  if (off[n] == 0) return HX_OK;
+  // the kernel walks from the END cell backwards; the reference's Path starts at the start cell: reverse and compact on
+  // the device, one copy over PCIe, scatter on the host
+  HIP_TRY(hipMemcpy(d_off, off.data(), sizeof(int64_t) * n, hipMemcpyHostToDevice));
+  launch_reverse_paths(d_paths, cap, d_n, d_off, d_out, n, st);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(b->h_trace, d_out, sizeof(int32_t) * 3 * (size_t)off[n], hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const hx_trace_cell* src = static_cast<const hx_trace_cell*>(b->h_trace);
+  for (int k = 0; k < n; ++k)
+    if (n_cells[k] > 0) memcpy(cells + (size_t)cap * k, src + off[k], sizeof(hx_trace_cell) * (size_t)n_cells[k]);
+  return HX_OK;
 }
 
 int hx_batch_read_prepared(hx_batch* b, int32_t job, double* subx, double* suby, double* insx, double* rootsubx,

@@ -38,6 +38,9 @@ void launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows,
 void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, const double* tab,
                        bool plane_valid, hipStream_t st);
 
+void launch_reverse_paths(const int32_t* d_paths, int64_t cap, const int32_t* d_n_cells, const int64_t* d_off, int32_t* d_out,
+                          int n_jobs, hipStream_t st);
+
 void launch_quickalign(const DevQuick* d_jobs, int n_jobs, int max_rows, int max_cols, bool all_full, hipStream_t st);
 
 }  // namespace hx

@@ -123,6 +123,24 @@ __global__ __launch_bounds__(64) void k_best_trace(const DevJob* __restrict__ jo
   if (lane == 0) n_cells[blockIdx.x] = status < 0 ? status : (int32_t)n;
 }
 
+// paths as walked (END cell first, [job][cap][3]) -> start-first, back to back at off[job]
+__global__ void k_reverse_paths(const int32_t* __restrict__ paths, int64_t cap, const int32_t* __restrict__ n_cells,
+                                const int64_t* __restrict__ off, int32_t* __restrict__ out) {
+  const int job = blockIdx.x;
+  const int n = n_cells[job];
+  const int32_t* src = paths + (int64_t)job * cap * 3;
+  int32_t* dst = out + off[job] * 3;
+  for (int c = threadIdx.x; c < n; c += blockDim.x) {
+    const int32_t* t = src + 3 * (int64_t)(n - 1 - c);
+    dst[3 * (int64_t)c] = t[0]; dst[3 * (int64_t)c + 1] = t[1]; dst[3 * (int64_t)c + 2] = t[2];
+  }
+}
+
+void launch_reverse_paths(const int32_t* d_paths, int64_t cap, const int32_t* d_n_cells, const int64_t* d_off, int32_t* d_out,
+                          int n_jobs, hipStream_t st) {
+  hipLaunchKernelGGL(k_reverse_paths, dim3(n_jobs), dim3(256), 0, st, d_paths, cap, d_n_cells, d_off, d_out);
+}
+
 void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, const double* tab,
                        bool plane_valid, hipStream_t st) {
   hipLaunchKernelGGL(k_best_trace, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_paths, cap, d_n_cells, tab, plane_valid ? 1 : 0);

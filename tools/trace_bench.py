@@ -27,8 +27,8 @@ for k in range(pairs):
         ex, ey = bench.envelope_coordinates(xrow, yrow)
         triples.append((hostmodel.leaf_profile(xs, a, c, ex), hostmodel.leaf_profile(ys, a, c, ey), hmm, band))
 out = {}
-for mode, flags in (("fast", capi.HX_LSE_FAST), ("exact", 0)):
-    b = capi.Batch(triples, flags | (capi.HX_SPARSE_ENVELOPE if band >= 0 else 0))
+for mode, flags in (("linear", capi.HX_LSE_LINEAR), ("fast", capi.HX_LSE_FAST), ("exact", 0)):
+    b = capi.Batch(triples, flags | (0 if band < 0 else capi.HX_BAND_COMPRESSED if mode == "linear" else capi.HX_SPARSE_ENVELOPE))
     b.forward(); b.sync()
     t0 = time.perf_counter(); b.forward(); b.sync(); t_fill = time.perf_counter() - t0
     b.best_trace(raw=True)
