@@ -105,5 +105,20 @@ def test_four_component_mixture_5000_columns():
     w2 = c_oracle.forward(*r2["img"])
     assert r2["lp_exact"] == w2["lp_end"]
     H.assert_same_bits(r2["be"].read_matrix(0), w2["cells"], "tall mixture forward cells")
+    # the scaled-probability fills on both shapes: 5000 columns per strip, and 79 strips over 16 waves (five rounds of the
+    # wrap-around link), Forward and Backward, against the oracle's recursion in libm arithmetic
+    for img in (r["img"], r2["img"]):
+        bl = capi.Batch([img], capi.HX_LSE_LINEAR)
+        bl.forward()
+        bl.backward()
+        tf, tb = c_oracle.forward(*img, true_math=True), c_oracle.backward(*img, true_math=True)
+        assert abs(bl.lp_end()[0] - tf["lp_end"]) <= 1e-12 * abs(tf["lp_end"])
+        assert abs(bl.lp_start()[0] - tb["lp_start"]) <= 1e-12 * abs(tb["lp_start"])
+        for which, want in ((0, tf["cells"]), (1, tb["cells"])):
+            got = bl.read_matrix(0, which)
+            assert np.array_equal(np.isneginf(got), np.isneginf(want))
+            fin = np.isfinite(got)
+            assert np.max(np.abs(got[fin] - want[fin])) < 1e-8
+        bl.close()
     for b in (r["be"], r["bf"], r2["be"], r2["bf"]):
         b.close()
