@@ -169,10 +169,9 @@ def main():
 
     def run_mode(mode):
         """K timed passes of the hot path in one fill mode; returns (seconds, kernel ms list, lp_end, cells)."""
-        # banded batches: the scaled-probability fill stores band-compressed planes, the others dense planes without
-        # the -inf pre-fill (readers test the envelope)
+        # banded batches are stored band-compressed (per strip only the swept step windows): thousands of pairs fit
         batch = capi.Batch(triples, {"exact": capi.HX_LSE_EXACT, "fast": capi.HX_LSE_FAST, "linear": capi.HX_LSE_LINEAR}[mode] |
-                           (0 if args.band < 0 else capi.HX_BAND_COMPRESSED if mode == "linear" else capi.HX_SPARSE_ENVELOPE))
+                           (capi.HX_BAND_COMPRESSED if args.band >= 0 else 0))
         n_cells = batch.total_cells()
         for _ in range(args.warmup):
             batch.forward(stream)
@@ -197,8 +196,6 @@ def main():
         assert np.all(np.isfinite(lp)) or os.environ.get("HX_BENCH_NOCHECK"), "non-finite Forward log-likelihood"
         return dt, k_ms, lp, n_cells
 
-    if args.band >= 0 and args.mode == "linear" and args.pairs * 5 * 8 * (args.length + 64) * (args.length + 1) > 200e9:
-        args.single_mode = True      # dense planes of this many pairs do not fit the device: only the compressed fill runs
     dt, kernel_ms, lp_end, cells = run_mode(args.mode)
     other = "exact" if args.mode != "exact" else "fast"
     dt_o, kernel_ms_o, lp_end_o, _ = run_mode(other) if not args.single_mode else (None, None, None, None)
@@ -229,7 +226,7 @@ def main():
                                    (args.length, args.model.upper(), args.tl, args.tr,
                                     "full (unbanded)" if args.band < 0 else
                                     "band-%d (guide = the pair's true alignment; in-envelope cells counted%s)" %
-                                    (args.band, "; band-compressed storage" if args.mode == "linear" else ""),
+                                    (args.band, "; band-compressed storage"),
                                     "exact table (cells bit-identical to the reference recursion)" if args.mode == "exact"
                                     else ("scaled-probability recursion (fp64 sums of probabilities with a per-cell exponent, "
                                           "log-probabilities at the store; lpEnd within 1e-5 rel. of the reference's table "

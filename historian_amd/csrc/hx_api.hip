@@ -570,10 +570,9 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     b->all_ylds = b->all_ylds && J.leaf_like && jo.y.lp_zero && jo.y.n <= 6144 && jo.y.n_cls + 1 <= 64 &&
                   (int64_t)(jo.x.n_cls + 1) * (jo.y.n_cls + 1) <= 1024;
   }
-  if (rc == HX_OK && (flags & HX_BAND_COMPRESSED) &&
-      !((flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && b->all_leaf && b->all_ylds && b->max_cls < 255 && !(flags & (HX_KEEP_BACKWARD | HX_FORCE_GENERIC))))
-    rc = fail(HX_ERR_INVALID_ARG, "HX_BAND_COMPRESSED is implemented by the scaled-probability Forward fill only: it needs HX_LSE_LINEAR and "
-                                  "a batch of leaf-profile pairs, without HX_KEEP_BACKWARD / HX_FORCE_GENERIC");
+  if (rc == HX_OK && (flags & HX_BAND_COMPRESSED) && !(b->all_chain && !(flags & (HX_KEEP_BACKWARD | HX_FORCE_GENERIC))))
+    rc = fail(HX_ERR_INVALID_ARG, "HX_BAND_COMPRESSED is implemented by the Forward fills of chain (leaf) profiles only: "
+                                  "no general profiles, no HX_KEEP_BACKWARD / HX_FORCE_GENERIC");
   if (rc != HX_OK) { delete b; return rc; }
 
   auto cleanup = [&](int code) { hx_batch_destroy(b); return code; };

@@ -376,6 +376,10 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
     const int64_t store_base2 = (int64_t)strip64 * ss + ((i0 & 63) << 1);
     const int t_off = row0 - (strip64 << 6) + 0;   // t64 = j + (i & 63) = step + t_off  (see below)
     const bool store_rows = i0 < ((R + 63) & ~63);
+    // band-compressed planes (HX_BAND_COMPRESSED, Forward): a window's cells are stored from the window's own offset
+    const int64_t* sbase = (BANDED && RPT == 1 && DIR == 0) ? J.strip_base : nullptr;
+    int64_t cstore_base = 0;
+    int cstore_t0 = 0;
 
     const int nsteps = Cc + SR - 1;
     // With a band, a strip only sweeps the step windows that hold its in-envelope cells (computed on
@@ -417,8 +421,8 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
           while (progp[prev_wave] < need) __builtin_amdgcn_s_sleep(1);
           const int jj = tb + lane;
           bnd = c5_neg_inf();
-          if (jj < Cc) {
-            const int64_t sl = cell_slot(ss, row0 - 1, jj);
+          const int64_t sl = jj < Cc ? (sbase ? stored_slot(J, row0 - 1, jj) : cell_slot(ss, row0 - 1, jj)) : -1;
+          if (sl >= 0) {                           // (not stored: outside the envelope, -inf)
             // agent-scope relaxed loads (global_load ... sc1): served by L2, never by a stale L1 line
             bnd.imm = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bnd.imd = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -554,8 +558,8 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
       // value of the previous step)
       const int need = above_base + wstart;
       while (progp[prev_wave] < need) __builtin_amdgcn_s_sleep(1);
-      if (lane == 0) {
-        const int64_t sl = cell_slot(ss, row0 - 1, wstart - 1);
+      const int64_t sl = sbase ? stored_slot(J, row0 - 1, wstart - 1) : cell_slot(ss, row0 - 1, wstart - 1);
+      if (lane == 0 && sl >= 0) {
         ub.imm = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ub.imd = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ub.idm = __hip_atomic_load(M + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -564,6 +568,7 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
         if (!above_in_envelope(wstart - 1)) ub = c5_neg_inf();
       }
     }
+    if (sbase) { cstore_base = sbase[2 * s + w] + ((i0 & 63) << 1); cstore_t0 = wstart; }
     init_words(wstart);
     if (!YL) {
       prefetch(wstart, Ya, ea);
@@ -597,7 +602,7 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
 #if HX_ABLATE == 8
         const int64_t sl = (store_base2 + ((int64_t)(t64 >> 1) << 7)) & 0xFFFF;   // stay in L2
 #else
-        const int64_t sl = store_base2 + ((int64_t)(t64 >> 1) << 7);
+        const int64_t sl = sbase ? cstore_base + ((int64_t)((t - cstore_t0) >> 1) << 7) : store_base2 + ((int64_t)(t64 >> 1) << 7);
 #endif
         HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
         const int64_t plane2 = plane >> 1;

@@ -390,8 +390,32 @@ def test_linear_mode_on_banded_leaf_pairs(ppw, monkeypatch):
             bd.close()
         be.close()
         bf.close()
-    with pytest.raises(capi.HxError):                    # only the scaled-probability fill writes compressed planes
-        capi.Batch(imgs, capi.HX_BAND_COMPRESSED)
+    with pytest.raises(capi.HxError):                    # no Backward matrices on compressed planes
+        capi.Batch(imgs, capi.HX_BAND_COMPRESSED | capi.HX_KEEP_BACKWARD)
+
+
+@pytest.mark.parametrize("fast", [False, True])
+def test_band_compressed_planes_in_the_table_policies(fast):
+    # HX_BAND_COMPRESSED with the exact / fast chain kernels: the same cells, bit for bit, as the dense planes hold -
+    # few pairs (several waves per pair) and many (one wave per pair), cells that are not stored read as -inf
+    few = [H.leaf_case(601, 200, 90, band=12), H.leaf_case(602, 130, 150, band=3), H.leaf_case(603, 70, 66), H.leaf_case(604, 300, 310, band=0)]
+    many = [H.leaf_case(700 + k, 60 + 3 * k, 50 + 2 * k, band=k % 7) for k in range(70)]
+    mode = capi.HX_LSE_FAST if fast else 0
+    for cases in (few, many):
+        imgs = [H.job_images(f) for f in cases]
+        bd, bc = capi.Batch(imgs, mode), capi.Batch(imgs, mode | capi.HX_BAND_COMPRESSED)
+        bd.forward()
+        bc.forward()
+        H.assert_same_bits(bd.lp_end(), bc.lp_end(), "lpEnd")
+        for k in range(len(cases)):
+            H.assert_same_bits(bd.read_matrix(k, 0), bc.read_matrix(k, 0), "job %d: compressed vs dense planes" % k)
+        assert bd.best_trace() == bc.best_trace()
+        with pytest.raises(capi.HxError):
+            bc.backward()
+        bd.close()
+        bc.close()
+    with pytest.raises(capi.HxError):                    # general profiles keep dense planes
+        capi.Batch([H.job_images(H.dag_case(43, band=3))], capi.HX_BAND_COMPRESSED)
 
 
 @pytest.mark.parametrize("waves", [0, 2])
