@@ -236,7 +236,7 @@ def main():
                        "parallelism": "pairs farmed across %d rank(s); RCCL broadcast of model constants only" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "hx::k_forward_leaf_linear<W,BANDED>" if linear else "hx::k_fill_chain<0,...>",
+                         "kernel": "hx::k_fill_leaf_linear<W,BANDED>" if linear else "hx::k_fill_chain<0,...>",
                          "kernel_ms": k_ms, "bytes_per_cell": BYTES_PER_CELL},
             "fill_mode": args.mode,
             "lp_end_pair0": float(lp_end[0]),

@@ -496,7 +496,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
       jo.bwd_windows = ar.put(wb.data(), sizeof(int32_t) * wb.size());
       if (flags & HX_BAND_COMPRESSED) {
         // Band-compressed storage: a strip keeps only the step windows it sweeps.  The windows are put into the
-        // form the fill uses them in (whole step pairs, clipped, merged when they touch - k_forward_leaf_linear),
+        // form the fill uses them in (whole step pairs, clipped, merged when they touch - k_fill_leaf_linear),
         // which that kernel's own widening leaves unchanged, and every window gets its offset in the state plane.
         std::vector<int32_t> we(wf);
         const int n_strips = (R + HX_STRIP - 1) / HX_STRIP, nsteps = (Cc + HX_STRIP) & ~1;

@@ -1,19 +1,22 @@
-// Forward fill of leaf-like pairs in SCALED LINEAR space (the HX_LSE_FAST policy of the headline path).
+// Forward and Backward fills of leaf-like pairs on SCALED PROBABILITIES (the HX_LSE_LINEAR policy).
 //
-// The reference (src/forward.cpp:68-223) works on log-probabilities and combines them with a table-driven
+// The reference (src/forward.cpp:68-223, 975-1088) works on log-probabilities and combines them with a table-driven
 // log-sum-exp: 18 table look-ups per cell for a pair of leaf profiles.  The same recursion on the probabilities
 // themselves is 18 multiply-adds.  This kernel keeps every cell as five fp64 mantissas plus ONE integer
 // exponent per cell (p_state = m_state * 2^e), so nothing under- or overflows however long the sequences are,
 // runs the recursion with fused multiply-adds, and converts each finished cell to the reference's storage format
 // - five log-probabilities, 40 B/cell, same strip-skewed layout - with an fp64 table-plus-polynomial logarithm
-// (256 intervals, |error| < 1e-14) just before the store.  Nothing is approximated beyond fp64 rounding: the
-// results differ from the reference's by the reference's OWN table-interpolation error (~1e-9 per look-up), which
-// is what HX_LSE_FAST allows (the bit-exact policy is ExactLse3 in hx_chain.hip).
+// (512 intervals, |error| < 2.3e-13) just before the store.  Nothing is approximated beyond fp64 rounding, so the
+// results do NOT carry the reference's truncation of log-sum-exp terms below e^-10: they differ from the reference's by
+// the reference's own approximation error (lpEnd ~3e-6 relative, north_star allows 1e-4), which is
+// why the policy is an explicit opt-in; the bit-exact policy is ExactLse3 in hx_chain.hip.
 //
 // Pipeline structure is that of k_fill_chain (hx_chain.hip): one workgroup per pair, 64-row strips dealt to the
-// waves round-robin, lane <-> row, step <-> anti-diagonal, up/diag neighbours by DPP wave_shr:1, the strip above's
-// last row block-loaded from the matrix behind a lagged LDS progress counter, the whole y side in LDS, two steps
-// per iteration so that a lane stores 16 contiguous bytes per state plane.
+// waves round-robin, lane <-> row, step <-> anti-diagonal, up/diag neighbours by DPP wave_shr:1, the whole y side in LDS,
+// two steps per iteration so that a lane stores 16 contiguous bytes per state plane.  Unlike there, the strip above's
+// last row travels between waves through LDS rings (mantissas + exponent); only the link from the last wave to the first
+// wave's next strip goes through the matrix.  Variants: banded batches (one wavefront per pair over the strips' step
+// windows, band-compressed planes, several pairs per workgroup) and the Backward fill (mirrored sweep).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "hx_device.h"
@@ -26,7 +29,7 @@ namespace hx {
 
 namespace {
 
-#define HXL_PUBLISH_LAG 16
+#define HXL_PUBLISH_LAG 16         // wrap-around link: a column is published 16 steps after its stores were issued
 #define HX_YL_MAX_CLS_LINEAR 64   // (hx_api.hip admits y sides of at most 63 emission classes to the LDS-resident path)
 #define HXL_EMIN (-(1 << 28))      // exponent of an all-zero cell: loses every max()
 #define HXL_RENORM_MASK 6          // mantissas are renormalised on steps with (t & 6) == 0: every 8th step
@@ -43,16 +46,7 @@ __device__ __forceinline__ double dpp_shr1_keep0(double old, double v) {
   const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), 0x138, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ L5 dpp_shr1_keep0(const L5& o, const L5& c) {
-  return L5{dpp_shr1_keep0(o.imm, c.imm), dpp_shr1_keep0(o.imd, c.imd), dpp_shr1_keep0(o.idm, c.idm),
-            dpp_shr1_keep0(o.imi, c.imi), dpp_shr1_keep0(o.iiw, c.iiw), dpp_shr1_keep0(o.e, c.e)};
-}
-// lane l receives v of lane l+1 (lane 63 keeps its own)
-__device__ __forceinline__ int dpp_shl1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
-__device__ __forceinline__ double dpp_shl1(double v) {
-  return __hiloint2double(dpp_shl1(__double2hiint(v)), dpp_shl1(__double2loint(v)));
-}
-// lane l >= 1 receives c of lane l-1; lane 0 receives its own o
+// lane l >= 1 receives c of lane l-1; lane 0 receives its own o (DPP wave_shr:1 leaves lanes without a source untouched)
 __device__ __forceinline__ L5 dpp_shr1_old(const L5& o, const L5& c) {
   return L5{dpp_shr1_keep0(o.imm, c.imm), dpp_shr1_keep0(o.imd, c.imd), dpp_shr1_keep0(o.idm, c.idm),
             dpp_shr1_keep0(o.imi, c.imi), dpp_shr1_keep0(o.iiw, c.iiw), dpp_shr1_keep0(o.e, c.e)};
@@ -117,7 +111,7 @@ struct LdsPlan { int elds, ycol, yclass, flags, zero;   // inside block A
 // recursion: B(i,j,s) = sum over the destination cells (i+1,j+1), (i+1,j), (i,j+1) of P[s][dest state] x emission x B(dest).
 template <int W, bool BANDED, int PPW, int DIR>
 __global__ void __launch_bounds__(W * PPW * 64, 4)   // four waves per SIMD: 128 vector registers
-k_forward_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const double* __restrict__ log_tab,
+k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const double* __restrict__ log_tab,
                       const LdsPlan plan, const int n_jobs) {
   static_assert(!BANDED || W == 1, "banded batches run one wavefront per pair");
   static_assert(PPW == 1 || BANDED, "several pairs per workgroup: banded batches only");
@@ -593,7 +587,7 @@ static LdsPlan plan_lds(int W, int PPW, bool banded, int yl_cols, int yl_emis, i
 void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
                                 int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
 #define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis, yl_cls); \
-    hipLaunchKernelGGL((k_forward_leaf_linear<W_, B_, PPW_, 0>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
+    hipLaunchKernelGGL((k_fill_leaf_linear<W_, B_, PPW_, 0>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
                        d_jobs, tab, log_tab, p, n_jobs); } while (0)
   if (banded) {
     // one wavefront per pair; with more pairs than fit the CUs one by one (LDS: four workgroups of one pair), six pairs
@@ -628,7 +622,7 @@ void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, 
 void launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* log_tab,
                                  int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
 #define HXL_LAUNCH(W_) do { const LdsPlan p = plan_lds(W_, 1, false, yl_cols, yl_emis, yl_cls); \
-    hipLaunchKernelGGL((k_forward_leaf_linear<W_, false, 1, 1>), dim3(n_jobs), dim3(W_ * 64), p.total, st, d_jobs, tab, log_tab, p, n_jobs); } while (0)
+    hipLaunchKernelGGL((k_fill_leaf_linear<W_, false, 1, 1>), dim3(n_jobs), dim3(W_ * 64), p.total, st, d_jobs, tab, log_tab, p, n_jobs); } while (0)
   const char* v = getenv("HX_LINEAR_WAVES");
   const int forced = v ? atoi(v) : 0;
   if (forced == 1) HXL_LAUNCH(1);

@@ -420,7 +420,7 @@ def test_band_compressed_planes_in_the_table_policies(fast):
 
 @pytest.mark.parametrize("waves", [0, 2])
 def test_linear_mode_backward_fill_on_unbanded_leaf_pairs(waves, monkeypatch):
-    # The Backward fill on scaled probabilities (k_forward_leaf_linear<.., DIR = 1>): every workgroup shape, the wrap-around
+    # The Backward fill on scaled probabilities (k_fill_leaf_linear<.., DIR = 1>): every workgroup shape, the wrap-around
     # link (waves = 2 with up to 24 strips), protein and mixture models.  Yardsticks as for Forward: the oracle's Backward
     # recursion in libm arithmetic (cells < 1e-9, lpStart < 1e-12 rel.) and the reference arithmetic (lpStart < 1e-5 rel.).
     # Without the reference's truncation Forward and Backward agree to rounding: lpStart == lpEnd to 1e-11 relative

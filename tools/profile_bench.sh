@@ -18,7 +18,7 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
         agg=collections.defaultdict(lambda: [0.0,0])
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"]!=c: continue
-            if "k_forward_leaf_linear" in r["Kernel_Name"]: key="linear"
+            if "k_fill_leaf_linear" in r["Kernel_Name"]: key="linear"
             elif "k_fill_chain<0" in r["Kernel_Name"]: key="fast" if "FastLse" in r["Kernel_Name"] else "exact"
             else: continue
             agg[key][0]+=float(r["Counter_Value"]); agg[key][1]+=1
