@@ -276,7 +276,7 @@ void bind_profile(DevProfile& d, const ProfOff& o, char* base) {
 struct JobOff {
   ProfOff x, y;
   size_t log_root, log_sub_l, log_sub_r, log_ins_l, log_ins_r, log_cptw_l, log_cptw_r, emis, emis_pad, scalars;
-  size_t fwd_windows, bwd_windows, strip_base, yword;
+  size_t fwd_windows, bwd_windows, strip_base, yword, yword_bwd;
   bool compressed;
   int64_t compact_plane;
   int64_t eplane_off;     // into hx_batch::d_eplane, or -1
@@ -466,7 +466,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     jo.emis = jo.table_emission ? ar.reserve(sizeof(double) * pairs) : 0;
     jo.emis_pad = jo.table_emission ? ar.reserve(sizeof(double) * (jo.x.n_cls + 1) * (jo.y.n_cls + 1)) : 0;
     jo.scalars = ar.reserve(sizeof(double) * 2);
-    jo.fwd_windows = jo.bwd_windows = jo.strip_base = jo.yword = 0;
+    jo.fwd_windows = jo.bwd_windows = jo.strip_base = jo.yword = jo.yword_bwd = 0;
     jo.compressed = false;
     jo.compact_plane = 0;
     if ((flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && jo.y.n_cls < 255 && jo.y.n >= 2) {
@@ -485,6 +485,15 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
         yw[jp] = (uint32_t)ecls[j] | (ready ? 0u : 0x100u) | ((yf[j] & F_EDGE) ? 0x200u : 0u) | (env << 10);
       }
       jo.yword = ar.put(yw.data(), sizeof(uint32_t) * yw.size());
+      // Backward: sweep column j is y state jc = Cc-1-j; its own readiness, edge flag and envelope coordinate, and the
+      // emission class of state jc+1
+      for (int jp = 0; jp < Cc + 328; ++jp) {
+        const int j = jp < 64 ? 0 : (jp - 64 >= Cc ? Cc - 1 : jp - 64), jc = Cc - 1 - j;
+        const bool ready = (yf[jc] & F_READY) || jo.y.empty;
+        const uint32_t env = (need_env && pj.y->env_pos) ? (uint32_t)pj.y->env_pos[jc] : 0u;
+        yw[jp] = (uint32_t)ecls[jc + 1] | (ready ? 0u : 0x100u) | ((yf[jc] & F_EDGE) ? 0x200u : 0u) | (env << 10);
+      }
+      jo.yword_bwd = ar.put(yw.data(), sizeof(uint32_t) * yw.size());
     }
     if (need_env) {
       const int R = jo.x.n - 1, Cc = jo.y.n - 1;
@@ -614,6 +623,7 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     J.bwd_windows = J.max_dist >= 0 ? reinterpret_cast<int32_t*>(base + jo.bwd_windows) : nullptr;
     J.strip_base = jo.compressed ? reinterpret_cast<int64_t*>(base + jo.strip_base) : nullptr;
     J.yword = jo.yword ? reinterpret_cast<uint32_t*>(base + jo.yword) : nullptr;
+    J.yword_bwd = jo.yword_bwd ? reinterpret_cast<uint32_t*>(base + jo.yword_bwd) : nullptr;
     J.lp_end = reinterpret_cast<double*>(base + jo.scalars);
     J.lp_start = J.lp_end + 1;
     J.fwd = b->d_fwd + mat_off[k];
@@ -709,8 +719,8 @@ int hx_batch_backward(hx_batch* b, void* stream) {
   HIP_TRY(hipEventRecord(b->ev[1][0], st));
   if (b->all_leaf && !(b->flags & HX_FORCE_GENERIC)) {
     if (b->any_banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_bwd, b->fwd_total, st);
-    if ((b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && b->all_ylds && !b->any_banded)
-      launch_backward_leaf_linear(b->d_jobs, b->n_jobs, b->max_rows, g_tab, g_log_tab, b->yl_cols, b->yl_emis, b->max_cls + 1, st);
+    if ((b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && b->all_ylds && b->max_cls < 255)
+      launch_backward_leaf_linear(b->d_jobs, b->n_jobs, b->max_rows, b->any_banded, g_tab, g_log_tab, b->yl_cols, b->yl_emis, b->max_cls + 1, st);
     else
     launch_backward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, (b->flags & HX_LSE_FAST) ? g_fast_tab : g_pair_tab, (b->flags & HX_LSE_FAST) != 0,
                           b->all_ylds ? 2 : 1, b->any_banded, b->yl_cols, b->yl_emis, st);

@@ -98,6 +98,7 @@ struct DevJob {
   const int64_t* strip_base;  // [n_strips][2] band-compressed storage (HX_BAND_COMPRESSED): offset of each Forward window in a
                               // state plane; fwd_windows then holds the windows exactly as swept.  nullptr: dense planes
   const uint32_t* yword;      // [n_cols + 328] per-column words of the banded scaled-probability fill (hx_linear.hip), or nullptr
+  const uint32_t* yword_bwd;  // the same for the Backward sweep (mirrored column order, class of the state an absorbing move leads to)
 };
 
 // One pair of the guide-alignment Viterbi batch (hx_quick.hip)

@@ -32,7 +32,7 @@ void build_log_table(double* out /* [log_table_doubles()] */);
 void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
                                 int yl_cols, int yl_emis, int yl_cls, hipStream_t st);
 
-void launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* log_tab,
+void launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
                                  int yl_cols, int yl_emis, int yl_cls, hipStream_t st);
 
 void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, const double* tab,

@@ -115,7 +115,6 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
                       const LdsPlan plan, const int n_jobs) {
   static_assert(!BANDED || W == 1, "banded batches run one wavefront per pair");
   static_assert(PPW == 1 || BANDED, "several pairs per workgroup: banded batches only");
-  static_assert(DIR == 0 || !BANDED, "the scaled-probability Backward fill exists for unbanded batches");
   constexpr int THREADS = W * PPW * 64, PT = W * 64;       // threads of the workgroup / of a pair
   constexpr int RING_ENTRIES = BANDED ? 0 : W * HXL_RING;  // (a banded pair is one wave: every strip boundary is the wrap-around link)
   typedef double d2v __attribute__((ext_vector_type(2)));
@@ -272,7 +271,7 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
       while (drainp[0] < need) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
       const int jj = c0 + lane;
-      const int64_t sl = jj < Cc ? (BANDED ? stored_slot(J, row0 - 1, jj) : cell_slot(ss, row0 - 1, jj)) : -1;
+      const int64_t sl = jj < Cc ? ((BANDED && DIR == 0) ? stored_slot(J, row0 - 1, jj) : cell_slot(ss, row0 - 1, jj)) : -1;
       if (jj < Cc && sl < 0) {                     // band-compressed storage: not stored = outside the envelope
         HX_LDS d2v* q = staging + (size_t)(jj & (HXL_STAGE - 1)) * 3;
         q[0] = d2v{0., 0.}; q[1] = d2v{0., 0.}; q[2] = d2v{0., __hiloint2double(0, HXL_EMIN)};
@@ -287,9 +286,10 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
         L5 v = from_logs(a, b, c, d, g);
         if (BANDED && max_dist >= 0) {
           // the strip above only wrote its in-envelope cells (HX_SPARSE_ENVELOPE: anything else is undefined)
-          int dist = J.x.env[row0 - 1] - J.y.env[jj];
+          const int ia = DIR ? R - row0 : row0 - 1, ja = DIR ? Cc - 1 - jj : jj;   // the cell's x and y states
+          int dist = J.x.env[ia] - J.y.env[ja];
           dist = dist < 0 ? -dist : dist;
-          if (!(((J.x.flags[row0 - 1] | J.y.flags[jj]) & F_EDGE) || dist <= max_dist)) v = l5_zero();
+          if (!(((J.x.flags[ia] | J.y.flags[ja]) & F_EDGE) || dist <= max_dist)) v = l5_zero();
         }
         HX_LDS d2v* q = staging + (size_t)(jj & (HXL_STAGE - 1)) * 3;
         q[0] = d2v{v.imm, v.imd};
@@ -317,7 +317,7 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
     // side).  Banded: a 256-word LDS ring refilled from memory (DevJob::yword) every 64 steps - a vector-memory load
     // inside the step loop would make every step wait for the stores before it (they retire in issue order).
     unsigned wnext = 0;
-    const HX_GLOBAL unsigned* ywords = (const HX_GLOBAL unsigned*)as_global(J.yword);
+    const HX_GLOBAL unsigned* ywords = (const HX_GLOBAL unsigned*)as_global(DIR ? J.yword_bwd : J.yword);
     auto refill_words = [&](const int i0) {             // word indices [i0, i0 + 64)
       const unsigned v = ywords[i0 + lane];
       ycol[(i0 + lane) & 255] = v;
@@ -403,7 +403,14 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
         u2 = ring_entry(t + 1);
         E = left.e > u1.e ? left.e : u1.e;
         E = E > e_diag ? E : e_diag;
-        const int du = (u1.e - E) - y_wait, dl = (left.e - E) - x_wait, dd = e_diag - E;
+        int du = (u1.e - E) - y_wait, dl = (left.e - E) - x_wait, dd = e_diag - E;
+        if (BANDED) {
+          // a cell outside the envelope (src/forward.h:92-98) is shifted to zero as a whole
+          int dist = env_x - (int)(w >> 10);
+          dist = dist < 0 ? -dist : dist;
+          const int out_of_env = (edge_x || (w & 0x200u) || dist <= max_dist) ? 0 : (1 << 29);
+          du -= out_of_env; dl -= out_of_env; dd -= out_of_env;
+        }
         const double D = __builtin_ldexp(tD, dd);
         const double d1x = __builtin_ldexp(t1x, du), d2x = __builtin_ldexp(t2x, du);
         const double d1y = __builtin_ldexp(t1y, dl), d2y = __builtin_ldexp(t2y, dl);
@@ -463,7 +470,7 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
     // step pairs; cells left of a window are outside the envelope, so the register window restarts from zero.
     int wlo[2] = {0, 0}, whi[2] = {nsteps, 0};
     if (BANDED) {
-      const HX_GLOBAL int32_t* win = as_global(J.fwd_windows);
+      const HX_GLOBAL int32_t* win = as_global(DIR ? J.bwd_windows : J.fwd_windows);
       if (win) {
         for (int w = 0; w < 2; ++w) {
           wlo[w] = win[4 * s + 2 * w] & ~1;
@@ -477,7 +484,7 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
     if (BANDED && whi[wi] <= wlo[wi]) continue;
     const int wstart = BANDED ? wlo[wi] : 0, wend = BANDED ? whi[wi] : nsteps;
     if (BANDED) { ca = l5_zero(); cb = l5_zero(); ua = l5_zero(); ub = l5_zero(); }
-    if (BANDED && J.strip_base) { store_base2 = J.strip_base[2 * s + wi] + (lane << 1); store_t0 = wstart; }
+    if (BANDED && DIR == 0 && J.strip_base) { store_base2 = J.strip_base[2 * s + wi] + (lane << 1); store_t0 = wstart; }
     open_sweep(wstart);
     first_words(wstart);
     // a pair of steps: in the strip-skewed layout its two cells per row are adjacent, 16 bytes per lane and state plane
@@ -618,21 +625,32 @@ void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, 
 #undef HXL_LAUNCH
 }
 
-// Backward fill of unbanded leaf batches on scaled probabilities (the same kernel, DIR = 1)
-void launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* log_tab,
+// Backward fill of leaf batches on scaled probabilities (the same kernel, DIR = 1)
+void launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
                                  int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
-#define HXL_LAUNCH(W_) do { const LdsPlan p = plan_lds(W_, 1, false, yl_cols, yl_emis, yl_cls); \
-    hipLaunchKernelGGL((k_fill_leaf_linear<W_, false, 1, 1>), dim3(n_jobs), dim3(W_ * 64), p.total, st, d_jobs, tab, log_tab, p, n_jobs); } while (0)
+#define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis, yl_cls); \
+    hipLaunchKernelGGL((k_fill_leaf_linear<W_, B_, PPW_, 1>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
+                       d_jobs, tab, log_tab, p, n_jobs); } while (0)
+  if (banded) {
+    const char* v = getenv("HX_LINEAR_PPW");
+    const int forced = v ? atoi(v) : 0;
+    if (forced > 1 || (forced == 0 && n_jobs > 1024)) {
+      if (plan_lds(1, 6, true, yl_cols, yl_emis, yl_cls).total <= 76 * 1024) HXL_LAUNCH(1, true, 6);
+      else if (plan_lds(1, 5, true, yl_cols, yl_emis, yl_cls).total <= 76 * 1024) HXL_LAUNCH(1, true, 5);
+      else HXL_LAUNCH(1, true, 4);
+    } else HXL_LAUNCH(1, true, 1);
+    return;
+  }
   const char* v = getenv("HX_LINEAR_WAVES");
   const int forced = v ? atoi(v) : 0;
-  if (forced == 1) HXL_LAUNCH(1);
-  else if (forced == 2) HXL_LAUNCH(2);
-  else if (forced == 8) HXL_LAUNCH(8);
-  else if (max_rows <= 64) HXL_LAUNCH(1);
-  else if (max_rows <= 128) HXL_LAUNCH(2);
-  else if (max_rows <= 256) HXL_LAUNCH(4);
-  else if (max_rows <= 512 || n_jobs > 256) HXL_LAUNCH(8);
-  else HXL_LAUNCH(16);
+  if (forced == 1) HXL_LAUNCH(1, false, 1);
+  else if (forced == 2) HXL_LAUNCH(2, false, 1);
+  else if (forced == 8) HXL_LAUNCH(8, false, 1);
+  else if (max_rows <= 64) HXL_LAUNCH(1, false, 1);
+  else if (max_rows <= 128) HXL_LAUNCH(2, false, 1);
+  else if (max_rows <= 256) HXL_LAUNCH(4, false, 1);
+  else if (max_rows <= 512 || n_jobs > 256) HXL_LAUNCH(8, false, 1);
+  else HXL_LAUNCH(16, false, 1);
 #undef HXL_LAUNCH
 }
 

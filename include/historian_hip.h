@@ -55,7 +55,7 @@ enum { HX_IMM = 0, HX_IMD = 1, HX_IDM = 2, HX_IMI = 3, HX_IIW = 4, HX_STATES = 5
 #define HX_LSE_FAST  1u  /* same truncation, higher-order LDS-resident table; cells
                             differ from HX_LSE_EXACT by <= ~1e-9 per op               */
 #define HX_LSE_LINEAR 17u /* HX_LSE_FAST, and the Forward fill of leaf-profile batches (the headline workload,
-                            banded or not; also the Backward fill of unbanded ones) runs on scaled PROBABILITIES instead of log-sum-exps: fp64 multiply-adds
+                            banded or not, and their Backward fill) runs on scaled PROBABILITIES instead of log-sum-exps: fp64 multiply-adds
                             with one integer exponent per cell, log-probabilities produced at the store
                             (hx_linear.hip).  Exact up to fp64 rounding, so it does NOT reproduce the
                             reference's truncation of terms below e^-10: lpEnd agrees with the reference to

@@ -377,6 +377,24 @@ def test_linear_mode_on_banded_leaf_pairs(ppw, monkeypatch):
                 assert abs(le[k] - lf[k]) <= 1e-5 * abs(le[k])
             else:
                 assert lf[k] == want["lp_end"] == le[k]
+        if flags != capi.HX_BAND_COMPRESSED:
+            # the banded Backward fill on scaled probabilities (dense planes only), same yardsticks
+            be.backward()
+            bf.backward()
+            se, sf = be.lp_start(), bf.lp_start()
+            for k, (x, y, hmm, md) in enumerate(imgs):
+                want = c_oracle.backward(x, y, hmm, md, true_math=True)
+                mb = bf.read_matrix(k, 1)
+                inside = np.isfinite(want["cells"])
+                if not flags:
+                    assert np.array_equal(np.isneginf(want["cells"]), np.isneginf(mb)), "job %d: backward -inf pattern" % k
+                assert np.max(np.abs(want["cells"][inside] - mb[inside]), initial=0.) < 1e-9, "job %d backward" % k
+                if np.isfinite(want["lp_start"]):
+                    assert abs(want["lp_start"] - sf[k]) <= 1e-12 * abs(sf[k])
+                    assert abs(se[k] - sf[k]) <= 1e-5 * abs(se[k])
+                    assert abs(sf[k] - lf[k]) <= 1e-11 * abs(lf[k])      # Forward == Backward to rounding
+                else:
+                    assert sf[k] == want["lp_start"]
         if flags == capi.HX_BAND_COMPRESSED:
             # a banded 2x500 pair takes a fraction of its dense planes; gathers and the device traceback see the same cells
             lay = bf.layout(6)
