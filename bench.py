@@ -282,6 +282,15 @@ def main():
                                    "sample": "first %d pair(s) of the same batch, oracle/oracle_fill.c "
                                              "(dense-array restatement of the reference fill), 1 thread, %.1f s"
                                              % (n_cpu, cpu_dt)}
+            # the same fill over the reference's own cell storage (a std::map per row, oracle_fill_map.cpp): the CPU
+            # baseline with the reference's cost structure (variant ii), on two pairs
+            n_map = min(2, n_cpu)
+            t1 = time.perf_counter()
+            for k in range(n_map):
+                x, y, h, md = triples[k]
+                c_oracle.forward_map(x, y, h, md)
+            map_dt = time.perf_counter() - t1
+            out["cpu_baseline"]["map_storage_value"] = (cpu_cells / n_cpu) * n_map / map_dt
             out["lp_end_max_rel_err_vs_cpu"] = rel
             out["best_trace_identical_to_cpu"] = {m: "%d of %d pairs" % (same.get(m, 0), n_cpu) for m in traces}
             assert rel <= 1e-4, "Forward log-likelihoods outside north_star's tolerance of the CPU path: %g" % rel

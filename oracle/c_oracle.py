@@ -116,3 +116,24 @@ def quickalign(xtok, ytok, alph_size, submat, scores, diagonals=None):
                         env.ctypes.data_as(C.POINTER(C.c_uint8)) if env is not None else None, _ptr(cells),
                         C.byref(xe), C.byref(ye))
     return dict(cells=cells, score=score, x_end=xe.value, y_end=ye.value)
+
+
+_map_lib = None
+
+
+def forward_map(x, y, hmm, max_distance=-1):
+    """lpEnd of the same Forward fill over the reference's cell storage (a std::map per row, oracle_fill_map.cpp):
+    the CPU baseline with the reference's cost structure.  The cells are not returned."""
+    global _map_lib
+    load()
+    if _map_lib is None:
+        lib = C.CDLL(os.path.join(_HERE, "_build", "liboracle_fill_map.so"))
+        lib.orc_set_table.argtypes = [_f64p]
+        lib.orc_forward_map.argtypes = [C.POINTER(capi.HxPairJob), C.POINTER(C.c_double)]
+        lib.orc_set_table(_tab.ctypes.data_as(_f64p))
+        _map_lib = lib
+    jobs = capi.make_jobs([(x, y, hmm, max_distance)])
+    lp_end = C.c_double()
+    rc = _map_lib.orc_forward_map(jobs, C.byref(lp_end))
+    assert rc == 0, rc
+    return lp_end.value

@@ -172,7 +172,13 @@ static double emission(const hx_hmm* h, const side_t* X, const side_t* Y, int i,
   return lip;
 }
 
+/* Cell storage: a dense array, or - ORC_MAP_STORAGE, see oracle_fill_map.cpp - the reference's own structure, a
+ * std::map per row (src/forward.h:22,68), for the CPU baseline that has the reference's cost structure. */
+#ifdef ORC_MAP_STORAGE
+#define CELL(i, j) orc_map_cell((i), (j))
+#else
 #define CELL(i, j) (cells + ((size_t)(i) * Cc + (j)) * 5)
+#endif
 #define TSRC(P, k) ((P)->trans_src[(P)->in_idx[k]])
 #define TLP(P, k) ((P)->trans_lp[(P)->in_idx[k]])
 

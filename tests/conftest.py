@@ -23,7 +23,8 @@ def native_pieces_built():
               os.path.join(ROOT, "historian_amd", "lib", "libhistorian_host.so"),
               os.path.join(ROOT, "historian_amd", "bin", "testmerge"),
               os.path.join(ROOT, "historian_amd", "bin", "hxrecon"),
-              os.path.join(ROOT, "oracle", "_build", "liboracle_fill.so")]
+              os.path.join(ROOT, "oracle", "_build", "liboracle_fill.so"),
+              os.path.join(ROOT, "oracle", "_build", "liboracle_fill_map.so")]
     if not all(os.path.exists(p) for p in needed):
         import __graft_entry__
         __graft_entry__.build()

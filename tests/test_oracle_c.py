@@ -121,3 +121,10 @@ def test_pod_image_traceback_equals_the_object_based_restatement():
         f.fill()
         if f.lp_end > H.NEG_INF:
             assert trace_oracle.best_trace(x, y, hmm, md, fwd) == [tuple(c) for c in f.best_trace()]
+
+
+def test_map_storage_variant_gives_the_same_likelihood():
+    # oracle_fill_map.cpp: the same fill over a std::map per row (the reference's storage), used as a CPU baseline
+    for f in [H.leaf_case(7, 70, 66), H.leaf_case(203, 90, 60, band=6), H.dag_case(31), H.dag_case(43, band=3)]:
+        x, y, hmm, md = H.job_images(f)
+        H.assert_same_bits([c_oracle.forward_map(x, y, hmm, md)], [c_oracle.forward(x, y, hmm, md)["lp_end"]], "lpEnd")

@@ -1,5 +1,6 @@
 """CPU baselines of SURVEY section 8(d) on the host cores of the GPU box, for the two pair DPs:
-(i) the plain-C oracle on one core, (iii) the same farmed over all cores (independent pairs; ctypes releases
+(i) the plain-C oracle on one core, (ii) the Forward fill over the reference's own cell storage (a std::map per row,
+oracle_fill_map.cpp) on one core, (iii) the plain-C oracle farmed over all cores (independent pairs; ctypes releases
 the GIL).  Usage: cpu_baseline.py [threads]"""
 import json, os, sys, time
 from concurrent.futures import ThreadPoolExecutor
@@ -44,4 +45,8 @@ for name, fn, cells in (("forward", fwd, (L + 1) ** 2), ("viterbi", qa, L * L)):
     allc = time.perf_counter() - t0
     out[name] = {"one_core_cells_per_s": cells / one, "all_cores_cells_per_s": n * cells / allc, "threads": threads,
                  "pairs": n, "length": L}
+t0 = time.perf_counter()
+lp_map = c_oracle.forward_map(pairs[0][0], pairs[0][1], hmm, -1)
+out["forward"]["one_core_map_storage_cells_per_s"] = (L + 1) ** 2 / (time.perf_counter() - t0)
+assert lp_map == fwd(0)
 print(json.dumps(out))
