@@ -27,12 +27,22 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
   return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
 }
 
-// a stored Forward cell, or -inf outside the storage (reference DPMatrix::cell, src/forward.h:74-88)
+// a stored Forward cell, or -inf outside the storage (reference DPMatrix::cell, src/forward.h:74-88); the envelope test
+// and the cell load are issued together
 __device__ __forceinline__ double forward_cell(const DevJob& J, int i, int j, int s) {
   if (i < 0 || j < 0 || i >= J.n_rows || j >= J.n_cols) return HX_NEG_INF;
-  if (J.max_dist >= 0 && !in_envelope(J, i, j)) return HX_NEG_INF;
   const int64_t slot = stored_slot(J, i, j);
-  return slot < 0 ? HX_NEG_INF : J.fwd[(int64_t)s * J.plane + slot];
+  const double v = J.fwd[(int64_t)s * J.plane + (slot < 0 ? 0 : slot)];
+  bool ok = slot >= 0;
+  if (J.max_dist >= 0) {
+    const FwdPack* px = J.x.fpack + i;
+    const FwdPack* py = J.y.fpack + j;
+    const int fl = (px->meta | py->meta) & 0xFF;
+    int d = px->env - py->env;
+    d = d < 0 ? -d : d;
+    ok = ok && ((fl & F_EDGE) || d <= J.max_dist);
+  }
+  return ok ? v : HX_NEG_INF;
 }
 
 }  // namespace
@@ -57,7 +67,11 @@ __global__ __launch_bounds__(64) void k_best_trace(const DevJob* __restrict__ jo
   else if (lane == 0) { out[0] = dx; out[1] = dy; out[2] = ds; }
   n = 1;
   while (status == 0 && (dx > 0 || dy > 0)) {
-    const uint8_t xf = J.x.flags[dx], yf = J.y.flags[dy];
+    // One 80-byte record per side holds what the step needs of the two states - flags, in-degree, the first three
+    // in-transitions, rootsub / ins, emission class (FwdPack, written by k_scatter_prepared) - so that a step is two
+    // dependent memory round trips (records, then source cells) instead of four.
+    const FwdPack xp = J.x.fpack[dx], yp = J.y.fpack[dy];
+    const int xf = xp.meta & 0xFF, yf = yp.meta & 0xFF;
     const bool x_null = xf & F_NULL, y_null = yf & F_NULL;
     const bool x_ready = (xf & F_READY) || J.x.empty, y_ready = (yf & F_READY) || J.y.empty;
     // which of the three factors a source cell may differ in (src/forward.cpp:326-398)
@@ -66,18 +80,18 @@ __global__ __launch_bounds__(64) void k_best_trace(const DevJob* __restrict__ jo
     if (ds == 1 || ds == 4) {            // IMD, IIW
       move_x = true;
       if (x_null) any = y_ready && dx < Nx - 1;
-      else { any = y_ready; hmm = true; lp_abs = ds == 1 ? J.x.rootsub[dx] : J.x.ins[dx]; }
+      else { any = y_ready; hmm = true; lp_abs = ds == 1 ? xp.rootsub : xp.ins; }
     } else if (ds == 2 || ds == 3) {     // IDM, IMI
       move_y = true;
       if (y_null) any = dy < Ny - 1;
-      else { any = x_ready; hmm = true; lp_abs = ds == 2 ? J.y.rootsub[dy] : J.y.ins[dy]; }
+      else { any = x_ready; hmm = true; lp_abs = ds == 2 ? yp.rootsub : yp.ins; }
     } else if (ds == 0) {                // IMM
       if (y_null && (xf & F_EMIT_OR_START)) { move_y = true; any = dy < Ny - 1; }
       else if (x_null) { move_x = true; any = y_ready && dx < Nx - 1; }
       else if (!y_null) {
         move_x = move_y = hmm = any = true;
         if (J.emis) {
-          const int cx = J.x.cls[dx], cy = J.y.cls[dy];
+          const int cx = xp.cls, cy = yp.cls;
           lp_abs = (cx < 0 || cy < 0) ? HX_NEG_INF : J.emis[(size_t)cx * J.y.n_cls + cy];
         } else if (plane_valid)
           lp_abs = J.emis_plane[cell_slot(J.strip_stride, dx, dy)];
@@ -87,9 +101,8 @@ __global__ __launch_bounds__(64) void k_best_trace(const DevJob* __restrict__ jo
     } else {                             // EEE: only the end cell
       move_x = move_y = hmm = any = true;
     }
-    const int xb = J.x.in_off[dx], yb = J.y.in_off[dy];
-    const int nx = move_x ? J.x.in_off[dx + 1] - xb : 1;
-    const int ny = move_y ? J.y.in_off[dy + 1] - yb : 1;
+    const int nx = move_x ? (xp.meta >> 8) : 1;
+    const int ny = move_y ? (yp.meta >> 8) : 1;
     const int ns = hmm ? 5 : 1;
     const int total = any ? nx * ny * ns : 0;
     if (total == 0) { status = -2; break; }
@@ -97,10 +110,16 @@ __global__ __launch_bounds__(64) void k_best_trace(const DevJob* __restrict__ jo
     unsigned long long bkey = NO_KEY;
     for (int c = lane; c < total; c += 64) {
       const int si = c % ns, r = c / ns, yi = r % ny, xi = r / ny;
-      const int sx = move_x ? J.x.in_src[xb + xi] : dx;
-      const int sy = move_y ? J.y.in_src[yb + yi] : dy;
-      const double xlp = move_x ? J.x.in_lp[xb + xi] : 0.;
-      const double ylp = move_y ? J.y.in_lp[yb + yi] : 0.;
+      int sx = dx, sy = dy;
+      double xlp = 0., ylp = 0.;
+      if (move_x) {
+        if (xi < HX_DAG_INLINE) { sx = xi == 0 ? xp.s0 : xi == 1 ? xp.s1 : xp.s2; xlp = xi == 0 ? xp.lp0 : xi == 1 ? xp.lp1 : xp.lp2; }
+        else { sx = J.x.in_src[xp.in_b + xi]; xlp = J.x.in_lp[xp.in_b + xi]; }
+      }
+      if (move_y) {
+        if (yi < HX_DAG_INLINE) { sy = yi == 0 ? yp.s0 : yi == 1 ? yp.s1 : yp.s2; ylp = yi == 0 ? yp.lp0 : yi == 1 ? yp.lp1 : yp.lp2; }
+        else { sy = J.y.in_src[yp.in_b + yi]; ylp = J.y.in_lp[yp.in_b + yi]; }
+      }
       const int s = hmm ? si : ds;
       const double h = hmm ? J.T[si][ds] : 0.;
       // sourceTransitions then sourceCells: ((hmm + x) + y) + emit, then + cell (absent terms are +0.0, exact)
