@@ -26,4 +26,8 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
 print(json.dumps(res))
 open("gpurun_out/$tag/pmc_summary.json","w").write(json.dumps(res,indent=1))
 PY
+# the box itself: achievable HBM write bandwidth for the fills' store pattern, clocks (the pool's boxes differ by up to 25 %
+# on the write-bound linear kernel while compute-bound kernels agree to 2 %)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o /tmp/ubench_store tools/ubench_store.hip 2>/dev/null && timeout -k 5 100 /tmp/ubench_store > gpurun_out/$tag/box_store_bandwidth.txt 2>&1
+(rocm-smi --showclocks --showmemuse 2>/dev/null | grep -v "^$" | head -30) >> gpurun_out/$tag/box_store_bandwidth.txt
 cat gpurun_out/$tag/kernel_stats.csv; cat gpurun_out/$tag/bench.json
