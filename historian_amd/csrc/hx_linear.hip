@@ -499,9 +499,16 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
                    h4 = log_scaled(cb.iiw, cb.e, lt);
       {
         // t64 = j + (i & 63) = t
+#if HX_ABLATE == 26      // layout experiment (timing only, readers not adapted): the five states of a step pair adjacent,
+                         // 5 KiB contiguous per wave and iteration
+        const int64_t sl = (int64_t)s * ss * 5 + (lane << 1) + (int64_t)((t - store_t0) >> 1) * 640;
+        HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
+        const int64_t plane2 = 64;
+#else
         const int64_t sl = store_base2 + ((int64_t)((t - store_t0) >> 1) << 7);
         HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
         const int64_t plane2 = plane >> 1;
+#endif
 #if HX_ABLATE == 21      // no stores (keeps the values alive)
         if (l0 + l1 + l2 + l3 + l4 + h0 + h1 + h2 + h3 + h4 == 12345.678) M2[0] = d2v{l0, h0};
 #elif HX_ABLATE == 23    // plain stores
