@@ -359,6 +359,7 @@ struct hx_batch {
   int yl_cols = 0, yl_emis = 0;       // LDS-resident y side: columns and padded class pairs of the largest job
   int64_t total_cells = 0;
   bool forward_done = false, backward_done = false;
+  bool sub_scattered = false;        // subx / suby of table-emission jobs exist per state (k_scatter_sub, on demand)
   hipStream_t last_stream = nullptr;
   hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   int32_t* d_trace = nullptr;        // hx_batch_best_trace: path buffers, kept between calls
@@ -1074,6 +1075,12 @@ int hx_batch_read_prepared(hx_batch* b, int32_t job, double* subx, double* suby,
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
   if (!b->forward_done) return fail(HX_ERR_STATE, "hx_batch_forward has not been launched");
+  if ((subx || suby) && !b->sub_scattered) {
+    // the fills use per-class tables; the per-state leftMultiply rows are produced when somebody asks for them
+    launch_scatter_sub(b->d_jobs, b->n_jobs, b->max_states, b->last_stream);
+    HIP_TRY(hipGetLastError());
+    b->sub_scattered = true;
+  }
   HIP_TRY(hipStreamSynchronize(b->last_stream));
   const DevJob& J = b->jobs[job];
   if (subx) HIP_TRY(hipMemcpy(subx, J.x.sub, sizeof(double) * (size_t)J.x.n * J.CA, hipMemcpyDeviceToHost));

@@ -9,6 +9,7 @@ struct PostCell { int32_t xpos, ypos, state, pad; double lpp; };   // == hx_cell
 
 void launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, int max_ca, int max_cls_pairs,
                  const double* tab, hipStream_t st);
+void launch_scatter_sub(const DevJob* d_jobs, int n_jobs, int max_states, hipStream_t st);
 void launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
 void launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
                           bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st);

@@ -76,7 +76,10 @@ __global__ void k_scatter_prepared(const DevJob* __restrict__ jobs) {
   const bool emit = kc >= 0 && i >= 1 && i < P.n - 1;     // the reference fills insx/rootsubx for 1 <= i < size-1
   const double ins = emit ? P.insc[kc] : HX_NEG_INF;
   const double rs = emit ? P.rootsubc[kc] : HX_NEG_INF;
-  for (int k = 0; k < CA; ++k) P.sub[(size_t)i * CA + k] = kc >= 0 ? P.subc[(size_t)kc * CA + k] : HX_NEG_INF;
+  // Per-state leftMultiply rows are only read on the device where there is no class-pair emission table (per-cell
+  // emission terms, k_emission_plane); otherwise they are scattered when the host asks for them (k_scatter_sub).
+  if (!J.emis)
+    for (int k = 0; k < CA; ++k) P.sub[(size_t)i * CA + k] = kc >= 0 ? P.subc[(size_t)kc * CA + k] : HX_NEG_INF;
   P.ins[i] = ins;
   P.rootsub[i] = rs;
   const bool ok = (P.flags[i] & F_READY) || P.empty;
@@ -102,6 +105,18 @@ __global__ void k_scatter_prepared(const DevJob* __restrict__ jobs) {
   f.env = P.env ? P.env[i] : 0;
   f.cls = kc;
   P.fpack[i] = f;
+}
+
+// subx / suby of the jobs that have a class-pair emission table, on demand (hx_batch_read_prepared)
+__global__ void k_scatter_sub(const DevJob* __restrict__ jobs) {
+  const DevJob& J = jobs[blockIdx.y >> 1];
+  if (!J.emis) return;                       // (already scattered by k_scatter_prepared)
+  const DevProfile& P = (blockIdx.y & 1) ? J.y : J.x;
+  const int CA = J.CA;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  const int kc = P.cls[i];
+  for (int k = 0; k < CA; ++k) P.sub[(size_t)i * CA + k] = kc >= 0 ? P.subc[(size_t)kc * CA + k] : HX_NEG_INF;
 }
 
 // one thread per (x class, y class)
@@ -408,6 +423,12 @@ void launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, 
     dim3 grid((unsigned)((max_cls_pairs + tpb - 1) / tpb), (unsigned)n_jobs);
     hipLaunchKernelGGL(k_emission_table, grid, dim3(tpb), 0, st, d_jobs, tab);
   }
+}
+
+void launch_scatter_sub(const DevJob* d_jobs, int n_jobs, int max_states, hipStream_t st) {
+  const int tpb = 256;
+  dim3 grid((unsigned)((max_states + tpb - 1) / tpb), (unsigned)(2 * n_jobs));
+  hipLaunchKernelGGL(k_scatter_sub, grid, dim3(tpb), 0, st, d_jobs);
 }
 
 void launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st) {
