@@ -14,13 +14,13 @@ tree, seqs = R.balanced_family(n_leaves, length, alphabet, seed=21, branch=.05)
 exe = os.path.join(ROOT, "historian_amd", "bin", "hxrecon")
 results = {}
 with tempfile.TemporaryDirectory() as d:
-    for mode in ("fast", "exact"):
+    for mode in ("linear", "fast", "exact"):
         for batch in (1, 0):
             job = os.path.join(d, "job_%d.txt" % batch)
             R.write_job(job, MODEL, tree, seqs, {}, os.path.join(d, "s.fa"), os.path.join(d, "g.fa"), samples=10, batch=batch)
             env = dict(os.environ, HX_TIMING="1")
-            if mode == "fast":
-                env["HX_FILL_MODE"] = "fast"
+            if mode != "exact":
+                env["HX_FILL_MODE"] = mode
             out = subprocess.run([exe, job], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=1500)
             assert out.returncode == 0, out.stderr.decode()[-2000:]
             results[(mode, batch)] = out.stdout
