@@ -48,7 +48,8 @@ class HxPairJob(C.Structure):
 class HxLayout(C.Structure):
     _fields_ = [("n_rows", C.c_int32), ("n_cols", C.c_int32), ("strip_rows", C.c_int32),
                 ("n_strips", C.c_int32), ("strip_stride", C.c_int64), ("plane_stride", C.c_int64),
-                ("mirrored", C.c_int32), ("compressed", C.c_int32)]
+                ("mirrored", C.c_int32), ("compressed", C.c_int32),
+                ("block_stride", C.c_int64), ("matrix_doubles", C.c_int64)]
 
 
 class HxQuickJob(C.Structure):
@@ -232,7 +233,7 @@ def slot_index(layout, i, j):
         i, j = layout.n_rows - 1 - i, layout.n_cols - 1 - j
     l = i % sr
     t = j + l
-    return (i // sr) * layout.strip_stride + (t // 2) * (2 * sr) + l * 2 + t % 2
+    return (i // sr) * layout.strip_stride + (t // 2) * (layout.block_stride or 2 * sr) + l * 2 + t % 2
 
 
 class Batch:
@@ -291,14 +292,13 @@ class Batch:
     def read_matrix(self, job, which=0):
         """Dense [n_rows][n_cols][5] copy of a matrix (un-skewed on the host)."""
         l = self.layout(job, which)
-        buf = np.empty(5 * l.plane_stride)
+        buf = np.empty(l.matrix_doubles)
         _check(load().hx_batch_read_matrix(self._h, job, which, _p(buf, _f64p)))
         if l.compressed:
             return self._dense_from_compressed(job, l, buf)
         ii, jj = np.meshgrid(np.arange(l.n_rows), np.arange(l.n_cols), indexing="ij")
         slot = slot_index(l, ii, jj)
-        planes = buf.reshape(5, l.plane_stride)
-        return np.stack([planes[s][slot] for s in range(5)], axis=-1)
+        return np.stack([buf[s * l.plane_stride + slot] for s in range(5)], axis=-1)
 
     def strip_windows(self, job):
         l = self.layout(job)

@@ -395,7 +395,7 @@ protected:
   // host copy does not exist, so that a best-path profile never moves 40 B/cell over PCIe
   mutable map<std::pair<ProfileStateIndex, ProfileStateIndex>, XYCell> sparseCells;
   void prefetchCells(const set<CellCoords>& cells) const;
-  long long stripStride, planeStride;
+  long long stripStride, planeStride, blockStride, matrixDoubles;   // hx_layout of this matrix
 
   void createBatchAndPrepare();  // flatten inputs -> hx_batch_create; run the fill; fetch the prepared vectors
   void attach(const std::shared_ptr<BatchHandle>& h, int job, double lpEndOfJob);   // adopt job `job` of a filled batch

@@ -94,7 +94,7 @@ DPMatrix::DPMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, const
       xNearStart(xSize, false), yNearEnd(ySize, false),
       insx(x.size(), NEG_INF), insy(y.size(), NEG_INF), rootsubx(x.size(), NEG_INF), rootsuby(y.size(), NEG_INF),
       absorbScratch(hmm.components(), vguard<LogProb>(hmm.alphabetSize())),
-      batch(NULL), jobIndex(0), which(0), hostCells(NULL), hostCellsCap(0), haveHostCells(false), stripStride(0), planeStride(0) {
+      batch(NULL), jobIndex(0), which(0), hostCells(NULL), hostCellsCap(0), haveHostCells(false), stripStride(0), planeStride(0), blockStride(128), matrixDoubles(0) {
   if (env.initialized()) {
     for (ProfileStateIndex i = 1; i < xSize; ++i) xClosestLeafPos[i] = x.state[i].seqCoords.at(env.row1);
     for (ProfileStateIndex j = 1; j < ySize; ++j) yClosestLeafPos[j] = y.state[j].seqCoords.at(env.row2);
@@ -238,6 +238,8 @@ void DPMatrix::attach(const std::shared_ptr<BatchHandle>& h, int job, double lpE
   hxCheck(hx_batch_layout(batch, jobIndex, 0, &lay), "hx_batch_layout");
   stripStride = lay.strip_stride;
   planeStride = lay.plane_stride;
+  blockStride = lay.block_stride;
+  matrixDoubles = lay.matrix_doubles;
   fetchPrepared();
 }
 
@@ -295,7 +297,7 @@ void DPMatrix::fetchPrepared() {
 void DPMatrix::ensureHostCells() const {
   if (haveHostCells) return;
   const double t0 = wallSeconds();
-  hostCells = g_pinned.take(5 * (size_t)planeStride, hostCellsCap);
+  hostCells = g_pinned.take((size_t)matrixDoubles, hostCellsCap);
   hxCheck(hx_batch_read_matrix(batch, jobIndex, which, hostCells), "hx_batch_read_matrix");
   haveHostCells = true;
   fillTiming.readMatrix += wallSeconds() - t0;
@@ -339,7 +341,7 @@ LogProb DPMatrix::cell(ProfileStateIndex xpos, ProfileStateIndex ypos, PairHMM::
     ypos = ySize - 2 - ypos;
   }
   const long long l = xpos & 63, t = ypos + l;
-  const long long slot = (long long)(xpos >> 6) * stripStride + ((t >> 1) << 7) + (l << 1) + (t & 1);
+  const long long slot = (long long)(xpos >> 6) * stripStride + (t >> 1) * blockStride + (l << 1) + (t & 1);
   return hostCells[(size_t)state * planeStride + slot];
 }
 
@@ -821,6 +823,8 @@ BackwardMatrix::BackwardMatrix(ForwardMatrix& fwd) : DPMatrix(fwd.x, fwd.y, fwd.
   which = 1;
   stripStride = fwd.stripStride;
   planeStride = fwd.planeStride;
+  blockStride = fwd.blockStride;
+  matrixDoubles = fwd.matrixDoubles;
   subx = fwd.subx;
   suby = fwd.suby;
   insx = fwd.insx; insy = fwd.insy; rootsubx = fwd.rootsubx; rootsuby = fwd.rootsuby;

@@ -553,6 +553,8 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     hx_layout& L = b->layouts[k];
     L.n_rows = J.n_rows; L.n_cols = J.n_cols; L.strip_rows = HX_STRIP; L.n_strips = J.n_strips;
     L.strip_stride = J.strip_stride; L.plane_stride = J.plane;
+    J.blk = 2 * HX_STRIP; J.matrix_doubles = 5 * J.plane;
+    L.block_stride = J.blk; L.matrix_doubles = J.matrix_doubles;
     L.mirrored = 0; L.compressed = jo.compressed ? 1 : 0;
     b->any_compressed = b->any_compressed || jo.compressed;
     mat_off[k] = mat_total;
@@ -580,6 +582,17 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     b->all_ylds = b->all_ylds && J.leaf_like && jo.y.lp_zero && jo.y.n <= 6144 && jo.y.n_cls + 1 <= 64 &&
                   (int64_t)(jo.x.n_cls + 1) * (jo.y.n_cls + 1) <= 1024;
   }
+  // Unbanded leaf batches of the scaled-probability fills keep the five states of a step pair adjacent: a wavefront then
+  // writes 5 KiB contiguous per iteration instead of 1 KiB into each of five planes (hx_linear.hip; same total size, so
+  // the offsets computed above stand).  Only those kernels and the layout-aware readers ever see such a batch.
+  if (rc == HX_OK && (flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && !(flags & HX_FORCE_GENERIC) && b->all_leaf && b->all_ylds &&
+      b->max_cls < 255 && !b->any_banded && !getenv("HX_PLANAR_LAYOUT"))
+    for (int k = 0; k < n_jobs; ++k) {
+      DevJob& J = b->jobs[k];
+      hx_layout& L = b->layouts[k];
+      J.strip_stride *= 5; J.plane = 2 * HX_STRIP; J.blk = 10 * HX_STRIP;
+      L.strip_stride = J.strip_stride; L.plane_stride = J.plane; L.block_stride = J.blk;
+    }
   if (rc == HX_OK && (flags & HX_BAND_COMPRESSED) && !(b->all_chain && !(flags & (HX_KEEP_BACKWARD | HX_FORCE_GENERIC))))
     rc = fail(HX_ERR_INVALID_ARG, "HX_BAND_COMPRESSED is implemented by the Forward fills of chain (leaf) profiles only: "
                                   "no general profiles, no HX_KEEP_BACKWARD / HX_FORCE_GENERIC");
@@ -706,14 +719,14 @@ int hx_batch_backward(hx_batch* b, void* stream) {
   if (!b->d_bwd) {
     // not pre-allocated with HX_KEEP_BACKWARD: allocate the Backward matrices now and re-publish the job table
     size_t total = 0;
-    for (int k = 0; k < b->n_jobs; ++k) total += 5 * (size_t)b->jobs[k].plane;
+    for (int k = 0; k < b->n_jobs; ++k) total += (size_t)b->jobs[k].matrix_doubles;
     HIP_TRY(hipStreamSynchronize(b->last_stream));
     if (hipMalloc(reinterpret_cast<void**>(&b->d_bwd), sizeof(double) * total) != hipSuccess)
       return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %zu Backward-matrix bytes failed", total * 8);
     size_t off = 0;
     for (int k = 0; k < b->n_jobs; ++k) {
       b->jobs[k].bwd = b->d_bwd + off;
-      off += 5 * (size_t)b->jobs[k].plane;
+      off += (size_t)b->jobs[k].matrix_doubles;
     }
     HIP_TRY(hipMemcpy(b->d_jobs, b->jobs.data(), sizeof(DevJob) * b->n_jobs, hipMemcpyHostToDevice));
   }
@@ -794,7 +807,7 @@ int hx_batch_read_matrix(hx_batch* b, int32_t job, int32_t which, double* out) {
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
   if (which == 0 ? !b->forward_done : !b->backward_done) return fail(HX_ERR_STATE, "fill has not been launched");
   HIP_TRY(hipStreamSynchronize(b->last_stream));
-  HIP_TRY(hipMemcpy(out, matrix_of(b, job, which), sizeof(double) * 5 * (size_t)b->jobs[job].plane, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, matrix_of(b, job, which), sizeof(double) * (size_t)b->jobs[job].matrix_doubles, hipMemcpyDeviceToHost));
   return HX_OK;
 }
 
@@ -872,6 +885,7 @@ int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_bat
     hx_layout& L = b->layouts[k];
     L.n_rows = q.x_len; L.n_cols = q.y_len; L.strip_rows = HX_STRIP; L.n_strips = J.n_strips;
     L.strip_stride = J.strip_stride; L.plane_stride = J.plane; L.mirrored = 0; L.compressed = 0;
+    L.block_stride = 2 * HX_STRIP; L.matrix_doubles = 3 * J.plane;
     cell_off[k] = cells_total;
     cells_total += 3 * J.plane;
     b->total_cells += (int64_t)q.x_len * q.y_len;

@@ -49,7 +49,7 @@ __device__ __forceinline__ bool in_envelope(const DevJob& J, int i, int j) {
 // Slot of Forward cell (i, j) inside a state plane, or -1 when a band-compressed job (HX_BAND_COMPRESSED) does not store
 // it: such a job keeps, per 64-row strip, only the step windows the fill sweeps (DevJob::fwd_windows / strip_base).
 __device__ __forceinline__ int64_t stored_slot(const DevJob& J, int i, int j) {
-  if (!J.strip_base) return cell_slot(J.strip_stride, i, j);
+  if (!J.strip_base) return cell_slot_blk(J.strip_stride, J.blk, i, j);
   const int s = i >> 6, l = i & (HX_STRIP - 1), t = j + l;
   const int32_t* w = J.fwd_windows + 4 * s;
   if (t >= w[0] && t < w[1]) return J.strip_base[2 * s] + ((int64_t)((t - w[0]) >> 1) << 7) + (l << 1) + (t & 1);

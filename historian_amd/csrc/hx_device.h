@@ -98,6 +98,10 @@ struct DevJob {
   const int64_t* strip_base;  // [n_strips][2] band-compressed storage (HX_BAND_COMPRESSED): offset of each Forward window in a
                               // state plane; fwd_windows then holds the windows exactly as swept.  nullptr: dense planes
   const uint32_t* yword;      // [n_cols + 328] per-column words of the banded scaled-probability fill (hx_linear.hip), or nullptr
+  int32_t blk;                // doubles per step-pair block of a strip: 128 (state planes apart), or 640 = the five states of a
+                              // step pair adjacent (interleaved layout; plane is then 128 and strip_stride five times as large)
+  int32_t pad3_;
+  int64_t matrix_doubles;     // doubles of one whole matrix (all five states)
   const uint32_t* yword_bwd;  // the same for the Backward sweep (mirrored column order, class of the state an absorbing move leads to)
 };
 
@@ -129,6 +133,14 @@ __host__ __device__ inline int64_t cell_slot(int64_t strip_stride, int i, int j)
   const int l = i & (HX_STRIP - 1);
   const int t = j + l;
   return (int64_t)(i >> 6) * strip_stride + ((int64_t)(t >> 1) << 7) + (l << 1) + (t & 1);
+}
+// General form: `blk` doubles per step-pair block.  value(i, j, state) = M[state * plane + cell_slot_blk(...)], with
+// (plane, blk) = (doubles per state plane, 128) for separate state planes, or (128, 640) when the five states of a step
+// pair are adjacent - a wavefront then writes 5 KiB contiguous per iteration (scaled-probability fills, hx_linear.hip).
+__host__ __device__ inline int64_t cell_slot_blk(int64_t strip_stride, int blk, int i, int j) {
+  const int l = i & (HX_STRIP - 1);
+  const int t = j + l;
+  return (int64_t)(i >> 6) * strip_stride + (int64_t)(t >> 1) * blk + (l << 1) + (t & 1);
 }
 // The Backward matrix uses the same layout in mirrored coordinates (i -> R-1-i, j -> C-1-j): its
 // fill sweeps from the bottom-right corner, and this keeps the sweep's stores coalesced.

@@ -376,8 +376,8 @@ __global__ void k_posterior_scan(const DevJob* __restrict__ jobs, int job, doubl
   for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(c / J.n_cols), j = (int)(c - (int64_t)i * J.n_cols);
     if (!in_envelope(J, i, j)) continue;
-    const int64_t slot = cell_slot(J.strip_stride, i, j);
-    const int64_t bslot = bwd_slot(J.strip_stride, J.n_rows, J.n_cols, i, j);
+    const int64_t slot = cell_slot_blk(J.strip_stride, J.blk, i, j);
+    const int64_t bslot = cell_slot_blk(J.strip_stride, J.blk, J.n_rows - 1 - i, J.n_cols - 1 - j);
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
       const double lpp = J.bwd[s * J.plane + bslot] + J.fwd[s * J.plane + slot] - fwd_end;
@@ -398,7 +398,7 @@ __global__ void k_gather_cells(const DevJob* __restrict__ jobs, int job, const d
   if (k >= n) return;
   const int i = ij[2 * k], j = ij[2 * k + 1];
   const bool ok = i >= 0 && j >= 0 && i < J.n_rows && j < J.n_cols && in_envelope(J, i, j);
-  const int64_t slot = !ok ? 0 : (mirrored ? bwd_slot(J.strip_stride, J.n_rows, J.n_cols, i, j) : stored_slot(J, i, j));
+  const int64_t slot = !ok ? 0 : (mirrored ? cell_slot_blk(J.strip_stride, J.blk, J.n_rows - 1 - i, J.n_cols - 1 - j) : stored_slot(J, i, j));
 #pragma unroll
   for (int s = 0; s < 5; ++s) out[5 * k + s] = (ok && slot >= 0) ? M[s * J.plane + slot] : HX_NEG_INF;
 }

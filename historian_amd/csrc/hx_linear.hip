@@ -174,6 +174,7 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
   const int max_dist = J.max_dist;
   const int lane = threadIdx.x & 63, wave = PPW == 1 ? (int)(threadIdx.x >> 6) : 0;   // wave within its pair
   const int64_t plane = J.plane, ss = J.strip_stride;
+  const int blk = J.blk;                                     // doubles per step-pair block (hx_device.h cell_slot_blk)
   HX_GLOBAL double* __restrict__ M = as_global(DIR ? J.bwd : J.fwd);
   const HX_GLOBAL d4v* xpack = (const HX_GLOBAL d4v*)as_global(J.x.pack);
   // the 18 transition probabilities (src/pairhmm.cpp:17-43), pinned in scalar registers
@@ -271,7 +272,7 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
       while (drainp[0] < need) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
       const int jj = c0 + lane;
-      const int64_t sl = jj < Cc ? ((BANDED && DIR == 0) ? stored_slot(J, row0 - 1, jj) : cell_slot(ss, row0 - 1, jj)) : -1;
+      const int64_t sl = jj < Cc ? ((BANDED && DIR == 0) ? stored_slot(J, row0 - 1, jj) : cell_slot_blk(ss, blk, row0 - 1, jj)) : -1;
       if (jj < Cc && sl < 0) {                     // band-compressed storage: not stored = outside the envelope
         HX_LDS d2v* q = staging + (size_t)(jj & (HXL_STAGE - 1)) * 3;
         q[0] = d2v{0., 0.}; q[1] = d2v{0., 0.}; q[2] = d2v{0., __hiloint2double(0, HXL_EMIN)};
@@ -499,16 +500,9 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
                    h4 = log_scaled(cb.iiw, cb.e, lt);
       {
         // t64 = j + (i & 63) = t
-#if HX_ABLATE == 26      // layout experiment (timing only, readers not adapted): the five states of a step pair adjacent,
-                         // 5 KiB contiguous per wave and iteration
-        const int64_t sl = (int64_t)s * ss * 5 + (lane << 1) + (int64_t)((t - store_t0) >> 1) * 640;
-        HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
-        const int64_t plane2 = 64;
-#else
-        const int64_t sl = store_base2 + ((int64_t)((t - store_t0) >> 1) << 7);
+        const int64_t sl = store_base2 + (int64_t)((t - store_t0) >> 1) * blk;
         HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
         const int64_t plane2 = plane >> 1;
-#endif
 #if HX_ABLATE == 21      // no stores (keeps the values alive)
         if (l0 + l1 + l2 + l3 + l4 + h0 + h1 + h2 + h3 + h4 == 12345.678) M2[0] = d2v{l0, h0};
 #elif HX_ABLATE == 23    // plain stores
@@ -557,7 +551,7 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
   __syncthreads();
   if (live && wave == 0 && lane == 0) {
     if (DIR == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
-    else *J.lp_start = J.bwd[cell_slot(ss, R - 1, Cc - 1)];   // B(0,0).IMM in mirrored coordinates
+    else *J.lp_start = J.bwd[cell_slot_blk(ss, blk, R - 1, Cc - 1)];   // B(0,0).IMM in mirrored coordinates
   }
 }
 

@@ -126,11 +126,14 @@ typedef struct hx_pair_job {
 /* Where cell (i,j), 0 <= i < n_rows = Nx-1, 0 <= j < n_cols = Ny-1, lives in the
  * buffers returned by hx_batch_read_matrix:
  *     l = i % strip_rows,  t = j + l
- *     slot(i,j) = (i / strip_rows) * strip_stride + (t / 2) * (2 * strip_rows) + l * 2 + t % 2
- *     value(i,j,state) = buf[state * plane_stride + slot(i,j)]
+ *     slot(i,j) = (i / strip_rows) * strip_stride + (t / 2) * block_stride + l * 2 + t % 2
+ *     value(i,j,state) = buf[state * plane_stride + slot(i,j)]          (buf: matrix_doubles doubles)
  * (64-row strips, anti-diagonal-major inside a strip, two anti-diagonals interleaved: a
  * wavefront stepping along anti-diagonals writes 16 contiguous bytes per lane and state
- * plane every second step).  Cells outside the envelope hold -inf, as
+ * every second step).  Two instances: separate state planes (block_stride = 2 * strip_rows,
+ * plane_stride = n_strips * strip_stride), and - the scaled-probability fills of unbanded leaf
+ * batches - the five states of a step pair adjacent (block_stride = 10 * strip_rows,
+ * plane_stride = 2 * strip_rows): read the fields, do not assume either.  Cells outside the envelope hold -inf, as
  * DPMatrix::cell() returns for them (reference src/forward.h:79-84). */
 typedef struct hx_layout {
   int32_t n_rows, n_cols;
@@ -145,6 +148,8 @@ typedef struct hx_layout {
                                   slot(i,j) = base_w + ((t - lo_w) / 2) * (2 * strip_rows) + l * 2 + t % 2
                                 for the window w with lo_w <= t < hi_w; a cell in neither window is not stored
                                 (it is outside the envelope and reads as -inf).                                  */
+  int64_t block_stride;      /* doubles per block of two anti-diagonals of a strip                    */
+  int64_t matrix_doubles;    /* doubles hx_batch_read_matrix writes (all five states)                 */
 } hx_layout;
 
 typedef struct hx_cell {
@@ -186,7 +191,7 @@ int hx_batch_sync(hx_batch* b);
 int hx_batch_lp_end(hx_batch* b, double* out /* [n_jobs] ForwardMatrix::lpEnd */);
 int hx_batch_lp_start(hx_batch* b, double* out /* [n_jobs] BackwardMatrix::lpStart() */);
 int hx_batch_layout(const hx_batch* b, int32_t job, int32_t which, hx_layout* out);
-/* which: 0 = Forward, 1 = Backward.  out holds 5 * plane_stride doubles. */
+/* which: 0 = Forward, 1 = Backward.  out holds hx_layout::matrix_doubles doubles. */
 int hx_batch_read_matrix(hx_batch* b, int32_t job, int32_t which, double* out);
 /* Gather n cells (ij[2k], ij[2k+1]) -> out[5k..5k+4] without copying the matrix. */
 int hx_batch_read_cells(hx_batch* b, int32_t job, int32_t which, const int32_t* ij, int64_t n, double* out);

@@ -42,14 +42,14 @@ def test_version_and_error_codes_without_a_device():
 
 def test_struct_sizes_match_the_header():
     assert C.sizeof(capi.HxCell) == 24
-    assert C.sizeof(capi.HxLayout) == 40
+    assert C.sizeof(capi.HxLayout) == 56
     assert C.sizeof(capi.HxHmm) == 8 + 5 * 6 * 8 + 7 * 8
     assert C.sizeof(capi.HxPairJob) == 32
 
 
 def test_slot_formula_is_a_bijection():
     ss = (((77 + 63) >> 1) + 1) * 128
-    l = capi.HxLayout(n_rows=130, n_cols=77, strip_rows=64, n_strips=3, strip_stride=ss, plane_stride=3 * ss)
+    l = capi.HxLayout(n_rows=130, n_cols=77, strip_rows=64, n_strips=3, strip_stride=ss, plane_stride=3 * ss, block_stride=128)
     ii, jj = np.meshgrid(np.arange(130), np.arange(77), indexing="ij")
     s = capi.slot_index(l, ii, jj).ravel()
     assert len(np.unique(s)) == s.size and s.min() >= 0 and s.max() < l.plane_stride
