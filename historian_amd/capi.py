@@ -425,7 +425,7 @@ class QuickBatch:
     def read_matrix(self, job):
         """[(xlen+1), (ylen+1), 3] array indexed by the reference's (i, j): row / column 0 are -inf."""
         lay = self.layout(job)
-        buf = np.empty(3 * lay.plane_stride)
+        buf = np.empty(lay.matrix_doubles)
         _check(load().hx_quick_batch_read_matrix(self._h, job, _p(buf, _f64p)))
         i, j = np.meshgrid(np.arange(lay.n_rows), np.arange(lay.n_cols), indexing="ij")
         slot = slot_index(lay, i, j)

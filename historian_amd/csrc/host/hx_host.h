@@ -665,7 +665,7 @@ protected:
   int jobIndex;
   mutable double* hostCells;
   mutable size_t hostCellsCap;
-  long long stripStride, planeStride;
+  long long stripStride, planeStride, blockStride, matrixDoubles;   // hx_layout of the matrix
   void attach(const std::shared_ptr<QuickHandle>& h, int job, double score, int xe, int ye);
 };
 

@@ -147,7 +147,7 @@ QuickAlignMatrix::QuickAlignMatrix(const DiagonalEnvelope& env, const RateModel&
     : penv(&env), px(env.px), py(env.py), xTok(unvalidatedTokens(*env.px, model.alphabet)),
       yTok(unvalidatedTokens(*env.py, model.alphabet)), xLen(px->length()), yLen(py->length()), xEnd(0), yEnd(0),
       start(NEG_INF), end(NEG_INF), result(NEG_INF), model(model), time(time), jobIndex(0), hostCells(NULL), hostCellsCap(0),
-      stripStride(0), planeStride(0) {
+      stripStride(0), planeStride(0), blockStride(128), matrixDoubles(0) {
   computeScores();
 }
 
@@ -213,6 +213,8 @@ void QuickAlignMatrix::attach(const std::shared_ptr<QuickHandle>& h, int job, do
   detail::check(hx_quick_batch_layout(h->b, job, &lay), "hx_quick_batch_layout");
   stripStride = lay.strip_stride;
   planeStride = lay.plane_stride;
+  blockStride = lay.block_stride;
+  matrixDoubles = lay.matrix_doubles;
 }
 
 QuickAlignMatrix::QuickAlignMatrix(const DiagonalEnvelope& env, const RateModel& model, double time)
@@ -265,12 +267,12 @@ QuickAlignMatrix::~QuickAlignMatrix() {
 LogProb QuickAlignMatrix::getCell(SeqIdx i, SeqIdx j, unsigned int offset) const {
   if (i < 1 || j < 1 || i > xLen || j > yLen) return NEG_INF;
   if (!hostCells) {
-    hostCells = detail::pinnedTake(3 * (size_t)planeStride, hostCellsCap);
+    hostCells = detail::pinnedTake((size_t)matrixDoubles, hostCellsCap);
     detail::check(hx_quick_batch_read_matrix(handle->b, jobIndex, hostCells), "hx_quick_batch_read_matrix");
   }
   const long long r = (long long)i - 1, c = (long long)j - 1;
   const long long l = r & 63, t = c + l;
-  const long long slot = (r >> 6) * stripStride + ((t >> 1) << 7) + (l << 1) + (t & 1);
+  const long long slot = (r >> 6) * stripStride + (t >> 1) * blockStride + (l << 1) + (t & 1);
   return hostCells[(size_t)offset * planeStride + slot];
 }
 

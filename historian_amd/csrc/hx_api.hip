@@ -879,15 +879,20 @@ int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_bat
     memset(&J, 0, sizeof(J));
     J.xlen = q.x_len; J.ylen = q.y_len; J.alph = q.alph_size;
     J.n_strips = (q.x_len + HX_STRIP - 1) / HX_STRIP;
-    J.strip_stride = strip_stride_for(q.y_len);
-    J.plane = J.n_strips * J.strip_stride;
+    // the three states of a step pair adjacent (a wavefront writes 3 KiB contiguous per iteration), unless
+    // HX_PLANAR_LAYOUT asks for separate state planes
+    const bool planar = getenv("HX_PLANAR_LAYOUT") != nullptr;
+    J.strip_stride = strip_stride_for(q.y_len) * (planar ? 1 : 3);
+    J.plane = planar ? J.n_strips * J.strip_stride : 2 * HX_STRIP;
+    J.blk = planar ? 2 * HX_STRIP : 6 * HX_STRIP;
+    const int64_t matrix_doubles = (planar ? 3 : 1) * (int64_t)J.n_strips * J.strip_stride;
     for (int s = 0; s < 11; ++s) J.sc[s] = q.scores[s];
     hx_layout& L = b->layouts[k];
     L.n_rows = q.x_len; L.n_cols = q.y_len; L.strip_rows = HX_STRIP; L.n_strips = J.n_strips;
     L.strip_stride = J.strip_stride; L.plane_stride = J.plane; L.mirrored = 0; L.compressed = 0;
-    L.block_stride = 2 * HX_STRIP; L.matrix_doubles = 3 * J.plane;
+    L.block_stride = J.blk; L.matrix_doubles = matrix_doubles;
     cell_off[k] = cells_total;
-    cells_total += 3 * J.plane;
+    cells_total += matrix_doubles;
     b->total_cells += (int64_t)q.x_len * q.y_len;
     if (q.x_len > b->max_rows) b->max_rows = q.x_len;
     if (q.y_len > b->max_cols) b->max_cols = q.y_len;
@@ -981,7 +986,7 @@ int hx_quick_batch_read_matrix(hx_quick_batch* b, int32_t job, double* out) {
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
   if (!b->done) return fail(HX_ERR_STATE, "hx_quick_batch_run has not been launched");
   HIP_TRY(hipStreamSynchronize(b->last_stream));
-  HIP_TRY(hipMemcpy(out, b->jobs[job].cells, sizeof(double) * 3 * (size_t)b->jobs[job].plane, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, b->jobs[job].cells, sizeof(double) * (size_t)b->layouts[job].matrix_doubles, hipMemcpyDeviceToHost));
   return HX_OK;
 }
 

@@ -114,7 +114,8 @@ struct DevQuick {
   double sc[11];              // m2m m2i m2d i2i i2m i2d d2d d2m gapOpen gapExtend noGap
   const uint8_t* in_env;      // [xlen+ylen+1] indexed (i - j) + ylen, or nullptr = full envelope
   double* cells;              // [3][plane]: mat, ins, del in the strip-skewed layout, row = i-1, column = j-1
-  int64_t plane, strip_stride;
+  int64_t plane, strip_stride;    // state stride and strip stride of the (interleaved, see cell_slot_blk) layout
+  int32_t blk, pad_;              // doubles per step-pair block: 3 * 128
   double* col_scratch;        // [2*ylen doubles + ylen ints] per-column constants when they do not fit LDS, else nullptr
   double* best_score;         // [xlen] per-row best mat + endGapScore ...
   int32_t* best_j;            // ... and the first column that attains it

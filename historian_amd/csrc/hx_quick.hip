@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
   const int R = J.xlen, Cc = J.ylen;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t plane = J.plane, ss = J.strip_stride;
+  const int blk = J.blk;
   HX_GLOBAL double* __restrict__ M = as_global(J.cells);
   const HX_GLOBAL uint8_t* in_env = as_global(J.in_env);
   const double m2m = J.sc[0], m2i = J.sc[1], m2d = J.sc[2], i2i = J.sc[3], i2m = J.sc[4], i2d = J.sc[5], d2d = J.sc[6],
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
           const int cc = t + lane;
           bnd = q3_neg_inf();
           if (cc < Cc) {
-            const int64_t sl = cell_slot(ss, row0 - 1, cc);
+            const int64_t sl = cell_slot_blk(ss, blk, row0 - 1, cc);
             bnd.mat = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bnd.ins = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bnd.del = __hip_atomic_load(M + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
       const Q3 ca = step(t);
       Q3 cb = q3_neg_inf();
       if (t + 1 < nsteps) cb = step(t + 1);
-      HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + store_base + ((int64_t)(t >> 1) << 7));
+      HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + store_base + (int64_t)(t >> 1) * blk);
       M2[0] = d2v{ca.mat, cb.mat};
       M2[plane2] = d2v{ca.ins, cb.ins};
       M2[2 * plane2] = d2v{ca.del, cb.del};
