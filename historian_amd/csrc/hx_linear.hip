@@ -513,7 +513,8 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
         M2[4 * plane2] = d2v{l4, h4};
 #else
         // write-once data that this kernel never reads again (the wrap-around link reads 1/64 of it, from L2 or
-        // memory): non-temporal stores, measured 17.4 -> 15.8 ms on the headline workload
+        // memory): non-temporal stores - 17.4 -> 15.8 ms on the headline workload with separate state planes; with the
+        // interleaved layout (5 KiB contiguous per iteration) they measure the same as plain stores
         __builtin_nontemporal_store(d2v{l0, h0}, &M2[0]);
         __builtin_nontemporal_store(d2v{l1, h1}, &M2[plane2]);
         __builtin_nontemporal_store(d2v{l2, h2}, &M2[2 * plane2]);
