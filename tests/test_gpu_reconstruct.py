@@ -164,3 +164,22 @@ def test_best_path_profiles_never_copy_a_matrix(tmp_path):
         traces = int(re.search(r"tracebacks [0-9.]+ s in (\d+) calls", out.stderr.decode()).group(1))
         assert (reads > 0) == host_traceback and (traces > 0) == (not host_traceback)
     assert outs[False] == outs[True]
+
+
+def test_posterior_profiles_in_linear_fill_mode(tmp_path):
+    # the same posterior-profile reconstruction with HX_FILL_MODE=linear: the leaf-pair nodes' Forward and Backward
+    # matrices are the scaled-probability fills' (interleaved layout, read back by the mirror); the root log-likelihood
+    # stays within north_star's tolerance of the oracle's and every sequence is aligned completely
+    alphabet = "acgt"
+    jc = os.path.join(ROOT, "tests", "golden", "models", "jc.json")
+    tree, seqs = R.balanced_family(8, 150, alphabet, seed=5)
+    job = str(tmp_path / "job.txt")
+    R.write_job(job, jc, tree, seqs, {}, str(tmp_path / "seqs.fa"), str(tmp_path / "guide.fa"), maxstates=0, posterior=0.01, batch=1)
+    out = subprocess.run([HXRECON, job], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                         env=dict(os.environ, HX_FILL_MODE="linear"))
+    assert out.returncode == 0, out.stderr.decode()
+    got = R.parse_hxrecon(out.stdout.decode())
+    res, rows = R.oracle_reconstruct(jc, tree, seqs, {}, min_post_prob=0.01)
+    assert abs(got["lpFinalFwd"] - res["lp_final_fwd"]) <= 1e-4 * abs(res["lp_final_fwd"])
+    assert {k: v.replace("-", "") for k, v in got["rows"].items() if k in rows} == {k: v.replace("-", "") for k, v in rows.items()}
+    assert len({len(v) for v in got["rows"].values()}) == 1
