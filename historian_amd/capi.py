@@ -66,7 +66,8 @@ class HxCell(C.Structure):
 EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_create", "hx_batch_destroy",
            "hx_batch_forward", "hx_batch_backward", "hx_batch_sync", "hx_batch_lp_end", "hx_batch_lp_start",
            "hx_batch_layout", "hx_batch_read_matrix", "hx_batch_read_cells", "hx_batch_read_prepared",
-           "hx_batch_posterior_scan", "hx_batch_best_trace", "hx_batch_strip_windows", "hx_batch_total_cells", "hx_batch_last_kernel_ms", "hx_host_alloc",
+           "hx_batch_posterior_scan", "hx_batch_best_trace", "hx_device_count", "hx_batch_create_on", "hx_batch_device",
+           "hx_quick_batch_create_on", "hx_batch_strip_windows", "hx_batch_total_cells", "hx_batch_last_kernel_ms", "hx_host_alloc",
            "hx_host_free", "hx_quick_batch_create", "hx_quick_batch_destroy", "hx_quick_batch_run",
            "hx_quick_batch_results", "hx_quick_batch_layout", "hx_quick_batch_read_matrix",
            "hx_quick_batch_total_cells", "hx_quick_batch_last_kernel_ms"]
@@ -94,6 +95,8 @@ def load():
     lib.hx_init.argtypes = [C.c_int, _f64p, C.c_size_t]
     lib.hx_last_error.restype = C.c_char_p
     lib.hx_batch_create.argtypes = [C.POINTER(HxPairJob), C.c_int32, C.c_uint32, C.POINTER(vp)]
+    lib.hx_batch_create_on.argtypes = [C.c_int, C.POINTER(HxPairJob), C.c_int32, C.c_uint32, C.POINTER(vp)]
+    lib.hx_batch_device.argtypes = [vp]
     lib.hx_batch_destroy.argtypes = [vp]
     lib.hx_batch_forward.argtypes = [vp, vp]
     lib.hx_batch_backward.argtypes = [vp, vp]
@@ -239,12 +242,15 @@ def slot_index(layout, i, j):
 class Batch:
     """n independent pair DPs resident on the device."""
 
-    def __init__(self, triples, flags=0):
+    def __init__(self, triples, flags=0, device=None):
         self._keep = triples
         self.n = len(triples)
         self._jobs = make_jobs(triples)
         self._h = C.c_void_p()
-        _check(load().hx_batch_create(self._jobs, self.n, flags, C.byref(self._h)))
+        if device is None:
+            _check(load().hx_batch_create(self._jobs, self.n, flags, C.byref(self._h)))
+        else:
+            _check(load().hx_batch_create_on(device, self._jobs, self.n, flags, C.byref(self._h)))
 
     def close(self):
         if self._h:

@@ -24,11 +24,19 @@ using namespace hx;
 namespace {
 
 thread_local char g_err[512] = "";
-int g_device = -1;
-double* g_tab = nullptr;      // device copy of the host-built log_sum_exp table
-double* g_fast_tab = nullptr; // device copy of the cubic table of the fast fill mode
-double* g_log_tab = nullptr;  // {c, -log c} entries of the scaled-linear Forward fill's logarithm (hx_linear.hip)
-double* g_pair_tab = nullptr; // {lookup[n], lookup[n+1]-lookup[n]} pairs, 16-byte aligned (exact fill mode)
+// Constant tables, one set per device hx_init was called for (the rate-model-independent part of the constant block of
+// SURVEY 8e).  A batch is bound to one device at creation; a process may drive several devices (hx_batch_create_on),
+// from one host thread or from one thread per device.
+#define HX_MAX_DEVICES 16
+struct DeviceTables {
+  double* tab = nullptr;      // device copy of the host-built log_sum_exp table (8-byte entries)
+  double* fast_tab = nullptr; // quadratic pieces of the fast fill mode (FastPiece, 16 bytes each)
+  double* log_tab = nullptr;  // {c, -log c} entries of the scaled-probability fills' logarithm (hx_linear.hip)
+  double* pair_tab = nullptr; // {lookup[n], lookup[n+1]-lookup[n]} pairs, 16-byte aligned (exact fill mode)
+  bool ready = false;
+};
+DeviceTables g_dev[HX_MAX_DEVICES];
+int g_device = -1;            // the default device: the one hx_init was last called for
 
 // Quadratic pieces of T(d) = log(1 + exp(-d)) on [0,10): piece k covers [k h, (k+1) h),
 // h = 10/N, as c0 + c1 t + c2 t^2 with t = (d - k h)/h, interpolating T at the three Chebyshev
@@ -275,8 +283,8 @@ void bind_profile(DevProfile& d, const ProfOff& o, char* base) {
 
 struct JobOff {
   ProfOff x, y;
-  size_t log_root, log_sub_l, log_sub_r, log_ins_l, log_ins_r, log_cptw_l, log_cptw_r, emis, emis_pad, scalars;
-  size_t fwd_windows, bwd_windows, strip_base, yword, yword_bwd;
+  size_t log_root, log_sub_l, log_sub_r, log_ins_l, log_ins_r, log_cptw_l, log_cptw_r, emis, emis_pad;
+  size_t fwd_windows, bwd_windows, strip_base, yword, yword_bwd, band_rows;
   bool compressed;
   int64_t compact_plane;
   int64_t eplane_off;     // into hx_batch::d_eplane, or -1
@@ -342,21 +350,46 @@ std::vector<int32_t> strip_windows(const uint8_t* xf, const int32_t* xenv, const
 
 }  // namespace
 
+// Kernel classes: the jobs of a batch are grouped by the fill kernel that suits them, each class is launched on its own
+// (same stream, one after the other), so a tree level that mixes leaf-leaf and internal-node pairs does not fall to the
+// slowest kernel as a whole.  Classes are contiguous in the class-ordered job table and in the matrix allocation.
+enum KernelClass {
+  KC_LEAF_LDS = 0,            // leaf-like pairs whose y side fits LDS: scaled-probability fills (HX_LSE_LINEAR) or k_fill_chain<YL>
+  KC_LEAF_LDS_BANDED,
+  KC_LEAF,                    // other leaf-like pairs: k_fill_chain<LEAF>
+  KC_LEAF_BANDED,
+  KC_CHAIN,                   // other in-degree-1 profiles: k_fill_chain (Forward); Backward runs the general pipeline
+  KC_CHAIN_BANDED,
+  KC_DAG,                     // general profiles: the strip pipelines of hx_dag.hip
+  KC_DAG_BANDED,
+  KC_GENERIC,                 // HX_FORCE_GENERIC: the first general kernels (barrier per anti-diagonal)
+  KC_COUNT
+};
+struct ClassRange {
+  int begin = 0, n = 0;       // positions in the class-ordered job table
+  int max_rows = 0, max_cls = 0, yl_cols = 0, yl_emis = 0;
+  int64_t mat_begin = 0, mat_doubles = 0;   // the class's matrices are contiguous: [mat_begin, mat_begin + mat_doubles)
+};
+
 struct hx_batch {
+  int device = 0;
   int n_jobs = 0;
   uint32_t flags = 0;
-  std::vector<DevJob> jobs;         // host copies (device pointers inside)
+  std::vector<DevJob> jobs;         // host copies in the caller's job order (device pointers inside)
   std::vector<hx_layout> layouts;
-  DevJob* d_jobs = nullptr;
+  std::vector<int> order;           // class-ordered table position -> caller's job index
+  ClassRange cls[KC_COUNT];
+  DevJob* d_jobs = nullptr;         // the caller's job order (readers, traceback, prep)
+  DevJob* d_jobs_cls = nullptr;     // class order (fills)
   char* d_arena = nullptr;
   double* d_fwd = nullptr;
   double* d_bwd = nullptr;
   double* d_eplane = nullptr;       // per-cell emission planes of the jobs without a class-pair table
-  double* d_agg = nullptr;          // outgoing-sum planes of the general-profile Forward pipeline (same size as d_fwd)
+  double* d_agg = nullptr;          // outgoing-sum planes of the general-profile Forward pipeline (KC_DAG* jobs only)
   int64_t fwd_total = 0, max_eplane = 0;
-  int max_states = 0, max_ca = 0, max_cls_pairs = 0, max_rows = 0, max_cls = 0;
-  bool all_chain = true, all_leaf = true, all_ylds = true, any_banded = false, any_compressed = false;
-  int yl_cols = 0, yl_emis = 0;       // LDS-resident y side: columns and padded class pairs of the largest job
+  int max_states = 0, max_ca = 0, max_cls_pairs = 0, max_cls = 0;
+  bool any_compressed = false;
+  size_t lp_end_off = 0, lp_start_off = 0;   // [n_jobs] doubles each in the arena, caller's order: one copy per read
   int64_t total_cells = 0;
   bool forward_done = false, backward_done = false;
   bool sub_scattered = false;        // subx / suby of table-emission jobs exist per state (k_scatter_sub, on demand)
@@ -369,68 +402,104 @@ struct hx_batch {
   bool ev_valid[2] = {false, false};
 };
 
+namespace {
+// (re)upload both job tables: the caller's order and the class order
+int publish_jobs(hx_batch* b) {
+  HIP_TRY(hipMemcpy(b->d_jobs, b->jobs.data(), sizeof(DevJob) * b->n_jobs, hipMemcpyHostToDevice));
+  std::vector<DevJob> sorted((size_t)b->n_jobs);
+  for (int p = 0; p < b->n_jobs; ++p) sorted[p] = b->jobs[b->order[p]];
+  HIP_TRY(hipMemcpy(b->d_jobs_cls, sorted.data(), sizeof(DevJob) * b->n_jobs, hipMemcpyHostToDevice));
+  return HX_OK;
+}
+// every entry point that touches a batch runs on the batch's device
+int use_device(const hx_batch* b) {
+  if (hipSetDevice(b->device) != hipSuccess) return fail(HX_ERR_HIP, "hipSetDevice(%d) failed", b->device);
+  return HX_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int hx_version(void) { return 1; }
 
 const char* hx_last_error(void) { return g_err; }
 
+namespace {
+void free_tables(DeviceTables& t) {
+  if (t.tab) (void)hipFree(t.tab);
+  if (t.fast_tab) (void)hipFree(t.fast_tab);
+  if (t.log_tab) (void)hipFree(t.log_tab);
+  if (t.pair_tab) (void)hipFree(t.pair_tab);
+  t = DeviceTables();
+}
+int upload(double** dst, const std::vector<double>& src) {
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), src.size() * sizeof(double)));
+  HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(double), hipMemcpyHostToDevice));
+  return HX_OK;
+}
+}  // namespace
+
+int hx_device_count(void) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess) return 0;
+  return n_dev;
+}
+
 int hx_init(int device_ordinal, const double* lse_table, size_t n_entries) {
   if (!lse_table || n_entries != HX_LSE_TABLE_ENTRIES)
     return fail(HX_ERR_INVALID_ARG, "lse_table must hold %d doubles (got %zu)", HX_LSE_TABLE_ENTRIES, n_entries);
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(HX_ERR_NO_DEVICE, "no HIP device available");
-  if (device_ordinal < 0 || device_ordinal >= n_dev) return fail(HX_ERR_NO_DEVICE, "device %d out of range (%d devices)", device_ordinal, n_dev);
+  if (device_ordinal < 0 || device_ordinal >= n_dev || device_ordinal >= HX_MAX_DEVICES)
+    return fail(HX_ERR_NO_DEVICE, "device %d out of range (%d devices)", device_ordinal, n_dev);
   if (hipSetDevice(device_ordinal) != hipSuccess) return fail(HX_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device_ordinal);
-  if (g_tab) { (void)hipFree(g_tab); g_tab = nullptr; }
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_tab), n_entries * sizeof(double)));
-  HIP_TRY(hipMemcpy(g_tab, lse_table, n_entries * sizeof(double), hipMemcpyHostToDevice));
-  {
+  DeviceTables& D = g_dev[device_ordinal];
+  free_tables(D);
+  try {
+    int rc;
+    if ((rc = upload(&D.tab, std::vector<double>(lse_table, lse_table + n_entries))) != HX_OK) { free_tables(D); return rc; }
     std::vector<double> pairs(2 * n_entries, 0.0);
     for (size_t n = 0; n < n_entries; ++n) {
       pairs[2 * n] = lse_table[n];
       pairs[2 * n + 1] = n + 1 < n_entries ? lse_table[n + 1] - lse_table[n] : 0.0;
     }
-    if (g_pair_tab) { (void)hipFree(g_pair_tab); g_pair_tab = nullptr; }
-  if (g_log_tab) { (void)hipFree(g_log_tab); g_log_tab = nullptr; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_pair_tab), pairs.size() * sizeof(double)));
-    HIP_TRY(hipMemcpy(g_pair_tab, pairs.data(), pairs.size() * sizeof(double), hipMemcpyHostToDevice));
-  }
-  {
+    if ((rc = upload(&D.pair_tab, pairs)) != HX_OK) { free_tables(D); return rc; }
+    std::vector<double> lt((size_t)log_table_doubles());
+    build_log_table(lt.data());
+    if ((rc = upload(&D.log_tab, lt)) != HX_OK) { free_tables(D); return rc; }
     std::vector<double> ft;
     build_fast_table(ft);
-    {
-      std::vector<double> lt((size_t)log_table_doubles());
-      build_log_table(lt.data());
-      if (g_log_tab) { (void)hipFree(g_log_tab); g_log_tab = nullptr; }
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_log_tab), lt.size() * sizeof(double)));
-      HIP_TRY(hipMemcpy(g_log_tab, lt.data(), lt.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
-    if (g_fast_tab) { (void)hipFree(g_fast_tab); g_fast_tab = nullptr; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g_fast_tab), ft.size() * sizeof(double)));
-    HIP_TRY(hipMemcpy(g_fast_tab, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = upload(&D.fast_tab, ft)) != HX_OK) { free_tables(D); return rc; }
+  } catch (const std::bad_alloc&) {
+    free_tables(D);
+    return fail(HX_ERR_OUT_OF_MEMORY, "host allocation failed");
   }
+  D.ready = true;
   g_device = device_ordinal;
   return HX_OK;
 }
 
 int hx_shutdown(void) {
-  if (g_tab) { (void)hipFree(g_tab); g_tab = nullptr; }
-  if (g_fast_tab) { (void)hipFree(g_fast_tab); g_fast_tab = nullptr; }
-  if (g_pair_tab) { (void)hipFree(g_pair_tab); g_pair_tab = nullptr; }
+  for (int d = 0; d < HX_MAX_DEVICES; ++d)
+    if (g_dev[d].ready || g_dev[d].tab) {
+      (void)hipSetDevice(d);
+      free_tables(g_dev[d]);
+    }
   g_device = -1;
   return HX_OK;
 }
 
-int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_batch** out) {
+static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_batch** out) {
   if (!out) return fail(HX_ERR_INVALID_ARG, "out is null");
   *out = nullptr;
-  if (g_device < 0 || !g_tab) return fail(HX_ERR_NOT_INITIALIZED, "hx_init has not been called");
+  if (device < 0 || device >= HX_MAX_DEVICES || !g_dev[device].ready)
+    return fail(HX_ERR_NOT_INITIALIZED, "hx_init has not been called for device %d", device);
   if (!jobs || n_jobs <= 0) return fail(HX_ERR_INVALID_ARG, "need at least one job");
-  HIP_TRY(hipSetDevice(g_device));
+  HIP_TRY(hipSetDevice(device));
 
   hx_batch* b = new (std::nothrow) hx_batch;
   if (!b) return fail(HX_ERR_OUT_OF_MEMORY, "host allocation failed");
+  b->device = device;
   b->n_jobs = n_jobs;
   b->flags = flags;
   b->jobs.resize(n_jobs);
@@ -439,8 +508,11 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
   Arena ar;
   std::vector<JobOff> offs(n_jobs);
   std::vector<int64_t> mat_off(n_jobs);
-  int64_t mat_total = 0, eplane_total = 0;
+  std::vector<int> kclass(n_jobs);
+  int64_t eplane_total = 0;
   int rc = HX_OK;
+  static const bool force_dag = getenv("HX_FORCE_DAG") != nullptr;   // tuning hook: the general pipeline for chain profiles too
+  const bool linear = (flags & HX_LSE_LINEAR) == HX_LSE_LINEAR;
   for (int k = 0; k < n_jobs && rc == HX_OK; ++k) {
     const hx_pair_job& pj = jobs[k];
     const hx_hmm* h = pj.hmm;
@@ -466,14 +538,32 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     jo.table_emission = pairs > 0 && pairs <= (1 << 16);
     jo.emis = jo.table_emission ? ar.reserve(sizeof(double) * pairs) : 0;
     jo.emis_pad = jo.table_emission ? ar.reserve(sizeof(double) * (jo.x.n_cls + 1) * (jo.y.n_cls + 1)) : 0;
-    jo.scalars = ar.reserve(sizeof(double) * 2);
-    jo.fwd_windows = jo.bwd_windows = jo.strip_base = jo.yword = jo.yword_bwd = 0;
+    jo.fwd_windows = jo.bwd_windows = jo.strip_base = jo.yword = jo.yword_bwd = jo.band_rows = 0;
     jo.compressed = false;
     jo.compact_plane = 0;
-    if ((flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && jo.y.n_cls < 255 && jo.y.n >= 2) {
+
+    // ---- kernel class of the job ----
+    const bool chain = jo.x.chain && jo.y.chain;
+    const bool leaf_like = chain && jo.x.interior_emit && jo.y.interior_emit && jo.table_emission;
+    // y side small enough for LDS (hx_chain.hip HX_YL_*, hx_linear.hip) and all its transitions have lpTrans 0
+    const bool ylds = leaf_like && jo.y.lp_zero && jo.y.n <= 6144 && jo.y.n_cls + 1 <= 64 && jo.x.n_cls < 255 &&
+                      (int64_t)(jo.x.n_cls + 1) * (jo.y.n_cls + 1) <= 1024;
+    int kc;
+    if (flags & HX_FORCE_GENERIC) kc = KC_GENERIC;
+    else if (force_dag || !chain) kc = need_env ? KC_DAG_BANDED : KC_DAG;
+    else if (ylds) kc = need_env ? KC_LEAF_LDS_BANDED : KC_LEAF_LDS;
+    else if (leaf_like) kc = need_env ? KC_LEAF_BANDED : KC_LEAF;
+    else kc = need_env ? KC_CHAIN_BANDED : KC_CHAIN;
+    kclass[k] = kc;
+    if ((flags & HX_BAND_COMPRESSED) && (kc >= KC_DAG || (flags & HX_KEEP_BACKWARD))) {
+      rc = fail(HX_ERR_INVALID_ARG, "HX_BAND_COMPRESSED is implemented by the Forward fills of chain (leaf) profiles only: "
+                                    "no general profiles (job %d), no HX_KEEP_BACKWARD / HX_FORCE_GENERIC", k);
+      break;
+    }
+
+    if (linear && (kc == KC_LEAF_LDS || kc == KC_LEAF_LDS_BANDED) && jo.y.n >= 2) {
       // per-column words of the banded scaled-probability fill (hx_linear.hip): {emission class : 8, not ready : 1,
       // always in envelope : 1, envelope coordinate : 22}, with 64 words of padding on either side (the edge columns').
-      // Built for every job: a banded batch may hold unbanded jobs too.
       const int Cc = jo.y.n - 1;
       const std::vector<uint8_t> yf(ar.host.data() + jo.y.flags, ar.host.data() + jo.y.flags + jo.y.n);
       const std::vector<int32_t> ecls(reinterpret_cast<const int32_t*>(ar.host.data() + jo.y.ecls),
@@ -517,8 +607,8 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
           int lo[2], hi[2];
           for (int w = 0; w < 2; ++w) {
             lo[w] = o[2 * w] & ~1;
-            const int h = (o[2 * w + 1] + 1) & ~1;
-            hi[w] = h < nsteps ? h : nsteps;
+            const int hh = (o[2 * w + 1] + 1) & ~1;
+            hi[w] = hh < nsteps ? hh : nsteps;
             if (hi[w] < lo[w]) hi[w] = lo[w];
           }
           if (hi[1] > lo[1] && lo[1] <= hi[0]) { hi[0] = std::max(hi[0], hi[1]); lo[1] = hi[1] = 0; }
@@ -548,17 +638,21 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     J.n_strips = (J.n_rows + HX_STRIP - 1) / HX_STRIP;
     J.strip_stride = strip_stride_for(J.n_cols);
     J.plane = jo.compressed ? jo.compact_plane : J.n_strips * J.strip_stride;
-    J.chain = jo.x.chain && jo.y.chain;
-    J.leaf_like = J.chain && jo.x.interior_emit && jo.y.interior_emit && jo.table_emission;
+    J.chain = chain;
+    J.leaf_like = leaf_like;
     hx_layout& L = b->layouts[k];
     L.n_rows = J.n_rows; L.n_cols = J.n_cols; L.strip_rows = HX_STRIP; L.n_strips = J.n_strips;
-    L.strip_stride = J.strip_stride; L.plane_stride = J.plane;
     J.blk = 2 * HX_STRIP; J.matrix_doubles = 5 * J.plane;
+    // Unbanded leaf pairs of the scaled-probability fills keep the five states of a step pair adjacent: a wavefront then
+    // writes 5 KiB contiguous per iteration instead of 1 KiB into each of five planes (hx_linear.hip; same total size).
+    // Only those kernels and the layout-aware readers ever see such a job.
+    if (linear && kc == KC_LEAF_LDS && !getenv("HX_PLANAR_LAYOUT")) {
+      J.strip_stride *= 5; J.plane = 2 * HX_STRIP; J.blk = 10 * HX_STRIP;
+    }
+    L.strip_stride = J.strip_stride; L.plane_stride = J.plane;
     L.block_stride = J.blk; L.matrix_doubles = J.matrix_doubles;
     L.mirrored = 0; L.compressed = jo.compressed ? 1 : 0;
     b->any_compressed = b->any_compressed || jo.compressed;
-    mat_off[k] = mat_total;
-    mat_total += 5 * J.plane;
     jo.eplane_off = -1;
     if (!jo.table_emission) {   // (also for a profile without emitting states: the pipeline's loads are unconditional)
       jo.eplane_off = eplane_total;
@@ -572,31 +666,40 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     if (jo.y.n_cls > b->max_cls) b->max_cls = jo.y.n_cls;
     if (CA > b->max_ca) b->max_ca = CA;
     if (jo.table_emission && pairs > b->max_cls_pairs) b->max_cls_pairs = (int)pairs;
-    if (J.n_rows > b->max_rows) b->max_rows = J.n_rows;
-    b->all_chain = b->all_chain && J.chain;
-    b->all_leaf = b->all_leaf && J.leaf_like;
-    b->any_banded = b->any_banded || pj.max_distance >= 0;
-    // y side small enough for LDS (hx_chain.hip HX_YL_*) and all its transitions have lpTrans 0
-    if (jo.y.n > b->yl_cols) b->yl_cols = (jo.y.n + 3) & ~3;
-    if ((jo.x.n_cls + 1) * (jo.y.n_cls + 1) > b->yl_emis) b->yl_emis = ((jo.x.n_cls + 1) * (jo.y.n_cls + 1) + 1) & ~1;
-    b->all_ylds = b->all_ylds && J.leaf_like && jo.y.lp_zero && jo.y.n <= 6144 && jo.y.n_cls + 1 <= 64 &&
-                  (int64_t)(jo.x.n_cls + 1) * (jo.y.n_cls + 1) <= 1024;
+    ClassRange& cr = b->cls[kc];
+    cr.n++;
+    if (J.n_rows > cr.max_rows) cr.max_rows = J.n_rows;
+    if (jo.x.n_cls > cr.max_cls) cr.max_cls = jo.x.n_cls;
+    if (jo.y.n_cls > cr.max_cls) cr.max_cls = jo.y.n_cls;
+    if (((jo.y.n + 3) & ~3) > cr.yl_cols) cr.yl_cols = (jo.y.n + 3) & ~3;
+    const int ep = ((jo.x.n_cls + 1) * (jo.y.n_cls + 1) + 1) & ~1;
+    if (ep > cr.yl_emis) cr.yl_emis = ep;
   }
-  // Unbanded leaf batches of the scaled-probability fills keep the five states of a step pair adjacent: a wavefront then
-  // writes 5 KiB contiguous per iteration instead of 1 KiB into each of five planes (hx_linear.hip; same total size, so
-  // the offsets computed above stand).  Only those kernels and the layout-aware readers ever see such a batch.
-  if (rc == HX_OK && (flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && !(flags & HX_FORCE_GENERIC) && b->all_leaf && b->all_ylds &&
-      b->max_cls < 255 && !b->any_banded && !getenv("HX_PLANAR_LAYOUT"))
-    for (int k = 0; k < n_jobs; ++k) {
-      DevJob& J = b->jobs[k];
-      hx_layout& L = b->layouts[k];
-      J.strip_stride *= 5; J.plane = 2 * HX_STRIP; J.blk = 10 * HX_STRIP;
-      L.strip_stride = J.strip_stride; L.plane_stride = J.plane; L.block_stride = J.blk;
-    }
-  if (rc == HX_OK && (flags & HX_BAND_COMPRESSED) && !(b->all_chain && !(flags & (HX_KEEP_BACKWARD | HX_FORCE_GENERIC))))
-    rc = fail(HX_ERR_INVALID_ARG, "HX_BAND_COMPRESSED is implemented by the Forward fills of chain (leaf) profiles only: "
-                                  "no general profiles, no HX_KEEP_BACKWARD / HX_FORCE_GENERIC");
   if (rc != HX_OK) { delete b; return rc; }
+
+  // class-ordered job table and matrix allocation (stable within a class)
+  int64_t mat_total = 0, agg_begin = 0, agg_end = 0;
+  {
+    int pos = 0;
+    b->order.resize(n_jobs);
+    for (int c = 0; c < KC_COUNT; ++c) {
+      ClassRange& cr = b->cls[c];
+      cr.begin = pos;
+      cr.mat_begin = mat_total;
+      if (c == KC_DAG) agg_begin = mat_total;
+      for (int k = 0; k < n_jobs; ++k)
+        if (kclass[k] == c) {
+          b->order[pos++] = k;
+          mat_off[k] = mat_total;
+          mat_total += b->jobs[k].matrix_doubles;
+        }
+      cr.mat_doubles = mat_total - cr.mat_begin;
+      if (c == KC_DAG_BANDED) agg_end = mat_total;
+    }
+  }
+  // lpEnd / lpStart of all jobs, contiguous (caller's order): one copy back per read
+  b->lp_end_off = ar.reserve(sizeof(double) * n_jobs);
+  b->lp_start_off = ar.reserve(sizeof(double) * n_jobs);
 
   auto cleanup = [&](int code) { hx_batch_destroy(b); return code; };
   if (hipMalloc(reinterpret_cast<void**>(&b->d_arena), ar.host.size() + 256) != hipSuccess)
@@ -609,9 +712,9 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
   if (eplane_total > 0)
     if (hipMalloc(reinterpret_cast<void**>(&b->d_eplane), sizeof(double) * (size_t)eplane_total) != hipSuccess)
       return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld emission-plane bytes failed", (long long)(eplane_total * 8)));
-  if ((!b->all_chain || getenv("HX_FORCE_DAG")) && !(flags & HX_FORCE_GENERIC))
-    if (hipMalloc(reinterpret_cast<void**>(&b->d_agg), sizeof(double) * (size_t)mat_total) != hipSuccess)
-      return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld scratch bytes failed", (long long)(mat_total * 8)));
+  if (agg_end > agg_begin)
+    if (hipMalloc(reinterpret_cast<void**>(&b->d_agg), sizeof(double) * (size_t)(agg_end - agg_begin)) != hipSuccess)
+      return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld scratch bytes failed", (long long)((agg_end - agg_begin) * 8)));
   if (flags & HX_KEEP_BACKWARD)
     if (hipMalloc(reinterpret_cast<void**>(&b->d_bwd), sizeof(double) * (size_t)mat_total) != hipSuccess)
       return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld Backward-matrix bytes failed", (long long)(mat_total * 8)));
@@ -632,21 +735,21 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
     J.emis = jo.table_emission ? reinterpret_cast<double*>(base + jo.emis) : nullptr;
     J.emis_pad = jo.table_emission ? reinterpret_cast<double*>(base + jo.emis_pad) : nullptr;
     J.emis_plane = jo.eplane_off >= 0 ? b->d_eplane + jo.eplane_off : nullptr;
-    J.agg = b->d_agg ? b->d_agg + mat_off[k] : nullptr;
+    J.agg = (kclass[k] == KC_DAG || kclass[k] == KC_DAG_BANDED) ? b->d_agg + (mat_off[k] - agg_begin) : nullptr;
     J.fwd_windows = J.max_dist >= 0 ? reinterpret_cast<int32_t*>(base + jo.fwd_windows) : nullptr;
     J.bwd_windows = J.max_dist >= 0 ? reinterpret_cast<int32_t*>(base + jo.bwd_windows) : nullptr;
     J.strip_base = jo.compressed ? reinterpret_cast<int64_t*>(base + jo.strip_base) : nullptr;
     J.yword = jo.yword ? reinterpret_cast<uint32_t*>(base + jo.yword) : nullptr;
     J.yword_bwd = jo.yword_bwd ? reinterpret_cast<uint32_t*>(base + jo.yword_bwd) : nullptr;
-    J.lp_end = reinterpret_cast<double*>(base + jo.scalars);
-    J.lp_start = J.lp_end + 1;
+    J.lp_end = reinterpret_cast<double*>(base + b->lp_end_off) + k;
+    J.lp_start = reinterpret_cast<double*>(base + b->lp_start_off) + k;
     J.fwd = b->d_fwd + mat_off[k];
     J.bwd = b->d_bwd ? b->d_bwd + mat_off[k] : nullptr;
   }
-  if (hipMalloc(reinterpret_cast<void**>(&b->d_jobs), sizeof(DevJob) * n_jobs) != hipSuccess)
+  if (hipMalloc(reinterpret_cast<void**>(&b->d_jobs), sizeof(DevJob) * n_jobs) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&b->d_jobs_cls), sizeof(DevJob) * n_jobs) != hipSuccess)
     return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of job table failed"));
-  if (hipMemcpy(b->d_jobs, b->jobs.data(), sizeof(DevJob) * n_jobs, hipMemcpyHostToDevice) != hipSuccess)
-    return cleanup(fail(HX_ERR_HIP, "job table upload failed"));
+  if ((rc = publish_jobs(b)) != HX_OK) return cleanup(rc);
   for (int w = 0; w < 2; ++w)
     for (int e = 0; e < 2; ++e)
       if (hipEventCreate(&b->ev[w][e]) != hipSuccess) return cleanup(fail(HX_ERR_HIP, "hipEventCreate failed"));
@@ -654,13 +757,31 @@ int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_
   return HX_OK;
 }
 
+int hx_batch_create_on(int device, const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_batch** out) {
+  try {
+    return batch_create_impl(device, jobs, n_jobs, flags, out);
+  } catch (const std::bad_alloc&) {         // (std::vector / Arena growth: nothing throws across the ABI)
+    if (out) *out = nullptr;
+    return fail(HX_ERR_OUT_OF_MEMORY, "host allocation failed while building the batch");
+  }
+}
+
+int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_batch** out) {
+  if (g_device < 0) { if (out) *out = nullptr; return fail(HX_ERR_NOT_INITIALIZED, "hx_init has not been called"); }
+  return hx_batch_create_on(g_device, jobs, n_jobs, flags, out);
+}
+
+int hx_batch_device(const hx_batch* b) { return b ? b->device : -1; }
+
 int hx_batch_destroy(hx_batch* b) {
   if (!b) return HX_OK;
+  (void)hipSetDevice(b->device);
   (void)hipDeviceSynchronize();
   for (int w = 0; w < 2; ++w)
     for (int e = 0; e < 2; ++e)
       if (b->ev[w][e]) (void)hipEventDestroy(b->ev[w][e]);
   if (b->d_jobs) (void)hipFree(b->d_jobs);
+  if (b->d_jobs_cls) (void)hipFree(b->d_jobs_cls);
   if (b->d_arena) (void)hipFree(b->d_arena);
   if (b->d_fwd) (void)hipFree(b->d_fwd);
   if (b->d_bwd) (void)hipFree(b->d_bwd);
@@ -673,35 +794,56 @@ int hx_batch_destroy(hx_batch* b) {
   return HX_OK;
 }
 
+// a launcher refused the shape (LDS plan over budget, grid too large ...): an error code, never a faulting launch
+#define LAUNCH_TRY(expr)                                                                             \
+  do {                                                                                               \
+    if ((expr) != 0) return fail(HX_ERR_INVALID_ARG, "unsupported batch shape: %s", launch_error()); \
+  } while (0)
+
 int hx_batch_forward(hx_batch* b, void* stream) {
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
+  int rc;
+  if ((rc = use_device(b)) != HX_OK) return rc;
+  const DeviceTables& D = g_dev[b->device];
   hipStream_t st = static_cast<hipStream_t>(stream);
-  launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_cls, b->max_ca, b->max_cls_pairs, g_tab, st);
+  const bool fast = (b->flags & HX_LSE_FAST) != 0, linear = (b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR;
+  const double* lse_tab = fast ? D.fast_tab : D.pair_tab;    // FastPiece table, or the exact mode's {f0, df} pairs
+  LAUNCH_TRY(launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_cls, b->max_ca, b->max_cls_pairs, D.tab, st));
   HIP_TRY(hipEventRecord(b->ev[0][0], st));
   // per-cell emission terms of the jobs without a class-pair table (general profiles).  Part of the fill:
   // the reference evaluates them inside its fill loop, so the launch is inside the timed region.
-  if (!(b->flags & HX_FORCE_GENERIC)) launch_emission_plane(b->d_jobs, b->n_jobs, b->max_eplane, g_tab, st);
-  static const bool force_dag = getenv("HX_FORCE_DAG") != nullptr;   // tuning hook: general pipeline for chain profiles too
-  if (b->all_chain && !(b->flags & HX_FORCE_GENERIC) && !(force_dag && b->d_agg)) {
-    // with a band the strip pipelines only visit in-envelope windows; everything else is -inf
-    // (band-compressed matrices hold nothing but the swept windows, which the fill writes completely)
-    if (b->any_banded && !(b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED))) launch_fill_neg_inf(b->d_fwd, b->fwd_total, st);
-    // HX_LSE_LINEAR on leaf pairs whose y side fits LDS (the headline workload, and its banded variant): the recursion runs on
-    // scaled probabilities instead of table log-sum-exps (hx_linear.hip)
-    if ((b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && b->all_leaf && b->all_ylds && b->max_cls < 255)
-      launch_forward_leaf_linear(b->d_jobs, b->n_jobs, b->max_rows, b->any_banded, g_tab, g_log_tab, b->yl_cols, b->yl_emis, b->max_cls + 1, st);
-    else
-    launch_forward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, (b->flags & HX_LSE_FAST) ? g_fast_tab : g_pair_tab, (b->flags & HX_LSE_FAST) != 0,
-                         b->all_leaf ? (b->all_ylds ? 2 : 1) : 0, b->any_banded, b->yl_cols, b->yl_emis, st);
-  } else if (b->flags & HX_FORCE_GENERIC)
-    launch_forward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
-  else {
-    // general profiles: the strip pipeline; with a band it only visits in-envelope windows, the rest is -inf
-    if (b->any_banded) {
-      launch_fill_neg_inf(b->d_fwd, b->fwd_total, st);
-      launch_fill_neg_inf(b->d_agg, b->fwd_total, st);
+  if (!(b->flags & HX_FORCE_GENERIC)) launch_emission_plane(b->d_jobs, b->n_jobs, b->max_eplane, D.tab, st);
+  for (int c = 0; c < KC_COUNT; ++c) {
+    const ClassRange& cr = b->cls[c];
+    if (cr.n == 0) continue;
+    const DevJob* jobs = b->d_jobs_cls + cr.begin;
+    const bool banded = c == KC_LEAF_LDS_BANDED || c == KC_LEAF_BANDED || c == KC_CHAIN_BANDED || c == KC_DAG_BANDED;
+    switch (c) {
+      case KC_LEAF_LDS: case KC_LEAF_LDS_BANDED: case KC_LEAF: case KC_LEAF_BANDED: case KC_CHAIN: case KC_CHAIN_BANDED: {
+        // with a band the strip pipelines only visit in-envelope windows; everything else is -inf
+        // (band-compressed matrices hold nothing but the swept windows, which the fill writes completely)
+        if (banded && !(b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED)))
+          launch_fill_neg_inf(b->d_fwd + cr.mat_begin, cr.mat_doubles, st);
+        const int leaf = (c == KC_LEAF_LDS || c == KC_LEAF_LDS_BANDED) ? 2 : ((c == KC_LEAF || c == KC_LEAF_BANDED) ? 1 : 0);
+        // HX_LSE_LINEAR on leaf pairs whose y side fits LDS: the recursion runs on scaled probabilities instead of
+        // table log-sum-exps (hx_linear.hip)
+        if (linear && leaf == 2)
+          LAUNCH_TRY(launch_forward_leaf_linear(jobs, cr.n, cr.max_rows, banded, D.tab, D.log_tab, cr.yl_cols, cr.yl_emis, cr.max_cls + 1, st));
+        else
+          LAUNCH_TRY(launch_forward_chain(jobs, cr.n, cr.max_rows, D.tab, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, st));
+        break;
+      }
+      case KC_DAG: case KC_DAG_BANDED:
+        // general profiles: the strip pipeline; with a band it only visits in-envelope windows, the rest is -inf
+        if (banded) {
+          launch_fill_neg_inf(b->d_fwd + cr.mat_begin, cr.mat_doubles, st);
+          launch_fill_neg_inf(b->d_agg + (cr.mat_begin - b->cls[KC_DAG].mat_begin), cr.mat_doubles, st);
+        }
+        LAUNCH_TRY(launch_forward_dag_pipe(jobs, cr.n, cr.max_rows, D.tab, lse_tab, fast, st));
+        break;
+      default:
+        LAUNCH_TRY(launch_forward_dag(jobs, cr.n, cr.max_rows, D.tab, st));
     }
-    launch_forward_dag_pipe(b->d_jobs, b->n_jobs, b->max_rows, g_tab, (b->flags & HX_LSE_FAST) ? g_fast_tab : g_pair_tab, (b->flags & HX_LSE_FAST) != 0, st);
   }
   HIP_TRY(hipEventRecord(b->ev[0][1], st));
   HIP_TRY(hipGetLastError());
@@ -715,34 +857,46 @@ int hx_batch_backward(hx_batch* b, void* stream) {
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
   if (!b->forward_done) return fail(HX_ERR_STATE, "hx_batch_backward needs a previous hx_batch_forward");
   if (b->any_compressed) return fail(HX_ERR_STATE, "the Backward fill does not support HX_BAND_COMPRESSED batches");
+  int rc;
+  if ((rc = use_device(b)) != HX_OK) return rc;
+  const DeviceTables& D = g_dev[b->device];
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool fast = (b->flags & HX_LSE_FAST) != 0, linear = (b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR;
+  const double* lse_tab = fast ? D.fast_tab : D.pair_tab;
   if (!b->d_bwd) {
-    // not pre-allocated with HX_KEEP_BACKWARD: allocate the Backward matrices now and re-publish the job table
-    size_t total = 0;
-    for (int k = 0; k < b->n_jobs; ++k) total += (size_t)b->jobs[k].matrix_doubles;
+    // not pre-allocated with HX_KEEP_BACKWARD: allocate the Backward matrices now and re-publish the job tables
     HIP_TRY(hipStreamSynchronize(b->last_stream));
-    if (hipMalloc(reinterpret_cast<void**>(&b->d_bwd), sizeof(double) * total) != hipSuccess)
-      return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %zu Backward-matrix bytes failed", total * 8);
-    size_t off = 0;
-    for (int k = 0; k < b->n_jobs; ++k) {
-      b->jobs[k].bwd = b->d_bwd + off;
-      off += (size_t)b->jobs[k].matrix_doubles;
-    }
-    HIP_TRY(hipMemcpy(b->d_jobs, b->jobs.data(), sizeof(DevJob) * b->n_jobs, hipMemcpyHostToDevice));
+    if (hipMalloc(reinterpret_cast<void**>(&b->d_bwd), sizeof(double) * (size_t)b->fwd_total) != hipSuccess)
+      return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld Backward-matrix bytes failed", (long long)(b->fwd_total * 8));
+    for (int k = 0; k < b->n_jobs; ++k) b->jobs[k].bwd = b->d_bwd + (b->jobs[k].fwd - b->d_fwd);
+    if ((rc = publish_jobs(b)) != HX_OK) return rc;
+  } else if (st != b->last_stream) {
+    // the Backward fill reads what the Forward launch prepared (and, for the posterior, follows it): order the streams
+    HIP_TRY(hipStreamWaitEvent(st, b->ev[0][1], 0));
   }
   HIP_TRY(hipEventRecord(b->ev[1][0], st));
-  if (b->all_leaf && !(b->flags & HX_FORCE_GENERIC)) {
-    if (b->any_banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_bwd, b->fwd_total, st);
-    if ((b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && b->all_ylds && b->max_cls < 255)
-      launch_backward_leaf_linear(b->d_jobs, b->n_jobs, b->max_rows, b->any_banded, g_tab, g_log_tab, b->yl_cols, b->yl_emis, b->max_cls + 1, st);
-    else
-    launch_backward_chain(b->d_jobs, b->n_jobs, b->max_rows, g_tab, (b->flags & HX_LSE_FAST) ? g_fast_tab : g_pair_tab, (b->flags & HX_LSE_FAST) != 0,
-                          b->all_ylds ? 2 : 1, b->any_banded, b->yl_cols, b->yl_emis, st);
-  } else if (b->flags & HX_FORCE_GENERIC)
-    launch_backward_dag(b->d_jobs, b->n_jobs, b->max_rows, g_tab, st);
-  else {
-    if (b->any_banded) launch_fill_neg_inf(b->d_bwd, b->fwd_total, st);
-    launch_backward_dag_pipe(b->d_jobs, b->n_jobs, b->max_rows, g_tab, (b->flags & HX_LSE_FAST) ? g_fast_tab : g_pair_tab, (b->flags & HX_LSE_FAST) != 0, st);
+  for (int c = 0; c < KC_COUNT; ++c) {
+    const ClassRange& cr = b->cls[c];
+    if (cr.n == 0) continue;
+    const DevJob* jobs = b->d_jobs_cls + cr.begin;
+    const bool banded = c == KC_LEAF_LDS_BANDED || c == KC_LEAF_BANDED || c == KC_CHAIN_BANDED || c == KC_DAG_BANDED;
+    switch (c) {
+      case KC_LEAF_LDS: case KC_LEAF_LDS_BANDED: case KC_LEAF: case KC_LEAF_BANDED: {
+        if (banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_bwd + cr.mat_begin, cr.mat_doubles, st);
+        const int leaf = (c == KC_LEAF_LDS || c == KC_LEAF_LDS_BANDED) ? 2 : 1;
+        if (linear && leaf == 2)
+          LAUNCH_TRY(launch_backward_leaf_linear(jobs, cr.n, cr.max_rows, banded, D.tab, D.log_tab, cr.yl_cols, cr.yl_emis, cr.max_cls + 1, st));
+        else
+          LAUNCH_TRY(launch_backward_chain(jobs, cr.n, cr.max_rows, D.tab, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, st));
+        break;
+      }
+      case KC_CHAIN: case KC_CHAIN_BANDED: case KC_DAG: case KC_DAG_BANDED:
+        if (banded) launch_fill_neg_inf(b->d_bwd + cr.mat_begin, cr.mat_doubles, st);
+        LAUNCH_TRY(launch_backward_dag_pipe(jobs, cr.n, cr.max_rows, D.tab, lse_tab, fast, st));
+        break;
+      default:
+        LAUNCH_TRY(launch_backward_dag(jobs, cr.n, cr.max_rows, D.tab, st));
+    }
   }
   HIP_TRY(hipEventRecord(b->ev[1][1], st));
   HIP_TRY(hipGetLastError());
@@ -754,6 +908,7 @@ int hx_batch_backward(hx_batch* b, void* stream) {
 
 int hx_batch_sync(hx_batch* b) {
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
+  { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
   HIP_TRY(hipStreamSynchronize(b->last_stream));
   return HX_OK;
 }
@@ -761,6 +916,7 @@ int hx_batch_sync(hx_batch* b) {
 int hx_batch_last_kernel_ms(hx_batch* b, int32_t which, float* ms) {
   if (!b || !ms || which < 0 || which > 1) return fail(HX_ERR_INVALID_ARG, "bad arguments");
   if (!b->ev_valid[which]) return fail(HX_ERR_STATE, "no such fill has been launched");
+  { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
   HIP_TRY(hipEventSynchronize(b->ev[which][1]));
   HIP_TRY(hipEventElapsedTime(ms, b->ev[which][0], b->ev[which][1]));
   return HX_OK;
@@ -769,9 +925,10 @@ int hx_batch_last_kernel_ms(hx_batch* b, int32_t which, float* ms) {
 static int read_scalars(hx_batch* b, double* out, int which) {
   if (!b || !out) return fail(HX_ERR_INVALID_ARG, "bad arguments");
   if (which == 0 ? !b->forward_done : !b->backward_done) return fail(HX_ERR_STATE, "fill has not been launched");
+  int rc;
+  if ((rc = use_device(b)) != HX_OK) return rc;
   HIP_TRY(hipStreamSynchronize(b->last_stream));
-  for (int k = 0; k < b->n_jobs; ++k)
-    HIP_TRY(hipMemcpy(out + k, which == 0 ? b->jobs[k].lp_end : b->jobs[k].lp_start, sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, b->d_arena + (which == 0 ? b->lp_end_off : b->lp_start_off), sizeof(double) * b->n_jobs, hipMemcpyDeviceToHost));
   return HX_OK;
 }
 
@@ -791,6 +948,7 @@ int hx_batch_strip_windows(const hx_batch* b, int32_t job, int32_t* windows, int
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
   const DevJob& J = b->jobs[job];
   if (!J.strip_base) return fail(HX_ERR_STATE, "job %d is not stored band-compressed", job);
+  { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
   HIP_TRY(hipMemcpy(windows, J.fwd_windows, sizeof(int32_t) * 4 * J.n_strips, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(bases, J.strip_base, sizeof(int64_t) * 2 * J.n_strips, hipMemcpyDeviceToHost));
   return HX_OK;
@@ -806,6 +964,7 @@ int hx_batch_read_matrix(hx_batch* b, int32_t job, int32_t which, double* out) {
   if (!b || !out || which < 0 || which > 1) return fail(HX_ERR_INVALID_ARG, "bad arguments");
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
   if (which == 0 ? !b->forward_done : !b->backward_done) return fail(HX_ERR_STATE, "fill has not been launched");
+  { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
   HIP_TRY(hipStreamSynchronize(b->last_stream));
   HIP_TRY(hipMemcpy(out, matrix_of(b, job, which), sizeof(double) * (size_t)b->jobs[job].matrix_doubles, hipMemcpyDeviceToHost));
   return HX_OK;
@@ -815,6 +974,7 @@ int hx_batch_read_matrix(hx_batch* b, int32_t job, int32_t which, double* out) {
 // guide-alignment Viterbi batch (hx_quick.hip)
 // ---------------------------------------------------------------------------
 struct hx_quick_batch {
+  int device = 0;
   int n_jobs = 0;
   std::vector<DevQuick> jobs;
   std::vector<hx_layout> layouts;
@@ -830,14 +990,16 @@ struct hx_quick_batch {
   size_t res_off = 0, xy_off = 0;
 };
 
-int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_batch** out) {
+static int quick_create_impl(int device, const hx_quick_job* jobs, int32_t n_jobs, hx_quick_batch** out) {
   if (!out) return fail(HX_ERR_INVALID_ARG, "out is null");
   *out = nullptr;
-  if (g_device < 0) return fail(HX_ERR_NOT_INITIALIZED, "hx_init has not been called");
+  if (device < 0 || device >= HX_MAX_DEVICES || !g_dev[device].ready)
+    return fail(HX_ERR_NOT_INITIALIZED, "hx_init has not been called for device %d", device);
   if (!jobs || n_jobs <= 0) return fail(HX_ERR_INVALID_ARG, "no jobs");
-  HIP_TRY(hipSetDevice(g_device));
+  HIP_TRY(hipSetDevice(device));
   hx_quick_batch* b = new (std::nothrow) hx_quick_batch;
   if (!b) return fail(HX_ERR_OUT_OF_MEMORY, "out of host memory");
+  b->device = device;
   b->n_jobs = n_jobs;
   b->jobs.resize(n_jobs);
   b->layouts.resize(n_jobs);
@@ -936,8 +1098,23 @@ int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_bat
   return HX_OK;
 }
 
+int hx_quick_batch_create_on(int device, const hx_quick_job* jobs, int32_t n_jobs, hx_quick_batch** out) {
+  try {
+    return quick_create_impl(device, jobs, n_jobs, out);
+  } catch (const std::bad_alloc&) {
+    if (out) *out = nullptr;
+    return fail(HX_ERR_OUT_OF_MEMORY, "host allocation failed while building the batch");
+  }
+}
+
+int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_batch** out) {
+  if (g_device < 0) { if (out) *out = nullptr; return fail(HX_ERR_NOT_INITIALIZED, "hx_init has not been called"); }
+  return hx_quick_batch_create_on(g_device, jobs, n_jobs, out);
+}
+
 int hx_quick_batch_destroy(hx_quick_batch* b) {
   if (!b) return HX_OK;
+  (void)hipSetDevice(b->device);
   (void)hipDeviceSynchronize();
   for (int e = 0; e < 2; ++e)
     if (b->ev[e]) (void)hipEventDestroy(b->ev[e]);
@@ -950,9 +1127,10 @@ int hx_quick_batch_destroy(hx_quick_batch* b) {
 
 int hx_quick_batch_run(hx_quick_batch* b, void* stream) {
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
+  if (hipSetDevice(b->device) != hipSuccess) return fail(HX_ERR_HIP, "hipSetDevice(%d) failed", b->device);
   hipStream_t st = static_cast<hipStream_t>(stream);
   HIP_TRY(hipEventRecord(b->ev[0], st));
-  launch_quickalign(b->d_jobs, b->n_jobs, b->max_rows, b->max_cols, b->all_full, st);
+  LAUNCH_TRY(launch_quickalign(b->d_jobs, b->n_jobs, b->max_rows, b->max_cols, b->all_full, st));
   HIP_TRY(hipEventRecord(b->ev[1], st));
   HIP_TRY(hipGetLastError());
   b->done = true;
@@ -963,6 +1141,7 @@ int hx_quick_batch_run(hx_quick_batch* b, void* stream) {
 int hx_quick_batch_results(hx_quick_batch* b, double* score, int32_t* x_end, int32_t* y_end) {
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
   if (!b->done) return fail(HX_ERR_STATE, "hx_quick_batch_run has not been launched");
+  if (hipSetDevice(b->device) != hipSuccess) return fail(HX_ERR_HIP, "hipSetDevice(%d) failed", b->device);
   HIP_TRY(hipStreamSynchronize(b->last_stream));
   if (score) HIP_TRY(hipMemcpy(score, b->d_arena + b->res_off, sizeof(double) * b->n_jobs, hipMemcpyDeviceToHost));
   std::vector<int32_t> xy(2 * (size_t)b->n_jobs);
@@ -985,6 +1164,7 @@ int hx_quick_batch_read_matrix(hx_quick_batch* b, int32_t job, double* out) {
   if (!b || !out) return fail(HX_ERR_INVALID_ARG, "bad arguments");
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
   if (!b->done) return fail(HX_ERR_STATE, "hx_quick_batch_run has not been launched");
+  if (hipSetDevice(b->device) != hipSuccess) return fail(HX_ERR_HIP, "hipSetDevice(%d) failed", b->device);
   HIP_TRY(hipStreamSynchronize(b->last_stream));
   HIP_TRY(hipMemcpy(out, b->jobs[job].cells, sizeof(double) * (size_t)b->layouts[job].matrix_doubles, hipMemcpyDeviceToHost));
   return HX_OK;
@@ -995,6 +1175,7 @@ int64_t hx_quick_batch_total_cells(const hx_quick_batch* b) { return b ? b->tota
 int hx_quick_batch_last_kernel_ms(hx_quick_batch* b, float* ms) {
   if (!b || !ms) return fail(HX_ERR_INVALID_ARG, "bad arguments");
   if (!b->done) return fail(HX_ERR_STATE, "hx_quick_batch_run has not been launched");
+  if (hipSetDevice(b->device) != hipSuccess) return fail(HX_ERR_HIP, "hipSetDevice(%d) failed", b->device);
   HIP_TRY(hipEventSynchronize(b->ev[1]));
   HIP_TRY(hipEventElapsedTime(ms, b->ev[0], b->ev[1]));
   return HX_OK;
@@ -1021,6 +1202,7 @@ int hx_batch_read_cells(hx_batch* b, int32_t job, int32_t which, const int32_t* 
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
   if (which == 0 ? !b->forward_done : !b->backward_done) return fail(HX_ERR_STATE, "fill has not been launched");
   if (n == 0) return HX_OK;
+  { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
   int32_t* d_ij = nullptr;
   double* d_out = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_ij), sizeof(int32_t) * 2 * n));
@@ -1045,6 +1227,7 @@ int hx_batch_read_cells(hx_batch* b, int32_t job, int32_t which, const int32_t* 
 int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t* n_cells) {
   if (!b || !cells || !n_cells || cap < 1) return fail(HX_ERR_INVALID_ARG, "bad arguments");
   if (!b->forward_done) return fail(HX_ERR_STATE, "hx_batch_best_trace needs a previous hx_batch_forward");
+  { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
   const int n = b->n_jobs;
   // device buffers and the page-locked staging buffer are kept with the batch (a host mirror asks once per fill batch,
   // a benchmark many times)
@@ -1066,7 +1249,7 @@ int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t*
   int64_t* d_off = b->d_trace_n + n;
   hipStream_t st = b->last_stream;
   // the per-cell emission plane is only filled by the strip pipelines (hx_batch_forward)
-  launch_best_trace(b->d_jobs, n, d_paths, cap, d_n, g_tab, !(b->flags & HX_FORCE_GENERIC), st);
+  launch_best_trace(b->d_jobs, n, d_paths, cap, d_n, g_dev[b->device].tab, !(b->flags & HX_FORCE_GENERIC), st);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
       hipMemcpy(n_cells, d_n, sizeof(int32_t) * n, hipMemcpyDeviceToHost) != hipSuccess)
     return fail(HX_ERR_HIP, "best-trace kernel failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1094,6 +1277,7 @@ int hx_batch_read_prepared(hx_batch* b, int32_t job, double* subx, double* suby,
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
   if (!b->forward_done) return fail(HX_ERR_STATE, "hx_batch_forward has not been launched");
+  { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
   if ((subx || suby) && !b->sub_scattered) {
     // the fills use per-class tables; the per-state leftMultiply rows are produced when somebody asks for them
     launch_scatter_sub(b->d_jobs, b->n_jobs, b->max_states, b->last_stream);
@@ -1115,6 +1299,7 @@ int hx_batch_posterior_scan(hx_batch* b, int32_t job, double min_post_prob, hx_c
   if (!b || !n_out || cap < 0 || (cap > 0 && !out)) return fail(HX_ERR_INVALID_ARG, "bad arguments");
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
   if (!b->forward_done || !b->backward_done) return fail(HX_ERR_STATE, "posterior scan needs Forward and Backward fills");
+  { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
   static_assert(sizeof(PostCell) == sizeof(hx_cell), "hx_cell layout");
   const double thr = std::log(min_post_prob);   // host libm, as reference src/forward.cpp:1304
   PostCell* d_out = nullptr;

@@ -618,8 +618,14 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
       }
       // publish progress.  The strip's last row has finished column (t + 1) - (SR - 1); a
       // column counts as published once its stores have left the wave.  Vector-memory
-      // operations retire in issue order and every step issues >= 4 of them, so everything
-      // stored HX_PUBLISH_LAG steps ago is older than the wave's 40 youngest operations.
+      // operations retire in issue order and every iteration (two steps) issues at least its
+      // 5 * RPT stores (the LDS-resident-y path issues nothing else), so everything stored
+      // HX_PUBLISH_LAG steps = HX_PUBLISH_LAG / 2 iterations ago is older than the wave's
+      // PUBLISH_WAIT youngest operations.
+      constexpr int STORES_PER_ITER = 5 * RPT;
+      constexpr int PUBLISH_WAIT = STORES_PER_ITER * (HX_PUBLISH_LAG / 2) < 63 ? STORES_PER_ITER * (HX_PUBLISH_LAG / 2) : 63;
+      static_assert(PUBLISH_WAIT <= STORES_PER_ITER * (HX_PUBLISH_LAG / 2) && PUBLISH_WAIT <= 63 && HX_PUBLISH_LAG % 2 == 0,
+                    "the wait count must not exceed the operations issued since the published column's stores");
       const int fin = (t + 2 < nsteps ? t + 2 : nsteps) - (SR - 1);
       if (fin >= Cc) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -628,7 +634,7 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
       } else {
         const int done = fin - HX_PUBLISH_LAG;
         if (done > (WIN ? published : 0) && ((done >> 6) != ((done - 2) >> 6))) {
-          asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PUBLISH_WAIT) : "memory");
           if (WIN) published = done;
           if (lane == 0) progp[wave] = my_base + done;
         }
@@ -659,12 +665,16 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
 }
 
 template <int DIR, int RPT, int W, int MINW = 1>
-static void launch_variant(const DevJob* d_jobs, int n_jobs, const double* tab, const double* fast_tab, bool fast,
+static int launch_variant(const DevJob* d_jobs, int n_jobs, const double* tab, const double* fast_tab, bool fast,
                            int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
   const dim3 g(n_jobs), b(W * 64);
   const size_t dyn = leaf == 2 ? sizeof(double) * (size_t)yl_emis + sizeof(unsigned) * (size_t)yl_cols : 0;
-#define HX_LAUNCH(LSE_, FAST_, LEAF_, YL_, BANDED_) \
-  hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, LSE_, FAST_, LEAF_, YL_, BANDED_, MINW>), g, b, dyn, st, d_jobs, tab, fast_tab, n_jobs, yl_emis)
+  // the kernels' fixed-size y-side tables (HX_YL_*): hx_api.hip admits only jobs within them to this path
+  if (leaf == 2 && (yl_cols > HX_YL_MAX_COLS || yl_emis > HX_YL_MAX_EMIS + 2))
+    return launch_fail("LDS-resident y side of %d columns / %d class pairs exceeds the chain kernel's tables", yl_cols, yl_emis);
+#define HX_LAUNCH(LSE_, FAST_, LEAF_, YL_, BANDED_) do { \
+  HX_CHECK_LDS((k_fill_chain<DIR, RPT, W, LSE_, FAST_, LEAF_, YL_, BANDED_, MINW>), dyn, "k_fill_chain"); \
+  hipLaunchKernelGGL((k_fill_chain<DIR, RPT, W, LSE_, FAST_, LEAF_, YL_, BANDED_, MINW>), g, b, dyn, st, d_jobs, tab, fast_tab, n_jobs, yl_emis); } while (0)
   if (leaf == 2 && !banded) {             // the headline configuration: unbanded leaf pairs, y side in LDS
     if (fast) HX_LAUNCH(FastLse, true, true, true, false); else HX_LAUNCH(ExactLse3, false, true, true, false);
   } else if (leaf == 2) {
@@ -676,8 +686,11 @@ static void launch_variant(const DevJob* d_jobs, int n_jobs, const double* tab, 
       hipLaunchKernelGGL((k_fill_chain<0, RPT, W, FastLse, true, false, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs, 0);
     else
       hipLaunchKernelGGL((k_fill_chain<0, RPT, W, ExactLse3, false, false, false, true, MINW>), g, b, 0, st, d_jobs, tab, fast_tab, n_jobs, 0);
+  } else {
+    return launch_fail("the Backward strip pipeline exists for leaf-like profiles only");
   }
 #undef HX_LAUNCH
+  return 0;
 }
 
 // banded leaf-like batches: one wave per pair, PPW pairs per workgroup (see k_fill_chain, PPW); few pairs
@@ -699,38 +712,38 @@ static void launch_banded_leaf(const DevJob* d_jobs, int n_jobs, const double* t
 }
 
 template <int DIR>
-static void launch_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+static int launch_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
                          bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
   const char* v = getenv("HX_CHAIN_VARIANT");   // tuning hook: override for long profiles
   const int vi = v ? atoi(v) : 0;
   if (banded && leaf >= 1 && vi == 0 && n_jobs >= 64) {
     launch_banded_leaf<DIR>(d_jobs, n_jobs, tab, fast_tab, fast, st);
-    return;
+    return 0;
   }
   if (max_rows <= 64)
-    launch_variant<DIR, 1, 1>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
-  else if (max_rows <= 128)
-    launch_variant<DIR, 1, 2>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
-  else if (max_rows <= 256)
-    launch_variant<DIR, 1, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
-  else if (vi == 2 || (vi == 0 && max_rows <= 512))
-    launch_variant<DIR, 1, 8>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
-  else if (vi == 4)
-    launch_variant<DIR, 2, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
-  else
-    launch_variant<DIR, 1, 16>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);   // measured fastest on 2x2000
+    return launch_variant<DIR, 1, 1>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
+  if (max_rows <= 128)
+    return launch_variant<DIR, 1, 2>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
+  if (max_rows <= 256)
+    return launch_variant<DIR, 1, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
+  if (vi == 2 || (vi == 0 && max_rows <= 512))
+    return launch_variant<DIR, 1, 8>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
+  if (vi == 4)
+    return launch_variant<DIR, 2, 4>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
+  return launch_variant<DIR, 1, 16>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);   // measured fastest on 2x2000
 }
 
 // leaf: 0 = general chain profiles, 1 = leaf-like, 2 = leaf-like with the y side in LDS
-void launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                          bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
-  launch_chain<0>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
+int launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+                         bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
+  return launch_chain<0>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
 }
 
 // leaf-like profiles only (leaf >= 1)
-void launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                           bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
-  launch_chain<1>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
+int launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+                          bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
+  if (leaf < 1) return launch_fail("the Backward strip pipeline exists for leaf-like profiles only");
+  return launch_chain<1>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
 }
 
 }  // namespace hx

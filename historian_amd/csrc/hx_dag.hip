@@ -848,8 +848,11 @@ __global__ void k_fill_neg_inf(double* __restrict__ p, int64_t n) {
 void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, const double* tab, hipStream_t st) {
   if (max_plane <= 0) return;
   const int tpb = 256;
-  dim3 grid((unsigned)((max_plane + tpb - 1) / tpb), (unsigned)n_jobs);
-  hipLaunchKernelGGL(k_emission_plane, grid, dim3(tpb), 0, st, d_jobs, tab);
+  for (int j0 = 0; j0 < n_jobs; j0 += 32768) {       // (grid.y is limited to 65535)
+    const int n = n_jobs - j0 < 32768 ? n_jobs - j0 : 32768;
+    dim3 grid((unsigned)((max_plane + tpb - 1) / tpb), (unsigned)n);
+    hipLaunchKernelGGL(k_emission_plane, grid, dim3(tpb), 0, st, d_jobs + j0, tab);
+  }
 }
 
 void launch_fill_neg_inf(double* p, int64_t n, hipStream_t st) {
@@ -864,18 +867,25 @@ static int dag_waves(int max_rows, int cap) {
   return w;
 }
 
-void launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                             bool fast, hipStream_t st) {
+int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+                            bool fast, hipStream_t st) {
   const dim3 g(n_jobs), b(dag_waves(max_rows, HX_DAGF_MAX_WAVES) * 64);
-  if (fast) hipLaunchKernelGGL((k_forward_dag_pipe<FastLse, true>), g, b, 0, st, d_jobs, tab, fast_tab);
-  else hipLaunchKernelGGL((k_forward_dag_pipe<ExactLse3, false>), g, b, 0, st, d_jobs, tab, fast_tab);
+  if (fast) {
+    HX_CHECK_LDS((k_forward_dag_pipe<FastLse, true>), 0, "k_forward_dag_pipe<fast>");
+    hipLaunchKernelGGL((k_forward_dag_pipe<FastLse, true>), g, b, 0, st, d_jobs, tab, fast_tab);
+  } else {
+    HX_CHECK_LDS((k_forward_dag_pipe<ExactLse3, false>), 0, "k_forward_dag_pipe<exact>");
+    hipLaunchKernelGGL((k_forward_dag_pipe<ExactLse3, false>), g, b, 0, st, d_jobs, tab, fast_tab);
+  }
+  return 0;
 }
 
-void launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                              bool fast, hipStream_t st) {
+int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+                             bool fast, hipStream_t st) {
   const dim3 g(n_jobs), b(dag_waves(max_rows, HX_DAG_MAX_WAVES) * 64);
   if (fast) hipLaunchKernelGGL((k_fill_dag<1, FastLse, true>), g, b, 0, st, d_jobs, tab, fast_tab);
   else hipLaunchKernelGGL((k_fill_dag<1, ExactLse3, false>), g, b, 0, st, d_jobs, tab, fast_tab);
+  return 0;
 }
 
 }  // namespace hx

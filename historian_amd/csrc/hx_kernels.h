@@ -7,21 +7,38 @@ namespace hx {
 
 struct PostCell { int32_t xpos, ypos, state, pad; double lpp; };   // == hx_cell
 
-void launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, int max_ca, int max_cls_pairs,
+// Launch guards.  A fill launcher checks on the host that the shape it was handed matches what its kernel and grid
+// assume (LDS plan within the CU's 160 KB, grid dimensions within the limits) BEFORE launching, and returns 0 or -1
+// with launch_error() describing the refusal: an unsupported shape becomes an error code of the C ABI, never a
+// faulting launch (a device fault would take the caller's process down inside the next synchronisation).
+#define HX_LDS_LIMIT (160 * 1024)
+const char* launch_error();
+int launch_fail(const char* fmt, ...);
+// static + dynamic LDS of a kernel against the workgroup limit
+#define HX_CHECK_LDS(kernel, dyn_bytes, what)                                                                         \
+  do {                                                                                                                \
+    hipFuncAttributes attr_;                                                                                          \
+    if (hipFuncGetAttributes(&attr_, reinterpret_cast<const void*>(&kernel)) == hipSuccess &&                        \
+        attr_.sharedSizeBytes + (size_t)(dyn_bytes) > (size_t)HX_LDS_LIMIT)                                           \
+      return launch_fail("%s needs %zu bytes of LDS (limit %d)", what, attr_.sharedSizeBytes + (size_t)(dyn_bytes),  \
+                         HX_LDS_LIMIT);                                                                               \
+  } while (0)
+
+int launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, int max_ca, int max_cls_pairs,
                  const double* tab, hipStream_t st);
 void launch_scatter_sub(const DevJob* d_jobs, int n_jobs, int max_states, hipStream_t st);
-void launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
-void launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+int launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
+int launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
                           bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st);
-void launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+int launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
                            bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st);
 void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, const double* tab, hipStream_t st);
 void launch_fill_neg_inf(double* p, int64_t n, hipStream_t st);
-void launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
                              bool fast, hipStream_t st);
-void launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
                               bool fast, hipStream_t st);
-void launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
+int launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
 void launch_posterior_scan(const DevJob* d_jobs, int job, double lpp_threshold, PostCell* out,
                            unsigned long long cap, unsigned long long* counter, hipStream_t st);
 void launch_gather_cells(const DevJob* d_jobs, int job, const double* M, int mirrored, const int* ij, int64_t n,
@@ -30,10 +47,10 @@ void launch_gather_cells(const DevJob* d_jobs, int job, const double* M, int mir
 // scaled-linear Forward fill of leaf-like pairs (hx_linear.hip); log_tab from build_log_table
 int log_table_doubles();
 void build_log_table(double* out /* [log_table_doubles()] */);
-void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
+int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
                                 int yl_cols, int yl_emis, int yl_cls, hipStream_t st);
 
-void launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
+int launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
                                  int yl_cols, int yl_emis, int yl_cls, hipStream_t st);
 
 void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, const double* tab,
@@ -42,6 +59,6 @@ void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64
 void launch_reverse_paths(const int32_t* d_paths, int64_t cap, const int32_t* d_n_cells, const int64_t* d_off, int32_t* d_out,
                           int n_jobs, hipStream_t st);
 
-void launch_quickalign(const DevQuick* d_jobs, int n_jobs, int max_rows, int max_cols, bool all_full, hipStream_t st);
+int launch_quickalign(const DevQuick* d_jobs, int n_jobs, int max_rows, int max_cols, bool all_full, hipStream_t st);
 
 }  // namespace hx

@@ -9,6 +9,8 @@
 //
 // Compiled with -ffp-contract=off (see hx_lse.h).
 #include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
 #include "hx_device.h"
 #include "hx_lse.h"
 #include "hx_common.h"
@@ -406,43 +408,68 @@ __global__ void k_gather_cells(const DevJob* __restrict__ jobs, int job, const d
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-void launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, int max_ca, int max_cls_pairs,
-                 const double* tab, hipStream_t st) {
+namespace {
+thread_local char g_launch_err[256] = "";
+}
+const char* launch_error() { return g_launch_err; }
+int launch_fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_launch_err, sizeof(g_launch_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+
+// The prep kernels put the job on grid.y (two blocks per job, x and y side); grid.y is limited to 65535, so large
+// batches are launched in chunks of HX_PREP_CHUNK jobs.
+#define HX_PREP_CHUNK 16384
+int launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, int max_ca, int max_cls_pairs,
+                const double* tab, hipStream_t st) {
   const int tpb = 256;
-  if (max_cls > 0) {
-    dim3 grid((unsigned)((max_cls * max_ca + tpb - 1) / tpb), (unsigned)(2 * n_jobs));
-    hipLaunchKernelGGL(k_left_multiply, grid, dim3(tpb), 0, st, d_jobs, tab);
-    dim3 grid2((unsigned)((max_cls + tpb - 1) / tpb), (unsigned)(2 * n_jobs));
-    hipLaunchKernelGGL(k_ins_rootsub, grid2, dim3(tpb), 0, st, d_jobs, tab);
+  for (int j0 = 0; j0 < n_jobs; j0 += HX_PREP_CHUNK) {
+    const int n = n_jobs - j0 < HX_PREP_CHUNK ? n_jobs - j0 : HX_PREP_CHUNK;
+    const DevJob* jobs = d_jobs + j0;
+    if (max_cls > 0) {
+      dim3 grid((unsigned)((max_cls * max_ca + tpb - 1) / tpb), (unsigned)(2 * n));
+      hipLaunchKernelGGL(k_left_multiply, grid, dim3(tpb), 0, st, jobs, tab);
+      dim3 grid2((unsigned)((max_cls + tpb - 1) / tpb), (unsigned)(2 * n));
+      hipLaunchKernelGGL(k_ins_rootsub, grid2, dim3(tpb), 0, st, jobs, tab);
+    }
+    {
+      dim3 grid((unsigned)((max_states + tpb - 1) / tpb), (unsigned)(2 * n));
+      hipLaunchKernelGGL(k_scatter_prepared, grid, dim3(tpb), 0, st, jobs);
+    }
+    if (max_cls_pairs > 0) {
+      dim3 grid((unsigned)((max_cls_pairs + tpb - 1) / tpb), (unsigned)n);
+      hipLaunchKernelGGL(k_emission_table, grid, dim3(tpb), 0, st, jobs, tab);
+    }
   }
-  {
-    dim3 grid((unsigned)((max_states + tpb - 1) / tpb), (unsigned)(2 * n_jobs));
-    hipLaunchKernelGGL(k_scatter_prepared, grid, dim3(tpb), 0, st, d_jobs);
-  }
-  if (max_cls_pairs > 0) {
-    dim3 grid((unsigned)((max_cls_pairs + tpb - 1) / tpb), (unsigned)n_jobs);
-    hipLaunchKernelGGL(k_emission_table, grid, dim3(tpb), 0, st, d_jobs, tab);
-  }
+  return 0;
 }
 
 void launch_scatter_sub(const DevJob* d_jobs, int n_jobs, int max_states, hipStream_t st) {
   const int tpb = 256;
-  dim3 grid((unsigned)((max_states + tpb - 1) / tpb), (unsigned)(2 * n_jobs));
-  hipLaunchKernelGGL(k_scatter_sub, grid, dim3(tpb), 0, st, d_jobs);
+  for (int j0 = 0; j0 < n_jobs; j0 += HX_PREP_CHUNK) {
+    const int n = n_jobs - j0 < HX_PREP_CHUNK ? n_jobs - j0 : HX_PREP_CHUNK;
+    dim3 grid((unsigned)((max_states + tpb - 1) / tpb), (unsigned)(2 * n));
+    hipLaunchKernelGGL(k_scatter_sub, grid, dim3(tpb), 0, st, d_jobs + j0);
+  }
 }
 
-void launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st) {
+int launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st) {
   int threads = ((max_rows + 63) / 64) * 64;
   if (threads > 1024) threads = 1024;
   if (threads < 64) threads = 64;
   hipLaunchKernelGGL(k_forward_dag, dim3(n_jobs), dim3(threads), 0, st, d_jobs, tab);
+  return 0;
 }
 
-void launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st) {
+int launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st) {
   int threads = ((max_rows + 63) / 64) * 64;
   if (threads > 1024) threads = 1024;
   if (threads < 64) threads = 64;
   hipLaunchKernelGGL(k_backward_dag, dim3(n_jobs), dim3(threads), 0, st, d_jobs, tab);
+  return 0;
 }
 
 void launch_posterior_scan(const DevJob* d_jobs, int job, double lpp_threshold, PostCell* out,

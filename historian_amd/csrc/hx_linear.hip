@@ -533,7 +533,10 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
         } else {
           const int done = fin - HXL_PUBLISH_LAG;
           if (done > 0 && ((done >> 6) != ((done - 2) >> 6))) {
-            asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+            // (five stores per iteration and nothing else: the HXL_PUBLISH_LAG / 2 iterations since hold exactly this many)
+            constexpr int PUBLISH_WAIT = 5 * (HXL_PUBLISH_LAG / 2);
+            static_assert(PUBLISH_WAIT <= 63 && HXL_PUBLISH_LAG % 2 == 0, "s_waitcnt vmcnt holds 6 bits");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PUBLISH_WAIT) : "memory");
             if (lane == 0) drainp[0] = my_base + done;
           }
         }
@@ -593,9 +596,11 @@ static LdsPlan plan_lds(int W, int PPW, bool banded, int yl_cols, int yl_emis, i
   return p;
 }
 
-void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
-                                int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
+int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
+                               int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
+  if (yl_cls > HX_YL_MAX_CLS_LINEAR + 1) return launch_fail("%d emission classes exceed the scaled-probability kernel's column words", yl_cls);
 #define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis, yl_cls); \
+    if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_leaf_linear<%d> needs %d bytes of LDS (limit %d)", W_, p.total, HX_LDS_LIMIT); \
     hipLaunchKernelGGL((k_fill_leaf_linear<W_, B_, PPW_, 0>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
                        d_jobs, tab, log_tab, p, n_jobs); } while (0)
   if (banded) {
@@ -609,7 +614,7 @@ void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, 
       else if (plan_lds(1, 5, true, yl_cols, yl_emis, yl_cls).total <= 76 * 1024) HXL_LAUNCH(1, true, 5);
       else HXL_LAUNCH(1, true, 4);
     } else HXL_LAUNCH(1, true, 1);
-    return;
+    return 0;
   }
   const char* v = getenv("HX_LINEAR_WAVES");     // tuning / test hook: waves per pair (any count works for any size)
   const int forced = v ? atoi(v) : 0;
@@ -625,12 +630,15 @@ void launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, 
   else if (max_rows <= 512 || n_jobs > 256) HXL_LAUNCH(8, false, 1);
   else HXL_LAUNCH(16, false, 1);
 #undef HXL_LAUNCH
+  return 0;
 }
 
 // Backward fill of leaf batches on scaled probabilities (the same kernel, DIR = 1)
-void launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
-                                 int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
+int launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
+                                int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
+  if (yl_cls > HX_YL_MAX_CLS_LINEAR + 1) return launch_fail("%d emission classes exceed the scaled-probability kernel's column words", yl_cls);
 #define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis, yl_cls); \
+    if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_leaf_linear<%d, bwd> needs %d bytes of LDS (limit %d)", W_, p.total, HX_LDS_LIMIT); \
     hipLaunchKernelGGL((k_fill_leaf_linear<W_, B_, PPW_, 1>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
                        d_jobs, tab, log_tab, p, n_jobs); } while (0)
   if (banded) {
@@ -641,7 +649,7 @@ void launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows,
       else if (plan_lds(1, 5, true, yl_cols, yl_emis, yl_cls).total <= 76 * 1024) HXL_LAUNCH(1, true, 5);
       else HXL_LAUNCH(1, true, 4);
     } else HXL_LAUNCH(1, true, 1);
-    return;
+    return 0;
   }
   const char* v = getenv("HX_LINEAR_WAVES");
   const int forced = v ? atoi(v) : 0;
@@ -654,6 +662,7 @@ void launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows,
   else if (max_rows <= 512 || n_jobs > 256) HXL_LAUNCH(8, false, 1);
   else HXL_LAUNCH(16, false, 1);
 #undef HXL_LAUNCH
+  return 0;
 }
 
 }  // namespace hx

@@ -220,26 +220,28 @@ __global__ void __launch_bounds__(W * 64) k_quickalign(const DevQuick* __restric
 
 #define HX_QA_LDS_COLS 7000
 template <int W>
-void launch_w(const DevQuick* d_jobs, int n_jobs, int max_cols, bool full, hipStream_t st) {
+int launch_w(const DevQuick* d_jobs, int n_jobs, int max_cols, bool full, hipStream_t st) {
   if (max_cols > HX_QA_LDS_COLS) {
     if (full) hipLaunchKernelGGL((k_quickalign<W, true, true>), dim3(n_jobs), dim3(W * 64), 16, st, d_jobs, max_cols);
     else hipLaunchKernelGGL((k_quickalign<W, false, true>), dim3(n_jobs), dim3(W * 64), 16, st, d_jobs, max_cols);
-    return;
+    return 0;
   }
   const size_t lds = (size_t)max_cols * (16 + 4) + 16;
+  HX_CHECK_LDS((k_quickalign<W, true, false>), lds, "k_quickalign");
   if (full) hipLaunchKernelGGL((k_quickalign<W, true, false>), dim3(n_jobs), dim3(W * 64), lds, st, d_jobs, max_cols);
   else hipLaunchKernelGGL((k_quickalign<W, false, false>), dim3(n_jobs), dim3(W * 64), lds, st, d_jobs, max_cols);
+  return 0;
 }
 
 }  // namespace
 
-void launch_quickalign(const DevQuick* d_jobs, int n_jobs, int max_rows, int max_cols, bool all_full, hipStream_t st) {
+int launch_quickalign(const DevQuick* d_jobs, int n_jobs, int max_rows, int max_cols, bool all_full, hipStream_t st) {
   const char* v = getenv("HX_QA_WAVES");   // tuning hook
   const int forced = v ? atoi(v) : 0;
-  if (forced == 8) { launch_w<8>(d_jobs, n_jobs, max_cols, all_full, st); return; }
-  if (forced == 4) { launch_w<4>(d_jobs, n_jobs, max_cols, all_full, st); return; }
-  if (forced == 2) { launch_w<2>(d_jobs, n_jobs, max_cols, all_full, st); return; }
-  if (forced == 1) { launch_w<1>(d_jobs, n_jobs, max_cols, all_full, st); return; }
+  if (forced == 8) return launch_w<8>(d_jobs, n_jobs, max_cols, all_full, st);
+  if (forced == 4) return launch_w<4>(d_jobs, n_jobs, max_cols, all_full, st);
+  if (forced == 2) return launch_w<2>(d_jobs, n_jobs, max_cols, all_full, st);
+  if (forced == 1) return launch_w<1>(d_jobs, n_jobs, max_cols, all_full, st);
   // Waves per pair: enough to cover the rows when the batch is small (latency of one pair), fewer when the
   // batch alone fills the GPU -- a pair's strips start one after the other, so fewer waves per pair waste
   // less of the sweep on the ramp (measured on 512 pairs of 2000x2000: 16 waves 0.54, 8: 0.57, 4: 0.59 of
@@ -249,11 +251,11 @@ void launch_quickalign(const DevQuick* d_jobs, int n_jobs, int max_rows, int max
   else if (n_jobs >= 128) cap = 8;
   const int need = (max_rows + 63) / 64;
   const int w = need < cap ? need : cap;
-  if (w <= 1) launch_w<1>(d_jobs, n_jobs, max_cols, all_full, st);
-  else if (w <= 2) launch_w<2>(d_jobs, n_jobs, max_cols, all_full, st);
-  else if (w <= 4) launch_w<4>(d_jobs, n_jobs, max_cols, all_full, st);
-  else if (w <= 8) launch_w<8>(d_jobs, n_jobs, max_cols, all_full, st);
-  else launch_w<16>(d_jobs, n_jobs, max_cols, all_full, st);
+  if (w <= 1) return launch_w<1>(d_jobs, n_jobs, max_cols, all_full, st);
+  if (w <= 2) return launch_w<2>(d_jobs, n_jobs, max_cols, all_full, st);
+  if (w <= 4) return launch_w<4>(d_jobs, n_jobs, max_cols, all_full, st);
+  if (w <= 8) return launch_w<8>(d_jobs, n_jobs, max_cols, all_full, st);
+  return launch_w<16>(d_jobs, n_jobs, max_cols, all_full, st);
 }
 
 }  // namespace hx

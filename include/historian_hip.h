@@ -12,7 +12,9 @@
  *   - extern "C", plain pointers and sizes, caller-owned input buffers (copied to
  *     the device inside hx_batch_create; the caller may free them afterwards).
  *   - every function returns HX_OK (0) or a negative hx_status; nothing aborts or
- *     throws across the ABI.  A zero-likelihood fill is NOT an error: lp_end is
+ *     throws across the ABI.  A batch is grouped by kernel class internally (leaf pairs, chain profiles, general
+ *     profiles; banded or not) and every class is launched with the kernel that suits it; a shape no kernel
+ *     supports (an LDS plan over the CU's 160 KB ...) is refused with HX_ERR_INVALID_ARG before anything is launched.  A zero-likelihood fill is NOT an error: lp_end is
  *     -inf and the caller widens the band (reference src/recon.cpp:956-975).
  *   - all log-probabilities are IEEE fp64; -inf means probability zero.
  *   - "stream" arguments are a hipStream_t passed as void* (NULL = default stream).
@@ -164,6 +166,11 @@ typedef struct hx_batch hx_batch;   /* opaque: inputs + matrices of n independen
 /* Select the device, upload the host-built lookup table.  Replaces the reference's
  * static LogSumExpLookupTable (src/logsumexp.cpp:6-16). */
 int hx_init(int device_ordinal, const double* lse_table, size_t n_entries);
+/* Several devices per process (independent pair DPs farmed over the GPUs of a node): call hx_init once per
+ * ordinal; the last one initialised is the default device of hx_batch_create / hx_quick_batch_create.  A batch lives on
+ * one device for its whole life; batches on different devices may be driven from one host thread (asynchronous launches,
+ * one stream per device) or from one thread per device.  hx_shutdown releases every device's tables. */
+int hx_device_count(void);
 int hx_shutdown(void);
 const char* hx_last_error(void);
 int hx_version(void);
@@ -173,6 +180,8 @@ int hx_version(void);
  * inputs.  Replaces the member initialisers of DPMatrix::DPMatrix
  * (src/forward.cpp:11-35). */
 int hx_batch_create(const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_batch** out);
+int hx_batch_create_on(int device_ordinal, const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_batch** out);
+int hx_batch_device(const hx_batch* b);
 int hx_batch_destroy(hx_batch* b);
 
 /* Asynchronous on `stream`: profile prep (leftMultiply, insx/rootsubx: reference
@@ -245,6 +254,7 @@ typedef struct hx_quick_job {
 typedef struct hx_quick_batch hx_quick_batch;
 
 int hx_quick_batch_create(const hx_quick_job* jobs, int32_t n_jobs, hx_quick_batch** out);
+int hx_quick_batch_create_on(int device_ordinal, const hx_quick_job* jobs, int32_t n_jobs, hx_quick_batch** out);
 int hx_quick_batch_destroy(hx_quick_batch* b);
 /* The fills (QuickAlignMatrix constructor, src/quickalign.cpp:63-99); asynchronous on `stream`. */
 int hx_quick_batch_run(hx_quick_batch* b, void* stream);
