@@ -54,56 +54,18 @@ def parse():
     return ap.parse_args()
 
 
-def synth_pair(rng, pi, length, want_guide=False):
-    """x ~ pi; y = x with ~20% substitutions (~pi) and ~2% indels, cut/padded to `length`.
-    With want_guide, also the true pairwise alignment as two boolean rows (the guide alignment)."""
-    a = len(pi)
-    x = rng.choice(a, size=length, p=pi)
-    keep = rng.random(length) >= .02
-    y = x[keep]
-    sub = rng.random(len(y)) < .2
-    y = np.where(sub, rng.choice(a, size=len(y), p=pi), y)
-    ins_at = np.flatnonzero(rng.random(len(y)) < .02)
-    y = np.insert(y, ins_at, rng.choice(a, size=len(ins_at), p=pi))
-    pad = max(0, length - len(y))
-    if pad:
-        y = np.concatenate([y, rng.choice(a, size=pad, p=pi)])
-    if not want_guide:
-        return x, y[:length]
-    xrow, yrow = [], []
-    ins = set(int(k) for k in ins_at)
-    k = 0                                   # index into the kept (pre-insertion) y residues
-    for p in range(length):
-        if keep[p]:
-            if k in ins:
-                xrow.append(False); yrow.append(True)
-            xrow.append(True); yrow.append(True)
-            k += 1
-        else:
-            xrow.append(True); yrow.append(False)
-    xrow += [False] * pad
-    yrow += [True] * pad
-    # y is cut to `length` residues: later y residues leave the alignment
-    seen = 0
-    for c in range(len(yrow)):
-        if yrow[c]:
-            seen += 1
-            if seen > length:
-                yrow[c] = False
-    cols = [c for c in range(len(xrow)) if xrow[c] or yrow[c]]
-    return x, y[:length], (np.array([xrow[c] for c in cols]), np.array([yrow[c] for c in cols]))
-
-
-def envelope_coordinates(xrow, yrow):
-    """Per-state envelope coordinate of the two leaf profiles under a pairwise guide alignment
-    (reference src/alignpath.cpp:282-310 + src/forward.cpp:26-35: cumulativeMatches[rowPosToCol[pos]];
-    START has position 0, END the position of the last residue)."""
-    cm = np.concatenate([[0], np.cumsum(xrow & yrow)])
-    def coords(row):
-        pos2col = np.concatenate([[0], np.flatnonzero(row) + 1])
-        e = cm[pos2col]
-        return np.concatenate([e, e[-1:]]).astype(np.int32)
-    return coords(xrow), coords(yrow)
+def _cpu_fill_worker(spec):
+    """CPU-baseline worker (all-cores variant, SURVEY 8d iii): rebuilds pair k of the batch from its seed and runs the
+    plain-C restatement of the reference fill on it.  Runs in a spawned process (the parent has initialised the GPU)."""
+    model_name, tl, tr, length, band, seed = spec
+    from historian_amd import hostmodel, workload
+    from oracle import c_oracle
+    model = hostmodel.RateModel.load(os.path.join(ROOT, "tests", "golden", "models", model_name + ".json"))
+    hmm = hostmodel.make_hmm(model, tl, tr)
+    x, y, h, md = workload.leaf_pair(np.random.default_rng(seed), model, hmm, length, band=band)
+    t0 = time.perf_counter()
+    c_oracle.forward(x, y, h, md)
+    return time.perf_counter() - t0
 
 
 def main():
@@ -122,7 +84,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from historian_amd import capi, farm, hostmodel
+    from historian_amd import capi, farm, hostmodel, workload
 
     # ---- rate-model constant block: built on rank 0, broadcast over RCCL/xGMI ----------------
     model = hostmodel.RateModel.load(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json"))
@@ -136,28 +98,23 @@ def main():
     pi = np.asarray(model.root[0], dtype=float)
     pi = pi / pi.sum()
 
+    # strong scaling: BASELINE configs[3] as written - `--pairs` pairs IN TOTAL, dealt to the ranks; weak: per rank
+    strong = args.scaling == "strong"
+    n_local = args.pairs // world + (1 if strong and rank < args.pairs % world else 0) if strong else args.pairs
+    first = (rank * (args.pairs // world) + min(rank, args.pairs % world)) if strong else rank * args.pairs
     triples = []
     env_cells = 0
     env_cells_of = []
-    for k in range(args.pairs):
-        rng = np.random.default_rng(farm.pair_seed(rank, args.pairs, k))
-        if args.band < 0:
-            xs, ys = synth_pair(rng, pi, args.length)
-            triples.append((hostmodel.leaf_profile(xs, a, c), hostmodel.leaf_profile(ys, a, c), hmm, -1))
-        else:
-            xs, ys, (xrow, yrow) = synth_pair(rng, pi, args.length, want_guide=True)
-            ex, ey = envelope_coordinates(xrow, yrow)
-            triples.append((hostmodel.leaf_profile(xs, a, c, ex), hostmodel.leaf_profile(ys, a, c, ey), hmm, args.band))
+    for k in range(n_local):
+        rng = np.random.default_rng(farm.pair_seed(0, 0, first + k))       # seed = 1000 + global pair index
+        triples.append(workload.leaf_pair(rng, model, hmm, args.length, band=args.band))
+        if args.band >= 0:
             # in-envelope cells (reference src/forward.h:92-98): within the band, or at an edge
-            # (x START row; y column of the last residue, the source of the transition into END).
-            # The envelope coordinates are non-decreasing, so a row's band is a range of columns.
-            exr, eyc = ex[:-1].astype(np.int64), ey[:-1].astype(np.int64)
-            in_band = np.searchsorted(eyc, exr + args.band, "right") - np.searchsorted(eyc, exr - args.band, "left")
-            n_in = int(in_band.sum()) + (len(eyc) - int(in_band[0])) + int((np.abs(exr[1:] - eyc[-1]) > args.band).sum())
+            n_in = workload.in_envelope_cells(triples[-1][0].env_pos, triples[-1][1].env_pos, args.band)
             env_cells_of.append(n_in)
             env_cells += n_in
-        if rank == 0 and args.pairs > 1024 and (k + 1) % 1024 == 0:
-            print("built %d of %d pairs" % (k + 1, args.pairs), file=sys.stderr, flush=True)
+        if rank == 0 and n_local > 1024 and (k + 1) % 1024 == 0:
+            print("built %d of %d pairs" % (k + 1, n_local), file=sys.stderr, flush=True)
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():

@@ -81,47 +81,52 @@ struct LogSumExpLookupTable {
 };
 extern LogSumExpLookupTable logSumExpLookupTable;
 
-inline double log_sum_exp_unary(double x) {
-  if (x >= LOG_SUM_EXP_LOOKUP_MAX || std::isnan(x) || std::isinf(x)) return 0;
-  if (x < 0) {
-    std::cerr << "Called log_sum_exp_unary(x) for negative x = " << x << std::endl;
-    return -x;
+// The table operator (reference src/logsumexp.h:42-100).  T(gap) = log(1 + exp(-gap)) read from the table with linear
+// interpolation for 0 <= gap < 10 and taken as 0 beyond (also for an infinite or NaN gap); the sum of two
+// log-probabilities is the larger one plus T of their distance.  The arithmetic - quotient gap / precision truncated to
+// the bin, the bin's offset divided by the precision again, one multiply, one add - is what every fixture carries, so it
+// is kept operation for operation; the device's hx_lse.h is the same sequence.
+inline double log_sum_exp_unary(double gap) {
+  const bool tabulated = gap < LOG_SUM_EXP_LOOKUP_MAX && std::isfinite(gap);
+  if (!tabulated) return 0;
+  if (gap < 0) {
+    std::cerr << "Called log_sum_exp_unary(x) for negative x = " << gap << std::endl;
+    return -gap;
   }
-  const int n = (int)(x / LOG_SUM_EXP_LOOKUP_PRECISION);
-  const double f0 = logSumExpLookupTable.lookup[n];
-  const double dx = x - (n * LOG_SUM_EXP_LOOKUP_PRECISION);
-  const double f1 = logSumExpLookupTable.lookup[n + 1];
-  const double df = f1 - f0;
-  return f0 + df * (dx / LOG_SUM_EXP_LOOKUP_PRECISION);
+  const int bin = (int)(gap / LOG_SUM_EXP_LOOKUP_PRECISION);
+  const double* entry = logSumExpLookupTable.lookup + bin;
+  const double within = (gap - (bin * LOG_SUM_EXP_LOOKUP_PRECISION)) / LOG_SUM_EXP_LOOKUP_PRECISION;
+  return entry[0] + (entry[1] - entry[0]) * within;
 }
 
 inline double log_sum_exp(double a, double b) {
-  double max, diff;
-  if (a == b) { max = a; diff = 0; }
-  else if (a < b) { max = b; diff = b - a; }
-  else { max = a; diff = a - b; }
-  return max + log_sum_exp_unary(diff);
+  // (equal operands first: -inf and -inf must not reach the subtraction)
+  if (a == b) return a + log_sum_exp_unary(0);
+  return a < b ? b + log_sum_exp_unary(b - a) : a + log_sum_exp_unary(a - b);
 }
+// more operands: folded from the left, as the reference's overloads are
 inline double log_sum_exp(double a, double b, double c) { return log_sum_exp(log_sum_exp(a, b), c); }
-inline double log_sum_exp(double a, double b, double c, double d) { return log_sum_exp(log_sum_exp(log_sum_exp(a, b), c), d); }
-inline double log_sum_exp(double a, double b, double c, double d, double e) {
-  return log_sum_exp(log_sum_exp(log_sum_exp(log_sum_exp(a, b), c), d), e);
-}
+inline double log_sum_exp(double a, double b, double c, double d) { return log_sum_exp(log_sum_exp(a, b, c), d); }
+inline double log_sum_exp(double a, double b, double c, double d, double e) { return log_sum_exp(log_sum_exp(a, b, c, d), e); }
 inline void log_accum_exp(double& a, double b) { a = log_sum_exp(a, b); }
 double log_sum_exp_slow(double a, double b);
 double log_sum_exp_slow(double a, double b, double c);
 double log_sum_exp_slow(double a, double b, double c, double d);
 void log_accum_exp_slow(double& a, double b);
 
+// log of sum_k exp(v1[k] + v2[k]), accumulated from -inf in index order (src/logsumexp.h:132-151); the nested form
+// sums the inner products of the rows the same way
 inline LogProb logInnerProduct(const vguard<LogProb>& v1, const vguard<LogProb>& v2) {
-  LogProb lip = -std::numeric_limits<double>::infinity();
-  for (size_t k = 0; k < v1.size(); ++k) lip = log_sum_exp(lip, v1[k] + v2[k]);
-  return lip;
+  LogProb total = -std::numeric_limits<double>::infinity();
+  auto q = v2.begin();
+  for (auto p = v1.begin(); p != v1.end(); ++p, ++q) log_accum_exp(total, *p + *q);
+  return total;
 }
 inline LogProb logInnerProduct(const vguard<vguard<LogProb> >& v1, const vguard<vguard<LogProb> >& v2) {
-  LogProb lip = -std::numeric_limits<double>::infinity();
-  for (size_t k = 0; k < v1.size(); ++k) lip = log_sum_exp(lip, logInnerProduct(v1[k], v2[k]));
-  return lip;
+  LogProb total = -std::numeric_limits<double>::infinity();
+  auto q = v2.begin();
+  for (auto p = v1.begin(); p != v1.end(); ++p, ++q) log_accum_exp(total, logInnerProduct(*p, *q));
+  return total;
 }
 vguard<LogProb> log_vector(const vguard<double>& v);
 
@@ -324,6 +329,11 @@ public:
                            DontCountIndelEvents = 0, CountIndelEvents = 4, DontIncludeBestTrace = 0, IncludeBestTrace = 8,
                            DontKeepGapsOpen = 0, KeepGapsOpen = 16 };
   typedef list<CellCoords> Path;
+  // (hx_host_walk.cpp) the cells next to a cell with the log-weight of the move between them, as a flat list: sorted by
+  // cell, one entry per cell.  Tracebacks and profile construction work on these; the map-returning members of the
+  // reference's interface are adapters.
+  typedef std::pair<CellCoords, LogProb> Move;
+  typedef vguard<Move> Moves;
   typedef std::mt19937 random_engine;
   static const char* random_engine_name() { return "mt19937"; }
 
@@ -410,6 +420,9 @@ protected:
     initAbsorbScratch(xpos, ypos);
     return logInnerProduct(hmm.logRoot, absorbScratch);
   }
+  static void settle(Moves& m);
+  static CellCoords pickBest(const Moves& m);
+  CellCoords pickSampled(const Moves& m, random_engine& generator) const;
   LogProb lpCellEmitOrAbsorb(const CellCoords& c);
   bool isAbsorbing(const CellCoords& c) const;
   bool changesX(const CellCoords& c) const;
@@ -462,6 +475,8 @@ public:
   void slowFillTest();
 
 private:
+  void movesInto(const CellCoords& dest, Moves& out) const;     // sourceTransitionsWithoutEmitOrAbsorb as a flat list
+  void scoredSources(const CellCoords& dest, Moves& out);       // ... + the destination's emission + the source's Forward cell
   map<CellCoords, LogProb> sourceCells(const CellCoords& destCell);
   LogProb eliminatedLogProbInsert(const CellCoords& cell) const;
   AlignPath cellAlignPath(const CellCoords& cell) const;
@@ -498,6 +513,8 @@ public:
   void sourceDestTransTest();
 
 private:
+  void movesOutOf(const CellCoords& src, Moves& out);           // destTransitions as a flat list
+  void scoredDestinations(const CellCoords& src, Moves& out);   // ... + the destination's Backward cell
   map<CellCoords, LogProb> destCells(const CellCoords& srcCell);
   bool addCells(set<CellCoords>& cells, size_t maxCells, const list<CellCoords>& fwdTrace, const list<CellCoords>& backTrace, bool keepGapsOpen);
   bool addTrace(const CellCoords& cell, set<CellCoords>& cells, size_t maxCells, bool keepGapsOpen);

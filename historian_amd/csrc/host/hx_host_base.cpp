@@ -2,6 +2,7 @@
 // util, logsumexp, fastseq, alignpath and model parts of the host mirror (see hx_host.h).
 #include "hx_host.h"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -21,68 +22,77 @@ double wallSeconds() {
 }
 
 
-// ---- errors (reference src/util.cpp:26-54) --------------------------------------------------
+// ---- diagnostics (behaviour of reference src/util.cpp:26-54: Warn continues, Abort terminates, Fail exits 1) -------
+namespace {
+enum Severity { kWarn, kAbort, kFail };
+void report(Severity sev, const char* format, va_list args) {
+  static const char* const label[] = {"Warning: ", "Abort: ", ""};
+  std::string line(label[sev]);
+  char text[2048];
+  vsnprintf(text, sizeof(text), format, args);
+  line += text;
+  line += '\n';
+  fputs(line.c_str(), stderr);       // one write per message: messages of concurrent device threads do not interleave
+}
+}  // namespace
+
 void Warn(const char* warning, ...) {
-  va_list argptr;
-  fprintf(stderr, "Warning: ");
-  va_start(argptr, warning);
-  vfprintf(stderr, warning, argptr);
-  fprintf(stderr, "\n");
-  va_end(argptr);
+  va_list args;
+  va_start(args, warning);
+  report(kWarn, warning, args);
+  va_end(args);
 }
 
 void Abort(const char* error, ...) {
-  va_list argptr;
-  va_start(argptr, error);
-  fprintf(stderr, "Abort: ");
-  vfprintf(stderr, error, argptr);
-  fprintf(stderr, "\n");
-  va_end(argptr);
-  std::terminate();   // the reference executes `throw;` with no active exception, i.e. std::terminate
+  va_list args;
+  va_start(args, error);
+  report(kAbort, error, args);
+  va_end(args);
+  std::terminate();   // (the reference reaches std::terminate through a `throw;` without an active exception)
 }
 
 void Fail(const char* error, ...) {
-  va_list argptr;
-  va_start(argptr, error);
-  vfprintf(stderr, error, argptr);
-  fprintf(stderr, "\n");
-  va_end(argptr);
+  va_list args;
+  va_start(args, error);
+  report(kFail, error, args);
+  va_end(args);
   exit(EXIT_FAILURE);
 }
 
-// ---- log-sum-exp table (reference src/logsumexp.cpp:6-53) -----------------------------------
-LogSumExpLookupTable logSumExpLookupTable = LogSumExpLookupTable();
+// ---- log-sum-exp table (semantics of reference src/logsumexp.cpp:6-53) ------------------------------------------
+// One entry more than the reference allocates: its interpolation reads lookup[n + 1] for n up to ENTRIES - 1.
+LogSumExpLookupTable logSumExpLookupTable;
 
-LogSumExpLookupTable::LogSumExpLookupTable() {
-  lookup = new double[LOG_SUM_EXP_LOOKUP_ENTRIES + 1];
-  for (int n = 0; n < LOG_SUM_EXP_LOOKUP_ENTRIES + 1; ++n) lookup[n] = log_sum_exp_unary_slow(n * LOG_SUM_EXP_LOOKUP_PRECISION);
+LogSumExpLookupTable::LogSumExpLookupTable() : lookup(new double[LOG_SUM_EXP_LOOKUP_ENTRIES + 1]) {
+  double* entry = lookup;
+  for (int bin = 0; bin <= LOG_SUM_EXP_LOOKUP_ENTRIES; ++bin) *entry++ = log_sum_exp_unary_slow(bin * LOG_SUM_EXP_LOOKUP_PRECISION);
 }
 LogSumExpLookupTable::~LogSumExpLookupTable() { delete[] lookup; }
 
+// log(1 + e^-x) by libm, the value the table samples
 double log_sum_exp_unary_slow(double x) { return log(1. + exp(-x)); }
 
 double log_sum_exp_slow(double a, double b) {
-  double min, max;
-  if (a < b) { min = a; max = b; } else { min = b; max = a; }
-  if (min == -std::numeric_limits<double>::infinity()) return max;
-  return max + log_sum_exp_unary_slow(max - min);
+  const double hi = a < b ? b : a, lo = a < b ? a : b;
+  return std::isinf(lo) && lo < 0 ? hi : hi + log_sum_exp_unary_slow(hi - lo);
 }
 double log_sum_exp_slow(double a, double b, double c) { return log_sum_exp_slow(log_sum_exp_slow(a, b), c); }
-double log_sum_exp_slow(double a, double b, double c, double d) { return log_sum_exp_slow(log_sum_exp_slow(log_sum_exp_slow(a, b), c), d); }
+double log_sum_exp_slow(double a, double b, double c, double d) { return log_sum_exp_slow(log_sum_exp_slow(a, b, c), d); }
 void log_accum_exp_slow(double& a, double b) { a = log_sum_exp_slow(a, b); }
 
 vguard<LogProb> log_vector(const vguard<double>& v) {
-  vguard<LogProb> l(v.size());
-  for (size_t i = 0; i < v.size(); ++i) l[i] = log(v[i]);
-  return l;
+  vguard<LogProb> out;
+  out.reserve(v.size());
+  for (double p : v) out.push_back(log(p));
+  return out;
 }
 
-// ---- sequences (reference src/fastseq.cpp:10-16) --------------------------------------------
+// ---- sequences ------------------------------------------------------------------------------------------------
+// index of a character in the alphabet, trying the other letter case second (reference src/fastseq.cpp:10-16)
 UnvalidatedAlphTok tokenize(char c, const string& alphabet) {
-  const char* alphStr = alphabet.c_str();
-  const char* ptok = strchr(alphStr, c);
-  if (ptok == NULL) ptok = strchr(alphStr, isupper(c) ? tolower(c) : toupper(c));
-  return ptok ? (UnvalidatedAlphTok)(ptok - alphStr) : InvalidAlphabetToken;
+  size_t at = alphabet.find(c);
+  if (at == string::npos) at = alphabet.find((char)(isupper((unsigned char)c) ? tolower((unsigned char)c) : toupper((unsigned char)c)));
+  return at == string::npos ? InvalidAlphabetToken : (UnvalidatedAlphTok)at;
 }
 
 vguard<FastSeq> readFastSeqs(const char* filename) {
@@ -107,50 +117,44 @@ vguard<FastSeq> readFastSeqs(const char* filename) {
   return seqs;
 }
 
-// ---- alignment paths (reference src/alignpath.cpp:6-81, 282-318) ----------------------------
+// ---- alignment paths (semantics of reference src/alignpath.cpp:6-81, 282-318) -------------------------------------
+// An AlignPath is a set of rows of equal length; every operation below first asks for that width.
 const char Alignment::gapChar = '-';
 const char Alignment::wildcardChar = '*';
 
 AlignColIndex alignPathColumns(const AlignPath& a) {
-  AlignColIndex cols = 0;
-  bool first = true;
-  AlignRowIndex firstRow = 0;
-  for (auto& row_path : a) {
-    if (first) {
-      firstRow = row_path.first;
-      cols = row_path.second.size();
-      first = false;
-    } else
-      Assert(cols == row_path.second.size(), "Alignment path is not flush: row %u has %u columns, but row %u has %u columns",
-             (unsigned)firstRow, (unsigned)cols, (unsigned)row_path.first, (unsigned)row_path.second.size());
-  }
-  return cols;
+  if (a.empty()) return 0;
+  const auto& ref = *a.begin();
+  for (const auto& row : a)
+    Assert(row.second.size() == ref.second.size(), "Alignment path is not flush: row %u has %u columns, but row %u has %u columns",
+           (unsigned)ref.first, (unsigned)ref.second.size(), (unsigned)row.first, (unsigned)row.second.size());
+  return ref.second.size();
 }
 
-SeqIdx alignPathResiduesInRow(const AlignRowPath& r) {
-  SeqIdx l = 0;
-  for (bool b : r)
-    if (b) ++l;
-  return l;
-}
+SeqIdx alignPathResiduesInRow(const AlignRowPath& r) { return (SeqIdx)std::count(r.begin(), r.end(), true); }
 
+// rows of both; a row present in both keeps the first argument's version
 AlignPath alignPathUnion(const AlignPath& a1, const AlignPath& a2) {
-  AlignPath a = a1;
-  a.insert(a2.begin(), a2.end());
-  return a;
+  AlignPath merged(a2);
+  for (const auto& row : a1) merged[row.first] = row.second;
+  return merged;
 }
 
+// columns of a1 followed by the columns of a2; a row missing on one side is gaps there
 AlignPath alignPathConcat(const AlignPath& a1, const AlignPath& a2) {
-  AlignPath a = a1;
-  const AlignColIndex c1 = alignPathColumns(a1), c2 = alignPathColumns(a2);
-  for (auto& iter : a)
-    if (a2.find(iter.first) == a2.end()) iter.second.insert(iter.second.end(), c2, false);
-  for (auto& iter2 : a2) {
-    AlignRowPath& lPath = a[iter2.first];
-    if (lPath.empty()) lPath.insert(lPath.end(), c1, false);
-    lPath.insert(lPath.end(), iter2.second.begin(), iter2.second.end());
+  const AlignColIndex w1 = alignPathColumns(a1), w2 = alignPathColumns(a2);
+  AlignPath joined;
+  for (const auto& row : a1) {
+    AlignRowPath& out = joined[row.first];
+    out = row.second;
+    out.resize(w1 + w2, false);
   }
-  return a;
+  for (const auto& row : a2) {
+    AlignRowPath& out = joined[row.first];
+    out.resize(w1, false);                   // (a new row: all gaps so far; an existing one: cut back to a1's part)
+    out.insert(out.end(), row.second.begin(), row.second.end());
+  }
+  return joined;
 }
 
 AlignPath alignPathConcat(const AlignPath& a1, const AlignPath& a2, const AlignPath& a3) {
@@ -158,35 +162,39 @@ AlignPath alignPathConcat(const AlignPath& a1, const AlignPath& a2, const AlignP
 }
 
 void ensureAlignPathHasRow(AlignPath& a, AlignRowIndex r) {
-  const AlignColIndex cols = alignPathColumns(a);
-  if (!a.count(r)) a[r] = AlignRowPath(cols, false);
+  const AlignColIndex width = alignPathColumns(a);
+  a.emplace(r, AlignRowPath(width, false));  // (no effect when the row exists)
 }
 
 string alignPathString(const AlignPath& a) {
-  std::ostringstream out;
-  for (auto& row_path : a) {
-    out << std::setw(4) << row_path.first << ' ';
-    for (bool s : row_path.second) out << (s ? '*' : '-');
-    out << std::endl;
+  std::ostringstream text;
+  for (const auto& row : a) {
+    text << std::setw(4) << row.first << ' ';
+    for (bool residue : row.second) text << (residue ? Alignment::wildcardChar : Alignment::gapChar);
+    text << std::endl;
   }
-  return out.str();
+  return text.str();
 }
 
+// The band of a pair DP (reference src/alignpath.cpp:282-310): per guide column the number of columns so far in which
+// both rows have a residue, and per sequence position of either row the column it sits in (position 0 = before the
+// first residue = column 0).
 GuideAlignmentEnvelope::GuideAlignmentEnvelope(const AlignPath& guide, AlignRowIndex row1, AlignRowIndex row2, int maxDistance)
     : row1(row1), row2(row2), maxDistance(maxDistance) {
-  Assert(guide.find(row1) != guide.end(), "Guide alignment is missing row #%u", (unsigned)row1);
-  Assert(guide.find(row2) != guide.end(), "Guide alignment is missing row #%u", (unsigned)row2);
-  const AlignColIndex cols = alignPathColumns(guide);
-  cumulativeMatches.reserve(cols + 1);
-  int matches = 0;
-  row1PosToCol.push_back(0);
-  row2PosToCol.push_back(0);
-  cumulativeMatches.push_back(0);
-  for (AlignColIndex col = 0; col < cols; ++col) {
-    if (guide.at(row1)[col]) row1PosToCol.push_back(col + 1);
-    if (guide.at(row2)[col]) row2PosToCol.push_back(col + 1);
-    if (guide.at(row1)[col] && guide.at(row2)[col]) ++matches;
-    cumulativeMatches.push_back(matches);
+  const auto r1 = guide.find(row1), r2 = guide.find(row2);
+  Assert(r1 != guide.end(), "Guide alignment is missing row #%u", (unsigned)row1);
+  Assert(r2 != guide.end(), "Guide alignment is missing row #%u", (unsigned)row2);
+  const AlignColIndex width = alignPathColumns(guide);
+  const AlignRowPath& in1 = r1->second;
+  const AlignRowPath& in2 = r2->second;
+  cumulativeMatches.assign(width + 1, 0);
+  row1PosToCol.assign(1, 0);
+  row2PosToCol.assign(1, 0);
+  for (AlignColIndex col = 1; col <= width; ++col) {
+    const bool has1 = in1[col - 1], has2 = in2[col - 1];
+    if (has1) row1PosToCol.push_back(col);
+    if (has2) row2PosToCol.push_back(col);
+    cumulativeMatches[col] = cumulativeMatches[col - 1] + (has1 && has2 ? 1 : 0);
   }
 }
 

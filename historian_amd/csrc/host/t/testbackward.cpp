@@ -1,32 +1,18 @@
-// Mirror of the reference's t/testbackward.cpp on the GPU-backed Forward/Backward matrices.
-#include <cstdlib>
-#include <iostream>
-#include "../hx_host.h"
+// testbackward <sequences> <modelfile> <xtime> [<ytime>]
+// Forward and Backward fills of two leaf profiles: the two scores (equal up to rounding) and every cell whose posterior
+// probability exceeds one half, most probable first - the output of the reference's t/testbackward.cpp.
+#include "pair_setup.h"
 using namespace historian;
 
 int main(int argc, char** argv) {
-  if (argc != 4 && argc != 5) {
-    std::cout << "Usage: " << argv[0] << " <sequences> <modelfile> <xtime> [<ytime>]\n";
-    exit(EXIT_FAILURE);
-  }
-  vguard<FastSeq> seqs = readFastSeqs(argv[1]);
-  Assert(seqs.size() == 2, "Expected two sequences in file %s", argv[1]);
-  RateModel rates;
-  rates.readFile(argv[2]);
-  ProbModel xprobs(rates, atof(argv[3]));
-  ProbModel yprobs(rates, atof(argv[argc > 4 ? 4 : 3]));
-  vguard<Vec> eqm = rates.insProb;
-  PairHMM hmm(xprobs, yprobs, eqm);
-  Profile xprof(1, rates.alphabet, seqs[0], 1);
-  Profile yprof(1, rates.alphabet, seqs[1], 2);
-  ForwardMatrix forward(xprof, yprof, hmm, 0, GuideAlignmentEnvelope());
+  if (argc < 4 || argc > 5) return usage(argv[0], "<sequences> <modelfile> <xtime> [<ytime>]");
+  const vguard<FastSeq> seqs = twoSequences(argv[1]);
+  const PairSetup setup(argv[2], argv[3], argc == 5 ? argv[4] : NULL);
+  const Profile x = setup.leaf(seqs[0], 1), y = setup.leaf(seqs[1], 2);
+  ForwardMatrix forward(x, y, setup.hmm(), 0, GuideAlignmentEnvelope());
   BackwardMatrix backward(forward);
-  std::cout << "Forward score: " << forward.lpEnd << std::endl;
-  std::cout << "Backward score: " << backward.lpStart() << std::endl;
-  auto bestCells = backward.cellsAbovePostProbThreshold(.5);
-  while (!bestCells.empty()) {
-    std::cout << "P" << backward.cellName(bestCells.top()) << " = " << exp(bestCells.top().logPostProb) << std::endl;
-    bestCells.pop();
-  }
-  exit(EXIT_SUCCESS);
+  std::cout << "Forward score: " << forward.lpEnd << std::endl << "Backward score: " << backward.lpStart() << std::endl;
+  for (auto likely = backward.cellsAbovePostProbThreshold(.5); !likely.empty(); likely.pop())
+    std::cout << "P" << backward.cellName(likely.top()) << " = " << exp(likely.top().logPostProb) << std::endl;
+  return EXIT_SUCCESS;
 }

@@ -348,6 +348,83 @@ std::vector<int32_t> strip_windows(const uint8_t* xf, const int32_t* xenv, const
   return w;
 }
 
+
+// Rows of the banded rotating-row sweep (hx_band.hip): for every row of a leaf-like pair the anti-diagonal steps
+// k = i + j it owns - its in-envelope span of columns (reference src/forward.h:92-98), widened to whole step pairs -
+// and the base of its cells in a state plane.  Returns false when the pair does not satisfy what that kernel assumes:
+//   * the envelope coordinates of both profiles are non-decreasing (true for leaf profiles under any guide alignment:
+//     cumulative match counts, reference src/alignpath.cpp:282-310), so a row's band is one span and spans move right;
+//   * the only always-in-envelope row is x START and the only such column the y state that feeds END (leaf profiles);
+//   * a lane that finishes row i is free before row i + 63's span opens (rows i .. i + 63 are never alive together).
+// Layout of a record: see BandRow in hx_band.hip.
+bool build_band_rows(const int32_t* xenv, const int32_t* yenv, const uint8_t* xf, const uint8_t* yf, const int32_t* xecls,
+                     bool x_empty, int R, int Cc, int band, int64_t ss, int blk, const int32_t* cwin, const int64_t* cbase,
+                     std::vector<int32_t>& out, int& n_steps) {
+  if (R < 2 || Cc < 2 || R + Cc > 60000) return false;
+  for (int i = 1; i <= R; ++i) if (xenv[i] < xenv[i - 1]) return false;
+  for (int j = 1; j <= Cc; ++j) if (yenv[j] < yenv[j - 1]) return false;
+  for (int i = 0; i < R; ++i) if (((xf[i] & F_EDGE) != 0) != (i == 0)) return false;
+  for (int j = 0; j < Cc; ++j) if (((yf[j] & F_EDGE) != 0) != (j == Cc - 1)) return false;
+  std::vector<int> lo(R), hi(R);
+  {
+    int a = 0, b = -1;                 // two pointers over the columns: first with yenv >= xenv - band, last with yenv <= xenv + band
+    for (int i = 0; i < R; ++i) {
+      while (a < Cc && (int64_t)yenv[a] < (int64_t)xenv[i] - band) ++a;
+      while (b + 1 < Cc && (int64_t)yenv[b + 1] <= (int64_t)xenv[i] + band) ++b;
+      if (b < a) return false;         // an empty band row: not a guide-alignment envelope
+      lo[i] = a; hi[i] = b;
+    }
+  }
+  lo[0] = 0;
+  hi[0] = std::max(hi[0], hi[1]);      // row 1 reads row 0 up to its own last column (row 0 is in the envelope throughout)
+  for (int i = 0; i < R; ++i) if (hi[i] >= Cc - 2) hi[i] = Cc - 1;   // the cells next to the band in the always-in column
+  const int n_strips = (R + HX_STRIP - 1) / HX_STRIP;
+  out.assign(2 * (size_t)(R + 64) + (size_t)n_strips + 4, 0);
+  int32_t* strip_store = &out[2 * (size_t)(R + 64)];
+  std::vector<int> os(R), oe(R);
+  std::vector<char> have(n_strips, 0);
+  n_steps = 0;
+  for (int i = 0; i < R; ++i) {
+    int as = i + lo[i], ae = i + hi[i];
+    os[i] = as & ~1; oe[i] = ae | 1;
+    // row 0's pad cell is inside the envelope (unless it is past the last column): the sweep computes it
+    if (i == 0) ae = std::min(oe[0], Cc - 1);
+    // where the strip's cells live: slot(i, k) = strip_store[q] + 2 (i % 64) + (k >> 1) blk + (k & 1)
+    const int q = i >> 6;
+    int64_t A;
+    if (!cwin) {
+      A = (int64_t)q * ss - (int64_t)32 * q * blk;
+    } else {
+      // band-compressed planes: the window of strip q that holds the row's steps t = k - 64 q (the same for all its rows)
+      const int t0 = os[i] - 64 * q, t1 = oe[i] - 64 * q;
+      int w = -1;
+      for (int c = 0; c < 2; ++c)
+        if (cwin[4 * q + 2 * c] <= t0 && t1 < cwin[4 * q + 2 * c + 1]) w = c;
+      if (w < 0) return false;
+      A = cbase[2 * q + w] - (int64_t)((64 * q + cwin[4 * q + 2 * w]) >> 1) * (2 * HX_STRIP);
+    }
+    if (A < INT32_MIN / 2 || A > INT32_MAX / 2) return false;
+    if (have[q] && strip_store[q] != (int32_t)A) return false;
+    have[q] = 1;
+    strip_store[q] = (int32_t)A;
+    const bool ready = (xf[i] & F_READY) || x_empty;
+    int32_t* o = &out[2 * (size_t)i];
+    if (oe[i] - os[i] > 0xFFFF || os[i] >= 0xFFFF) return false;
+    o[0] = os[i] | ((oe[i] - os[i]) << 16);
+    o[1] = (xecls[i] & 0xFF) | (ready ? 0 : 0x100) | ((as - os[i]) << 9) | ((oe[i] - ae) << 10);
+    n_steps = std::max(n_steps, oe[i] + 1);
+  }
+  // a lane must be idle for at least one whole step pair between two rows (its register window restarts from zero cells),
+  // and the lane above must have left row i - 1 + 64's predecessor... i.e. rows i and i + 63 are never alive together
+  for (int i = 0; i + 63 < R; ++i) if (os[i + 63] < oe[i] + 1) return false;
+  for (int i = 0; i + 64 < R; ++i) if (os[i + 64] < oe[i] + 3) return false;
+  // the largest slot must fit the converting wave's 32-bit slot
+  if ((int64_t)n_steps / 2 * blk + INT32_MAX / 2 > INT32_MAX) return false;
+  for (int i = R; i < R + 64; ++i) out[2 * (size_t)i] = 0xFFFF;    // sentinels: never owned
+  n_steps = (n_steps + 1) & ~1;
+  return true;
+}
+
 }  // namespace
 
 // Kernel classes: the jobs of a batch are grouped by the fill kernel that suits them, each class is launched on its own
@@ -356,6 +433,7 @@ std::vector<int32_t> strip_windows(const uint8_t* xf, const int32_t* xenv, const
 enum KernelClass {
   KC_LEAF_LDS = 0,            // leaf-like pairs whose y side fits LDS: scaled-probability fills (HX_LSE_LINEAR) or k_fill_chain<YL>
   KC_LEAF_LDS_BANDED,
+  KC_LEAF_ROT_BANDED,         // ... of them, those the banded rotating-row sweep takes (hx_band.hip), Forward only
   KC_LEAF,                    // other leaf-like pairs: k_fill_chain<LEAF>
   KC_LEAF_BANDED,
   KC_CHAIN,                   // other in-degree-1 profiles: k_fill_chain (Forward); Backward runs the general pipeline
@@ -367,7 +445,7 @@ enum KernelClass {
 };
 struct ClassRange {
   int begin = 0, n = 0;       // positions in the class-ordered job table
-  int max_rows = 0, max_cls = 0, yl_cols = 0, yl_emis = 0;
+  int max_rows = 0, max_cols = 0, max_cls = 0, yl_cols = 0, yl_emis = 0;
   int64_t mat_begin = 0, mat_doubles = 0;   // the class's matrices are contiguous: [mat_begin, mat_begin + mat_doubles)
 };
 
@@ -512,6 +590,7 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
   int64_t eplane_total = 0;
   int rc = HX_OK;
   static const bool force_dag = getenv("HX_FORCE_DAG") != nullptr;   // tuning hook: the general pipeline for chain profiles too
+  const bool band_old = getenv("HX_BAND_OLD") != nullptr;             // tuning / test hook: banded leaf pairs on the strip pipelines
   const bool linear = (flags & HX_LSE_LINEAR) == HX_LSE_LINEAR;
   for (int k = 0; k < n_jobs && rc == HX_OK; ++k) {
     const hx_pair_job& pj = jobs[k];
@@ -586,6 +665,8 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
       }
       jo.yword_bwd = ar.put(yw.data(), sizeof(uint32_t) * yw.size());
     }
+    std::vector<int32_t> cwin_keep;
+    std::vector<int64_t> cbase_keep;
     if (need_env) {
       const int R = jo.x.n - 1, Cc = jo.y.n - 1;
       // (copies: put() may reallocate the staging image the pointers would point into)
@@ -620,6 +701,7 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
         }
         jo.fwd_windows = ar.put(we.data(), sizeof(int32_t) * we.size());
         jo.strip_base = ar.put(sb.data(), sizeof(int64_t) * sb.size());
+        cwin_keep = we; cbase_keep = sb;
         jo.compressed = true;
         jo.compact_plane = (off + 1) & ~(int64_t)1;
       } else {
@@ -649,6 +731,24 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
     if (linear && kc == KC_LEAF_LDS && !getenv("HX_PLANAR_LAYOUT")) {
       J.strip_stride *= 5; J.plane = 2 * HX_STRIP; J.blk = 10 * HX_STRIP;
     }
+    if (kc == KC_LEAF_LDS_BANDED && jo.x.lp_zero && !band_old) {
+      // the banded rotating-row sweep (hx_band.hip), when the pair satisfies its assumptions and its sides fit LDS
+      const int pol = linear ? 0 : ((flags & HX_LSE_FAST) ? 1 : 2);
+      std::vector<int32_t> rows;
+      int n_steps = 0;
+      const std::vector<uint8_t> xf(ar.host.data() + jo.x.flags, ar.host.data() + jo.x.flags + jo.x.n);
+      const std::vector<uint8_t> yf(ar.host.data() + jo.y.flags, ar.host.data() + jo.y.flags + jo.y.n);
+      const std::vector<int32_t> xecls(reinterpret_cast<const int32_t*>(ar.host.data() + jo.x.ecls),
+                                       reinterpret_cast<const int32_t*>(ar.host.data() + jo.x.ecls) + jo.x.n);
+      if (band_kernel_fits(pol, J.n_rows, J.n_cols, std::max(jo.x.n_cls, jo.y.n_cls)) &&
+          build_band_rows(pj.x->env_pos, pj.y->env_pos, xf.data(), yf.data(), xecls.data(), jo.x.empty != 0, J.n_rows, J.n_cols,
+                          pj.max_distance, J.strip_stride, J.blk, jo.compressed ? cwin_keep.data() : nullptr,
+                          jo.compressed ? cbase_keep.data() : nullptr, rows, n_steps)) {
+        jo.band_rows = ar.put(rows.data(), sizeof(int32_t) * rows.size());
+        J.band_steps = n_steps;
+        kc = kclass[k] = KC_LEAF_ROT_BANDED;
+      }
+    }
     L.strip_stride = J.strip_stride; L.plane_stride = J.plane;
     L.block_stride = J.blk; L.matrix_doubles = J.matrix_doubles;
     L.mirrored = 0; L.compressed = jo.compressed ? 1 : 0;
@@ -669,6 +769,7 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
     ClassRange& cr = b->cls[kc];
     cr.n++;
     if (J.n_rows > cr.max_rows) cr.max_rows = J.n_rows;
+    if (J.n_cols > cr.max_cols) cr.max_cols = J.n_cols;
     if (jo.x.n_cls > cr.max_cls) cr.max_cls = jo.x.n_cls;
     if (jo.y.n_cls > cr.max_cls) cr.max_cls = jo.y.n_cls;
     if (((jo.y.n + 3) & ~3) > cr.yl_cols) cr.yl_cols = (jo.y.n + 3) & ~3;
@@ -741,6 +842,7 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
     J.strip_base = jo.compressed ? reinterpret_cast<int64_t*>(base + jo.strip_base) : nullptr;
     J.yword = jo.yword ? reinterpret_cast<uint32_t*>(base + jo.yword) : nullptr;
     J.yword_bwd = jo.yword_bwd ? reinterpret_cast<uint32_t*>(base + jo.yword_bwd) : nullptr;
+    J.band_rows = jo.band_rows ? base + jo.band_rows : nullptr;
     J.lp_end = reinterpret_cast<double*>(base + b->lp_end_off) + k;
     J.lp_start = reinterpret_cast<double*>(base + b->lp_start_off) + k;
     J.fwd = b->d_fwd + mat_off[k];
@@ -819,6 +921,11 @@ int hx_batch_forward(hx_batch* b, void* stream) {
     const DevJob* jobs = b->d_jobs_cls + cr.begin;
     const bool banded = c == KC_LEAF_LDS_BANDED || c == KC_LEAF_BANDED || c == KC_CHAIN_BANDED || c == KC_DAG_BANDED;
     switch (c) {
+      case KC_LEAF_ROT_BANDED:
+        if (!(b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED))) launch_fill_neg_inf(b->d_fwd + cr.mat_begin, cr.mat_doubles, st);
+        LAUNCH_TRY(launch_forward_band(jobs, cr.n, linear ? 0 : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, D.tab,
+                                       linear ? D.log_tab : lse_tab, (b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED)) != 0, st));
+        break;
       case KC_LEAF_LDS: case KC_LEAF_LDS_BANDED: case KC_LEAF: case KC_LEAF_BANDED: case KC_CHAIN: case KC_CHAIN_BANDED: {
         // with a band the strip pipelines only visit in-envelope windows; everything else is -inf
         // (band-compressed matrices hold nothing but the swept windows, which the fill writes completely)
@@ -879,11 +986,11 @@ int hx_batch_backward(hx_batch* b, void* stream) {
     const ClassRange& cr = b->cls[c];
     if (cr.n == 0) continue;
     const DevJob* jobs = b->d_jobs_cls + cr.begin;
-    const bool banded = c == KC_LEAF_LDS_BANDED || c == KC_LEAF_BANDED || c == KC_CHAIN_BANDED || c == KC_DAG_BANDED;
+    const bool banded = c == KC_LEAF_LDS_BANDED || c == KC_LEAF_ROT_BANDED || c == KC_LEAF_BANDED || c == KC_CHAIN_BANDED || c == KC_DAG_BANDED;
     switch (c) {
-      case KC_LEAF_LDS: case KC_LEAF_LDS_BANDED: case KC_LEAF: case KC_LEAF_BANDED: {
+      case KC_LEAF_LDS: case KC_LEAF_LDS_BANDED: case KC_LEAF_ROT_BANDED: case KC_LEAF: case KC_LEAF_BANDED: {
         if (banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_bwd + cr.mat_begin, cr.mat_doubles, st);
-        const int leaf = (c == KC_LEAF_LDS || c == KC_LEAF_LDS_BANDED) ? 2 : 1;
+        const int leaf = (c == KC_LEAF_LDS || c == KC_LEAF_LDS_BANDED || c == KC_LEAF_ROT_BANDED) ? 2 : 1;
         if (linear && leaf == 2)
           LAUNCH_TRY(launch_backward_leaf_linear(jobs, cr.n, cr.max_rows, banded, D.tab, D.log_tab, cr.yl_cols, cr.yl_emis, cr.max_cls + 1, st));
         else

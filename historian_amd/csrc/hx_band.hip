@@ -16,16 +16,27 @@
 // the reference reads for cells outside the envelope.  No envelope arithmetic is left in the step: "inside the envelope"
 // is `first step <= k <= last step` of the lane's row.
 //
-// The two envelope edges that are NOT part of the band - the rest of row 0 (x START: every column is in the envelope) and
-// of column Ny-2 (the y state that feeds END) - are one-dimensional: the row-0 cells beyond the band form a chain
-// IDM(0,j) = (IDM(0,j-1) + T[IDM][IDM]) + rootsuby[j], IMI likewise (every other term of the reference's sums is -inf,
-// and log_sum_exp(-inf, v) = v exactly), and the column's cells away from the band are -inf (y state not ready: no IMD /
-// IIW; the cells to their left are outside the envelope).  A second wavefront of the workgroup writes them while the
-// first sweeps.
+// A pair's critical path is its Nx + Ny anti-diagonals, and with 512 pairs on 1024 SIMDs nothing else runs on the sweep's
+// SIMD: the step's instruction count is the fill's speed.  The workgroup therefore gives every pair a SECOND wavefront:
+//   * scaled probabilities (HX_LSE_LINEAR): the sweep only runs the recursion (18 multiply-adds, exponent bookkeeping,
+//     the DPP hand-over) and drops each cell - five mantissas, the exponent, the store slot - into an LDS ring; the second
+//     wave takes the cells out, turns them into the reference's storage format (five logarithms per cell, 60 of the
+//     step's ~170 vector instructions) and stores them.  Monotonic step counters in LDS in both directions.
+//   * all policies: the two envelope edges that are NOT part of the band - the rest of row 0 (x START: every column is
+//     in the envelope) and of column Ny-2 (the y state that feeds END) - are one-dimensional: the row-0 cells beyond the
+//     band form a chain IDM(0,j) = (IDM(0,j-1) + T[IDM][IDM]) + rootsuby[j], IMI likewise (every other term of the
+//     reference's sums is -inf, and log_sum_exp(-inf, v) = v exactly); the column's cells away from the band are -inf
+//     (y state not ready: no IMD / IIW; the cells to their left are outside the envelope) except (1, Ny-2), whose diagonal
+//     source lies in row 0.  The second wave writes them.
 //
-// Three arithmetic policies, as everywhere: scaled probabilities (HX_LSE_LINEAR: the step of hx_linear.hip), the
-// LDS-table log-sum-exp (HX_LSE_FAST) and the reference's table bit for bit (HX_LSE_EXACT) - the latter two through the
-// same leaf_cell as the strip pipeline, so exact mode stays bit-identical to the reference recursion.
+// Three arithmetic policies, as everywhere: scaled probabilities (the step of hx_linear.hip), the LDS-table log-sum-exp
+// (HX_LSE_FAST) and the reference's table bit for bit (HX_LSE_EXACT) - the latter two through the same leaf_cell as the
+// strip pipeline, so exact mode stays bit-identical to the reference recursion.
+//
+// Storage: the strip-skewed planes of hx_device.h, dense or band-compressed, written only where a row owns steps
+// (its span widened to whole step pairs; the pad cells are outside the envelope and get -inf).  Cells outside the
+// envelope that a dense plane holds are -inf from the pre-fill; with HX_SPARSE_ENVELOPE or HX_BAND_COMPRESSED they
+// are undefined (readers test the envelope, as with the reference's sparse cell map).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "hx_device.h"
@@ -40,10 +51,11 @@ namespace hx {
 namespace {
 
 typedef double d2v __attribute__((ext_vector_type(2)));
-typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i2v __attribute__((ext_vector_type(2)));
 
 #define HXB_EMIN (-(1 << 28))
 #define HXB_LOG_ENTRIES 1536       // the logarithm table of hx_linear.hip (build_log_table)
+#define HXB_RING 8                 // steps of cells in flight between the sweep and the converting wave
 
 // value of the previous lane, lane 0 receives lane 63's: one v_mov_b32_dpp wave_ror:1 per dword
 __device__ __forceinline__ int ror1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false); }
@@ -76,20 +88,22 @@ __device__ __forceinline__ double read_lane(double v, int l) {
 enum { POL_LINEAR = 0, POL_FAST = 1, POL_EXACT = 2 };
 
 // LDS plan (bytes), computed on the host (plan_band): the arithmetic's table first, then one block per pair
-struct BandPlan { int table, xrec, ycol, yclass, xclass, elds, stride, total, max_rows, max_cols; };
+struct BandPlan { int table, xrec, sbase, ycol, yclass, xclass, elds, ring, flags, stride, total; };
 
-// One row of the sweep (built by hx_api.hip build_band_rows), 16 bytes:
+// One row of the sweep (built by hx_api.hip build_band_rows), 8 bytes:
 //   x = first owned step | (owned steps - 1) << 16     (owned: an even first and an odd last step - the two cells a row
-//       produces on steps 2m, 2m+1 are stored together; the lane is busy with the row from its first to its last owned step)
+//       produces on steps 2m, 2m+1 are stored together; the lane is busy with the row from its first to its last owned step;
+//       0xFFFF in the low half: a sentinel row past the end, never owned)
 //   y = emission class | not ready << 8 | lead pad << 9 | tail pad << 10   (pads: owned steps that lie outside the envelope)
-//   z = store base A: the cell of step k lives at  A + (k >> 1) * blk + (k & 1)  in a state plane
-struct BandRow { int32_t steps, meta, store, pad_; };
+// followed, after the Nx - 1 + 64 records, by one int32 per 64-row strip: the cell of row i, step k lives at
+//   strip_store[i / 64] + 2 * (i % 64) + (k >> 1) * blk + (k & 1)   in a state plane.
 
 template <int POL, int PPW>
 __global__ void __launch_bounds__(2 * PPW * 64)
 k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const double* __restrict__ pol_tab,
             const BandPlan plan, const int n_jobs, const int write_edges) {
   constexpr int THREADS = 2 * PPW * 64;
+  constexpr bool OFFLOAD = POL == POL_LINEAR;        // the second wave converts and stores the sweep's cells
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
@@ -99,12 +113,18 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   const bool live = job < n_jobs;
   const DevJob& J = jobs[live ? job : 0];
   unsigned char* blkp = lds + plan.table + pair * plan.stride;
-  i4v* xrec = reinterpret_cast<i4v*>(blkp + plan.xrec);
-  unsigned* ycol = reinterpret_cast<unsigned*>(blkp + plan.ycol);
-  double* yclass = reinterpret_cast<double*>(blkp + plan.yclass);
-  double* xclass = reinterpret_cast<double*>(blkp + plan.xclass);
-  double* elds = reinterpret_cast<double*>(blkp + plan.elds);
   double* ptab = reinterpret_cast<double*>(lds);
+  // LDS views in their own address space (generic pointers would turn every access into a flat load, which also waits
+  // for the vector-memory queue, i.e. for the stores)
+  HX_LDS i2v* xrecL = (HX_LDS i2v*)(blkp + plan.xrec);
+  HX_LDS int* sbaseL = (HX_LDS int*)(blkp + plan.sbase);
+  HX_LDS unsigned* ycolL = (HX_LDS unsigned*)(blkp + plan.ycol);
+  HX_LDS d2v* yclassL = (HX_LDS d2v*)(blkp + plan.yclass);
+  HX_LDS d2v* xclassL = (HX_LDS d2v*)(blkp + plan.xclass);
+  HX_LDS double* eldsL = (HX_LDS double*)(blkp + plan.elds);
+  HX_LDS d2v* ringL = (HX_LDS d2v*)(blkp + plan.ring);           // [HXB_RING][3][64]
+  volatile HX_LDS int* progL = (volatile HX_LDS int*)(blkp + plan.flags);   // steps the sweep has put into the ring
+  volatile HX_LDS int* consL = progL + 1;                                   // steps the converting wave has taken out
 
   // ---- stage the shared table and the pair's two sides ----
   if (POL == POL_LINEAR) {
@@ -115,53 +135,95 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 2; k += THREADS) ptab[k] = pol_tab[k];
   }
   const int R = J.n_rows, Cc = J.n_cols;
+  const int n_strips = (R + 63) >> 6;
   {
-    const int pt = (int)(threadIdx.x & 63) + (helper ? 64 : 0);       // the pair's two waves stage together
+    const int pt = lane + (helper ? 64 : 0);                            // the pair's two waves stage together
     const int Ky1 = J.y.n_cls + 1, Kx1 = J.x.n_cls + 1;
-    const i4v* rows = reinterpret_cast<const i4v*>(J.band_rows);
-    for (int i = pt; i < R + 64; i += 128) xrec[i] = rows[i];           // (64 sentinel rows past the end: never owned)
+    const i2v* rows = reinterpret_cast<const i2v*>(J.band_rows);
+    const int* sb = reinterpret_cast<const int*>(rows + (R + 64));
+    for (int i = pt; i < R + 64; i += 128) xrecL[i] = rows[i];          // (64 sentinel rows past the end: never owned)
+    for (int q = pt; q < n_strips; q += 128) sbaseL[q] = sb[q];
     for (int j = pt; j < Cc; j += 128)
-      ycol[j] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0x100u : 0u);
+      ycolL[j] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0x100u : 0u);
     for (int c = pt; c < Ky1; c += 128) {
       const bool real = c < J.y.n_cls;
       const int rep = real ? J.y.cls_rep[c] : 0;
       const double rs = real ? J.y.pack[4 * (size_t)rep + 1] : HX_NEG_INF, in = real ? J.y.pack[4 * (size_t)rep + 2] : HX_NEG_INF;
-      yclass[2 * c] = POL == POL_LINEAR ? exp(rs) : rs;
-      yclass[2 * c + 1] = POL == POL_LINEAR ? exp(in) : in;
+      yclassL[c] = POL == POL_LINEAR ? d2v{exp(rs), exp(in)} : d2v{rs, in};
     }
     for (int c = pt; c < Kx1; c += 128) {
       const bool real = c < J.x.n_cls;
       const int rep = real ? J.x.cls_rep[c] : 0;
       const double rs = real ? J.x.pack[4 * (size_t)rep + 1] : HX_NEG_INF, in = real ? J.x.pack[4 * (size_t)rep + 2] : HX_NEG_INF;
-      xclass[2 * c] = POL == POL_LINEAR ? exp(rs) : rs;
-      xclass[2 * c + 1] = POL == POL_LINEAR ? exp(in) : in;
+      xclassL[c] = POL == POL_LINEAR ? d2v{exp(rs), exp(in)} : d2v{rs, in};
     }
-    for (int e = pt; e < Kx1 * Ky1; e += 128) elds[e] = POL == POL_LINEAR ? exp(J.emis_pad[e]) : J.emis_pad[e];
+    for (int e = pt; e < Kx1 * Ky1; e += 128) eldsL[e] = POL == POL_LINEAR ? exp(J.emis_pad[e]) : J.emis_pad[e];
+    if (pt < 2) progL[pt] = 0;
   }
   __syncthreads();
   const int64_t plane = J.plane;
   const int blk = J.blk;
   HX_GLOBAL double* __restrict__ M = as_global(J.fwd);
   const int Ky1 = J.y.n_cls + 1;
+  // anti-diagonal steps of the sweep, in whole blocks of eight (the extra steps own nothing)
+  const int n_steps = live ? (J.band_steps + 7) & ~7 : 0;
+  const HX_LDS double* lt = (const HX_LDS double*)ptab;
 
   if (helper) {
     // =====================================================================================================
-    // the envelope's one-dimensional edges (see the header comment).  Nothing here is read by the sweep.
+    // the second wave.  (1) scaled probabilities: cells out of the ring, logarithms, stores.
     // =====================================================================================================
-    if (!live) return;
+    if (OFFLOAD) {
+      int seen = 0;
+      for (int k = 0; k < n_steps; k += 2) {
+        while (seen < k + 2) {
+          seen = __builtin_amdgcn_readfirstlane(progL[0]);
+          if (seen < k + 2) __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
+        const HX_LDS d2v* s0 = ringL + (size_t)(k & (HXB_RING - 1)) * 192 + lane;
+        const HX_LDS d2v* s1 = ringL + (size_t)((k + 1) & (HXB_RING - 1)) * 192 + lane;
+        const d2v a0 = s0[0], b0 = s0[64], c0 = s0[128], a1 = s1[0], b1 = s1[64], c1 = s1[128];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) consL[0] = k + 2;               // (the slots may be overwritten: their contents are in registers)
+        const int e0 = __double2loint(c0.y), e1 = __double2loint(c1.y);
+        const int sl = __double2hiint(c0.y);           // the pair's slot in a state plane, or -1: the lane does not own it
+        const double l0 = log_scaled(a0.x, e0, lt), l1 = log_scaled(a0.y, e0, lt), l2 = log_scaled(b0.x, e0, lt),
+                     l3 = log_scaled(b0.y, e0, lt), l4 = log_scaled(c0.x, e0, lt);
+        const double h0 = log_scaled(a1.x, e1, lt), h1 = log_scaled(a1.y, e1, lt), h2 = log_scaled(b1.x, e1, lt),
+                     h3 = log_scaled(b1.y, e1, lt), h4 = log_scaled(c1.x, e1, lt);
+        if (sl >= 0) {
+          HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
+          const int64_t plane2 = plane >> 1;
+          // write-once data: non-temporal stores
+          __builtin_nontemporal_store(d2v{l0, h0}, &M2[0]);
+          __builtin_nontemporal_store(d2v{l1, h1}, &M2[plane2]);
+          __builtin_nontemporal_store(d2v{l2, h2}, &M2[2 * plane2]);
+          __builtin_nontemporal_store(d2v{l3, h3}, &M2[3 * plane2]);
+          __builtin_nontemporal_store(d2v{l4, h4}, &M2[4 * plane2]);
+        }
+      }
+    }
+    // =====================================================================================================
+    // (2) the envelope's one-dimensional edges (see the header comment).  Nothing here is read by the sweep.
+    // =====================================================================================================
+    if (live) {
     // row 0 beyond what the sweep owns: the chain in log space (every policy stores log-probabilities)
-    const int own0 = (xrec[0].x >> 16) & 0xFFFF;                       // row 0 is owned from step 0 to this step = column
+    const int own0 = (xrecL[0].x >> 16) & 0xFFFF;                      // row 0 is owned from step 0 to this step = column
+    const i2v rec1 = xrecL[1];
+    const bool row1_edge = ((rec1.x & 0xFFFF) + ((rec1.x >> 16) & 0xFFFF) - 1) < Cc - 1;   // row 1 does not own column Ny-2
     const double T02 = J.T[0][2], T03 = J.T[0][3], T22 = J.T[2][2], T33 = J.T[3][3];
     const double pen0 = J.x.pack[3];                                   // x START ready (or x empty): 0, else -inf
-    if (own0 < Cc - 1) {
+    double d_idm = HX_NEG_INF, d_imi = HX_NEG_INF;                     // cell (0, Ny-3): the diagonal source of (1, Ny-2)
+    if (own0 < Cc - 1 || row1_edge) {
       double idm = HX_NEG_INF, imi = HX_NEG_INF;                       // (the chain's value in every lane)
       for (int j0 = 0; j0 < Cc; j0 += 64) {
         const int jl = j0 + lane < Cc ? j0 + lane : Cc - 1;
-        const unsigned w = ycol[jl];
-        const double lrs = POL == POL_LINEAR ? J.y.pack[4 * (size_t)jl + 1] : yclass[2 * (w & 0xFFu)];
-        const double lin = POL == POL_LINEAR ? J.y.pack[4 * (size_t)jl + 2] : yclass[2 * (w & 0xFFu) + 1];
+        const unsigned w = ycolL[jl];
+        const double lrs = POL == POL_LINEAR ? J.y.pack[4 * (size_t)jl + 1] : yclassL[w & 0xFFu].x;
+        const double lin = POL == POL_LINEAR ? J.y.pack[4 * (size_t)jl + 2] : yclassL[w & 0xFFu].y;
         double kidm = HX_NEG_INF, kimi = HX_NEG_INF;
-#pragma unroll
+#pragma unroll 2
         for (int m = 0; m < 64; ++m) {
           const int j = j0 + m;                                         // (wave-uniform)
           const double r = read_lane(lrs, m), n = read_lane(lin, m);
@@ -170,6 +232,7 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
             idm = (((j == 1 ? T02 : idm + T22) + 0.0) + r) + pen0;
             imi = (((j == 1 ? T03 : imi + T33) + 0.0) + n) + pen0;
           }
+          if (j == Cc - 2) { d_idm = idm; d_imi = imi; }
           if (lane == m) { kidm = idm; kimi = imi; }
         }
         const int j = j0 + lane;
@@ -181,10 +244,45 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
         }
       }
     }
-    // column Ny-2 away from the band: -inf (only where the matrix was not pre-filled)
+    // Cell (1, Ny-2) when row 1's band does not reach it: always in the envelope (column Ny-2), and its diagonal source
+    // (0, Ny-3) is too (row 0) - the one cell of that column away from the band that is not -inf.  The same leaf_cell
+    // (log policies; the scaled-probability policy: the same sum with libm, written as a log-probability) with -inf above
+    // and to the left.
+    if (row1_edge) {
+      C5 diag = c5_neg_inf();
+      if (Cc - 2 == 0) diag.imm = 0.0; else { diag.idm = d_idm; diag.imi = d_imi; }
+      const unsigned w = ycolL[Cc - 1];
+      const unsigned c = w & 0xFFu;
+      const unsigned eo = (unsigned)(rec1.y & 0xFF) * (unsigned)Ky1;
+      C5 nw = c5_neg_inf();
+      if (POL == POL_LINEAR) {
+        double sum = 0.;
+        const double dv[5] = {diag.imm, diag.imd, diag.idm, diag.imi, diag.iiw};
+        double mx = HX_NEG_INF;
+        for (int q = 0; q < 5; ++q) mx = vmax(mx, dv[q] + J.T[q][0]);
+        for (int q = 0; q < 5; ++q) sum += (dv[q] + J.T[q][0] > HX_NEG_INF) ? exp(dv[q] + J.T[q][0] - mx) : 0.;
+        nw.imm = mx > HX_NEG_INF ? mx + log(sum) + J.emis_pad[eo + c] : HX_NEG_INF;
+      } else {
+        XLeaf X;
+        const d2v xc = xclassL[rec1.y & 0xFF];
+        X.lp = 0.0; X.rootsub = xc.x; X.ins = xc.y; X.pen = (rec1.y & 0x100) ? HX_NEG_INF : 0.0; X.eoff = eo; X.valid = true;
+        const d2v rc = yclassL[c];
+        const d4v Y = d4v{0.0, rc.x, rc.y, __hiloint2double((w & 0x100u) ? (int)0xFFF00000 : 0, 0)};
+        double Tk[5][6];
+        for (int a = 0; a < 5; ++a) for (int d = 0; d < 6; ++d) Tk[a][d] = J.T[a][d];
+        const C5 ninf = c5_neg_inf();
+        if (POL == POL_FAST) nw = leaf_cell(Tk, FastLse::make(ptab), X, Y, eldsL[eo + c], 0.0, ninf, ninf, diag);
+        else nw = leaf_cell(Tk, ExactLse3::make(pol_tab), X, Y, eldsL[eo + c], 0.0, ninf, ninf, diag);
+      }
+      const int64_t sl = stored_slot(J, 1, Cc - 1);
+      if (lane == 0 && sl >= 0) {
+        M[sl] = nw.imm; M[plane + sl] = nw.imd; M[2 * plane + sl] = nw.idm; M[3 * plane + sl] = nw.imi; M[4 * plane + sl] = nw.iiw;
+      }
+    }
+    // the rest of column Ny-2 away from the band: -inf (only where the matrix was not pre-filled)
     if (write_edges)
-      for (int i = 1 + lane; i < R; i += 64) {
-        const i4v rec = xrec[i];
+      for (int i = 2 + lane; i < R; i += 64) {
+        const i2v rec = xrecL[i];
         const int last_col = (rec.x & 0xFFFF) + ((rec.x >> 16) & 0xFFFF) - i;   // column of the row's last owned step
         if (last_col < Cc - 1) {
           const int64_t sl = stored_slot(J, i, Cc - 1);
@@ -193,53 +291,54 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
           }
         }
       }
-    return;
-  }
-
+    }
+  } else {
   // =======================================================================================================
   // the sweep
   // =======================================================================================================
-  const int n_steps = live ? J.band_steps : 0;
   // the lane's row, decoded; and the raw record of the row it takes next (i + 64), fetched a whole row ahead
   int i = lane, os, oe, as, ae, store;
   unsigned eoff;
   double xc_rs, xc_in;         // exp(rootsubx), exp(insx) (scaled probabilities) or rootsubx, insx
   int x_wait;                  // x state not ready: 2^29 (an exponent shift) / the 0 or -inf penalty lives in xpen
   double xpen;
-  i4v nrec;
+  i2v nrec;
   d2v nxc = d2v{0., 0.};
-  auto decode = [&](const i4v r, const d2v xc) {
+  int nstore = 0;
+  auto decode = [&](const i2v r, const d2v xc, const int sb) {
     os = r.x & 0xFFFF; oe = os + ((r.x >> 16) & 0xFFFF);
     as = os + ((r.y >> 9) & 1); ae = oe - ((r.y >> 10) & 1);
     if ((r.x & 0xFFFF) == 0xFFFF) { os = 0x7FFFFFF0; oe = 0x7FFFFFF1; as = os; ae = oe; }     // sentinel: never owned
-    store = r.z;
+    store = sb;
     eoff = (unsigned)(r.y & 0xFF) * (unsigned)Ky1;
     x_wait = (r.y & 0x100) ? (1 << 29) : 0;
     xpen = (r.y & 0x100) ? HX_NEG_INF : 0.0;
     xc_rs = xc.x; xc_in = xc.y;
   };
+  auto store_base = [&](const int row) -> int { return sbaseL[row < R ? row >> 6 : 0] + 2 * (row & 63); };
   {
-    const i4v r0 = xrec[lane < R ? lane : R];
-    decode(r0, reinterpret_cast<const d2v*>(xclass)[r0.y & 0xFF]);
-    nrec = xrec[lane + 64 < R ? lane + 64 : R];
+    const i2v r0 = xrecL[lane < R ? lane : R];
+    decode(r0, xclassL[r0.y & 0xFF], store_base(lane));
+    nrec = xrecL[lane + 64 < R ? lane + 64 : R];
   }
-  // the 18 transition weights, pinned in scalar registers: probabilities or log-probabilities
+  // the 18 transition weights the recursion reads, pinned in scalar registers: probabilities or log-probabilities
+  // (dest 5 = EEE is only read by lpEnd)
   double P[5][6];
 #pragma unroll
   for (int a = 0; a < 5; ++a)
 #pragma unroll
     for (int d = 0; d < 6; ++d) {
+      const bool used = d == 0 || (d == 1 && a != 4) || (d == 2 && a != 3) || (d == 3 && (a == 0 || a == 3)) ||
+                        (d == 4 && (a == 0 || a == 3 || a == 4));
       double v = J.T[a][d];
+      if (!used) { P[a][d] = POL == POL_LINEAR ? 0. : v; continue; }
       if (POL == POL_LINEAR) {
-        const bool used = d == 0 || (d == 1 && a != 4) || (d == 2 && a != 3) || (d == 3 && (a == 0 || a == 3)) ||
-                          (d == 4 && (a == 0 || a == 3 || a == 4));
-        const double pv = used ? exp(v) : 0.;
+        const double pv = exp(v);
         v = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(pv)), __builtin_amdgcn_readfirstlane(__double2loint(pv)));
       }
       asm volatile("" : "+s"(v));
       P[a][d] = v;
     }
-  const HX_LDS double* lt = (const HX_LDS double*)ptab;
   const FastLse LF = FastLse::make(ptab);
   const ExactLse3 LE = ExactLse3::make(pol_tab);
 
@@ -248,39 +347,51 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   L5 la = l5_zero(), lb = l5_zero(), lua = l5_zero(), lub = l5_zero();
   C5 ca = c5_neg_inf(), cb = c5_neg_inf(), cua = c5_neg_inf(), cub = c5_neg_inf();
 
-  // the y word of the lane's column, fetched one step ahead
+  // The y side of a step, fetched ahead so that no LDS round trip is ever waited for: the column's word two steps
+  // ahead, and - from the word fetched the step before - the column's class constants and the emission term one step
+  // ahead.  A lane that is about to change rows looks up the NEXT row's column / emission row.
   auto word_at = [&](const int col) -> unsigned {
     const int c = col < 0 ? 0 : (col >= Cc ? Cc - 1 : col);
-    return ycol[c];
+    return ycolL[c];
   };
-  unsigned wnext = word_at(0 - i);
+  unsigned neoff = 0;
+  unsigned w_cur = word_at(0 - i), w_nxt = word_at(1 - i);        // words of steps k, k + 1
+  d2v rc_cur = yclassL[w_cur & 0xFFu];                            // class constants of step k
+  double em_cur = eldsL[eoff + (w_cur & 0xFFu)];
 
-  // beginning of a step: a lane whose row ended with the previous step takes row i + 64; a lane whose row ends with this
-  // step fetches the class constants of its next row now (so that neither LDS round trip is ever waited for)
-  auto roll = [&](const int k) {
-    if (k + 1 > oe) {
-      if (k > oe) {
-        i += 64;
-        decode(nrec, nxc);
-        nrec = xrec[i + 64 < R ? i + 64 : R];
-      } else {
-        nxc = reinterpret_cast<const d2v*>(xclass)[nrec.y & 0xFF];
-      }
+  // Owned spans are whole step pairs, so a lane changes rows at even steps only: at the even step after its row's last
+  // step it takes row i + 64 (record fetched a row ago, class constants one step ago), and at the odd step that ends a
+  // row it fetches the next row's class constants and store base.
+  auto roll_even = [&](const int k) {
+    if (k > oe) {
+      i += 64;
+      decode(nrec, nxc, nstore);
+      nrec = xrecL[i + 64 < R ? i + 64 : R];
     }
   };
-  // the word of step k + 1: of the next row's column when the lane is about to change rows
-  auto next_word = [&](const int k) -> unsigned {
-    const unsigned w = wnext;
-    const int inext = (k + 1 > oe) ? i + 64 : i;
-    wnext = word_at(k + 1 - inext);
-    return w;
+  auto roll_odd = [&](const int k) {
+    if (k == oe) {
+      nxc = xclassL[nrec.y & 0xFF];
+      nstore = store_base(i + 64);
+      neoff = (unsigned)(nrec.y & 0xFF) * (unsigned)Ky1;
+    }
+  };
+  struct YSide { unsigned w; d2v rc; double em; };
+  // hand out step k's y side, issue the fetches for steps k + 1 (constants) and k + 2 (word)
+  auto y_side = [&](const int k) -> YSide {
+    const YSide now{w_cur, rc_cur, em_cur};
+    const unsigned c1 = w_nxt & 0xFFu;
+    rc_cur = yclassL[c1];
+    em_cur = eldsL[((k + 1 > oe) ? neoff : eoff) + c1];
+    w_cur = w_nxt;
+    w_nxt = word_at(k + 2 - ((oe <= k + 1) ? i + 64 : i));
+    return now;
   };
 
-  auto step_linear = [&](const int k, const L5& left, L5& out, L5& u1, L5& u2, const unsigned w) {
-    const unsigned c = w & 0xFFu;
-    const d2v rc = reinterpret_cast<const d2v*>(yclass)[c];
-    const int y_wait = (int)((w & 0x100u) << 21);           // y state not ready: 2^29, else 0
-    const double em = elds[eoff + c];
+  auto step_linear = [&](const int k, const bool renorm, const L5& left, L5& out, L5& u1, L5& u2, const YSide ys) {
+    const d2v rc = ys.rc;
+    const int y_wait = (int)((ys.w & 0x100u) << 21);        // y state not ready: 2^29, else 0
+    const double em = ys.em;
     // the five sums of src/forward.cpp:103-115,139-150,171-180 on probabilities
     double s_imd = u1.imm * P[0][1];
     double s_iiw = u1.imm * P[0][4];
@@ -312,7 +423,7 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     out.imi = __builtin_ldexp(s_imi * rc.y, dl);
     out.imm = __builtin_ldexp(s_imm * em, dd);
     out.e = E;
-    if ((k & 6) == 0) {                            // wave-uniform: renormalise every 8th step
+    if (renorm) {                                  // (compile-time: the first two steps of every block of eight)
       if (k == 0 && lane == 0) { out.imm = 1.0; out.e = 0; }     // cell (0,0): lpStart() = 0 (src/forward.cpp:73)
       const double mx = vmax(vmax(vmax(out.imm, out.imd), vmax(out.idm, out.imi)), out.iiw);
       const int kk = __builtin_amdgcn_frexp_exp(mx);
@@ -326,11 +437,10 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     u2 = ror1(out);                                // the previous lane's new cell: next step's upper neighbour
   };
 
-  auto step_log = [&](const int k, const C5& left, C5& out, C5& u1, C5& u2, const unsigned w) {
-    const unsigned c = w & 0xFFu;
-    const d2v rc = reinterpret_cast<const d2v*>(yclass)[c];
-    const double em = elds[eoff + c];
-    const double ypen = __hiloint2double((w & 0x100u) ? (int)0xFFF00000 : 0, 0);     // y state not ready: -inf
+  auto step_log = [&](const int k, const C5& left, C5& out, C5& u1, C5& u2, const YSide ys) {
+    const d2v rc = ys.rc;
+    const double em = ys.em;
+    const double ypen = __hiloint2double((ys.w & 0x100u) ? (int)0xFFF00000 : 0, 0);  // y state not ready: -inf
     const double pj = (k >= as && k <= ae) ? 0.0 : HX_NEG_INF;
     XLeaf X;
     X.lp = 0.0; X.rootsub = xc_rs; X.ins = xc_in; X.pen = xpen; X.eoff = eoff; X.valid = true;
@@ -343,54 +453,71 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     u2 = ror1(nw);
   };
 
-  for (int k = 0; k < n_steps; k += 2) {
-    // a pair of steps: in the strip-skewed layout the two cells are adjacent, 16 bytes per lane and state plane
-    double s0[5], s1[5];
-    roll(k);
+  // a pair of steps: in the strip-skewed layout the two cells are adjacent, 16 bytes per lane and state plane
+  int cons_seen = 0;
+  auto step_pair = [&](const int k, const bool renorm) {
+    roll_even(k);
     const bool own = k >= os && k <= oe;           // (owned spans are whole step pairs)
-    const int64_t sl = (int64_t)store + (int64_t)(k >> 1) * blk;
-    if (POL == POL_LINEAR) {
-      step_linear(k, lb, la, lua, lub, next_word(k));
-      s0[0] = log_scaled(la.imm, la.e, lt); s0[1] = log_scaled(la.imd, la.e, lt); s0[2] = log_scaled(la.idm, la.e, lt);
-      s0[3] = log_scaled(la.imi, la.e, lt); s0[4] = log_scaled(la.iiw, la.e, lt);
-      roll(k + 1);
-      step_linear(k + 1, la, lb, lub, lua, next_word(k + 1));
-      s1[0] = log_scaled(lb.imm, lb.e, lt); s1[1] = log_scaled(lb.imd, lb.e, lt); s1[2] = log_scaled(lb.idm, lb.e, lt);
-      s1[3] = log_scaled(lb.imi, lb.e, lt); s1[4] = log_scaled(lb.iiw, lb.e, lt);
+    const int sl = store + (k >> 1) * blk;
+    if (OFFLOAD) {
+      // the ring slots of steps k, k + 1 were last used by steps k - 8, k - 7: the converting wave must be past them
+      while (cons_seen < k + 2 - HXB_RING) {
+        cons_seen = __builtin_amdgcn_readfirstlane(consL[0]);
+        if (cons_seen < k + 2 - HXB_RING) __builtin_amdgcn_s_sleep(1);
+      }
+      step_linear(k, renorm, lb, la, lua, lub, y_side(k));
+      HX_LDS d2v* s0 = ringL + (size_t)(k & (HXB_RING - 1)) * 192 + lane;
+      s0[0] = d2v{la.imm, la.imd}; s0[64] = d2v{la.idm, la.imi}; s0[128] = d2v{la.iiw, __hiloint2double(own ? sl : -1, la.e)};
+      roll_odd(k + 1);
+      step_linear(k + 1, renorm, la, lb, lub, lua, y_side(k + 1));
+      HX_LDS d2v* s1 = ringL + (size_t)((k + 1) & (HXB_RING - 1)) * 192 + lane;
+      s1[0] = d2v{lb.imm, lb.imd}; s1[64] = d2v{lb.idm, lb.imi}; s1[128] = d2v{lb.iiw, __hiloint2double(0, lb.e)};
+      asm volatile("" ::: "memory");               // data before flag (LDS operations of a wave complete in order)
+      if (lane == 0) progL[0] = k + 2;
     } else {
-      step_log(k, cb, ca, cua, cub, next_word(k));
-      s0[0] = ca.imm; s0[1] = ca.imd; s0[2] = ca.idm; s0[3] = ca.imi; s0[4] = ca.iiw;
-      roll(k + 1);
-      step_log(k + 1, ca, cb, cub, cua, next_word(k + 1));
-      s1[0] = cb.imm; s1[1] = cb.imd; s1[2] = cb.idm; s1[3] = cb.imi; s1[4] = cb.iiw;
+      step_log(k, cb, ca, cua, cub, y_side(k));
+      const C5 first = ca;
+      roll_odd(k + 1);
+      step_log(k + 1, ca, cb, cub, cua, y_side(k + 1));
+      if (own) {
+        HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
+        const int64_t plane2 = plane >> 1;
+        // write-once data: non-temporal stores
+        __builtin_nontemporal_store(d2v{first.imm, cb.imm}, &M2[0]);
+        __builtin_nontemporal_store(d2v{first.imd, cb.imd}, &M2[plane2]);
+        __builtin_nontemporal_store(d2v{first.idm, cb.idm}, &M2[2 * plane2]);
+        __builtin_nontemporal_store(d2v{first.imi, cb.imi}, &M2[3 * plane2]);
+        __builtin_nontemporal_store(d2v{first.iiw, cb.iiw}, &M2[4 * plane2]);
+      }
     }
-    if (own) {
-      HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
-      const int64_t plane2 = plane >> 1;
-      // write-once data: non-temporal stores
-      __builtin_nontemporal_store(d2v{s0[0], s1[0]}, &M2[0]);
-      __builtin_nontemporal_store(d2v{s0[1], s1[1]}, &M2[plane2]);
-      __builtin_nontemporal_store(d2v{s0[2], s1[2]}, &M2[2 * plane2]);
-      __builtin_nontemporal_store(d2v{s0[3], s1[3]}, &M2[3 * plane2]);
-      __builtin_nontemporal_store(d2v{s0[4], s1[4]}, &M2[4 * plane2]);
-    }
+  };
+  for (int k = 0; k < n_steps; k += 8) {
+    step_pair(k, true);                            // (scaled probabilities: mantissas renormalised every eighth step)
+    step_pair(k + 2, false);
+    step_pair(k + 4, false);
+    step_pair(k + 6, false);
   }
+  }
+  // lpEnd reads cell (Nx-2, Ny-2): the sweep's last cell (stored by either wave), or - a one-row band - an edge cell
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (live && lane == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
+  __syncthreads();
+  if (!helper && live && lane == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
 }
 
 BandPlan plan_band(int pol, int ppw, int max_rows, int max_cols, int max_cls) {
   BandPlan p;
   p.table = pol == POL_LINEAR ? 16 * HXB_LOG_ENTRIES : (pol == POL_FAST ? 16 * (HX_FAST_INTERVALS + 1) : 16);
   int a = 0;
-  p.xrec = a; a += 16 * (max_rows + 64);
+  p.xrec = a; a += (8 * (max_rows + 64) + 15) & ~15;
+  p.sbase = a; a += (4 * ((max_rows + 63) / 64 + 1) + 15) & ~15;
   p.ycol = a; a += (4 * max_cols + 15) & ~15;
   p.yclass = a; a += 16 * (max_cls + 1);
   p.xclass = a; a += 16 * (max_cls + 1);
   p.elds = a; a += (8 * (max_cls + 1) * (max_cls + 1) + 15) & ~15;
+  p.ring = a; a += pol == POL_LINEAR ? HXB_RING * 3 * 64 * 16 : 0;
+  p.flags = a; a += 16;
   p.stride = a;
   p.total = p.table + ppw * a;
-  p.max_rows = max_rows; p.max_cols = max_cols;
   return p;
 }
 
@@ -410,23 +537,18 @@ bool band_kernel_fits(int pol, int rows, int cols, int cls) { return plan_band(p
 
 int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, const double* tab,
                         const double* pol_tab, bool write_edges, hipStream_t st) {
-  // pairs per workgroup (they share the policy's table): as many as keep two workgroups on a CU while the batch still
-  // gives every CU a workgroup
+  // Pairs per workgroup (they share the policy's table).  A CU holds 160 KB of LDS and four SIMDs; a pair is two waves.
+  // One pair per workgroup while two such workgroups fit a CU; else two pairs share the table if that fits (the 64 KB
+  // table of the fast policy); large batches put up to four pairs in a workgroup.
   const char* v = getenv("HX_BAND_PPW");           // tuning / test hook
   int ppw = v ? atoi(v) : 0;
   if (ppw <= 0) {
+    const int half = 72 * 1024;                    // (two workgroups of exactly 80 KB were measured NOT to fit a CU)
     ppw = 1;
-    const int half = HX_LDS_LIMIT / 2 - 1024;
-    if (n_jobs > 512) {
-      for (int c = 2; c <= 4; c *= 2)
-        if (plan_band(pol, c, max_rows, max_cols, max_cls).total <= half && n_jobs >= 256 * c) ppw = c;
-    }
-    if (plan_band(pol, ppw, max_rows, max_cols, max_cls).total > HX_LDS_LIMIT) ppw = 1;
-    // the fast table alone is 64 KB: two pairs share it when that lets a CU hold four pairs instead of one
-    if (pol == POL_FAST && ppw == 1 && plan_band(pol, 2, max_rows, max_cols, max_cls).total <= HX_LDS_LIMIT &&
-        plan_band(pol, 1, max_rows, max_cols, max_cls).total > half)
-      ppw = 2;
+    if (plan_band(pol, 1, max_rows, max_cols, max_cls).total > half && plan_band(pol, 2, max_rows, max_cols, max_cls).total <= HX_LDS_LIMIT) ppw = 2;
+    if (n_jobs > 1024 && plan_band(pol, 4, max_rows, max_cols, max_cls).total <= HX_LDS_LIMIT) ppw = 4;
   }
+  if (ppw > 1 && plan_band(pol, ppw, max_rows, max_cols, max_cls).total > HX_LDS_LIMIT) ppw = 1;
   const int we = write_edges ? 1 : 0;
 #define HXB_GO(POL_) do { \
     if (ppw >= 4) return launch_pol<POL_, 4>(d_jobs, n_jobs, plan_band(POL_, 4, max_rows, max_cols, max_cls), tab, pol_tab, we, st); \

@@ -103,6 +103,11 @@ struct DevJob {
   int32_t pad3_;
   int64_t matrix_doubles;     // doubles of one whole matrix (all five states)
   const uint32_t* yword_bwd;  // the same for the Backward sweep (mirrored column order, class of the state an absorbing move leads to)
+  // banded rotating-row sweep (hx_band.hip): one 16-byte record per row + 64 sentinel records, and the number of
+  // anti-diagonal steps of the sweep; nullptr when the pair does not run on that kernel
+  const void* band_rows;
+  int32_t band_steps;
+  int32_t pad4_;
 };
 
 // One pair of the guide-alignment Viterbi batch (hx_quick.hip)

@@ -53,6 +53,11 @@ int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, b
 int launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
                                  int yl_cols, int yl_emis, int yl_cls, hipStream_t st);
 
+// banded leaf-like pairs, rotating-row sweep (hx_band.hip); pol: 0 = scaled probabilities, 1 = fast, 2 = exact
+bool band_kernel_fits(int pol, int rows, int cols, int cls);
+int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, const double* tab,
+                        const double* pol_tab, bool write_edges, hipStream_t st);
+
 void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, const double* tab,
                        bool plane_valid, hipStream_t st);
 

@@ -76,7 +76,8 @@ enum { HX_IMM = 0, HX_IMD = 1, HX_IDM = 2, HX_IMI = 3, HX_IIW = 4, HX_STATES = 5
                                  with band 20 takes ~15 MB instead of 169 MB, so thousands of pairs fit one batch (the
                                  reference's sparse cell map, src/forward.h:22,68, is the same idea).  hx_layout::compressed
                                  is set and hx_batch_strip_windows describes the planes; hx_batch_read_cells,
-                                 hx_batch_best_trace and lpEnd work as usual.  Implemented by the Forward fills of chain
+                                 hx_batch_best_trace and lpEnd work as usual.  As with HX_SPARSE_ENVELOPE, a stored cell that
+                                 lies outside the envelope is undefined in hx_batch_read_matrix (test the envelope).  Implemented by the Forward fills of chain
                                  (leaf) profiles, in every arithmetic policy; no general profiles, no Backward fill.   */
 
 /* POD image of a reference Profile (src/profile.h:13-76) restricted to what the

@@ -57,6 +57,11 @@ def oracle_dense(dp):
     return out
 
 
+def envelope_mask(dp):
+    """[R][Cc] bool: the cells of an oracle DPMatrix that lie inside its envelope (reference src/forward.h:92-98)."""
+    return np.array([[dp.in_envelope(i, j) for j in range(dp.y_size - 1)] for i in range(dp.x_size - 1)], dtype=bool)
+
+
 def same_bits(a, b):
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
