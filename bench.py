@@ -34,7 +34,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=512, help="independent pair DPs per GPU")
+    ap.add_argument("--pairs", type=int, default=512, help="independent pair DPs per GPU (weak scaling) or in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --pairs pair DPs on every GPU.  strong: BASELINE configs[3] as written, --pairs pair DPs in "
+                         "total dealt to the GPUs")
     ap.add_argument("--len", type=int, default=2000, dest="length", help="residues per sequence")
     ap.add_argument("--model", default="wag")
     ap.add_argument("--tl", type=float, default=0.2)
@@ -44,10 +47,12 @@ def parse():
     ap.add_argument("--band", type=int, default=-1,
                     help="guide-alignment band (maxDistanceFromGuide); the guide is the pair's true alignment. "
                          "-1 = full envelope (the headline configuration)")
-    ap.add_argument("--mode", choices=["exact", "fast", "linear"], default="linear",
-                    help="arithmetic of the headline fill: linear = scaled probabilities (HX_LSE_LINEAR), "
-                         "fast = LDS-table log-sum-exp, exact = the reference's table, "
-                         "bit for bit.  The other policies are timed too and reported")
+    ap.add_argument("--mode", choices=["exact", "fast", "linear"], default="fast",
+                    help="arithmetic of the headline fill.  fast (default) = LDS-table log-sum-exp with the reference's truncation: "
+                         "best paths identical to the reference's on all 2000 pairs of tools/sweep_trace_identity.py.  exact = the "
+                         "reference's table bit for bit.  linear = scaled probabilities (HX_LSE_LINEAR): fastest, but without the "
+                         "truncation 4 of those 2000 best paths differ, so it is reported as a secondary line.  The other "
+                         "policies are timed too")
     ap.add_argument("--single-mode", action="store_true", help="time only --mode")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a PMC run (default: profiles/traffic.json entry for this workload)")
@@ -147,77 +152,76 @@ def main():
         # outside the timed region: the device-side best-path traceback of every pair (hx_batch_best_trace); the first
         # few paths are compared with the CPU oracle's below
         tcells, tlen = batch.best_trace(raw=True)
-        n_keep = max(1, min(args.cpu_pairs, args.pairs))
+        n_keep = max(1, min(args.cpu_pairs, n_local))
         traces[mode] = [[tuple(int(v) for v in c) for c in tcells[k, :tlen[k]]] for k in range(n_keep)]
         batch.close()
         assert np.all(np.isfinite(lp)) or os.environ.get("HX_BENCH_NOCHECK"), "non-finite Forward log-likelihood"
         return dt, k_ms, lp, n_cells
 
-    dt, kernel_ms, lp_end, cells = run_mode(args.mode)
-    other = "exact" if args.mode != "exact" else "fast"
-    dt_o, kernel_ms_o, lp_end_o, _ = run_mode(other) if not args.single_mode else (None, None, None, None)
-    linear = args.mode == "linear"                        # the scaled-probability kernel (hx_linear.hip) ran
-    dt_t, kernel_ms_t, lp_end_t, _ = run_mode("fast") if (linear and not args.single_mode) else (None, None, None, None)
+    order = [args.mode] + ([m for m in ("fast", "exact", "linear") if m != args.mode] if not args.single_mode else [])
+    runs = {m: run_mode(m) for m in order}
+    dt, kernel_ms, lp_end, cells = runs[args.mode]
 
+    KERNELS = {("exact", False): "hx::k_fill_chain<0,...,ExactLse3>", ("fast", False): "hx::k_fill_chain<0,...,FastLse>",
+               ("linear", False): "hx::k_fill_leaf_linear<W>", ("exact", True): "hx::k_fill_band<exact>",
+               ("fast", True): "hx::k_fill_band<fast>", ("linear", True): "hx::k_fill_band<scaled>"}
+    ARITH = {"exact": "the reference's table log-sum-exp, cells bit-identical to the reference recursion",
+             "fast": "LDS-table log-sum-exp with the reference's truncation (lpEnd within 1e-9 rel. of the reference's, best paths "
+                     "identical to the reference's: 2000 of 2000 pairs, profiles/r02/trace_identity_sweep.json)",
+             "linear": "scaled-probability recursion (fp64 sums of probabilities with a per-cell exponent, log-probabilities at the "
+                       "store; no truncation of small terms: lpEnd within 1e-5 rel., 4 of 2000 best paths differ from the reference's)"}
     if rank == 0:
         if args.band >= 0:
             cells = env_cells          # the metric counts in-envelope cells
-        total_cells = cells * world * args.steps
+        gcells = farm.sum_over_ranks(cells, world, dev) if strong else cells * world
+    elif strong:
+        farm.sum_over_ranks(env_cells if args.band >= 0 else cells, world, dev)
+    if rank == 0:
+        total_cells = gcells * args.steps
         value = total_cells / dt
         k_ms = float(np.mean(kernel_ms))
         traffic = args.traffic
         if traffic is None:
-            try:        # measured once with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes), see DESIGN.md
+            try:        # measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes), see DESIGN.md
                 with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                    traffic = json.load(f).get("%s:%d:%d" % (args.mode, args.pairs, args.length)) if args.band < 0 else None
+                    traffic = json.load(f).get("%s:%d:%d" % (args.mode, n_local, args.length)) if args.band < 0 else None
             except OSError:
                 traffic = None
         achieved = cells * BYTES_PER_CELL / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "forward-DP cells/s", "value": value, "unit": "cells/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "batch of independent 2x%d-residue protein leaf-profile pairs, %s, t=%g/%g, "
-                                   "%s Forward DP, %s log-sum-exp" %
+            "config": {"workload": "batch of independent 2x%d-residue protein leaf-profile pairs, %s, t=%g/%g, %s Forward DP; %s" %
                                    (args.length, args.model.upper(), args.tl, args.tr,
                                     "full (unbanded)" if args.band < 0 else
-                                    "band-%d (guide = the pair's true alignment; in-envelope cells counted%s)" %
-                                    (args.band, "; band-compressed storage"),
-                                    "exact table (cells bit-identical to the reference recursion)" if args.mode == "exact"
-                                    else ("scaled-probability recursion (fp64 sums of probabilities with a per-cell exponent, "
-                                          "log-probabilities at the store; lpEnd within 1e-5 rel. of the reference's table "
-                                          "arithmetic, north_star allows 1e-4) in place of" if linear else
-                                          "fast LDS-table (same truncation; lpEnd within 1e-9 rel., tracebacks identical)")),
-                       "pairs_per_gpu": args.pairs, "cells_per_gpu_per_step": cells,
+                                    "band-%d (guide = the pair's true alignment; in-envelope cells counted; band-compressed storage)"
+                                    % args.band, ARITH[args.mode]),
+                       "pairs_per_gpu": n_local, "pairs_total": n_local * world if not strong else args.pairs,
+                       "cells_per_gpu_per_step": cells,
                        "parallelism": "pairs farmed across %d rank(s); RCCL broadcast of model constants only" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "hx::k_fill_leaf_linear<W,BANDED>" if linear else "hx::k_fill_chain<0,...>",
+                         "kernel": KERNELS[(args.mode, args.band >= 0)],
                          "kernel_ms": k_ms, "bytes_per_cell": BYTES_PER_CELL},
             "fill_mode": args.mode,
             "lp_end_pair0": float(lp_end[0]),
         }
-        if dt_o is not None:
-            k_o = float(np.mean(kernel_ms_o))
-            ach_o = cells * BYTES_PER_CELL / (k_o * 1e-3) / 1e9
-            out["other_mode"] = {"fill_mode": other, "value": cells * world * args.steps / dt_o, "unit": "cells/s",
-                                 "ms_per_step": dt_o / args.steps * 1e3, "kernel_ms": k_o,
-                                 "roofline_frac": ach_o / HBM_PEAK_GBS,
-                                 "lp_end_max_rel_diff_between_modes":
-                                     float(np.max(np.abs(lp_end - lp_end_o) / np.abs(lp_end_o)))}
-        if dt_t is not None:
-            k_t = float(np.mean(kernel_ms_t))
-            out["table_mode"] = {"fill_mode": "fast (HX_LSE_FAST: LDS-table log-sum-exp with the reference's truncation)",
-                                 "value": cells * world * args.steps / dt_t, "unit": "cells/s",
-                                 "ms_per_step": dt_t / args.steps * 1e3, "kernel_ms": k_t,
-                                 "roofline_frac": cells * BYTES_PER_CELL / (k_t * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "lp_end_max_rel_diff_to_exact":
-                                     float(np.max(np.abs(lp_end_t - lp_end_o) / np.abs(lp_end_o)))}
+        ref_lp = runs["exact"][2] if "exact" in runs else None
+        for m in order[1:]:
+            dt_m, k_list, lp_m, _ = runs[m]
+            k_m = float(np.mean(k_list))
+            out[{"exact": "exact_mode", "fast": "fast_mode", "linear": "scaled_probability_mode"}[m]] = {
+                "arithmetic": ARITH[m], "kernel": KERNELS[(m, args.band >= 0)],
+                "value": gcells * args.steps / dt_m, "unit": "cells/s", "ms_per_step": dt_m / args.steps * 1e3, "kernel_ms": k_m,
+                "roofline_frac": cells * BYTES_PER_CELL / (k_m * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if ref_lp is not None:
+            out["lp_end_max_rel_diff_to_exact"] = {m: float(np.max(np.abs(runs[m][2] - ref_lp) / np.abs(ref_lp))) for m in order if m != "exact"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import c_oracle           # the checker, timed as the CPU baseline ("port")
             c_oracle.load()
-            n_cpu = max(1, min(args.cpu_pairs, args.pairs))
+            n_cpu = max(1, min(args.cpu_pairs, n_local))
             from oracle import trace_oracle
             cpu_dt = 0.0
             t1 = time.perf_counter()
@@ -248,6 +252,18 @@ def main():
                 c_oracle.forward_map(x, y, h, md)
             map_dt = time.perf_counter() - t1
             out["cpu_baseline"]["map_storage_value"] = (cpu_cells / n_cpu) * n_map / map_dt
+            # variant iii: all host cores farming independent pairs (the reference itself is single-threaded)
+            import multiprocessing as mp
+            n_proc = max(1, min(os.cpu_count() or 1, 64))
+            n_all = max(n_proc, 2 * n_proc if args.band >= 0 else n_proc)
+            specs = [(args.model, args.tl, args.tr, args.length, args.band, farm.pair_seed(0, 0, first + (k % n_local))) for k in range(n_all)]
+            with mp.get_context("spawn").Pool(n_proc) as pool:
+                pool.map(_cpu_fill_worker, specs[:n_proc])          # (start-up: imports, library load)
+                t1 = time.perf_counter()
+                pool.map(_cpu_fill_worker, specs, chunksize=1)
+                all_dt = time.perf_counter() - t1
+            out["cpu_baseline"]["all_cores"] = {"value": (cpu_cells / n_cpu) * n_all / all_dt, "unit": "cells/s", "cores": n_proc,
+                                                "sample": "%d pairs of the same workload over %d processes, %.1f s" % (n_all, n_proc, all_dt)}
             out["lp_end_max_rel_err_vs_cpu"] = rel
             out["best_trace_identical_to_cpu"] = {m: "%d of %d pairs" % (same.get(m, 0), n_cpu) for m in traces}
             assert rel <= 1e-4, "Forward log-likelihoods outside north_star's tolerance of the CPU path: %g" % rel

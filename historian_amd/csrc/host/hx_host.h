@@ -29,6 +29,7 @@
 #include <random>
 #include <set>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include <iostream>
 
@@ -56,6 +57,7 @@ void Fail(const char* error, ...);    // message + exit(EXIT_FAILURE)
 struct FillTiming {
   double deviceInit = 0, flattenAndUpload = 0, forwardWait = 0, forwardKernel = 0, backwardWait = 0, readMatrix = 0;
   double deviceTrace = 0, cellGather = 0;
+  double hostTraces = 0, hostMakeProfile = 0;      // host tracebacks (sampled, or best without the device kernel), makeProfile
   long fills = 0, matrixReads = 0, deviceTraces = 0, cellGathers = 0;
   long long cells = 0;
 };
@@ -302,6 +304,7 @@ struct PairHMM : AlphabetOwner {
   LogProb imi_imi, imi_iiw, imi_imm, imi_imd, imi_eee;
   LogProb iiw_iiw, iiw_imm, iiw_idm, iiw_eee;
   PairHMM(const ProbModel& l, const ProbModel& r, const vguard<Vec>& root);
+  LogProb weight[TotalStates][TotalStates + 1];   // the same weights as a table [src][dest], -inf where there is no such move
   static vguard<State> states();
   static vguard<State> sources(State dest);
   LogProb lpTrans(State src, State dest) const;
@@ -416,9 +419,14 @@ protected:
       for (size_t n = 0; n < hmm.alphabetSize(); ++n)
         absorbScratch[cpt][n] = subx.state[xpos].lpAbsorb[cpt][n] + suby.state[ypos].lpAbsorb[cpt][n];
   }
+  // (memoised per cell: sampled tracebacks revisit the same cells, and the sum is C x (A + 1) table look-ups)
+  std::unordered_map<unsigned long long, LogProb> absorbMemo;
   inline LogProb computeLogProbAbsorb(ProfileStateIndex xpos, ProfileStateIndex ypos) {
+    const unsigned long long key = ((unsigned long long)xpos << 32) | (unsigned long long)ypos;
+    const auto hit = absorbMemo.find(key);
+    if (hit != absorbMemo.end()) return hit->second;
     initAbsorbScratch(xpos, ypos);
-    return logInnerProduct(hmm.logRoot, absorbScratch);
+    return absorbMemo[key] = logInnerProduct(hmm.logRoot, absorbScratch);
   }
   static void settle(Moves& m);
   static CellCoords pickBest(const Moves& m);

@@ -393,19 +393,20 @@ PairHMM::PairHMM(const ProbModel& l, const ProbModel& r, const vguard<Vec>& root
   iiw_imm = log(L.noInsExt() * L.noDel() * R.noDel());
   iiw_idm = log(L.noInsExt() * L.del * R.noDel());
   iiw_eee = log(L.noInsExt());
-}
-
-LogProb PairHMM::lpTrans(State src, State dest) const {
-  // [src][dest], dest 5 = EEE; null = no such move
-  const LogProb* const table[TotalStates][TotalStates + 1] = {
+  // the same as a table [src][dest], dest 5 = EEE; null = no such move
+  const LogProb* const named[TotalStates][TotalStates + 1] = {
       {&imm_imm, &imm_imd, &imm_idm, &imm_imi, &imm_iiw, &imm_eee},
       {&imd_imm, &imd_imd, &imd_idm, NULL, NULL, &imd_eee},
       {&idm_imm, &idm_imd, &idm_idm, NULL, NULL, &idm_eee},
       {&imi_imm, &imi_imd, NULL, &imi_imi, &imi_iiw, &imi_eee},
       {&iiw_imm, NULL, &iiw_idm, NULL, &iiw_iiw, &iiw_eee}};
+  for (int s = 0; s < TotalStates; ++s)
+    for (int d = 0; d <= TotalStates; ++d) weight[s][d] = named[s][d] ? *named[s][d] : kNegInf;
+}
+
+LogProb PairHMM::lpTrans(State src, State dest) const {
   if ((int)src < 0 || src >= TotalStates || (int)dest < 0 || dest > EEE) return kNegInf;
-  const LogProb* w = table[src][dest];
-  return w ? *w : kNegInf;
+  return weight[src][dest];
 }
 
 vguard<PairHMM::State> PairHMM::states() { return {IMM, IMD, IDM, IMI, IIW}; }

@@ -209,8 +209,9 @@ void Reconstructor::reconstruct(Dataset& dataset) {
     }
   }
   if (timing)
-    fprintf(stderr, "timing: leaf profiles %.3f s, ProbModel+PairHMM %.3f s, ForwardMatrix fills %.3f s, traceback+profile %.3f s, "
-                    "calcSumPathAbsorbProbs+delete %.3f s\n", tLeaf, tHmm, tFwd, tProf, tCheck);
+    fprintf(stderr, "timing: leaf profiles %.3f s, ProbModel+PairHMM %.3f s, ForwardMatrix fills %.3f s, traceback+profile %.3f s "
+                    "(host tracebacks %.3f s, makeProfile %.3f s), calcSumPathAbsorbProbs+delete %.3f s\n", tLeaf, tHmm, tFwd, tProf,
+            fillTiming.hostTraces, fillTiming.hostMakeProfile, tCheck);
   dataset.path = path;
 }
 

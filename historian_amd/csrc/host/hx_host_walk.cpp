@@ -51,7 +51,16 @@ std::map<Cell, LogProb> asMap(const DPMatrix::Moves& m) { return std::map<Cell, 
 // as a map assignment would leave it
 void DPMatrix::settle(Moves& m) {
   if (m.size() < 2) return;
-  std::stable_sort(m.begin(), m.end(), [](const Move& a, const Move& b) { return a.first < b.first; });
+  if (m.size() <= 32) {
+    // (the usual case - a handful of candidates: a stable insertion sort, no scratch allocation)
+    for (size_t k = 1; k < m.size(); ++k) {
+      const Move v = m[k];
+      size_t at = k;
+      while (at > 0 && v.first < m[at - 1].first) { m[at] = m[at - 1]; --at; }
+      m[at] = v;
+    }
+  } else
+    std::stable_sort(m.begin(), m.end(), [](const Move& a, const Move& b) { return a.first < b.first; });
   size_t w = 0;
   for (size_t r = 0; r < m.size(); ++r) {
     if (w > 0 && m[w - 1].first == m[r].first) m[w - 1] = m[r];
@@ -78,7 +87,9 @@ DPMatrix::CellCoords DPMatrix::pickBest(const Moves& m) {
 DPMatrix::CellCoords DPMatrix::pickSampled(const Moves& m, random_engine& generator) const {
   double top = kNegInf;
   for (const Move& c : m) top = std::max(top, c.second);
-  vguard<double> share(m.size());
+  double fewShares[64];
+  vguard<double> manyShares(m.size() > 64 ? m.size() : 0);
+  double* const share = m.size() > 64 ? manyShares.data() : fewShares;
   double total = 0;
   for (size_t k = 0; k < m.size(); ++k) total += share[k] = exp(m[k].second - top);
   std::uniform_real_distribution<double> pick(0, total);
@@ -263,6 +274,7 @@ void ForwardMatrix::scoredSources(const CellCoords& dest, Moves& m) {
 // ---- tracebacks -------------------------------------------------------------------------------------------------------
 ForwardMatrix::Path ForwardMatrix::sampleTrace(random_engine& generator) {
   Assert(lpEnd > kNegInf, "Forward likelihood is zero; traceback fail");
+  const double t0 = wallSeconds();
   Path path(1, endCell);
   Moves m;
   CellCoords at = endCell;
@@ -271,6 +283,7 @@ ForwardMatrix::Path ForwardMatrix::sampleTrace(random_engine& generator) {
     at = pickSampled(m, generator);
     path.push_front(at);
   } while (at.xpos != 0 || at.ypos != 0);
+  fillTiming.hostTraces += wallSeconds() - t0;
   return path;
 }
 
@@ -404,6 +417,7 @@ ForwardMatrix::EffectiveTransition::EffectiveTransition() : lpPath(kNegInf), lpB
 Profile ForwardMatrix::makeProfile(const set<CellCoords>& cells, ProfilingStrategy strategy) {
   Assert(cells.count(startCell), "Missing SSS");
   Assert(cells.count(endCell), "Missing EEE");
+  const double tStart = wallSeconds();
   if (!haveHostCells && batch) prefetchCells(cells);   // the fwdLogProb annotations below read these cells
 
   const vguard<Cell> chosen(cells.begin(), cells.end());            // cell order
@@ -531,6 +545,7 @@ Profile ForwardMatrix::makeProfile(const set<CellCoords>& cells, ProfilingStrate
   prof.assertPathToEndExists();
   prof = prof.addReadyStates();
   prof.assertSeqCoordsConsistent();
+  fillTiming.hostMakeProfile += wallSeconds() - tStart;
   return prof;
 }
 

@@ -909,12 +909,12 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   const DeviceTables& D = g_dev[b->device];
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool fast = (b->flags & HX_LSE_FAST) != 0, linear = (b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR;
-  const double* lse_tab = fast ? D.fast_tab : D.pair_tab;    // FastPiece table, or the exact mode's {f0, df} pairs
-  LAUNCH_TRY(launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_cls, b->max_ca, b->max_cls_pairs, D.tab, st));
+  const Tab16 lse_tab{fast ? D.fast_tab : D.pair_tab};    // FastPiece table, or the exact mode's {f0, df} pairs
+  LAUNCH_TRY(launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_cls, b->max_ca, b->max_cls_pairs, Tab8{D.tab}, st));
   HIP_TRY(hipEventRecord(b->ev[0][0], st));
   // per-cell emission terms of the jobs without a class-pair table (general profiles).  Part of the fill:
   // the reference evaluates them inside its fill loop, so the launch is inside the timed region.
-  if (!(b->flags & HX_FORCE_GENERIC)) launch_emission_plane(b->d_jobs, b->n_jobs, b->max_eplane, D.tab, st);
+  if (!(b->flags & HX_FORCE_GENERIC)) launch_emission_plane(b->d_jobs, b->n_jobs, b->max_eplane, Tab8{D.tab}, st);
   for (int c = 0; c < KC_COUNT; ++c) {
     const ClassRange& cr = b->cls[c];
     if (cr.n == 0) continue;
@@ -923,8 +923,8 @@ int hx_batch_forward(hx_batch* b, void* stream) {
     switch (c) {
       case KC_LEAF_ROT_BANDED:
         if (!(b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED))) launch_fill_neg_inf(b->d_fwd + cr.mat_begin, cr.mat_doubles, st);
-        LAUNCH_TRY(launch_forward_band(jobs, cr.n, linear ? 0 : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, D.tab,
-                                       linear ? D.log_tab : lse_tab, (b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED)) != 0, st));
+        LAUNCH_TRY(launch_forward_band(jobs, cr.n, linear ? 0 : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab},
+                                       linear ? Tab16{D.log_tab} : lse_tab, (b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED)) != 0, st));
         break;
       case KC_LEAF_LDS: case KC_LEAF_LDS_BANDED: case KC_LEAF: case KC_LEAF_BANDED: case KC_CHAIN: case KC_CHAIN_BANDED: {
         // with a band the strip pipelines only visit in-envelope windows; everything else is -inf
@@ -935,9 +935,9 @@ int hx_batch_forward(hx_batch* b, void* stream) {
         // HX_LSE_LINEAR on leaf pairs whose y side fits LDS: the recursion runs on scaled probabilities instead of
         // table log-sum-exps (hx_linear.hip)
         if (linear && leaf == 2)
-          LAUNCH_TRY(launch_forward_leaf_linear(jobs, cr.n, cr.max_rows, banded, D.tab, D.log_tab, cr.yl_cols, cr.yl_emis, cr.max_cls + 1, st));
+          LAUNCH_TRY(launch_forward_leaf_linear(jobs, cr.n, cr.max_rows, banded, Tab8{D.tab}, Tab16{D.log_tab}, cr.yl_cols, cr.yl_emis, cr.max_cls + 1, st));
         else
-          LAUNCH_TRY(launch_forward_chain(jobs, cr.n, cr.max_rows, D.tab, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, st));
+          LAUNCH_TRY(launch_forward_chain(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, st));
         break;
       }
       case KC_DAG: case KC_DAG_BANDED:
@@ -946,10 +946,10 @@ int hx_batch_forward(hx_batch* b, void* stream) {
           launch_fill_neg_inf(b->d_fwd + cr.mat_begin, cr.mat_doubles, st);
           launch_fill_neg_inf(b->d_agg + (cr.mat_begin - b->cls[KC_DAG].mat_begin), cr.mat_doubles, st);
         }
-        LAUNCH_TRY(launch_forward_dag_pipe(jobs, cr.n, cr.max_rows, D.tab, lse_tab, fast, st));
+        LAUNCH_TRY(launch_forward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, st));
         break;
       default:
-        LAUNCH_TRY(launch_forward_dag(jobs, cr.n, cr.max_rows, D.tab, st));
+        LAUNCH_TRY(launch_forward_dag(jobs, cr.n, cr.max_rows, Tab8{D.tab}, st));
     }
   }
   HIP_TRY(hipEventRecord(b->ev[0][1], st));
@@ -969,7 +969,7 @@ int hx_batch_backward(hx_batch* b, void* stream) {
   const DeviceTables& D = g_dev[b->device];
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool fast = (b->flags & HX_LSE_FAST) != 0, linear = (b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR;
-  const double* lse_tab = fast ? D.fast_tab : D.pair_tab;
+  const Tab16 lse_tab{fast ? D.fast_tab : D.pair_tab};
   if (!b->d_bwd) {
     // not pre-allocated with HX_KEEP_BACKWARD: allocate the Backward matrices now and re-publish the job tables
     HIP_TRY(hipStreamSynchronize(b->last_stream));
@@ -992,17 +992,17 @@ int hx_batch_backward(hx_batch* b, void* stream) {
         if (banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_bwd + cr.mat_begin, cr.mat_doubles, st);
         const int leaf = (c == KC_LEAF_LDS || c == KC_LEAF_LDS_BANDED || c == KC_LEAF_ROT_BANDED) ? 2 : 1;
         if (linear && leaf == 2)
-          LAUNCH_TRY(launch_backward_leaf_linear(jobs, cr.n, cr.max_rows, banded, D.tab, D.log_tab, cr.yl_cols, cr.yl_emis, cr.max_cls + 1, st));
+          LAUNCH_TRY(launch_backward_leaf_linear(jobs, cr.n, cr.max_rows, banded, Tab8{D.tab}, Tab16{D.log_tab}, cr.yl_cols, cr.yl_emis, cr.max_cls + 1, st));
         else
-          LAUNCH_TRY(launch_backward_chain(jobs, cr.n, cr.max_rows, D.tab, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, st));
+          LAUNCH_TRY(launch_backward_chain(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, st));
         break;
       }
       case KC_CHAIN: case KC_CHAIN_BANDED: case KC_DAG: case KC_DAG_BANDED:
         if (banded) launch_fill_neg_inf(b->d_bwd + cr.mat_begin, cr.mat_doubles, st);
-        LAUNCH_TRY(launch_backward_dag_pipe(jobs, cr.n, cr.max_rows, D.tab, lse_tab, fast, st));
+        LAUNCH_TRY(launch_backward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, st));
         break;
       default:
-        LAUNCH_TRY(launch_backward_dag(jobs, cr.n, cr.max_rows, D.tab, st));
+        LAUNCH_TRY(launch_backward_dag(jobs, cr.n, cr.max_rows, Tab8{D.tab}, st));
     }
   }
   HIP_TRY(hipEventRecord(b->ev[1][1], st));
@@ -1356,7 +1356,7 @@ int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t*
   int64_t* d_off = b->d_trace_n + n;
   hipStream_t st = b->last_stream;
   // the per-cell emission plane is only filled by the strip pipelines (hx_batch_forward)
-  launch_best_trace(b->d_jobs, n, d_paths, cap, d_n, g_dev[b->device].tab, !(b->flags & HX_FORCE_GENERIC), st);
+  launch_best_trace(b->d_jobs, n, d_paths, cap, d_n, Tab8{g_dev[b->device].tab}, !(b->flags & HX_FORCE_GENERIC), st);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
       hipMemcpy(n_cells, d_n, sizeof(int32_t) * n, hipMemcpyDeviceToHost) != hipSuccess)
     return fail(HX_ERR_HIP, "best-trace kernel failed: %s", hipGetErrorString(hipGetLastError()));

@@ -535,8 +535,10 @@ int launch_pol(const DevJob* d_jobs, int n_jobs, const BandPlan& p, const double
 // workgroup: hx_api.hip admits a pair to this kernel's class only below it
 bool band_kernel_fits(int pol, int rows, int cols, int cls) { return plan_band(pol, 1, rows, cols, cls).total <= HX_LDS_LIMIT; }
 
-int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, const double* tab,
-                        const double* pol_tab, bool write_edges, hipStream_t st) {
+int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, Tab8 tab8,
+                        Tab16 tab16, bool write_edges, hipStream_t st) {
+  const double* tab = tab8.p;
+  const double* pol_tab = tab16.p;
   // Pairs per workgroup (they share the policy's table).  A CU holds 160 KB of LDS and four SIMDs; a pair is two waves.
   // One pair per workgroup while two such workgroups fit a CU; else two pairs share the table if that fits (the 64 KB
   // table of the fast policy); large batches put up to four pairs in a workgroup.

@@ -630,14 +630,18 @@ static int launch_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const do
 }
 
 // leaf: 0 = general chain profiles, 1 = leaf-like, 2 = leaf-like with the y side in LDS
-int launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+int launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 tab16,
                          bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
+  const double* tab = tab8.p;
+  const double* fast_tab = tab16.p;
   return launch_chain<0>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
 }
 
 // leaf-like profiles only (leaf >= 1)
-int launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+int launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 tab16,
                           bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
+  const double* tab = tab8.p;
+  const double* fast_tab = tab16.p;
   if (leaf < 1) return launch_fail("the Backward strip pipeline exists for leaf-like profiles only");
   return launch_chain<1>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
 }

@@ -845,7 +845,8 @@ __global__ void k_fill_neg_inf(double* __restrict__ p, int64_t n) {
 
 }  // namespace
 
-void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, const double* tab, hipStream_t st) {
+void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, Tab8 tab8, hipStream_t st) {
+  const double* tab = tab8.p;
   if (max_plane <= 0) return;
   const int tpb = 256;
   for (int j0 = 0; j0 < n_jobs; j0 += 32768) {       // (grid.y is limited to 65535)
@@ -867,8 +868,10 @@ static int dag_waves(int max_rows, int cap) {
   return w;
 }
 
-int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 tab16,
                             bool fast, hipStream_t st) {
+  const double* tab = tab8.p;
+  const double* fast_tab = tab16.p;
   const dim3 g(n_jobs), b(dag_waves(max_rows, HX_DAGF_MAX_WAVES) * 64);
   if (fast) {
     HX_CHECK_LDS((k_forward_dag_pipe<FastLse, true>), 0, "k_forward_dag_pipe<fast>");
@@ -880,8 +883,10 @@ int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, cons
   return 0;
 }
 
-int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 tab16,
                              bool fast, hipStream_t st) {
+  const double* tab = tab8.p;
+  const double* fast_tab = tab16.p;
   const dim3 g(n_jobs), b(dag_waves(max_rows, HX_DAG_MAX_WAVES) * 64);
   if (fast) hipLaunchKernelGGL((k_fill_dag<1, FastLse, true>), g, b, 0, st, d_jobs, tab, fast_tab);
   else hipLaunchKernelGGL((k_fill_dag<1, ExactLse3, false>), g, b, 0, st, d_jobs, tab, fast_tab);

@@ -12,6 +12,13 @@ struct PostCell { int32_t xpos, ypos, state, pad; double lpp; };   // == hx_cell
 // with launch_error() describing the refusal: an unsupported shape becomes an error code of the C ABI, never a
 // faulting launch (a device fault would take the caller's process down inside the next synchronisation).
 #define HX_LDS_LIMIT (160 * 1024)
+
+// The device tables come in two element sizes behind the same `const double*`: the reference's log_sum_exp table as 8-byte
+// entries (profile prep, emission tables, lpEnd), and 16-byte entries - {f0, df} pairs of the exact policy, FastPiece
+// records of the fast policy, {c, -log c} of the scaled-probability logarithm.  Indexing the 8-byte table as 16-byte
+// entries reads up to 800 KB past its end, so the launchers take them as distinct types.
+struct Tab8 { const double* p; };
+struct Tab16 { const double* p; };
 const char* launch_error();
 int launch_fail(const char* fmt, ...);
 // static + dynamic LDS of a kernel against the workgroup limit
@@ -25,20 +32,20 @@ int launch_fail(const char* fmt, ...);
   } while (0)
 
 int launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, int max_ca, int max_cls_pairs,
-                 const double* tab, hipStream_t st);
+                Tab8 tab, hipStream_t st);
 void launch_scatter_sub(const DevJob* d_jobs, int n_jobs, int max_states, hipStream_t st);
-int launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
-int launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+int launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, hipStream_t st);
+int launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 fast_tab,
                           bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st);
-int launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+int launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 fast_tab,
                            bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st);
-void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, const double* tab, hipStream_t st);
+void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, Tab8 tab, hipStream_t st);
 void launch_fill_neg_inf(double* p, int64_t n, hipStream_t st);
-int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 fast_tab,
                              bool fast, hipStream_t st);
-int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
+int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 fast_tab,
                               bool fast, hipStream_t st);
-int launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st);
+int launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, hipStream_t st);
 void launch_posterior_scan(const DevJob* d_jobs, int job, double lpp_threshold, PostCell* out,
                            unsigned long long cap, unsigned long long* counter, hipStream_t st);
 void launch_gather_cells(const DevJob* d_jobs, int job, const double* M, int mirrored, const int* ij, int64_t n,
@@ -47,18 +54,18 @@ void launch_gather_cells(const DevJob* d_jobs, int job, const double* M, int mir
 // scaled-linear Forward fill of leaf-like pairs (hx_linear.hip); log_tab from build_log_table
 int log_table_doubles();
 void build_log_table(double* out /* [log_table_doubles()] */);
-int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
+int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, Tab8 tab, Tab16 log_tab,
                                 int yl_cols, int yl_emis, int yl_cls, hipStream_t st);
 
-int launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
+int launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, Tab8 tab, Tab16 log_tab,
                                  int yl_cols, int yl_emis, int yl_cls, hipStream_t st);
 
 // banded leaf-like pairs, rotating-row sweep (hx_band.hip); pol: 0 = scaled probabilities, 1 = fast, 2 = exact
 bool band_kernel_fits(int pol, int rows, int cols, int cls);
-int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, const double* tab,
-                        const double* pol_tab, bool write_edges, hipStream_t st);
+int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, Tab8 tab,
+                        Tab16 pol_tab, bool write_edges, hipStream_t st);
 
-void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, const double* tab,
+void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, Tab8 tab,
                        bool plane_valid, hipStream_t st);
 
 void launch_reverse_paths(const int32_t* d_paths, int64_t cap, const int32_t* d_n_cells, const int64_t* d_off, int32_t* d_out,

@@ -424,7 +424,8 @@ int launch_fail(const char* fmt, ...) {
 // batches are launched in chunks of HX_PREP_CHUNK jobs.
 #define HX_PREP_CHUNK 16384
 int launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, int max_ca, int max_cls_pairs,
-                const double* tab, hipStream_t st) {
+                Tab8 tab8, hipStream_t st) {
+  const double* tab = tab8.p;
   const int tpb = 256;
   for (int j0 = 0; j0 < n_jobs; j0 += HX_PREP_CHUNK) {
     const int n = n_jobs - j0 < HX_PREP_CHUNK ? n_jobs - j0 : HX_PREP_CHUNK;
@@ -456,7 +457,8 @@ void launch_scatter_sub(const DevJob* d_jobs, int n_jobs, int max_states, hipStr
   }
 }
 
-int launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st) {
+int launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, hipStream_t st) {
+  const double* tab = tab8.p;
   int threads = ((max_rows + 63) / 64) * 64;
   if (threads > 1024) threads = 1024;
   if (threads < 64) threads = 64;
@@ -464,7 +466,8 @@ int launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const dou
   return 0;
 }
 
-int launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, hipStream_t st) {
+int launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, hipStream_t st) {
+  const double* tab = tab8.p;
   int threads = ((max_rows + 63) / 64) * 64;
   if (threads > 1024) threads = 1024;
   if (threads < 64) threads = 64;

@@ -596,8 +596,10 @@ static LdsPlan plan_lds(int W, int PPW, bool banded, int yl_cols, int yl_emis, i
   return p;
 }
 
-int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
+int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, Tab8 tab8, Tab16 tab16,
                                int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
+  const double* tab = tab8.p;
+  const double* log_tab = tab16.p;
   if (yl_cls > HX_YL_MAX_CLS_LINEAR + 1) return launch_fail("%d emission classes exceed the scaled-probability kernel's column words", yl_cls);
 #define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis, yl_cls); \
     if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_leaf_linear<%d> needs %d bytes of LDS (limit %d)", W_, p.total, HX_LDS_LIMIT); \
@@ -634,8 +636,10 @@ int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, b
 }
 
 // Backward fill of leaf batches on scaled probabilities (the same kernel, DIR = 1)
-int launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, const double* tab, const double* log_tab,
+int launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, Tab8 tab8, Tab16 tab16,
                                 int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
+  const double* tab = tab8.p;
+  const double* log_tab = tab16.p;
   if (yl_cls > HX_YL_MAX_CLS_LINEAR + 1) return launch_fail("%d emission classes exceed the scaled-probability kernel's column words", yl_cls);
 #define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis, yl_cls); \
     if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_leaf_linear<%d, bwd> needs %d bytes of LDS (limit %d)", W_, p.total, HX_LDS_LIMIT); \

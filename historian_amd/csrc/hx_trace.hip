@@ -160,8 +160,9 @@ void launch_reverse_paths(const int32_t* d_paths, int64_t cap, const int32_t* d_
   hipLaunchKernelGGL(k_reverse_paths, dim3(n_jobs), dim3(256), 0, st, d_paths, cap, d_n_cells, d_off, d_out);
 }
 
-void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, const double* tab,
+void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, Tab8 tab8,
                        bool plane_valid, hipStream_t st) {
+  const double* tab = tab8.p;
   hipLaunchKernelGGL(k_best_trace, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_paths, cap, d_n_cells, tab, plane_valid ? 1 : 0);
 }
 

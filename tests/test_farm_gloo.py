@@ -37,7 +37,7 @@ def _worker(rank, world, port, pairs, length, q):
     out = []
     for k in range(pairs):
         rng = np.random.default_rng(farm.pair_seed(rank, pairs, k))
-        xs, ys = bench.synth_pair(rng, pi / pi.sum(), length)
+        xs, ys = workload.synth_pair(rng, pi / pi.sum(), length)
         x, y = hostmodel.leaf_profile(xs, 4), hostmodel.leaf_profile(ys, 4)
         out.append(c_oracle.forward(x, y, hmm)["lp_end"])
     t = farm.max_over_ranks(1.0 + rank, world)
@@ -73,6 +73,6 @@ def test_two_rank_farm_matches_single_process():
     single = []
     for k in range(world * pairs):
         rng = np.random.default_rng(farm.pair_seed(0, world * pairs, k))
-        xs, ys = bench.synth_pair(rng, pi / pi.sum(), length)
+        xs, ys = workload.synth_pair(rng, pi / pi.sum(), length)
         single.append(c_oracle.forward(hostmodel.leaf_profile(xs, 4), hostmodel.leaf_profile(ys, 4), hmm)["lp_end"])
     assert res[0][3] + res[1][3] == single

@@ -1,0 +1,107 @@
+"""BASELINE configs[4] at size: the 4-component mixture (model/prot4.json) on 5000-column profiles.
+
+One level of that workload, both kinds of pair DP a tree level holds:
+  * a leaf-level pair, 5000 x 5000 residues, C = 4: 25 M cells, 1 GB of Forward matrix.  Exact mode against the
+    plain-C oracle (oracle_fill.c, ~30 s on one core): lpEnd bit for bit, 200 000 gathered cells bit for bit
+    (hx_batch_read_cells: no 1 GB host copy un-skewed in numpy), the device traceback = the reference's bestTrace;
+    fast mode within north_star's tolerance with the same best path;
+  * an internal-node pair built the way Reconstructor::reconstruct builds them (best trace + 10 sampled traces of two
+    leaf-level DPs, reference src/recon.cpp:1010), from 2000-column C = 4 leaves: general profiles with thousands of
+    states, all emission columns distinct, so the per-cell emission plane (k_emission_plane) and the general pipeline
+    (k_forward_dag_pipe, k_fill_dag<1>) run with C = 4 at size.  Forward and Backward cells bit for bit against the
+    oracle, lpEnd / lpStart, Forward == Backward.
+The sampled profiles are made with the oracle's traceback / makeProfile code over matrices the GPU filled (the pure-Python
+fill would take hours at this size); the oracle stays the checker, the HIP path is what is checked."""
+import os
+
+import numpy as np
+import pytest
+
+from historian_amd import capi, hostmodel, workload
+from oracle import c_oracle, trace_oracle
+from oracle import historian_oracle as ho
+from tests import helpers as H
+from tests.test_gpu_traceback import ArrayForward
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROT4 = os.path.join(ROOT, "tests", "golden", "models", "prot4.json")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def engine():
+    capi.init(0, c_oracle.table())
+    yield
+    capi.shutdown()
+
+
+def test_leaf_pair_5000_columns_four_components():
+    model = hostmodel.RateModel.load(PROT4)
+    assert model.components() == 4
+    hmm = hostmodel.make_hmm(model, .05, .05)
+    x, y, h, md = workload.leaf_pair(np.random.default_rng(5000), model, hmm, 5000, sub=.1, indel=.01)
+    want = c_oracle.forward(x, y, h, md)
+    path = trace_oracle.best_trace(x, y, h, md, want)
+    rng = np.random.default_rng(1)
+    ij = np.stack([rng.integers(0, 5001, 200000), rng.integers(0, 5001, 200000)], axis=1)
+    ij[:5001, 0] = 5000                      # the last row and the last column in full
+    ij[:5001, 1] = np.arange(5001)
+    ij[5001:10002, 0] = np.arange(5001)
+    ij[5001:10002, 1] = 5000
+    b = capi.Batch([(x, y, h, md)], capi.HX_LSE_EXACT)
+    b.forward()
+    assert b.layout(0).matrix_doubles * 8 > 1e9            # a 1 GB matrix
+    H.assert_same_bits(b.lp_end(), [want["lp_end"]], "lpEnd")
+    H.assert_same_bits(b.read_cells(0, ij), want["cells"][ij[:, 0], ij[:, 1]], "gathered Forward cells")
+    assert b.best_trace()[0] == path
+    b.close()
+    f = capi.Batch([(x, y, h, md)], capi.HX_LSE_FAST)
+    f.forward()
+    assert abs(f.lp_end()[0] - want["lp_end"]) <= 1e-9 * abs(want["lp_end"])
+    assert f.best_trace()[0] == path
+    f.close()
+
+
+def _sampled_profile(model, sx, sy, rows, parent_row, seed, tl=.05, tr=.05, samples=10):
+    """Internal-node profile of two leaves: the oracle's sampleProfile (best trace + sampled traces, makeProfile,
+    addReadyStates) over a Forward matrix filled by the GPU in exact mode."""
+    hmm = H.make_hmm(model, tl, tr)
+    proto = ho.ForwardMatrix(H.leaf(model, sx, rows[0]), H.leaf(model, sy, rows[1]), hmm, parent_row,
+                             ho.GuideAlignmentEnvelope(), fill=False)
+    b = capi.Batch([H.job_images(proto)], capi.HX_LSE_EXACT)
+    b.forward()
+    filled = ArrayForward(proto, b.read_matrix(0), float(b.lp_end()[0]))
+    b.close()
+    strat = ho.DPMatrix.CollapseChains | ho.DPMatrix.IncludeBestTrace
+    return filled.sample_profile(ho.MT19937(seed), samples, 0, strat)
+
+
+def test_internal_node_pair_of_sampled_four_component_profiles():
+    import json
+    import random
+    with open(PROT4) as f:
+        model = ho.RateModel(json.load(f))
+    rng = random.Random(64)
+    alphabet = model.alphabet
+    anc = H.random_seq(rng, alphabet, 2000)
+    leaves = [H.mutate(rng, anc, alphabet, .08, .01) for _ in range(4)]
+    p1 = _sampled_profile(model, leaves[0], leaves[1], (0, 1), 4, 11)
+    p2 = _sampled_profile(model, leaves[2], leaves[3], (2, 3), 5, 12)
+    assert p1.size() > 2000 and p2.size() > 2000
+    assert any(len(s.in_) > 1 for s in p1.state) and any(s.is_null() for s in p1.state[1:-1])     # a DAG with null states
+    fwd = ho.ForwardMatrix(p1, p2, H.make_hmm(model, .05, .05), 6, ho.GuideAlignmentEnvelope(), fill=False)
+    img = H.job_images(fwd)
+    wf, wb = c_oracle.forward(*img), c_oracle.backward(*img)
+    for flags in (capi.HX_LSE_EXACT, capi.HX_LSE_FAST):
+        b = capi.Batch([img], flags | capi.HX_KEEP_BACKWARD)
+        b.forward()
+        b.backward()
+        lp_end, lp_start = b.lp_end()[0], b.lp_start()[0]
+        if flags == capi.HX_LSE_EXACT:
+            H.assert_same_bits(b.read_matrix(0, 0), wf["cells"], "Forward cells")
+            H.assert_same_bits(b.read_matrix(0, 1), wb["cells"], "Backward cells")
+            H.assert_same_bits([lp_end, lp_start], [wf["lp_end"], wb["lp_start"]], "lpEnd, lpStart")
+        else:
+            assert abs(lp_end - wf["lp_end"]) <= 1e-9 * abs(wf["lp_end"])
+        assert abs(lp_start - lp_end) <= 1e-6 * abs(lp_end)              # Forward == Backward
+        b.close()
