@@ -105,8 +105,7 @@ def main():
 
     # strong scaling: BASELINE configs[3] as written - `--pairs` pairs IN TOTAL, dealt to the ranks; weak: per rank
     strong = args.scaling == "strong"
-    n_local = args.pairs // world + (1 if strong and rank < args.pairs % world else 0) if strong else args.pairs
-    first = (rank * (args.pairs // world) + min(rank, args.pairs % world)) if strong else rank * args.pairs
+    n_local, first = farm.deal(args.pairs, world, rank, strong)
     triples = []
     env_cells = 0
     env_cells_of = []

@@ -61,7 +61,7 @@ struct FillTiming {
   long fills = 0, matrixReads = 0, deviceTraces = 0, cellGathers = 0;
   long long cells = 0;
 };
-extern FillTiming fillTiming;
+extern thread_local FillTiming fillTiming;     // per host thread; worker threads of a device farm are merged into the caller's
 double wallSeconds();
 #define Test(assertion, ...) ((assertion) ? true : (::historian::Warn(__VA_ARGS__), false))
 #define Assert(assertion, ...) do { if (!(assertion)) ::historian::Abort("Assertion Failed: " __VA_ARGS__); } while (0)
@@ -388,6 +388,7 @@ protected:
   struct BatchHandle {
     hx_batch* b;
     int nJobs;
+    vguard<int> jobOf;                       // fillBatch over several devices: caller's job index of each job of this batch
     bool backwardDone;
     // ForwardMatrix::bestTrace of every job, found on the device on first use (hx_batch_best_trace)
     bool bestTracesDone;
@@ -466,6 +467,9 @@ public:
     GuideAlignmentEnvelope env;
   };
   static vguard<ForwardMatrix*> fillBatch(const vguard<JobSpec>& jobs);
+  // ... farmed over several devices: jobs sorted by lattice cells, longest first, each dealt to the least loaded device
+  // (lptAssign); one device batch per device, all launched before the first result is awaited.  Same results.
+  static vguard<ForwardMatrix*> fillBatch(const vguard<JobSpec>& jobs, const vguard<int>& devices);
 
   Path sampleTrace(random_engine& generator);
   Path bestTrace();
@@ -578,13 +582,30 @@ struct Reconstructor {
     vguard<FastSeq> gappedRecon() const; // Alignment(ungapped, path).gapped()
   };
 
+  // Not in the reference (which is one process, one core): the devices independent pair DPs are farmed over.
+  // Empty = the thread's device (HX_DEVICE or 0).  With several: the ready nodes of a tree level are dealt to the devices
+  // (reconstruct), and whole families are dealt to one host thread per device (reconstructAll) - in both cases longest
+  // job first.  Tracebacks and sampling stay in node order per family, each family has its own generator seeded as the
+  // reference seeds it, so the results do not depend on the number of devices.
+  vguard<int> devices;
+
   Reconstructor();
   void seedGenerator();
   void reconstruct(Dataset& dataset);
+  void reconstructAll(vguard<Dataset*>& datasets);   // reference src/recon.cpp:1368-1372: every family
+  static double familyCost(const Dataset& dataset);   // estimated lattice cells of a family's pair DPs
 };
 
+// Longest-processing-time-first list scheduling: jobs in order of decreasing cost, each to the device with the least
+// load so far (ties: the lower device, the lower job index first).  Returns the device index of every job.
+vguard<int> lptAssign(const vguard<double>& cost, int nDevices);
+
 namespace detail {          // shared by the device-backed classes (hx_host_forward.cpp)
-void ensureDevice();
+void ensureDevice();                  // the calling thread's device
+void ensureDevice(int ordinal);       // hx_init for that device, once per process
+int threadDevice();                   // the device this host thread creates its matrices on (HX_DEVICE or 0 by default)
+void setThreadDevice(int ordinal);
+void mergeTiming(const FillTiming& from, FillTiming& into);
 double* pinnedTake(size_t doubles, size_t& capacity);
 void pinnedGive(double* p, size_t capacity);
 void check(int rc, const char* what);

@@ -14,7 +14,7 @@
 
 namespace historian {
 
-FillTiming fillTiming;
+thread_local FillTiming fillTiming;
 double wallSeconds() {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <iomanip>
 #include <sstream>
 
@@ -16,7 +17,10 @@ namespace historian {
 static const double NEG_INF = -std::numeric_limits<double>::infinity();
 
 static unsigned g_fillMode = HX_LSE_EXACT;
-static bool g_deviceReady = false;
+static std::mutex g_deviceMutex;                  // device initialisation and the pinned-buffer pool
+static bool g_deviceReady[32] = {false};
+static bool g_modeRead = false;
+static thread_local int t_device = -1;
 
 void DPMatrix::setFillMode(unsigned hxFlags) { g_fillMode = hxFlags & HX_LSE_LINEAR; }
 static int g_deviceTraceback = -1;
@@ -31,18 +35,31 @@ static void hxCheck(int rc, const char* what) {
   if (rc != HX_OK) Abort("%s failed (%d): %s", what, rc, hx_last_error());
 }
 
-static void ensureDevice() {
-  if (g_deviceReady) return;
+static int threadDevice() {
+  if (t_device < 0) {
+    const char* dev = getenv("HX_DEVICE");
+    t_device = dev ? atoi(dev) : 0;
+  }
+  return t_device;
+}
+
+static void ensureDevice(int ordinal) {
+  std::lock_guard<std::mutex> lock(g_deviceMutex);
+  Require(ordinal >= 0 && ordinal < 32, "device ordinal %d out of range", ordinal);
+  if (!g_modeRead) {
+    const char* mode = getenv("HX_FILL_MODE");   // "fast" selects the fast log-sum-exp policy for this process
+    if (mode && string(mode) == "fast") g_fillMode = HX_LSE_FAST;
+    if (mode && string(mode) == "linear") g_fillMode = HX_LSE_LINEAR;
+    g_modeRead = true;
+  }
+  if (g_deviceReady[ordinal]) return;
   const double t0 = wallSeconds();
-  const char* dev = getenv("HX_DEVICE");
   // the device gets the table the host built with its own libm (reference src/logsumexp.cpp:6-16)
-  hxCheck(hx_init(dev ? atoi(dev) : 0, logSumExpLookupTable.lookup, HX_LSE_TABLE_ENTRIES), "hx_init");
-  const char* mode = getenv("HX_FILL_MODE");   // "fast" selects the fast log-sum-exp policy for this process
-  if (mode && string(mode) == "fast") g_fillMode = HX_LSE_FAST;
-  if (mode && string(mode) == "linear") g_fillMode = HX_LSE_LINEAR;
-  g_deviceReady = true;
+  hxCheck(hx_init(ordinal, logSumExpLookupTable.lookup, HX_LSE_TABLE_ENTRIES), "hx_init");
+  g_deviceReady[ordinal] = true;
   fillTiming.deviceInit += wallSeconds() - t0;
 }
+static void ensureDevice() { ensureDevice(threadDevice()); }
 
 // POD image of a Profile for the C ABI
 namespace {
@@ -112,6 +129,7 @@ namespace {
 struct PinnedPool {
   std::vector<std::pair<size_t, double*> > freeList;   // (capacity in doubles, buffer)
   double* take(size_t n, size_t& cap) {
+    std::lock_guard<std::mutex> lock(g_deviceMutex);
     size_t best = freeList.size();
     for (size_t k = 0; k < freeList.size(); ++k)
       if (freeList[k].first >= n && (best == freeList.size() || freeList[k].first < freeList[best].first)) best = k;
@@ -133,7 +151,10 @@ struct PinnedPool {
     hxCheck(hx_host_alloc(cap * sizeof(double), &p), "hx_host_alloc");
     return static_cast<double*>(p);
   }
-  void give(double* p, size_t cap) { freeList.push_back(std::make_pair(cap, p)); }
+  void give(double* p, size_t cap) {
+    std::lock_guard<std::mutex> lock(g_deviceMutex);
+    freeList.push_back(std::make_pair(cap, p));
+  }
 };
 PinnedPool g_pinned;
 }  // namespace
@@ -144,6 +165,15 @@ DPMatrix::~DPMatrix() {
 
 namespace detail {
 void ensureDevice() { historian::ensureDevice(); }
+void ensureDevice(int ordinal) { historian::ensureDevice(ordinal); }
+int threadDevice() { return historian::threadDevice(); }
+void setThreadDevice(int ordinal) { t_device = ordinal; }
+void mergeTiming(const FillTiming& a, FillTiming& b) {
+  b.deviceInit += a.deviceInit; b.flattenAndUpload += a.flattenAndUpload; b.forwardWait += a.forwardWait;
+  b.forwardKernel += a.forwardKernel; b.backwardWait += a.backwardWait; b.readMatrix += a.readMatrix;
+  b.deviceTrace += a.deviceTrace; b.cellGather += a.cellGather; b.hostTraces += a.hostTraces; b.hostMakeProfile += a.hostMakeProfile;
+  b.fills += a.fills; b.matrixReads += a.matrixReads; b.deviceTraces += a.deviceTraces; b.cellGathers += a.cellGathers; b.cells += a.cells;
+}
 double* pinnedTake(size_t doubles, size_t& capacity) { return g_pinned.take(doubles, capacity); }
 void pinnedGive(double* p, size_t capacity) { g_pinned.give(p, capacity); }
 void check(int rc, const char* what) { hxCheck(rc, what); }
@@ -213,7 +243,7 @@ void DPMatrix::createBatchAndPrepare() {
   JobImage im;
   buildJobImage(*this, xClosestLeafPos, yClosestLeafPos, im);
   hx_batch* b = NULL;
-  hxCheck(hx_batch_create(&im.job, 1, g_fillMode | HX_SPARSE_ENVELOPE, &b), "hx_batch_create");
+  hxCheck(hx_batch_create_on(threadDevice(), &im.job, 1, g_fillMode | HX_SPARSE_ENVELOPE, &b), "hx_batch_create");
   std::shared_ptr<BatchHandle> h(new BatchHandle(b, 1));
   const double t1 = wallSeconds();
   hxCheck(hx_batch_forward(b, NULL), "hx_batch_forward");
@@ -243,39 +273,74 @@ void DPMatrix::attach(const std::shared_ptr<BatchHandle>& h, int job, double lpE
   fetchPrepared();
 }
 
-// n independent fills, one device batch (not in the reference; see hx_host.h)
+// n independent fills as device batches (not in the reference; see hx_host.h)
 vguard<ForwardMatrix*> ForwardMatrix::fillBatch(const vguard<JobSpec>& jobs) {
+  return fillBatch(jobs, vguard<int>(1, threadDevice()));
+}
+
+vguard<int> lptAssign(const vguard<double>& cost, int nDevices) {
+  vguard<size_t> order(cost.size());
+  for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+  vguard<double> load((size_t)std::max(nDevices, 1), 0.);
+  vguard<int> device(cost.size(), 0);
+  for (size_t k : order) {
+    const size_t d = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+    device[k] = (int)d;
+    load[d] += cost[k];
+  }
+  return device;
+}
+
+vguard<ForwardMatrix*> ForwardMatrix::fillBatch(const vguard<JobSpec>& jobs, const vguard<int>& devices) {
   vguard<ForwardMatrix*> out;
   if (jobs.empty()) return out;
-  ensureDevice();
+  Require(!devices.empty(), "fillBatch needs at least one device");
   const double t0 = wallSeconds();
   const size_t n = jobs.size();
   vguard<JobImage> images(n);          // sized once: hx_pair_job holds pointers into its elements
-  vguard<hx_pair_job> pods(n);
+  vguard<double> cells(n);
   for (size_t k = 0; k < n; ++k) {
     const JobSpec& js = jobs[k];
     ForwardMatrix* f = new ForwardMatrix(*js.x, *js.y, *js.hmm, js.parentRowIndex, js.env, Deferred());
     out.push_back(f);
     buildJobImage(*f, f->xClosestLeafPos, f->yClosestLeafPos, images[k]);
-    pods[k] = images[k].job;
+    cells[k] = (double)(f->xSize - 1) * (double)(f->ySize - 1);
   }
-  hx_batch* b = NULL;
-  hxCheck(hx_batch_create(pods.data(), (int32_t)n, g_fillMode | HX_SPARSE_ENVELOPE, &b), "hx_batch_create");
-  std::shared_ptr<BatchHandle> h(new BatchHandle(b, (int)n));
+  // deal the jobs to the devices, longest first; one batch per device, every batch launched before any result is awaited
+  const vguard<int> dealt = lptAssign(cells, (int)devices.size());
+  vguard<std::shared_ptr<BatchHandle> > handles(devices.size());
+  for (size_t d = 0; d < devices.size(); ++d) {
+    vguard<hx_pair_job> pods;
+    vguard<int> jobOf;
+    for (size_t k = 0; k < n; ++k)
+      if ((size_t)dealt[k] == d) { pods.push_back(images[k].job); jobOf.push_back((int)k); }
+    if (pods.empty()) continue;
+    ensureDevice(devices[d]);
+    hx_batch* b = NULL;
+    hxCheck(hx_batch_create_on(devices[d], pods.data(), (int32_t)pods.size(), g_fillMode | HX_SPARSE_ENVELOPE, &b), "hx_batch_create");
+    handles[d].reset(new BatchHandle(b, (int)pods.size()));
+    handles[d]->jobOf = jobOf;
+  }
   const double t1 = wallSeconds();
-  hxCheck(hx_batch_forward(b, NULL), "hx_batch_forward");
-  vguard<double> lp(n, NEG_INF);
-  hxCheck(hx_batch_lp_end(b, lp.data()), "hx_batch_lp_end");
+  for (auto& h : handles)
+    if (h) hxCheck(hx_batch_forward(h->b, NULL), "hx_batch_forward");
+  for (auto& h : handles) {
+    if (!h) continue;
+    vguard<double> lp((size_t)h->nJobs, NEG_INF);
+    hxCheck(hx_batch_lp_end(h->b, lp.data()), "hx_batch_lp_end");
+    float kms = 0;
+    if (hx_batch_last_kernel_ms(h->b, 0, &kms) == HX_OK) fillTiming.forwardKernel += 1e-3 * kms;
+    for (int j = 0; j < h->nJobs; ++j) {
+      ForwardMatrix* f = out[(size_t)h->jobOf[(size_t)j]];
+      f->attach(h, j, lp[(size_t)j]);
+      fillTiming.fills += 1;
+      fillTiming.cells += (long long)(f->xSize - 1) * (long long)(f->ySize - 1);
+    }
+  }
   const double t2 = wallSeconds();
-  float kms = 0;
-  if (hx_batch_last_kernel_ms(b, 0, &kms) == HX_OK) fillTiming.forwardKernel += 1e-3 * kms;
   fillTiming.flattenAndUpload += t1 - t0;
   fillTiming.forwardWait += t2 - t1;
-  for (size_t k = 0; k < n; ++k) {
-    out[k]->attach(h, (int)k, lp[k]);
-    fillTiming.fills += 1;
-    fillTiming.cells += (long long)(out[k]->xSize - 1) * (long long)(out[k]->ySize - 1);
-  }
   return out;
 }
 

@@ -1,5 +1,9 @@
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstdio>
+#include <mutex>
+#include <thread>
 // Progressive reconstruction loop of the host mirror (see hx_host.h): the part of
 // Reconstructor that drives the DP (reference src/recon.cpp:864-915, 917-1052).
 #include "hx_host.h"
@@ -146,7 +150,7 @@ void Reconstructor::reconstruct(Dataset& dataset) {
         js.env = envelopeFor(node, work[node].maxDist);
         specs.push_back(js);
       }
-      const vguard<ForwardMatrix*> filled = ForwardMatrix::fillBatch(specs);
+      const vguard<ForwardMatrix*> filled = devices.empty() ? ForwardMatrix::fillBatch(specs) : ForwardMatrix::fillBatch(specs, devices);
       for (size_t k = 0; k < ready.size(); ++k) work[ready[k]].forward = filled[k];
     }
     tFwd += wallSeconds() - tb1;
@@ -213,6 +217,51 @@ void Reconstructor::reconstruct(Dataset& dataset) {
                     "(host tracebacks %.3f s, makeProfile %.3f s), calcSumPathAbsorbProbs+delete %.3f s\n", tLeaf, tHmm, tFwd, tProf,
             fillTiming.hostTraces, fillTiming.hostMakeProfile, tCheck);
   dataset.path = path;
+}
+
+// A family's pair DPs in lattice cells, estimated before any profile exists: every internal node pairs two subtrees, and
+// a subtree's profile is about as long as its longest leaf sequence.
+double Reconstructor::familyCost(const Dataset& dataset) {
+  const ReconTree& tree = dataset.tree;
+  vguard<double> len((size_t)tree.nodes(), 0.);
+  double cells = 0;
+  for (TreeNodeIndex n = 0; n < tree.nodes(); ++n) {
+    if (tree.isLeaf(n)) { len[n] = (double)dataset.seqs.at(n).length() + 2; continue; }
+    const double l = len[tree.getChild(n, 0)], r = len[tree.getChild(n, 1)];
+    cells += l * r;
+    len[n] = std::max(l, r);
+  }
+  return cells;
+}
+
+// Every family (reference src/recon.cpp:1368-1372 runs them one after the other).  With several devices the families
+// are the farm's jobs: sorted by estimated cost, longest first, and taken from that list by one host thread per device
+// (list scheduling = longest-processing-time-first); each thread drives its own device.  A family is reconstructed by a
+// copy of this Reconstructor, so its generator is seeded exactly as in a sequential run: same results, any device count.
+void Reconstructor::reconstructAll(vguard<Dataset*>& datasets) {
+  if (devices.size() < 2 || datasets.size() < 2) {
+    for (Dataset* d : datasets) reconstruct(*d);
+    return;
+  }
+  vguard<double> cost;
+  for (const Dataset* d : datasets) cost.push_back(familyCost(*d));
+  vguard<size_t> order(datasets.size());
+  for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });
+  std::atomic<size_t> nextJob(0);
+  std::mutex merge;
+  FillTiming& mine = fillTiming;
+  vguard<std::thread> workers;
+  for (int device : devices)
+    workers.emplace_back([&, device]() {
+      detail::setThreadDevice(device);
+      Reconstructor own(*this);
+      own.devices.clear();                         // (this worker's fills all go to its device)
+      for (size_t k = nextJob++; k < order.size(); k = nextJob++) own.reconstruct(*datasets[order[k]]);
+      std::lock_guard<std::mutex> lock(merge);
+      detail::mergeTiming(fillTiming, mine);
+    });
+  for (std::thread& w : workers) w.join();
 }
 
 // Alignment(ungapped, path).gapped(): leaves show residues, internal nodes the wildcard character

@@ -154,9 +154,14 @@ list<DPMatrix::CellCoords> DPMatrix::equivAbsorbCells(const CellCoords& c) const
 }
 
 string DPMatrix::cellName(const CellCoords& c) const {
-  std::ostringstream name;
-  name << '(' << hmm.stateName(c.state, c.xpos == 0, c.ypos == 0) << ',' << x.state[c.xpos].name << ',' << y.state[c.ypos].name << ')';
-  return name.str();
+  string name("(");
+  name += hmm.stateName(c.state, c.xpos == 0, c.ypos == 0);
+  name += ',';
+  name += x.state[c.xpos].name;
+  name += ',';
+  name += y.state[c.ypos].name;
+  name += ')';
+  return name;
 }
 
 void DPMatrix::write(std::ostream& out, bool edgeOnly) const {
@@ -554,24 +559,45 @@ Profile ForwardMatrix::makeProfile(const set<CellCoords>& cells, ProfilingStrate
 Profile ForwardMatrix::sampleProfile(random_engine& generator, size_t profileSamples, size_t maxCells, ProfilingStrategy strategy,
                                      size_t minLen, size_t maxLen) {
   Require((strategy & IncludeBestTrace) || profileSamples > 0, "Must allow at least one sample path in the profile");
+  const auto ancestralLength = [](const Path& p) {
+    return (size_t)std::count_if(p.begin(), p.end(), [](const CellCoords& c) {
+      return c.state == PairHMM::IMM || c.state == PairHMM::IDM || c.state == PairHMM::IMD;
+    });
+  };
+  set<CellCoords> keep;
+  if (maxCells == 0) {
+    // no cell budget: every visited cell stays, so the visits need not be counted - collect, sort, drop repeats
+    vguard<CellCoords> seen;
+    if (strategy & IncludeBestTrace) {
+      const Path best = bestTrace();
+      seen.assign(best.begin(), best.end());
+    }
+    for (size_t accepted = 0; accepted < profileSamples; ++accepted) {
+      const Path sampled = sampleTrace(generator);
+      const size_t ancestral = ancestralLength(sampled);
+      if (ancestral < minLen || ancestral > maxLen) break;
+      seen.insert(seen.end(), sampled.begin(), sampled.end());
+    }
+    std::sort(seen.begin(), seen.end());
+    seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+    keep.insert(seen.begin(), seen.end());        // (sorted input: linear-time construction)
+    return makeProfile(keep, strategy);
+  }
   map<CellCoords, size_t> visits;
   size_t traces = 0;
   if (strategy & IncludeBestTrace) {
     for (const CellCoords& c : bestTrace()) visits[c] = 2;
     ++traces;
   }
-  for (size_t accepted = 0; accepted < profileSamples && (maxCells == 0 || visits.size() < maxCells); ++accepted) {
+  for (size_t accepted = 0; accepted < profileSamples && visits.size() < maxCells; ++accepted) {
     const Path sampled = sampleTrace(generator);
-    const size_t ancestral = (size_t)std::count_if(sampled.begin(), sampled.end(), [](const CellCoords& c) {
-      return c.state == PairHMM::IMM || c.state == PairHMM::IDM || c.state == PairHMM::IMD;
-    });
+    const size_t ancestral = ancestralLength(sampled);
     if (ancestral < minLen || ancestral > maxLen) break;
     for (const CellCoords& c : sampled) ++visits[c];
     ++traces;
   }
   // with a cell budget that the traces have used up, only cells seen twice stay
-  const size_t needed = (traces > 1 && maxCells > 0 && visits.size() >= maxCells) ? 2 : 1;
-  set<CellCoords> keep;
+  const size_t needed = (traces > 1 && visits.size() >= maxCells) ? 2 : 1;
   for (const auto& v : visits)
     if (v.second >= needed) keep.insert(keep.end(), v.first);
   return makeProfile(keep, strategy);

@@ -1,4 +1,4 @@
-// Progressive reconstruction driver over the GPU-backed mirror.  Input is a small job file (the
+// Progressive reconstruction driver over the GPU-backed mirror.  Input is one small job file per family (the
 // reference's own readers for Newick / Stockholm / guide files are outside this build's scope):
 //   model <rate model json>
 //   seqs <fasta of ungapped leaf sequences>
@@ -11,30 +11,28 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <list>
 #include <sstream>
 #include "../hx_host.h"
 using namespace historian;
 
-int main(int argc, char** argv) {
-  if (argc != 2) {
-    std::cout << "Usage: " << argv[0] << " <jobfile>\n";
-    exit(EXIT_FAILURE);
-  }
-  std::ifstream in(argv[1]);
-  Require(in.good(), "Couldn't open %s", argv[1]);
-  Reconstructor recon;
-  Reconstructor::Dataset ds;
+// one job file -> the reconstruction parameters (the first file's stand for all) and one family
+static void readJob(const char* file, Reconstructor& recon, bool setParams, Reconstructor::Dataset& ds) {
+  std::ifstream in(file);
+  Require(in.good(), "Couldn't open %s", file);
+  Reconstructor scratch;
+  Reconstructor& r = setParams ? recon : scratch;
   string key, seqFile, guideFile;
   while (in >> key) {
-    if (key == "model") { string f; in >> f; recon.model.readFile(f.c_str()); }
+    if (key == "model") { string f; in >> f; if (setParams) r.model.readFile(f.c_str()); }
     else if (key == "seqs") in >> seqFile;
     else if (key == "guide") in >> guideFile;
-    else if (key == "band") in >> recon.maxDistanceFromGuide;
-    else if (key == "samples") in >> recon.profileSamples;
-    else if (key == "maxstates") in >> recon.profileMaxStates;
-    else if (key == "seed") in >> recon.rndSeed;
-    else if (key == "batch") { int b; in >> b; recon.batchReadyNodes = b != 0; }
-    else if (key == "posterior") { in >> recon.minPostProb; recon.usePosteriorsForProfile = true; }
+    else if (key == "band") in >> r.maxDistanceFromGuide;
+    else if (key == "samples") in >> r.profileSamples;
+    else if (key == "maxstates") in >> r.profileMaxStates;
+    else if (key == "seed") in >> r.rndSeed;
+    else if (key == "batch") { int b; in >> b; r.batchReadyNodes = b != 0; }
+    else if (key == "posterior") { in >> r.minPostProb; r.usePosteriorsForProfile = true; }
     else if (key == "tree") {
       int n; in >> n;
       for (int k = 0; k < n; ++k) {
@@ -43,7 +41,7 @@ int main(int argc, char** argv) {
         ds.tree.addNode(parent, len, name);
       }
       ds.tree.finish();
-    } else Fail("Unknown key %s in %s", key.c_str(), argv[1]);
+    } else Fail("Unknown key %s in %s", key.c_str(), file);
   }
   map<string, string> ungapped, gapped;
   for (const auto& fs : readFastSeqs(seqFile.c_str())) ungapped[fs.name] = fs.seq;
@@ -65,8 +63,53 @@ int main(int argc, char** argv) {
       }
     }
   ds.prepareRecon();
+}
+
+static void printFamily(const Reconstructor::Dataset& ds) {
+  printf("lpFinalFwd %a %.6f\n", ds.lpFinalFwd, ds.lpFinalFwd);
+  printf("lpFinalTrace %a %.6f\n", ds.lpFinalTrace, ds.lpFinalTrace);
+  for (const auto& nb : ds.bandUsed) printf("band %d %d\n", nb.first, nb.second);
+  fflush(stdout);
+  for (const auto& row_path : ds.path) {
+    const TreeNodeIndex node = (TreeNodeIndex)row_path.first;
+    std::cout << "row " << node << " " << ds.tree.nodeName[node] << " ";
+    const bool leaf = ds.seqs.count(node) > 0;
+    size_t k = 0;
+    for (bool b : row_path.second) std::cout << (b ? (leaf ? ds.seqs.at(node).seq[k++] : Alignment::wildcardChar) : Alignment::gapChar);
+    std::cout << "\n";
+  }
+  std::cout.flush();
+}
+
+// hxrecon [-devices d0,d1,...] <jobfile> [<jobfile> ...]
+// Several job files = several families (the first file's parameters apply to all); with -devices they are farmed over
+// those devices, one host thread each (an ordinal may be repeated: two threads sharing a device).  Output per family as
+// for a single one, preceded by a line "family <k>" when there are several.
+int main(int argc, char** argv) {
+  vguard<int> devices;
+  int first = 1;
+  if (argc > 2 && string(argv[1]) == "-devices") {
+    std::stringstream list(argv[2]);
+    string tok;
+    while (std::getline(list, tok, ',')) devices.push_back(atoi(tok.c_str()));
+    first = 3;
+  }
+  if (argc <= first) {
+    std::cout << "Usage: " << argv[0] << " [-devices d0,d1,...] <jobfile> [<jobfile> ...]\n";
+    exit(EXIT_FAILURE);
+  }
+  Reconstructor recon;
+  recon.devices = devices;
+  std::list<Reconstructor::Dataset> families;
+  vguard<Reconstructor::Dataset*> all;
+  for (int k = first; k < argc; ++k) {
+    families.emplace_back();
+    readJob(argv[k], recon, k == first, families.back());
+    all.push_back(&families.back());
+  }
   const double t0 = wallSeconds();
-  recon.reconstruct(ds);
+  if (all.size() == 1) recon.reconstruct(*all[0]);
+  else recon.reconstructAll(all);
   if (getenv("HX_TIMING")) {
     const double total = wallSeconds() - t0;
     const FillTiming& f = fillTiming;
@@ -77,16 +120,9 @@ int main(int argc, char** argv) {
             f.matrixReads, f.deviceTrace, f.deviceTraces, f.cellGather, f.cellGathers,
             total - f.deviceInit - f.flattenAndUpload - f.forwardWait - f.readMatrix - f.backwardWait - f.deviceTrace - f.cellGather);
   }
-  printf("lpFinalFwd %a %.6f\n", ds.lpFinalFwd, ds.lpFinalFwd);
-  printf("lpFinalTrace %a %.6f\n", ds.lpFinalTrace, ds.lpFinalTrace);
-  for (const auto& nb : ds.bandUsed) printf("band %d %d\n", nb.first, nb.second);
-  for (const auto& row_path : ds.path) {
-    const TreeNodeIndex node = (TreeNodeIndex)row_path.first;
-    std::cout << "row " << node << " " << ds.tree.nodeName[node] << " ";
-    const bool leaf = ds.seqs.count(node) > 0;
-    size_t k = 0;
-    for (bool b : row_path.second) std::cout << (b ? (leaf ? ds.seqs.at(node).seq[k++] : Alignment::wildcardChar) : Alignment::gapChar);
-    std::cout << "\n";
+  for (size_t k = 0; k < all.size(); ++k) {
+    if (all.size() > 1) { printf("family %zu\n", k); fflush(stdout); }
+    printFamily(*all[k]);
   }
   exit(EXIT_SUCCESS);
 }

@@ -1292,7 +1292,7 @@ int hx_host_alloc(size_t bytes, void** out) {
   if (!out) return fail(HX_ERR_INVALID_ARG, "out is null");
   *out = nullptr;
   if (bytes == 0) return HX_OK;
-  if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc(out, bytes, hipHostMallocPortable) != hipSuccess) {     // (usable from every device of the process)
     *out = nullptr;
     return fail(HX_ERR_OUT_OF_MEMORY, "hipHostMalloc of %zu bytes failed", bytes);
   }

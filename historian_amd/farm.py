@@ -72,3 +72,12 @@ def sum_over_ranks(value, world, device=None):
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(round(float(t.item())))
+
+
+def deal(pairs, world, rank, strong):
+    """(number of pair DPs of this rank, global index of its first one).  Weak scaling: `pairs` per rank.  Strong scaling
+    (BASELINE configs[3] as written): `pairs` in total, contiguous slices, the first `pairs % world` ranks get one more."""
+    if not strong:
+        return pairs, rank * pairs
+    base, extra = divmod(pairs, world)
+    return base + (1 if rank < extra else 0), rank * base + min(rank, extra)

@@ -26,7 +26,7 @@ def _worker(rank, world, port, pairs, length, q):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import bench
-    from historian_amd import farm, hostmodel
+    from historian_amd import farm, hostmodel, workload
     from oracle import c_oracle
     model = hostmodel.RateModel.load(os.path.join(ROOT, "tests", "golden", "models", "jc.json"))
     block = farm.constant_block(model, .2, .3) if rank == 0 else None
@@ -41,7 +41,10 @@ def _worker(rank, world, port, pairs, length, q):
         x, y = hostmodel.leaf_profile(xs, 4), hostmodel.leaf_profile(ys, 4)
         out.append(c_oracle.forward(x, y, hmm)["lp_end"])
     t = farm.max_over_ranks(1.0 + rank, world)
-    q.put((rank, float(np.sum(table)), [float(np.sum(m)) for m in sub_l], out, t))
+    # strong scaling (bench.py --scaling strong): 7 pair DPs in total dealt to the ranks, cell counts summed over ranks
+    n_local, first = farm.deal(7, world, rank, True)
+    total = farm.sum_over_ranks(n_local, world)
+    q.put((rank, float(np.sum(table)), [float(np.sum(m)) for m in sub_l], out, t, (n_local, first, total)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,10 +65,12 @@ def test_two_rank_farm_matches_single_process():
     assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
     # max over ranks of the per-rank times
     assert res[0][4] == res[1][4] == 2.0
+    # strong dealing: contiguous slices that cover the 7 pairs exactly once; the all-reduced count is the total
+    assert [r[5] for r in res] == [(4, 0, 7), (3, 4, 7)]
     # union over ranks == what one process with world*pairs pairs computes
     sys.path.insert(0, ROOT)
     import bench
-    from historian_amd import farm, hostmodel
+    from historian_amd import farm, hostmodel, workload
     from oracle import c_oracle
     model = hostmodel.RateModel.load(os.path.join(ROOT, "tests", "golden", "models", "jc.json"))
     hmm = hostmodel.make_hmm(model, .2, .3)
