@@ -58,6 +58,13 @@ class HxQuickJob(C.Structure):
                 ("submat", C.POINTER(C.c_double)), ("diagonals", C.POINTER(C.c_int32)), ("scores", C.c_double * 11)]
 
 
+class HxSumprodModel(C.Structure):
+    _fields_ = [("alph_size", C.c_int32), ("components", C.c_int32), ("n_nodes", C.c_int32), ("parent", _i32p),
+                ("ins_prob", _f64p), ("log_cpt_weight", _f64p), ("branch_sub", _f64p),
+                ("evec_re", _f64p), ("evec_im", _f64p), ("evec_inv_re", _f64p), ("evec_inv_im", _f64p),
+                ("esc_re", _f64p), ("esc_im", _f64p)]
+
+
 class HxCell(C.Structure):
     _fields_ = [("xpos", C.c_int32), ("ypos", C.c_int32), ("state", C.c_int32), ("pad_", C.c_int32),
                 ("log_post_prob", C.c_double)]
@@ -70,7 +77,7 @@ EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_cr
            "hx_quick_batch_create_on", "hx_batch_strip_windows", "hx_batch_total_cells", "hx_batch_last_kernel_ms", "hx_host_alloc",
            "hx_host_free", "hx_quick_batch_create", "hx_quick_batch_destroy", "hx_quick_batch_run",
            "hx_quick_batch_results", "hx_quick_batch_layout", "hx_quick_batch_read_matrix",
-           "hx_quick_batch_total_cells", "hx_quick_batch_last_kernel_ms"]
+           "hx_quick_batch_total_cells", "hx_quick_batch_last_kernel_ms", "hx_sumprod_columns", "hx_sumprod_last_kernel_ms"]
 
 
 class HxError(RuntimeError):
@@ -123,6 +130,9 @@ def load():
     lib.hx_quick_batch_total_cells.argtypes = [vp]
     lib.hx_quick_batch_total_cells.restype = C.c_int64
     lib.hx_quick_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.hx_sumprod_columns.argtypes = [C.POINTER(HxSumprodModel), C.POINTER(C.c_int8), _f64p, C.c_int64, _f64p, _f64p, _f64p, _f64p,
+                                       _f64p, vp]
+    lib.hx_sumprod_last_kernel_ms.argtypes = [C.POINTER(C.c_float)]
     _lib = lib
     return lib
 
@@ -447,3 +457,55 @@ class QuickBatch:
         ms = C.c_float()
         _check(load().hx_quick_batch_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+
+def sumprod_columns(parent, ins_prob, log_cpt_weight, branch_sub, evec, evec_inv, esc, tokens, weight=None, want_root_post=False):
+    """hx_sumprod_columns: parent [N]; ins_prob [C][A]; log_cpt_weight [C]; branch_sub [C][N][A][A]; evec, evec_inv [C][A][A]
+    complex; esc [C][N][A][A] complex; tokens [n_cols][N] int8 (-1 wildcard, -2 gap); weight [n_cols] or None.
+    Returns col_log_like [n_cols], root_counts [C][A], eigen_counts [C][A][A] complex, root_post [n_cols][A] or None."""
+    ins_prob = np.ascontiguousarray(ins_prob, dtype=np.float64)
+    c, a = ins_prob.shape
+    parent = np.ascontiguousarray(parent, dtype=np.int32)
+    n = parent.size
+    tokens = np.ascontiguousarray(tokens, dtype=np.int8)
+    if tokens.ndim != 2 or tokens.shape[1] != n:
+        raise ValueError("tokens must be [n_cols][n_nodes]")
+    n_cols = tokens.shape[0]
+    parts = {}
+
+    def real(name, arr, shape):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        if arr.shape != shape:
+            raise ValueError("%s must have shape %s, not %s" % (name, shape, arr.shape))
+        parts[name] = arr
+        return _p(arr, _f64p)
+
+    def split(name, arr, shape):
+        arr = np.asarray(arr, dtype=np.complex128)
+        return real(name + "_re", arr.real, shape), real(name + "_im", arr.imag, shape)
+    m = HxSumprodModel()
+    m.alph_size, m.components, m.n_nodes = a, c, n
+    m.parent = _p(parent, _i32p)
+    m.ins_prob = _p(ins_prob, _f64p)
+    m.log_cpt_weight = real("log_cpt_weight", log_cpt_weight, (c,))
+    m.branch_sub = real("branch_sub", branch_sub, (c, n, a, a))
+    m.evec_re, m.evec_im = split("evec", evec, (c, a, a))
+    m.evec_inv_re, m.evec_inv_im = split("evec_inv", evec_inv, (c, a, a))
+    m.esc_re, m.esc_im = split("esc", esc, (c, n, a, a))
+    w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
+    if w is not None and w.shape != (n_cols,):
+        raise ValueError("weight must be [n_cols]")
+    cll = np.empty(n_cols)
+    root = np.empty((c, a))
+    ere, eim = np.empty((c, a, a)), np.empty((c, a, a))
+    post = np.empty((n_cols, a)) if want_root_post else None
+    _check(load().hx_sumprod_columns(C.byref(m), _p(tokens, C.POINTER(C.c_int8)), _p(w, _f64p) if w is not None else C.cast(None, _f64p),
+                                     n_cols, _p(cll, _f64p), _p(root, _f64p), _p(ere, _f64p), _p(eim, _f64p),
+                                     _p(post, _f64p) if post is not None else C.cast(None, _f64p), None))
+    return cll, root, ere + 1j * eim, post
+
+
+def sumprod_kernel_ms():
+    ms = C.c_float()
+    _check(load().hx_sumprod_last_kernel_ms(C.byref(ms)))
+    return ms.value

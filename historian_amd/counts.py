@@ -1,0 +1,111 @@
+"""Counts mode on a fixed alignment: the host side of hx_sumprod_columns.
+
+Mirrors the reference's EigenModel (src/model.cpp:1135-1373) and EigenCounts::accumulateSubstitutionCounts
+(src/sumprod.cpp:430-459): the rate matrices are diagonalised once on the host (numpy in place of GSL), every column
+of the alignment goes through the device's sum-product kernel in one launch, and getSubCounts turns the summed
+eigen-basis matrix into wait times (diagonal) and substitution counts (off-diagonal).  The device path is the only
+path: without the HIP library capi.load() raises."""
+import math
+
+import numpy as np
+
+from . import capi
+
+GAP, WILD = -2, -1
+EPSILON = 1e-6        # EIGENMODEL_EPSILON: eigenvalues this close are treated as degenerate (src/model.cpp:1339)
+
+
+def _fcmp_equal(a, b, eps):
+    m = a if abs(a) > abs(b) else b
+    return abs(a - b) <= math.ldexp(eps, math.frexp(m)[1])
+
+
+class EigenModel:
+    def __init__(self, model):
+        self.model = model
+        self.ev, self.evec, self.evec_inv = [], [], []
+        for r in model.sub_rate:
+            w, v = np.linalg.eig(np.asarray(r, dtype=float))
+            v = v.astype(complex)
+            self.ev.append(w.astype(complex))
+            self.evec.append(v)
+            self.evec_inv.append(np.linalg.inv(v))
+
+    def sub_prob(self, t):
+        """exp(R t) of every component (EigenModel::getSubProbMatrix)"""
+        out = []
+        for ev, v, vi in zip(self.ev, self.evec, self.evec_inv):
+            p = np.real((v * np.exp(ev * t)) @ vi)
+            out.append(np.clip(p, 0., 1.))
+        return out
+
+    def eigen_sub_count(self, t):
+        """J[k][l] = integral over the branch of exp(ev_k s) exp(ev_l (t - s))  (EigenModel::eigenSubCount)"""
+        out = []
+        for ev in self.ev:
+            e = np.exp(ev * t)
+            a = len(ev)
+            dk, dl = np.meshgrid(ev, ev, indexing="ij")
+            ek, el = np.meshgrid(e, e, indexing="ij")
+            same = np.eye(a, dtype=bool)
+            for k in range(a):
+                for l in range(a):
+                    if k != l and _fcmp_equal(ev[k].real, ev[l].real, EPSILON) and _fcmp_equal(ev[k].imag, ev[l].imag, EPSILON):
+                        same[k, l] = True
+            with np.errstate(divide="ignore", invalid="ignore"):
+                j = np.where(same, ek * t, (ek - el) / np.where(same, 1., dk - dl))
+            out.append(j)
+        return out
+
+    def sub_counts(self, eigen_counts):
+        """EigenModel::getSubCounts: [C][A][A], wait times on the diagonal, substitution counts off it"""
+        out = []
+        for cpt, ec in enumerate(eigen_counts):
+            scale = np.array(self.model.sub_rate[cpt], dtype=float)
+            np.fill_diagonal(scale, 1.)
+            out.append(np.real(self.evec_inv[cpt].T @ ec @ self.evec[cpt].T) * scale)
+        return out
+
+
+def tokenize_columns(alphabet, rows):
+    """rows: [N] gapped strings of equal length, one per tree node (gap characters '-' and '.').
+    -> int8 [n_cols][N] tokens: -2 gap, -1 wildcard (a character outside the alphabet, either case)."""
+    n, width = len(rows), len(rows[0])
+    lut = np.full(256, WILD, dtype=np.int8)
+    for k, ch in enumerate(alphabet):
+        lut[ord(ch.lower())] = lut[ord(ch.upper())] = k
+    lut[ord("-")] = lut[ord(".")] = GAP
+    out = np.empty((width, n), dtype=np.int8)
+    for r, row in enumerate(rows):
+        if len(row) != width:
+            raise ValueError("alignment rows differ in length")
+        out[:, r] = lut[np.frombuffer(row.encode("latin-1"), dtype=np.uint8)]
+    return out
+
+
+class ColumnCounter:
+    """Sum-product over alignment columns on one tree (children-before-parents node order, root last)."""
+
+    def __init__(self, model, parent, branch_length, branch_sub=None):
+        self.model, self.parent = model, np.asarray(parent, dtype=np.int32)
+        self.eigen = EigenModel(model)
+        c, a, n = model.components(), len(model.alphabet), len(parent)
+        self.ins_prob = np.asarray(model.root, dtype=float).reshape(c, a)
+        self.log_cpt_weight = np.log(np.asarray(model.cpt_weight, dtype=float))
+        self.branch_sub = np.zeros((c, n, a, a))
+        self.esc = np.zeros((c, n, a, a), dtype=complex)
+        for r in range(n):
+            if parent[r] < 0:
+                continue
+            sub = branch_sub[r] if branch_sub is not None else self.eigen.sub_prob(branch_length[r])
+            esc = self.eigen.eigen_sub_count(branch_length[r])
+            for cpt in range(c):
+                self.branch_sub[cpt, r] = sub[cpt]
+                self.esc[cpt, r] = esc[cpt]
+
+    def run(self, tokens, weight=None, want_root_post=False):
+        """-> dict(col_log_like [n_cols], root_counts [C][A], eigen_counts [C][A][A] complex, counts [C][A][A], root_post)"""
+        cll, root, eig, post = capi.sumprod_columns(self.parent, self.ins_prob, self.log_cpt_weight, self.branch_sub,
+                                                    np.asarray(self.eigen.evec), np.asarray(self.eigen.evec_inv), self.esc, tokens,
+                                                    weight, want_root_post)
+        return dict(col_log_like=cll, root_counts=root, eigen_counts=eig, counts=self.eigen.sub_counts(eig), root_post=post)

@@ -496,6 +496,14 @@ int use_device(const hx_batch* b) {
 }
 }  // namespace
 
+namespace hx {
+// hx_sumprod.hip: the 8-byte log_sum_exp table of an initialised device, or null
+const double* device_lse_table(int device) {
+  return device >= 0 && device < HX_MAX_DEVICES && g_dev[device].ready ? g_dev[device].tab : nullptr;
+}
+int api_fail(int code, const char* what) { return fail(code, "%s", what); }
+}  // namespace hx
+
 extern "C" {
 
 int hx_version(void) { return 1; }

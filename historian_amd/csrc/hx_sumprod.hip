@@ -3,18 +3,23 @@
 // accumulateRootCounts and accumulateEigenCounts (src/sumprod.cpp:264-271, 294-372), for a BATCH of alignment columns.
 //
 // In the reference one SumProduct object walks the columns one after the other (AlignColSumProduct, and once per
-// posterior-weighted DP cell in BackwardMatrix::getCounts).  Columns are independent, so here a column is a thread:
-// every thread runs the tip-to-root and root-to-tip passes of its column - tiny tree recursions, A x A matrix-vector
-// products per branch and mixture component - with its messages E, F, G in a global scratch laid out [.][column] so that
-// the threads of a wavefront touch consecutive addresses, then turns the branch messages into the eigen basis and adds
-// weight x D_k J_kl U_l to the count matrices.  The count matrices are accumulated per workgroup in LDS (fp64 LDS atomics)
-// and added to the global result once per workgroup.
+// posterior-weighted DP cell in BackwardMatrix::getCounts).  Columns are independent, so here a column is a thread
+// (k_sumprod_columns): every thread runs the tip-to-root and root-to-tip passes of its column - tiny tree recursions,
+// A x A matrix-vector products per branch and mixture component - with its messages E, F, G in a global scratch laid out
+// [.][column] so that the threads of a wavefront touch consecutive addresses, then turns the messages of every branch
+// into the eigen basis (D_k, U_l).  The reference adds weight x D_k J_kl U_l to the count matrix column by column; J_kl
+// (eigenSubCount of the branch) does not depend on the column, so the sum over columns is an outer-product sum
+// J_kl x sum_col D_k(col) U_l(col): a second kernel (k_outer_counts) reduces the columns of one (component, branch) per
+// workgroup, A x A accumulators in registers, the bases staged through LDS, and multiplies by J once at the end.  When
+// every eigenvector is real (reversible models: all the reference's presets) the imaginary halves are neither written nor
+// read.  Root counts are written per column and summed by rows (k_row_sums).
 //
 // Arithmetic follows the reference: linear-space messages with per-node log scale factors, rescaling below 1e-30, the
-// column likelihood combined over components with the table log_sum_exp.  Sums over columns are atomic, so their order
-// differs from the reference's: results agree to rounding (tests/test_gpu_sumprod.py: 1e-10 relative), not bit for bit.
+// column likelihood combined over components with the table log_sum_exp.  Sums over columns are taken in a different
+// order from the reference's: results agree to rounding (tests/test_gpu_sumprod.py: 1e-10), not bit for bit.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "../../include/historian_hip.h"
 #include "hx_lse.h"
@@ -25,9 +30,11 @@ namespace hx {
 namespace {
 
 #define HX_SP_RESCALE 1e-30        // SUMPROD_RESCALE_THRESHOLD (src/sumprod.cpp:8)
+#define HX_SP_TILE 32              // columns per LDS tile of k_outer_counts
+#define HX_SP_PAIRS 16             // (k,l) pairs per thread of k_outer_counts: A*A <= 256 * 16, A <= 64
 
 struct SpModel {
-  int A, C, N;
+  int A, C, N, real_basis;
   const int* parent;               // [N] post-order: children before parents, root last; -1 for the root
   const int* child;                // [N][2] children or -1 (binary trees, as the reconstruction builds them)
   const double* ins_prob;          // [C][A]
@@ -41,21 +48,16 @@ struct SpModel {
   const double* esc_im;
 };
 
-// scratch of one batch: [kind][cpt][node][a][column]
-struct SpScratch { double* E; double* F; double* G; double* logE; double* logF; double* logG; double* basis; };
+// scratch of one chunk of columns: messages [cpt][node][a][column], scale factors [cpt][node][column],
+// root-count terms [cpt][a][column], bases [cpt][node][Ur, Dr, Ui, Di][a][column]
+struct SpScratch { double* E; double* F; double* G; double* logE; double* logF; double* logG; double* rootc; double* basis; };
 
 __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const signed char* __restrict__ tok, const double* __restrict__ weight,
                                                          const long long n_cols, const SpScratch s, const double* __restrict__ lse_tab,
-                                                         double* __restrict__ col_log_like, double* __restrict__ root_post,
-                                                         double* __restrict__ root_counts, double* __restrict__ eig_re, double* __restrict__ eig_im) {
-  extern __shared__ double acc[];   // [C][A] root counts, [C][A][A] re, [C][A][A] im
+                                                         double* __restrict__ col_log_like, double* __restrict__ root_post) {
   const int A = m.A, C = m.C, N = m.N, AA = A * A;
-  double* acc_root = acc;
-  double* acc_re = acc + C * A;
-  double* acc_im = acc_re + C * AA;
-  for (int k = threadIdx.x; k < C * A + 2 * C * AA; k += blockDim.x) acc[k] = 0.;
-  __syncthreads();
   const long long stride = n_cols;
+  const int parts = m.real_basis ? 2 : 4;
 #define AT(P, cpt, r, a) P[(((long long)(cpt) * N + (r)) * A + (a)) * stride + col]
 #define LG(P, cpt, r) P[((long long)(cpt) * N + (r)) * stride + col]
   for (long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x; col < n_cols; col += (long long)gridDim.x * blockDim.x) {
@@ -137,27 +139,33 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
           AT(s.G, cpt, r, b) = g;
         }
       }
-    if (root < 0) continue;
     // ---- posterior of the root's residue (src/sumprod.cpp:208-217) ----
     if (root_post)
       for (int a = 0; a < A; ++a) {
         double lp = HX_NEG_INF;
-        for (int cpt = 0; cpt < C; ++cpt)
-          lp = lse(lp, m.log_cpt_weight[cpt] + LG(s.logF, cpt, root) + log(AT(s.F, cpt, root, a)) + LG(s.logG, cpt, root) +
-                           log(AT(s.G, cpt, root, a)) - cll, lse_tab);
+        if (root >= 0)
+          for (int cpt = 0; cpt < C; ++cpt)
+            lp = lse(lp, m.log_cpt_weight[cpt] + LG(s.logF, cpt, root) + log(AT(s.F, cpt, root, a)) + LG(s.logG, cpt, root) +
+                             log(AT(s.G, cpt, root, a)) - cll, lse_tab);
         root_post[col * A + a] = lp < 0. ? lp : 0.;
       }
-    // ---- root counts (src/sumprod.cpp:264-271) ----
+    // ---- this column's terms of the root counts (src/sumprod.cpp:264-271) ----
     for (int cpt = 0; cpt < C; ++cpt) {
-      const double norm = exp(m.log_cpt_weight[cpt] + LG(s.logF, cpt, root) - cll);
-      for (int a = 0; a < A; ++a) atomicAdd(&acc_root[cpt * A + a], w * m.ins_prob[cpt * A + a] * AT(s.F, cpt, root, a) * norm);
+      const double norm = root >= 0 ? exp(m.log_cpt_weight[cpt] + LG(s.logF, cpt, root) - cll) : 0.;
+      for (int a = 0; a < A; ++a)
+        s.rootc[((long long)cpt * A + a) * stride + col] = root >= 0 ? w * m.ins_prob[cpt * A + a] * AT(s.F, cpt, root, a) * norm : 0.;
     }
-    // ---- eigen-basis substitution counts of every branch above an ungapped node (src/sumprod.cpp:294-372) ----
+    // ---- the messages of every branch above an ungapped node in the eigen basis (src/sumprod.cpp:294-360) ----
     for (int r = 0; r < N; ++r) {
-      if (t[r] == -2 || r == root) continue;
+      const bool live = root >= 0 && t[r] != -2 && r != root;
       const int p = m.parent[r];
-      const int sib = m.child[2 * p] == r ? m.child[2 * p + 1] : m.child[2 * p];
+      const int sib = !live ? -1 : m.child[2 * p] == r ? m.child[2 * p + 1] : m.child[2 * p];
       for (int cpt = 0; cpt < C; ++cpt) {
+        double* bs = s.basis + ((long long)cpt * N + r) * parts * A * stride + col;       // [Ur, Dr, (Ui, Di)][A][column]
+        if (!live) {
+          for (int l = 0; l < parts * A; ++l) bs[l * stride] = 0.;
+          continue;
+        }
         double max_u = 0., max_d = 0.;
         for (int a = 0; a < A; ++a) {
           const double u = AT(s.F, cpt, r, a), d = AT(s.G, cpt, p, a) * (sib >= 0 ? AT(s.E, cpt, sib, a) : 1.);
@@ -171,48 +179,114 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
         const double* vi = m.evec_im + (long long)cpt * AA;
         const double* ir = m.einv_re + (long long)cpt * AA;
         const double* ii = m.einv_im + (long long)cpt * AA;
-        // Ubasis[l] = sum_b evecInv[l][b] U[b];  Dbasis[k] = sum_a D[a] evec[a][k]   (scratch: [4][A] per column)
+        // Ubasis[l] = sum_b evecInv[l][b] U[b];  Dbasis[k] = sum_a D[a] evec[a][k], the column's weight / norm folded into D
         for (int l = 0; l < A; ++l) {
           double ur = 0., ui = 0., dr = 0., di = 0.;
           for (int b = 0; b < A; ++b) {
             const double u = AT(s.F, cpt, r, b) / max_u;
-            ur += ir[l * A + b] * u; ui += ii[l * A + b] * u;
             const double d = AT(s.G, cpt, p, b) * (sib >= 0 ? AT(s.E, cpt, sib, b) : 1.) / max_d;
-            dr += vr[b * A + l] * d; di += vi[b * A + l] * d;
+            ur += ir[l * A + b] * u;
+            dr += vr[b * A + l] * d;
+            if (!m.real_basis) { ui += ii[l * A + b] * u; di += vi[b * A + l] * d; }
           }
-          s.basis[(0 * A + l) * stride + col] = ur; s.basis[(1 * A + l) * stride + col] = ui;
-          s.basis[(2 * A + l) * stride + col] = dr; s.basis[(3 * A + l) * stride + col] = di;
-        }
-        const double* jr = m.esc_re + ((long long)cpt * N + r) * AA;
-        const double* ji = m.esc_im + ((long long)cpt * N + r) * AA;
-        for (int k = 0; k < A; ++k) {
-          const double dr = s.basis[(2 * A + k) * stride + col], di = s.basis[(3 * A + k) * stride + col];
-          for (int l = 0; l < A; ++l) {
-            const double ur = s.basis[(0 * A + l) * stride + col], ui = s.basis[(1 * A + l) * stride + col];
-            // D_k * (J_kl * U_l)
-            const double xr = jr[k * A + l] * ur - ji[k * A + l] * ui, xi = jr[k * A + l] * ui + ji[k * A + l] * ur;
-            atomicAdd(&acc_re[(cpt * A + k) * A + l], (dr * xr - di * xi) * scale);
-            atomicAdd(&acc_im[(cpt * A + k) * A + l], (dr * xi + di * xr) * scale);
-          }
+          bs[(0 * A + l) * stride] = ur;
+          bs[(1 * A + l) * stride] = dr * scale;
+          if (!m.real_basis) { bs[(2 * A + l) * stride] = ui; bs[(3 * A + l) * stride] = di * scale; }
         }
       }
     }
   }
 #undef AT
 #undef LG
-  __syncthreads();
-  for (int k = threadIdx.x; k < C * A; k += blockDim.x) atomicAdd(&root_counts[k], acc_root[k]);
-  for (int k = threadIdx.x; k < C * AA; k += blockDim.x) {
-    atomicAdd(&eig_re[k], acc_re[k]);
-    atomicAdd(&eig_im[k], acc_im[k]);
+}
+
+// eigenCounts[cpt][k][l] += J[cpt][node][k][l] * sum over this chunk's columns of D_k(col) U_l(col)   (src/sumprod.cpp:361-370)
+// grid (C * N branches, column slices); 256 threads, thread t owns the pairs (k,l) = t, t + 256, ...
+template <bool REAL>
+__global__ void __launch_bounds__(256) k_outer_counts(const SpModel m, const double* __restrict__ basis, const long long n_cols,
+                                                      double* __restrict__ eig_re, double* __restrict__ eig_im) {
+  extern __shared__ double tile[];                 // [parts * A][HX_SP_TILE + 1]
+  constexpr int PARTS = REAL ? 2 : 4, TS = HX_SP_TILE + 1;
+  const int A = m.A, AA = A * A, N = m.N;
+  const int branch = blockIdx.x, cpt = branch / N, r = branch - cpt * N;
+  if (m.parent[r] < 0) return;
+  const double* bs = basis + (long long)branch * PARTS * A * n_cols;
+  double acc_re[HX_SP_PAIRS], acc_im[HX_SP_PAIRS];
+#pragma unroll
+  for (int q = 0; q < HX_SP_PAIRS; ++q) acc_re[q] = acc_im[q] = 0.;
+  const long long n_tiles = (n_cols + HX_SP_TILE - 1) / HX_SP_TILE;
+  for (long long tl = blockIdx.y; tl < n_tiles; tl += gridDim.y) {
+    const long long c0 = tl * HX_SP_TILE;
+    for (int e = threadIdx.x; e < PARTS * A * HX_SP_TILE; e += 256) {
+      const int row = e / HX_SP_TILE, c = e - row * HX_SP_TILE;
+      tile[row * TS + c] = c0 + c < n_cols ? bs[(long long)row * n_cols + c0 + c] : 0.;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < HX_SP_PAIRS; ++q) {
+      const int pr = q * 256 + threadIdx.x;
+      if (q * 256 >= AA) break;
+      if (pr < AA) {
+        const int k = pr / A, l = pr - k * A;
+        const double* u_re = tile + l * TS;
+        const double* d_re = tile + (A + k) * TS;
+        double sr = acc_re[q], si = acc_im[q];
+        if (REAL) {
+#pragma unroll 8
+          for (int c = 0; c < HX_SP_TILE; ++c) sr += d_re[c] * u_re[c];
+        } else {
+          const double* u_im = tile + (2 * A + l) * TS;
+          const double* d_im = tile + (3 * A + k) * TS;
+#pragma unroll 4
+          for (int c = 0; c < HX_SP_TILE; ++c) {
+            sr += d_re[c] * u_re[c] - d_im[c] * u_im[c];
+            si += d_re[c] * u_im[c] + d_im[c] * u_re[c];
+          }
+        }
+        acc_re[q] = sr;
+        acc_im[q] = si;
+      }
+    }
+    __syncthreads();
   }
+  const double* jr = m.esc_re + (long long)branch * AA;
+  const double* ji = m.esc_im + (long long)branch * AA;
+#pragma unroll
+  for (int q = 0; q < HX_SP_PAIRS; ++q) {
+    const int pr = q * 256 + threadIdx.x;
+    if (pr < AA) {
+      atomicAdd(&eig_re[(long long)cpt * AA + pr], acc_re[q] * jr[pr] - acc_im[q] * ji[pr]);
+      atomicAdd(&eig_im[(long long)cpt * AA + pr], acc_re[q] * ji[pr] + acc_im[q] * jr[pr]);
+    }
+  }
+}
+
+// out[row] += sum of the row's n_cols entries; one workgroup per row
+__global__ void __launch_bounds__(256) k_row_sums(const double* __restrict__ rows, const long long n_cols, double* __restrict__ out) {
+  __shared__ double part[256];
+  const double* row = rows + (long long)blockIdx.x * n_cols;
+  double sum = 0.;
+  for (long long c = threadIdx.x; c < n_cols; c += 256) sum += row[c];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if ((int)threadIdx.x < h) part[threadIdx.x] += part[threadIdx.x + h];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] += part[0];
 }
 
 thread_local float g_sp_ms = 0.f;
 
+struct Buf {
+  void* p = nullptr;
+  ~Buf() { if (p) (void)hipFree(p); }
+};
+
 }  // namespace
 
 const double* device_lse_table(int device);    // hx_api.hip: the 8-byte log_sum_exp table of an initialised device, or null
+int api_fail(int code, const char* what);       // hx_api.hip: sets hx_last_error()
 
 }  // namespace hx
 
@@ -220,93 +294,125 @@ using namespace hx;
 
 extern "C" {
 
-// See include/historian_hip.h.  One call = upload, one launch over all columns, download.
+// See include/historian_hip.h.  One call = upload, the kernels over chunks of columns that fit the scratch budget, download.
 int hx_sumprod_columns(const hx_sumprod_model* hm, const int8_t* tokens, const double* weight, int64_t n_cols, double* col_log_like,
                        double* root_counts, double* eigen_re, double* eigen_im, double* root_post, void* stream) {
-  if (!hm || !tokens || n_cols <= 0 || !col_log_like || !root_counts || !eigen_re || !eigen_im) return HX_ERR_INVALID_ARG;
+  if (!hm || !tokens || n_cols <= 0 || !col_log_like || !root_counts || !eigen_re || !eigen_im)
+    return api_fail(HX_ERR_INVALID_ARG, "hx_sumprod_columns: null argument or no columns");
   const int A = hm->alph_size, C = hm->components, N = hm->n_nodes, AA = A * A;
   if (A <= 0 || C <= 0 || N <= 0 || !hm->parent || !hm->ins_prob || !hm->log_cpt_weight || !hm->branch_sub || !hm->evec_re || !hm->evec_im ||
       !hm->evec_inv_re || !hm->evec_inv_im || !hm->esc_re || !hm->esc_im)
-    return HX_ERR_INVALID_ARG;
+    return api_fail(HX_ERR_INVALID_ARG, "hx_sumprod_columns: incomplete model");
+  if (AA > 256 * HX_SP_PAIRS) return api_fail(HX_ERR_INVALID_ARG, "hx_sumprod_columns: alphabets of more than 64 symbols are not supported");
   int device = 0;
-  if (hipGetDevice(&device) != hipSuccess) return HX_ERR_NO_DEVICE;
+  if (hipGetDevice(&device) != hipSuccess) return api_fail(HX_ERR_NO_DEVICE, "no HIP device");
   const double* lse_tab = device_lse_table(device);
-  if (!lse_tab) return HX_ERR_NOT_INITIALIZED;
-  const size_t lds = sizeof(double) * ((size_t)C * A + 2 * (size_t)C * AA);
-  if (lds > HX_LDS_LIMIT) return HX_ERR_INVALID_ARG;
-  // children from parents; binary, post-order
+  if (!lse_tab) return api_fail(HX_ERR_NOT_INITIALIZED, "hx_init has not been called for the current device");
+  // children from parents; binary, children before parents
   std::vector<int> child(2 * (size_t)N, -1);
   for (int r = 0; r < N; ++r) {
     const int p = hm->parent[r];
     if (p < 0) continue;
-    if (p <= r || p >= N) return HX_ERR_NOT_TOPOSORTED;
+    if (p <= r || p >= N) return api_fail(HX_ERR_NOT_TOPOSORTED, "hx_sumprod_columns: a node precedes its child");
     if (child[2 * p] < 0) child[2 * p] = r;
     else if (child[2 * p + 1] < 0) child[2 * p + 1] = r;
-    else return HX_ERR_INVALID_ARG;
+    else return api_fail(HX_ERR_INVALID_ARG, "hx_sumprod_columns: a node has more than two children");
   }
+  bool real_basis = true;
+  for (size_t k = 0; k < (size_t)C * AA && real_basis; ++k) real_basis = hm->evec_im[k] == 0. && hm->evec_inv_im[k] == 0.;
+  for (size_t k = 0; k < (size_t)C * N * AA && real_basis; ++k) real_basis = hm->esc_im[k] == 0.;
+  const int parts = real_basis ? 2 : 4;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // one arena for the model, one for the scratch
-  const size_t n_model = (size_t)N + 2 * N + 0;
-  (void)n_model;
-  struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } };
   Buf b_int, b_dbl, b_tok, b_w, b_scr, b_out;
-  const size_t ints = 3 * (size_t)N;
   const size_t dbls = (size_t)C * A + C + (size_t)C * N * AA + 4 * (size_t)C * AA + 2 * (size_t)C * N * AA;
-  if (hipMalloc(&b_int.p, ints * sizeof(int)) != hipSuccess || hipMalloc(&b_dbl.p, dbls * sizeof(double)) != hipSuccess ||
+  if (hipMalloc(&b_int.p, 3 * (size_t)N * sizeof(int)) != hipSuccess || hipMalloc(&b_dbl.p, dbls * sizeof(double)) != hipSuccess ||
       hipMalloc(&b_tok.p, (size_t)n_cols * N) != hipSuccess)
-    return HX_ERR_OUT_OF_MEMORY;
+    return api_fail(HX_ERR_OUT_OF_MEMORY, "hx_sumprod_columns: device allocation failed");
   int* d_int = static_cast<int*>(b_int.p);
-  double* d_dbl = static_cast<double*>(b_dbl.p);
-#define UP(dst, src, n) if (hipMemcpy(dst, src, (n), hipMemcpyHostToDevice) != hipSuccess) return HX_ERR_HIP
+#define UP(dst, src, n) if (hipMemcpy(dst, src, (n), hipMemcpyHostToDevice) != hipSuccess) return api_fail(HX_ERR_HIP, "hx_sumprod_columns: copy failed")
   UP(d_int, hm->parent, N * sizeof(int));
   UP(d_int + N, child.data(), 2 * N * sizeof(int));
   SpModel m;
-  m.A = A; m.C = C; m.N = N; m.parent = d_int; m.child = d_int + N;
-  double* q = d_dbl;
-  auto put = [&](const double* src, size_t n) -> const double* { double* at = q; q += n; return hipMemcpy(at, src, n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess ? at : nullptr; };
+  m.A = A; m.C = C; m.N = N; m.real_basis = real_basis; m.parent = d_int; m.child = d_int + N;
+  double* q = static_cast<double*>(b_dbl.p);
+  bool copied = true;
+  auto put = [&](const double* src, size_t n) -> const double* {
+    double* at = q;
+    q += n;
+    copied = copied && hipMemcpy(at, src, n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    return at;
+  };
   m.ins_prob = put(hm->ins_prob, (size_t)C * A);
   m.log_cpt_weight = put(hm->log_cpt_weight, C);
   m.branch_sub = put(hm->branch_sub, (size_t)C * N * AA);
-  m.evec_re = put(hm->evec_re, (size_t)C * AA); m.evec_im = put(hm->evec_im, (size_t)C * AA);
-  m.einv_re = put(hm->evec_inv_re, (size_t)C * AA); m.einv_im = put(hm->evec_inv_im, (size_t)C * AA);
-  m.esc_re = put(hm->esc_re, (size_t)C * N * AA); m.esc_im = put(hm->esc_im, (size_t)C * N * AA);
-  if (!m.ins_prob || !m.log_cpt_weight || !m.branch_sub || !m.evec_re || !m.evec_im || !m.einv_re || !m.einv_im || !m.esc_re || !m.esc_im) return HX_ERR_HIP;
+  m.evec_re = put(hm->evec_re, (size_t)C * AA);
+  m.evec_im = put(hm->evec_im, (size_t)C * AA);
+  m.einv_re = put(hm->evec_inv_re, (size_t)C * AA);
+  m.einv_im = put(hm->evec_inv_im, (size_t)C * AA);
+  m.esc_re = put(hm->esc_re, (size_t)C * N * AA);
+  m.esc_im = put(hm->esc_im, (size_t)C * N * AA);
+  if (!copied) return api_fail(HX_ERR_HIP, "hx_sumprod_columns: copy failed");
   UP(b_tok.p, tokens, (size_t)n_cols * N);
   if (weight) {
-    if (hipMalloc(&b_w.p, n_cols * sizeof(double)) != hipSuccess) return HX_ERR_OUT_OF_MEMORY;
+    if (hipMalloc(&b_w.p, n_cols * sizeof(double)) != hipSuccess) return api_fail(HX_ERR_OUT_OF_MEMORY, "hx_sumprod_columns: device allocation failed");
     UP(b_w.p, weight, n_cols * sizeof(double));
   }
 #undef UP
-  const size_t per_col = 3 * (size_t)C * N * A + 3 * (size_t)C * N + 4 * (size_t)A;
+  // columns per chunk: the scratch of a chunk stays within the budget (HX_SUMPROD_SCRATCH_MB, default 16 GiB)
+  const size_t per_col = (3 + (size_t)parts) * C * N * A + 3 * (size_t)C * N + (size_t)C * A;
+  size_t budget = (size_t)16 << 30;
+  if (const char* e = getenv("HX_SUMPROD_SCRATCH_MB")) budget = (size_t)atoll(e) << 20;
+  long long chunk = (long long)(budget / (per_col * sizeof(double)));
+  if (chunk < 1) chunk = 1;
+  if (chunk > n_cols) chunk = n_cols;
   const size_t n_out = (size_t)n_cols * (1 + (root_post ? A : 0)) + (size_t)C * A + 2 * (size_t)C * AA;
-  if (hipMalloc(&b_scr.p, per_col * n_cols * sizeof(double)) != hipSuccess || hipMalloc(&b_out.p, n_out * sizeof(double)) != hipSuccess)
-    return HX_ERR_OUT_OF_MEMORY;
-  double* scr = static_cast<double*>(b_scr.p);
-  SpScratch s;
-  const size_t msg = (size_t)C * N * A * n_cols, lg = (size_t)C * N * n_cols;
-  s.E = scr; s.F = scr + msg; s.G = scr + 2 * msg; s.logE = scr + 3 * msg; s.logF = s.logE + lg; s.logG = s.logF + lg; s.basis = s.logG + lg;
+  if (hipMalloc(&b_scr.p, per_col * chunk * sizeof(double)) != hipSuccess || hipMalloc(&b_out.p, n_out * sizeof(double)) != hipSuccess)
+    return api_fail(HX_ERR_OUT_OF_MEMORY, "hx_sumprod_columns: device allocation failed");
   double* out = static_cast<double*>(b_out.p);
   double* d_cll = out;
   double* d_post = root_post ? out + n_cols : nullptr;
   double* d_root = out + (size_t)n_cols * (1 + (root_post ? A : 0));
   double* d_re = d_root + (size_t)C * A;
   double* d_im = d_re + (size_t)C * AA;
-  if (hipMemsetAsync(d_root, 0, ((size_t)C * A + 2 * (size_t)C * AA) * sizeof(double), st) != hipSuccess) return HX_ERR_HIP;
+  if (hipMemsetAsync(d_root, 0, ((size_t)C * A + 2 * (size_t)C * AA) * sizeof(double), st) != hipSuccess)
+    return api_fail(HX_ERR_HIP, "hx_sumprod_columns: HIP call failed");
+  const size_t lds = sizeof(double) * (size_t)parts * A * (HX_SP_TILE + 1);
+  if (lds > HX_LDS_LIMIT) return api_fail(HX_ERR_INVALID_ARG, "hx_sumprod_columns: basis tile exceeds the LDS of a CU");
   hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return HX_ERR_HIP;
-  const int tpb = 128;
-  long long blocks = (n_cols + tpb - 1) / tpb;
-  if (blocks > 4096) blocks = 4096;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return api_fail(HX_ERR_HIP, "hx_sumprod_columns: HIP call failed");
   (void)hipEventRecord(e0, st);
-  hipLaunchKernelGGL(k_sumprod_columns, dim3((unsigned)blocks), dim3(tpb), lds, st, m, static_cast<const signed char*>(b_tok.p),
-                     static_cast<const double*>(b_w.p), (long long)n_cols, s, lse_tab, d_cll, d_post, d_root, d_re, d_im);
+  for (long long first = 0; first < n_cols; first += chunk) {
+    const long long nc = n_cols - first < chunk ? n_cols - first : chunk;
+    double* scr = static_cast<double*>(b_scr.p);
+    SpScratch s;
+    const size_t msg = (size_t)C * N * A * nc, lg = (size_t)C * N * nc;
+    s.E = scr; s.F = scr + msg; s.G = scr + 2 * msg;
+    s.logE = scr + 3 * msg; s.logF = s.logE + lg; s.logG = s.logF + lg;
+    s.rootc = s.logG + lg;
+    s.basis = s.rootc + (size_t)C * A * nc;
+    const int tpb = 128;
+    long long blocks = (nc + tpb - 1) / tpb;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(k_sumprod_columns, dim3((unsigned)blocks), dim3(tpb), 0, st, m, static_cast<const signed char*>(b_tok.p) + first * N,
+                       b_w.p ? static_cast<const double*>(b_w.p) + first : nullptr, nc, s, lse_tab, d_cll + first,
+                       d_post ? d_post + first * A : nullptr);
+    const long long tiles = (nc + HX_SP_TILE - 1) / HX_SP_TILE;
+    long long slices = 4096 / ((long long)C * N) + 1;
+    if (slices > tiles) slices = tiles;
+    if (real_basis)
+      hipLaunchKernelGGL(k_outer_counts<true>, dim3((unsigned)(C * N), (unsigned)slices), dim3(256), lds, st, m, s.basis, nc, d_re, d_im);
+    else
+      hipLaunchKernelGGL(k_outer_counts<false>, dim3((unsigned)(C * N), (unsigned)slices), dim3(256), lds, st, m, s.basis, nc, d_re, d_im);
+    hipLaunchKernelGGL(k_row_sums, dim3((unsigned)(C * A)), dim3(256), 0, st, s.rootc, nc, d_root);
+  }
   (void)hipEventRecord(e1, st);
   int rc = HX_OK;
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = HX_ERR_HIP;
   if (rc == HX_OK) (void)hipEventElapsedTime(&g_sp_ms, e0, e1);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  if (rc != HX_OK) return rc;
-#define DOWN(dst, src, n) if (hipMemcpy(dst, src, (n) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return HX_ERR_HIP
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != HX_OK) return api_fail(rc, "hx_sumprod_columns: kernel launch or execution failed");
+#define DOWN(dst, src, n) if (hipMemcpy(dst, src, (n) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return api_fail(HX_ERR_HIP, "hx_sumprod_columns: copy failed")
   DOWN(col_log_like, d_cll, (size_t)n_cols);
   if (root_post) DOWN(root_post, d_post, (size_t)n_cols * A);
   DOWN(root_counts, d_root, (size_t)C * A);

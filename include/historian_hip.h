@@ -268,6 +268,43 @@ int hx_quick_batch_read_matrix(hx_quick_batch* b, int32_t job, double* out /* [3
 int64_t hx_quick_batch_total_cells(const hx_quick_batch* b);     /* sum xLen * yLen */
 int hx_quick_batch_last_kernel_ms(hx_quick_batch* b, float* ms);
 
+/* -- counts mode: column sum-product and substitution counts (reference src/sumprod.cpp) ----------
+ * A batch of alignment columns on one tree: SumProduct::initColumn / fillUp / fillDown for every column
+ * (src/sumprod.cpp:58-198), the column log-likelihoods (colLogLike), the root residue posteriors
+ * (logNodePostProb at the column's root, src/sumprod.cpp:208-217) and the weighted sums over columns of
+ * accumulateRootCounts (src/sumprod.cpp:264-271) and accumulateEigenCounts (src/sumprod.cpp:294-372) - what
+ * AlignColSumProduct-driven EigenCounts::accumulateSubstitutionCounts (src/sumprod.cpp:430-459) adds up
+ * before getSubCounts turns the eigen-basis matrix into wait times and substitution counts on the host.
+ * The eigen decomposition itself (GSL in the reference) stays with the caller: it hands over the eigenvectors,
+ * their inverse, exp(R t) and EigenModel::eigenSubCount(t) of every branch. */
+typedef struct hx_sumprod_model {
+  int32_t alph_size;             /* A                                                                    */
+  int32_t components;            /* C mixture components                                                 */
+  int32_t n_nodes;               /* N tree nodes, numbered children-before-parents (Tree's node order), root last */
+  const int32_t* parent;         /* [N] parent node or -1 (Tree::parentNode); at most two children per node */
+  const double* ins_prob;        /* [C][A] RateModel::insProb                                            */
+  const double* log_cpt_weight;  /* [C] log RateModel::cptWeight                                         */
+  const double* branch_sub;      /* [C][N][A][A] EigenModel::getSubProbMatrix(branchLength(n)) (unused at the root) */
+  const double* evec_re;         /* [C][A][A] EigenModel::evec, split into real and imaginary parts      */
+  const double* evec_im;
+  const double* evec_inv_re;     /* [C][A][A] EigenModel::evecInv                                        */
+  const double* evec_inv_im;
+  const double* esc_re;          /* [C][N][A][A] EigenModel::eigenSubCount(branchLength(n)) (src/model.cpp) */
+  const double* esc_im;
+} hx_sumprod_model;
+
+/* tokens: [n_cols][N] one byte per node and column: the residue's token, -1 for a wildcard, -2 for a gap
+ * (a column's ungapped nodes form one subtree: Alignment::isGap / SumProduct::initColumn's contract).
+ * weight: [n_cols] multiplier of each column's counts, or NULL for 1.
+ * Outputs, host memory: col_log_like [n_cols]; root_counts [C][A]; eigen_re, eigen_im [C][A][A]
+ * (EigenCounts::rootCount, eigenCount); root_post [n_cols][A] log posteriors, or NULL.
+ * Runs on the calling thread's current HIP device, which hx_init must have been called for; synchronous. */
+int hx_sumprod_columns(const hx_sumprod_model* model, const int8_t* tokens, const double* weight, int64_t n_cols,
+                       double* col_log_like, double* root_counts, double* eigen_re, double* eigen_im, double* root_post,
+                       void* stream);
+/* Duration of the most recent hx_sumprod_columns kernel on this thread (HIP events on its stream). */
+int hx_sumprod_last_kernel_ms(float* ms);
+
 /* Page-locked host memory for the destination of hx_batch_read_matrix: a device-to-host copy into
  * pageable memory runs at a fraction of the link rate (measured 4.7 GB/s for a 55 MB matrix).
  * Plain memory to the caller; release with hx_host_free. */
