@@ -109,3 +109,89 @@ class ColumnCounter:
                                                     np.asarray(self.eigen.evec), np.asarray(self.eigen.evec_inv), self.esc, tokens,
                                                     weight, want_root_post)
         return dict(col_log_like=cll, root_counts=root, eigen_counts=eig, counts=self.eigen.sub_counts(eig), root_post=post)
+
+
+# ---- `historian count -recon`: event counts of a fixed reconstruction (src/recon.cpp:1284-1291) ----
+
+def decay_wait_time(rate, t):
+    """IndelCounts::decayWaitTime"""
+    return 1 / rate - t / (math.exp(rate * t) - 1)
+
+
+def _branch_indels(model, t, parent_in, child_in, c):
+    """IndelCounts::accumulateIndelCounts of one branch (src/model.cpp:847-893): a three-state walk over the columns
+    where either end of the branch has a residue.  Host work: O(columns) byte comparisons per branch."""
+    ins, dele = 1 - math.exp(-model.ins_rate * t), 1 - math.exp(-model.del_rate * t)
+    ie, de = model.ins_ext, model.del_ext
+    ins_wait, del_wait = decay_wait_time(model.ins_rate, t), decay_wait_time(model.del_rate, t)
+    trans = {("M", "M"): (1 - ins) * (1 - dele), ("M", "I"): ins, ("M", "D"): (1 - ins) * dele, ("M", "E"): 1 - ins,
+             ("I", "M"): (1 - ie) * (1 - dele), ("I", "I"): ie, ("I", "D"): (1 - ie) * dele, ("I", "E"): 1 - ie,
+             ("D", "M"): 1 - de, ("D", "E"): 1 - de, ("D", "I"): 0., ("D", "D"): de}
+    used = parent_in | child_in
+    kinds = np.where(parent_in & child_in, 0, np.where(parent_in, 2, 1))[used]        # 0 match, 1 insert, 2 delete
+    state = "M"
+    for k in kinds:
+        nxt = "MID"[k]
+        if nxt == "M":
+            if state == "M":
+                c["insTime"] += t
+                c["delTime"] += t
+        elif nxt == "I":
+            if state == "I":
+                c["insExt"] += 1
+            else:
+                c["ins"] += 1
+                c["insTime"] += ins_wait
+        else:
+            if state == "D":
+                c["delExt"] += 1
+            else:
+                c["del"] += 1
+                c["delTime"] += del_wait
+        p = trans[(state, nxt)]
+        c["lp"] += math.log(p) if p > 0 else -math.inf
+        state = nxt
+    p = trans[(state, "E")]
+    c["lp"] += math.log(p) if p > 0 else -math.inf
+
+
+def count_reconstruction(model, parent, branch_length, rows):
+    """EigenCounts::accumulateCounts + transform for a dataset that comes with its reconstruction.
+    rows: gapped strings, one per tree node (ancestors included, '*' where the residue is unknown).
+    -> (indel dict, root counts [C][A], substitution counts and wait times [C][A][A])"""
+    tok = tokenize_columns(model.alphabet, rows)
+    present = tok != GAP
+    c = {"ins": 0., "del": 0., "insExt": 0., "delExt": 0., "insTime": 0., "delTime": 0., "lp": 0.}
+    for node, p in enumerate(parent):
+        if p >= 0:
+            _branch_indels(model, branch_length[node], present[:, p], present[:, node], c)
+    res = ColumnCounter(model, parent, branch_length).run(tok)
+    c["lp"] += float(np.sum(res["col_log_like"]))
+    return c, res["root_counts"], res["counts"]
+
+
+def _g(x):
+    s = "%g" % x
+    return "0" if s == "-0" else s
+
+
+def event_counts_json(alphabet, indel, root, sub):
+    """EventCounts::writeJson (src/model.cpp:933-956): the counts file of `historian count`, character for character"""
+    def component(r, c, indent):
+        ind, n = " " * indent, range(len(alphabet))
+        body = [ind + "{", ind + " \"root\":",
+                ind + "  {" + ",".join("\n%s   \"%s\": %s" % (ind, alphabet[i], _g(r[i])) for i in n), ind + "  },", ind + " \"sub\":",
+                ind + "  {" + ",".join("\n%s   \"%s\": {%s }" % (ind, alphabet[i], ",".join(" \"%s\": %s" % (alphabet[j], _g(c[i][j])) for j in n if j != i))
+                                       for i in n), ind + "  },", ind + " \"wait\":",
+                ind + "  {" + ",".join("\n%s   \"%s\": %s" % (ind, alphabet[i], _g(c[i][i])) for i in n), ind + "  }", ind + "}"]
+        return "\n".join(body)
+    lines = ["{", " \"alphabet\": \"%s\"," % alphabet, " \"indel\":", "  {"]
+    for k in ("ins", "del", "insExt", "delExt", "insTime", "delTime"):
+        lines.append("   \"%s\": %s%s" % (k, _g(indel[k]), "" if k.endswith("Time") else ","))
+    lines += ["  },", " \"sub\":"]
+    if len(root) > 1:
+        lines += ["  {", "   \"mixture\": [", ",\n".join(component(root[k], sub[k], 4) for k in range(len(root))), "   ]", "  },"]
+    else:
+        lines.append(component(root[0], sub[0], 2) + ",")
+    lines += [" \"logLikelihood\": %s" % _g(indel["lp"]), "}", ""]
+    return "\n".join(lines)

@@ -48,18 +48,29 @@ struct SpModel {
   const double* esc_im;
 };
 
-// scratch of one chunk of columns: messages [cpt][node][a][column], scale factors [cpt][node][column],
-// root-count terms [cpt][a][column], bases [cpt][node][Ur, Dr, Ui, Di][a][column]
-struct SpScratch { double* E; double* F; double* G; double* logE; double* logF; double* logG; double* rootc; double* basis; };
+// scratch of one chunk of columns: messages E, G [cpt][node][a][column]; scale factors and max U [cpt][node][column];
+// F at the column's root and the root-count terms [cpt][a][column]; bases [cpt][node][Ur, Dr, (Ui, Di)][a][column]
+struct SpScratch { double* E; double* G; double* logE; double* logF; double* logG; double* maxU; double* Froot; double* rootc; double* basis; };
 
+// Model matrices are read through the constant address space: their addresses are uniform over the wavefront and
+// nothing writes them, so the compiler fetches them with scalar loads and feeds the FMAs from SGPRs.
+typedef const __attribute__((address_space(4))) double* CMat;
+__device__ __forceinline__ CMat cmat(const double* p) { return (CMat)(unsigned long long)p; }
+
+// TA: the alphabet size as a compile-time constant (message vectors live in registers, loops unrolled), or 0 for any
+// alphabet of up to 64 symbols (vectors in private memory).
+template <int TA>
 __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const signed char* __restrict__ tok, const double* __restrict__ weight,
                                                          const long long n_cols, const SpScratch s, const double* __restrict__ lse_tab,
                                                          double* __restrict__ col_log_like, double* __restrict__ root_post) {
-  const int A = m.A, C = m.C, N = m.N, AA = A * A;
+  constexpr int AX = TA ? TA : 64;
+  const int A = TA ? TA : m.A, C = m.C, N = m.N, AA = A * A;
   const long long stride = n_cols;
   const int parts = m.real_basis ? 2 : 4;
 #define AT(P, cpt, r, a) P[(((long long)(cpt) * N + (r)) * A + (a)) * stride + col]
 #define LG(P, cpt, r) P[((long long)(cpt) * N + (r)) * stride + col]
+#define BS(cpt, r, part, l) s.basis[((((long long)(cpt) * N + (r)) * parts + (part)) * A + (l)) * stride + col]
+#define FR(cpt, a) s.Froot[((long long)(cpt) * A + (a)) * stride + col]
   for (long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x; col < n_cols; col += (long long)gridDim.x * blockDim.x) {
     const signed char* t = tok + col * N;       // -2 gap, -1 wildcard, else the residue's token
     const double w = weight ? weight[col] : 1.;
@@ -67,85 +78,174 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
     for (int r = 0; r < N; ++r)
       if (t[r] != -2 && (m.parent[r] < 0 || t[m.parent[r]] == -2)) root = r;     // (one root per column: the caller's contract)
     double cll = HX_NEG_INF;
-    // ---- tip-to-root (src/sumprod.cpp:99-161) ----
+    // ---- tip-to-root (src/sumprod.cpp:99-161); U of every branch in the eigen basis on the way (src/sumprod.cpp:318-340) ----
     for (int cpt = 0; cpt < C; ++cpt) {
       double cpt_ll = 0.;
+      CMat ins = cmat(m.ins_prob + cpt * A);
       for (int r = 0; r < N; ++r) {
         const int c0 = m.child[2 * r], c1 = m.child[2 * r + 1];
         double lf = (c0 >= 0 ? LG(s.logE, cpt, c0) : 0.) + (c1 >= 0 ? LG(s.logE, cpt, c1) : 0.);
-        if (t[r] == -2) {
-          // a gap: its message to the parent is all ones
+        const int tk = t[r];
+        if (tk == -2) {
+          // a gap: its message to the parent is all ones, and no counts on the branch above it
+#pragma unroll
           for (int a = 0; a < A; ++a) AT(s.E, cpt, r, a) = 1.;
           LG(s.logE, cpt, r) = 0.;
           LG(s.logF, cpt, r) = lf;
+#pragma unroll
+          for (int l = 0; l < A; ++l) BS(cpt, r, 0, l) = 0.;
+          if (parts == 4)
+            for (int l = 0; l < A; ++l) BS(cpt, r, 2, l) = 0.;
           continue;
         }
-        if (t[r] == -1) {
-          double fmax = 0.;
-          for (int a = 0; a < A; ++a) {
-            const double f = (c0 >= 0 ? AT(s.E, cpt, c0, a) : 1.) * (c1 >= 0 ? AT(s.E, cpt, c1, a) : 1.);
-            AT(s.F, cpt, r, a) = f;
-            fmax = f > fmax ? f : fmax;
-          }
-          if (fmax < HX_SP_RESCALE) {
-            for (int a = 0; a < A; ++a) AT(s.F, cpt, r, a) /= fmax;
-            lf += log(fmax);
-          }
-        } else {
-          const int tk = t[r];
+        CMat sub = cmat(m.branch_sub + ((long long)cpt * N + r) * AA);
+        CMat ir = cmat(m.einv_re + (long long)cpt * AA);
+        CMat ii = cmat(m.einv_im + (long long)cpt * AA);
+        if (tk >= 0) {
+          // a residue: F is one-hot, E and U are columns of the matrices
           double f = (c0 >= 0 ? AT(s.E, cpt, c0, tk) : 1.) * (c1 >= 0 ? AT(s.E, cpt, c1, tk) : 1.);
           if (f < HX_SP_RESCALE) { lf += log(f); f = 1.; }
-          for (int a = 0; a < A; ++a) AT(s.F, cpt, r, a) = a == tk ? f : 0.;
+          LG(s.logF, cpt, r) = lf;
+          if (r == root) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) FR(cpt, a) = a == tk ? f : 0.;
+            cpt_ll += lf + log(f * m.ins_prob[cpt * A + tk]);
+          } else {
+            LG(s.logE, cpt, r) = lf;
+            LG(s.maxU, cpt, r) = f;
+            const double* subg = m.branch_sub + ((long long)cpt * N + r) * AA;
+#pragma unroll
+            for (int a = 0; a < A; ++a) AT(s.E, cpt, r, a) = subg[a * A + tk] * f;
+#pragma unroll
+            for (int l = 0; l < A; ++l) BS(cpt, r, 0, l) = m.einv_re[(long long)cpt * AA + l * A + tk] * (f / f);
+            if (parts == 4)
+              for (int l = 0; l < A; ++l) BS(cpt, r, 2, l) = m.einv_im[(long long)cpt * AA + l * A + tk] * (f / f);
+          }
+          continue;
+        }
+        // a wildcard: the full vector
+        double f[AX];
+        double fmax = 0.;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          f[a] = (c0 >= 0 ? AT(s.E, cpt, c0, a) : 1.) * (c1 >= 0 ? AT(s.E, cpt, c1, a) : 1.);
+          fmax = f[a] > fmax ? f[a] : fmax;
+        }
+        if (fmax < HX_SP_RESCALE) {
+#pragma unroll
+          for (int a = 0; a < A; ++a) f[a] /= fmax;
+          lf += log(fmax);
+          fmax = 1.;
         }
         LG(s.logF, cpt, r) = lf;
         if (r == root) {
           double ip = 0.;
-          for (int a = 0; a < A; ++a) ip += AT(s.F, cpt, r, a) * m.ins_prob[cpt * A + a];
-          cpt_ll += lf + log(ip);
-        } else {
-          LG(s.logE, cpt, r) = lf;
-          const double* sub = m.branch_sub + ((long long)cpt * N + r) * AA;
+#pragma unroll
           for (int a = 0; a < A; ++a) {
-            double e = 0.;
-            for (int b = 0; b < A; ++b) e += sub[a * A + b] * AT(s.F, cpt, r, b);
-            AT(s.E, cpt, r, a) = e;
+            FR(cpt, a) = f[a];
+            ip += f[a] * ins[a];
           }
+          cpt_ll += lf + log(ip);
+          continue;
         }
+        LG(s.logE, cpt, r) = lf;
+        LG(s.maxU, cpt, r) = fmax;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          double e = 0.;
+#pragma unroll
+          for (int b = 0; b < A; ++b) e += sub[a * A + b] * f[b];
+          AT(s.E, cpt, r, a) = e;
+        }
+#pragma unroll
+        for (int a = 0; a < A; ++a) f[a] /= fmax;
+#pragma unroll
+        for (int l = 0; l < A; ++l) {
+          double ur = 0.;
+#pragma unroll
+          for (int b = 0; b < A; ++b) ur += ir[l * A + b] * f[b];
+          BS(cpt, r, 0, l) = ur;
+        }
+        if (parts == 4)
+          for (int l = 0; l < A; ++l) {
+            double ui = 0.;
+#pragma unroll
+            for (int b = 0; b < A; ++b) ui += ii[l * A + b] * f[b];
+            BS(cpt, r, 2, l) = ui;
+          }
       }
       cll = lse(cll, m.log_cpt_weight[cpt] + cpt_ll, lse_tab);
     }
     col_log_like[col] = cll;
-    // ---- root-to-tip (src/sumprod.cpp:163-198) ----
-    for (int cpt = 0; cpt < C; ++cpt)
+    // ---- root-to-tip (src/sumprod.cpp:163-198); D of every branch in the eigen basis on the way (src/sumprod.cpp:341-360) ----
+    for (int cpt = 0; cpt < C; ++cpt) {
+      CMat ins = cmat(m.ins_prob + cpt * A);
       for (int r = N - 1; r >= 0; --r) {
-        if (t[r] == -2) continue;
-        if (r == root) {
-          for (int a = 0; a < A; ++a) AT(s.G, cpt, r, a) = m.ins_prob[cpt * A + a];
-          LG(s.logG, cpt, r) = 0.;
+        if (t[r] == -2 || r == root) {
+          if (r == root) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) AT(s.G, cpt, r, a) = ins[a];
+            LG(s.logG, cpt, r) = 0.;
+            for (int l = 0; l < A; ++l) BS(cpt, r, 0, l) = 0.;        // no branch above the root: U was not written on the way up
+            if (parts == 4)
+              for (int l = 0; l < A; ++l) BS(cpt, r, 2, l) = 0.;
+          }
+#pragma unroll
+          for (int l = 0; l < A; ++l) BS(cpt, r, 1, l) = 0.;
+          if (parts == 4)
+            for (int l = 0; l < A; ++l) BS(cpt, r, 3, l) = 0.;
           continue;
         }
         const int p = m.parent[r];
         const int sib = m.child[2 * p] == r ? m.child[2 * p + 1] : m.child[2 * p];
-        LG(s.logG, cpt, r) = LG(s.logG, cpt, p) + (sib >= 0 ? LG(s.logE, cpt, sib) : 0.);
-        const double* sub = m.branch_sub + ((long long)cpt * N + r) * AA;
-        const bool sib_in = sib >= 0 && t[sib] != -2;
+        const double le_sib = sib >= 0 ? LG(s.logE, cpt, sib) : 0.;
+        const double lg_p = LG(s.logG, cpt, p);
+        LG(s.logG, cpt, r) = lg_p + le_sib;
+        CMat sub = cmat(m.branch_sub + ((long long)cpt * N + r) * AA);
+        CMat vr = cmat(m.evec_re + (long long)cpt * AA);
+        CMat vi = cmat(m.evec_im + (long long)cpt * AA);
+        // what flows down the branch: the parent's outside message times the sibling's subtree
+        double d[AX];
+        double max_d = 0.;
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+          d[a] = AT(s.G, cpt, p, a) * (sib >= 0 ? AT(s.E, cpt, sib, a) : 1.);
+          max_d = d[a] > max_d ? d[a] : max_d;
+        }
+#pragma unroll
         for (int b = 0; b < A; ++b) {
           double g = 0.;
-          for (int a = 0; a < A; ++a) {
-            double pw = AT(s.G, cpt, p, a) * sub[a * A + b];
-            if (sib_in) pw *= AT(s.E, cpt, sib, a);
-            g += pw;
-          }
+#pragma unroll
+          for (int a = 0; a < A; ++a) g += d[a] * sub[a * A + b];
           AT(s.G, cpt, r, b) = g;
         }
+        const double norm = exp(cll - m.log_cpt_weight[cpt] - LG(s.logF, cpt, r) - lg_p - le_sib) / (LG(s.maxU, cpt, r) * max_d);
+        const double scale = w / norm;
+#pragma unroll
+        for (int a = 0; a < A; ++a) d[a] /= max_d;
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+          double dr = 0.;
+#pragma unroll
+          for (int a = 0; a < A; ++a) dr += vr[a * A + k] * d[a];
+          BS(cpt, r, 1, k) = dr * scale;
+        }
+        if (parts == 4)
+          for (int k = 0; k < A; ++k) {
+            double di = 0.;
+#pragma unroll
+            for (int a = 0; a < A; ++a) di += vi[a * A + k] * d[a];
+            BS(cpt, r, 3, k) = di * scale;
+          }
       }
+    }
     // ---- posterior of the root's residue (src/sumprod.cpp:208-217) ----
     if (root_post)
       for (int a = 0; a < A; ++a) {
         double lp = HX_NEG_INF;
         if (root >= 0)
           for (int cpt = 0; cpt < C; ++cpt)
-            lp = lse(lp, m.log_cpt_weight[cpt] + LG(s.logF, cpt, root) + log(AT(s.F, cpt, root, a)) + LG(s.logG, cpt, root) +
+            lp = lse(lp, m.log_cpt_weight[cpt] + LG(s.logF, cpt, root) + log(FR(cpt, a)) + LG(s.logG, cpt, root) +
                              log(AT(s.G, cpt, root, a)) - cll, lse_tab);
         root_post[col * A + a] = lp < 0. ? lp : 0.;
       }
@@ -153,51 +253,13 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
     for (int cpt = 0; cpt < C; ++cpt) {
       const double norm = root >= 0 ? exp(m.log_cpt_weight[cpt] + LG(s.logF, cpt, root) - cll) : 0.;
       for (int a = 0; a < A; ++a)
-        s.rootc[((long long)cpt * A + a) * stride + col] = root >= 0 ? w * m.ins_prob[cpt * A + a] * AT(s.F, cpt, root, a) * norm : 0.;
-    }
-    // ---- the messages of every branch above an ungapped node in the eigen basis (src/sumprod.cpp:294-360) ----
-    for (int r = 0; r < N; ++r) {
-      const bool live = root >= 0 && t[r] != -2 && r != root;
-      const int p = m.parent[r];
-      const int sib = !live ? -1 : m.child[2 * p] == r ? m.child[2 * p + 1] : m.child[2 * p];
-      for (int cpt = 0; cpt < C; ++cpt) {
-        double* bs = s.basis + ((long long)cpt * N + r) * parts * A * stride + col;       // [Ur, Dr, (Ui, Di)][A][column]
-        if (!live) {
-          for (int l = 0; l < parts * A; ++l) bs[l * stride] = 0.;
-          continue;
-        }
-        double max_u = 0., max_d = 0.;
-        for (int a = 0; a < A; ++a) {
-          const double u = AT(s.F, cpt, r, a), d = AT(s.G, cpt, p, a) * (sib >= 0 ? AT(s.E, cpt, sib, a) : 1.);
-          max_u = u > max_u ? u : max_u;
-          max_d = d > max_d ? d : max_d;
-        }
-        const double norm = exp(cll - m.log_cpt_weight[cpt] - LG(s.logF, cpt, r) - LG(s.logG, cpt, p) - (sib >= 0 ? LG(s.logE, cpt, sib) : 0.)) /
-                            (max_u * max_d);
-        const double scale = w / norm;
-        const double* vr = m.evec_re + (long long)cpt * AA;
-        const double* vi = m.evec_im + (long long)cpt * AA;
-        const double* ir = m.einv_re + (long long)cpt * AA;
-        const double* ii = m.einv_im + (long long)cpt * AA;
-        // Ubasis[l] = sum_b evecInv[l][b] U[b];  Dbasis[k] = sum_a D[a] evec[a][k], the column's weight / norm folded into D
-        for (int l = 0; l < A; ++l) {
-          double ur = 0., ui = 0., dr = 0., di = 0.;
-          for (int b = 0; b < A; ++b) {
-            const double u = AT(s.F, cpt, r, b) / max_u;
-            const double d = AT(s.G, cpt, p, b) * (sib >= 0 ? AT(s.E, cpt, sib, b) : 1.) / max_d;
-            ur += ir[l * A + b] * u;
-            dr += vr[b * A + l] * d;
-            if (!m.real_basis) { ui += ii[l * A + b] * u; di += vi[b * A + l] * d; }
-          }
-          bs[(0 * A + l) * stride] = ur;
-          bs[(1 * A + l) * stride] = dr * scale;
-          if (!m.real_basis) { bs[(2 * A + l) * stride] = ui; bs[(3 * A + l) * stride] = di * scale; }
-        }
-      }
+        s.rootc[((long long)cpt * A + a) * stride + col] = root >= 0 ? w * m.ins_prob[cpt * A + a] * FR(cpt, a) * norm : 0.;
     }
   }
 #undef AT
 #undef LG
+#undef BS
+#undef FR
 }
 
 // eigenCounts[cpt][k][l] += J[cpt][node][k][l] * sum over this chunk's columns of D_k(col) U_l(col)   (src/sumprod.cpp:361-370)
@@ -359,7 +421,7 @@ int hx_sumprod_columns(const hx_sumprod_model* hm, const int8_t* tokens, const d
   }
 #undef UP
   // columns per chunk: the scratch of a chunk stays within the budget (HX_SUMPROD_SCRATCH_MB, default 16 GiB)
-  const size_t per_col = (3 + (size_t)parts) * C * N * A + 3 * (size_t)C * N + (size_t)C * A;
+  const size_t per_col = (2 + (size_t)parts) * C * N * A + 4 * (size_t)C * N + 2 * (size_t)C * A;
   size_t budget = (size_t)16 << 30;
   if (const char* e = getenv("HX_SUMPROD_SCRATCH_MB")) budget = (size_t)atoll(e) << 20;
   long long chunk = (long long)(budget / (per_col * sizeof(double)));
@@ -386,16 +448,23 @@ int hx_sumprod_columns(const hx_sumprod_model* hm, const int8_t* tokens, const d
     double* scr = static_cast<double*>(b_scr.p);
     SpScratch s;
     const size_t msg = (size_t)C * N * A * nc, lg = (size_t)C * N * nc;
-    s.E = scr; s.F = scr + msg; s.G = scr + 2 * msg;
-    s.logE = scr + 3 * msg; s.logF = s.logE + lg; s.logG = s.logF + lg;
-    s.rootc = s.logG + lg;
+    s.E = scr; s.G = scr + msg;
+    s.logE = scr + 2 * msg; s.logF = s.logE + lg; s.logG = s.logF + lg; s.maxU = s.logG + lg;
+    s.Froot = s.maxU + lg;
+    s.rootc = s.Froot + (size_t)C * A * nc;
     s.basis = s.rootc + (size_t)C * A * nc;
     const int tpb = 128;
     long long blocks = (nc + tpb - 1) / tpb;
     if (blocks > 65535) blocks = 65535;
-    hipLaunchKernelGGL(k_sumprod_columns, dim3((unsigned)blocks), dim3(tpb), 0, st, m, static_cast<const signed char*>(b_tok.p) + first * N,
-                       b_w.p ? static_cast<const double*>(b_w.p) + first : nullptr, nc, s, lse_tab, d_cll + first,
-                       d_post ? d_post + first * A : nullptr);
+    const signed char* d_tok = static_cast<const signed char*>(b_tok.p) + first * N;
+    const double* d_w = b_w.p ? static_cast<const double*>(b_w.p) + first : nullptr;
+    double* d_p = d_post ? d_post + first * A : nullptr;
+    if (A == 4)
+      hipLaunchKernelGGL(k_sumprod_columns<4>, dim3((unsigned)blocks), dim3(tpb), 0, st, m, d_tok, d_w, nc, s, lse_tab, d_cll + first, d_p);
+    else if (A == 20)
+      hipLaunchKernelGGL(k_sumprod_columns<20>, dim3((unsigned)blocks), dim3(tpb), 0, st, m, d_tok, d_w, nc, s, lse_tab, d_cll + first, d_p);
+    else
+      hipLaunchKernelGGL(k_sumprod_columns<0>, dim3((unsigned)blocks), dim3(tpb), 0, st, m, d_tok, d_w, nc, s, lse_tab, d_cll + first, d_p);
     const long long tiles = (nc + HX_SP_TILE - 1) / HX_SP_TILE;
     long long slices = 4096 / ((long long)C * N) + 1;
     if (slices > tiles) slices = tiles;

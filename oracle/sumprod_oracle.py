@@ -335,3 +335,109 @@ def main_testsumprod(model, tree, gapped):
 def main_testaligncount(model, tree, gapped):
     root, counts, _, _ = counts_for_alignment(model, tree, gapped)
     return write_sub_counts(model, root, counts) + "\n"
+
+
+# ---- counts of a fixed reconstruction: `historian count -recon` (src/recon.cpp:1284-1291, src/model.cpp:847-923) ----
+
+def decay_wait_time(rate, t):
+    """IndelCounts::decayWaitTime (src/model.cpp:1106-1108)"""
+    return 1 / rate - t / (math.exp(rate * t) - 1)
+
+
+def _trans_prob(pm, src, dest):
+    """ProbModel::transProb (src/model.cpp:400-447); states M, I, D, E"""
+    ins, dele, ie, de = pm.ins, pm.dele, pm.ins_ext, pm.del_ext
+    if src == "M":
+        return {"M": (1 - ins) * (1 - dele), "I": ins, "D": (1 - ins) * dele, "E": 1 - ins}[dest]
+    if src == "I":
+        return {"M": (1 - ie) * (1 - dele), "I": ie, "D": (1 - ie) * dele, "E": 1 - ie}[dest]
+    return {"M": 1 - de, "E": 1 - de, "I": 0., "D": de}[dest]
+
+
+def indel_counts_of_branch(model, t, parent_row, child_row, c, weight=1.):
+    """IndelCounts::accumulateIndelCounts on one branch (src/model.cpp:847-893).  parent_row, child_row: per-column
+    presence flags; c: dict ins del insExt delExt insTime delTime lp, updated in place."""
+    ins_wait, del_wait = decay_wait_time(model.ins_rate, t), decay_wait_time(model.del_rate, t)
+    pm = ho.ProbModel(model, t, sub_mat=[])
+    state = "M"
+    for p, ch in zip(parent_row, child_row):
+        if p and ch:
+            nxt = "M"
+        elif p:
+            nxt = "D"
+        elif ch:
+            nxt = "I"
+        else:
+            continue
+        if nxt == "M":
+            if state == nxt:
+                c["insTime"] += weight * t
+                c["delTime"] += weight * t
+        elif nxt == "I":
+            if state == nxt:
+                c["insExt"] += weight
+            else:
+                c["ins"] += weight
+                c["insTime"] += weight * ins_wait
+        else:
+            if state == nxt:
+                c["delExt"] += weight
+            else:
+                c["del"] += weight
+                c["delTime"] += weight * del_wait
+        c["lp"] += _log(_trans_prob(pm, state, nxt)) * weight
+        state = nxt
+    c["lp"] += _log(_trans_prob(pm, state, "E")) * weight
+
+
+def count_reconstruction(model, tree, gapped):
+    """EigenCounts::accumulateCounts + transform for one dataset with a reconstruction: indel counts of every branch,
+    substitution counts of every column, log-likelihood = indel path + column likelihoods.
+    -> (indel dict, root counts [C][A], counts [C][A][A])"""
+    c = dict(ins=0., insExt=0., insTime=0., delExt=0., delTime=0., lp=0.)
+    c["del"] = 0.
+    present = {n: [ch not in "-." for ch in gapped[n]] for n in range(tree.nodes())}
+    for node in range(tree.nodes() - 1):
+        indel_counts_of_branch(model, tree.branch_length[node], present[tree.parent[node]], present[node], c)
+    sp = SumProduct(model, tree)
+    a = len(model.alphabet)
+    root = [np.zeros(a) for _ in range(sp.C)]
+    eig = [np.zeros((a, a), dtype=complex) for _ in range(sp.C)]
+    for seq in columns_of(tree, gapped):
+        sp.init_column(seq)
+        sp.fill_up()
+        sp.fill_down()
+        sp.accumulate_eigen_counts(root, eig)
+        c["lp"] += sp.col_log_like
+    return c, root, sp.eigen.get_sub_counts(eig)
+
+
+def _sub_counts_component(alph, r, c, indent):
+    """AlphabetOwner::writeSubCountsComponent (src/model.cpp:675-705)"""
+    ind = " " * indent
+    n = range(len(alph))
+    out = ind + "{\n" + ind + " \"root\":\n" + ind + "  {"
+    out += ",".join("\n" + ind + "   \"%s\": %s" % (alph[i], _g(r[i])) for i in n)
+    out += "\n" + ind + "  },\n" + ind + " \"sub\":\n" + ind + "  {"
+    out += ",".join("\n" + ind + "   \"%s\": {" % alph[i] + ",".join(" \"%s\": %s" % (alph[j], _g(c[i][j])) for j in n if j != i) + " }" for i in n)
+    out += "\n" + ind + "  },\n" + ind + " \"wait\":\n" + ind + "  {"
+    out += ",".join("\n" + ind + "   \"%s\": %s" % (alph[i], _g(c[i][i])) for i in n)
+    out += "\n" + ind + "  }\n" + ind + "}"
+    return out
+
+
+def write_event_counts(model, indel, root, counts):
+    """EventCounts::writeJson (src/model.cpp:933-956, 657-673)"""
+    alph = model.alphabet
+    out = "{\n \"alphabet\": \"%s\",\n \"indel\":\n" % alph
+    out += "  {\n" + "".join("   \"%s\": %s%s\n" % (k, _g(indel[k]), "," if k not in ("insTime", "delTime") else "")
+                            for k in ("ins", "del", "insExt", "delExt", "insTime", "delTime")) + "  }"
+    out += ",\n \"sub\":\n"
+    if len(root) > 1:
+        out += "  {\n   \"mixture\": [\n"
+        out += ",\n".join(_sub_counts_component(alph, root[k], counts[k], 4) for k in range(len(root))) + "\n"
+        out += "   ]\n  }"
+    else:
+        out += _sub_counts_component(alph, root[0], counts[0], 2)
+    out += ",\n \"logLikelihood\": %s\n}\n" % _g(indel["lp"])
+    return out

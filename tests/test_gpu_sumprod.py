@@ -165,6 +165,19 @@ def test_complex_eigenvectors_and_column_chunks(monkeypatch):
     np.testing.assert_array_equal(whole["col_log_like"], got["col_log_like"])
 
 
+@pytest.mark.parametrize("model_file,fasta,newick,expected", [
+    ("testcount.jukescantor.json", "testcount.fa", "testcount.nh", "testcount.out.json"),
+    ("testcount.jukescantor.json", "testcount.historian.fa", "testcount.nh", "testcount.count.json"),
+    ("testrates.mix2.json", "testcount.mix2.fa", "testcount.mix2.nh", "testcount.mix2.count.json")])
+def test_count_of_a_reconstruction_prints_the_reference_files(model_file, fasta, newick, expected):
+    """`historian count -recon` end to end (reference Makefile testcount): the counts file, character for character -
+    single-component, and the two-component cyclic mixture whose eigenvectors are complex."""
+    _, model, tree, gapped = _fixture(model_file, fasta, newick)
+    indel, root, sub = counts.count_reconstruction(model, tree.parent, tree.branch_length, [gapped[n] for n in range(tree.nodes())])
+    with open(G + expected) as f:
+        assert counts.event_counts_json(model.alphabet, indel, root, sub) == f.read()
+
+
 def test_refused_arguments():
     model = hostmodel.RateModel.load(G + "testnj.jukescantor.json")
     cc = counts.ColumnCounter(model, [2, 2, -1], [.1, .2, 0.])

@@ -35,3 +35,16 @@ def test_testaligncount_fixtures():
     model, tree, gapped = load("testcount.jukescantor.json", "testaligncount2.fa", "testcount.nh")
     with open(G + "testaligncount2.out.json") as f:
         assert so.main_testaligncount(model, tree, gapped) == f.read()
+
+
+def test_count_of_a_fixed_reconstruction_fixtures():
+    """`historian count -recon` (reference Makefile testcount): indel counts of every branch of a given reconstruction,
+    substitution counts of its columns, the log-likelihood - single component and the two-component cyclic mixture."""
+    for model_file, fasta, newick, expected in (
+            ("testcount.jukescantor.json", "testcount.fa", "testcount.nh", "testcount.out.json"),
+            ("testcount.jukescantor.json", "testcount.historian.fa", "testcount.nh", "testcount.count.json"),
+            ("testrates.mix2.json", "testcount.mix2.fa", "testcount.mix2.nh", "testcount.mix2.count.json")):
+        model, tree, gapped = load(model_file, fasta, newick)
+        indel, root, counts = so.count_reconstruction(model, tree, gapped)
+        with open(G + expected) as f:
+            assert so.write_event_counts(model, indel, root, counts) == f.read(), expected

@@ -42,9 +42,10 @@ def main():
     rng = np.random.default_rng(3)
     parent, length = balanced(leaves, rng)
     n, a, c = len(parent), len(model.alphabet), model.components()
-    # ungapped columns evolved down the tree are not needed for timing: random residues, 5 % of leaves gapped in
-    # sibling pairs is not expressible in general, so every node present
+    # the shape of a reconstruction (`historian count -recon`): residues at the leaves, unknown residues ('*') at the
+    # ancestors, so that every internal node carries full message vectors; no gaps
     tok = rng.integers(0, a, (n_cols, n)).astype(np.int8)
+    tok[:, leaves:] = -1
     capi.init(0, hostmodel.lse_table())
     cc = counts.ColumnCounter(model, parent, length)
     cc.run(tok[:1000])
@@ -52,10 +53,14 @@ def main():
     out = cc.run(tok)
     wall = time.perf_counter() - t0
     ms = capi.sumprod_kernel_ms()
-    flops = c * (n - 1) * (2 * a * a + 3 * a * a + 8 * a * a + 12 * a * a)        # E, G, the two bases, D J U
+    # per component: G and D matrix-vector products on every branch, E and U on the branches above internal nodes,
+    # the outer-product term D_k U_l on every branch
+    flops = c * ((n - 1) * (4 * a * a + 2 * a * a) + (n - leaves - 1) * 4 * a * a)
+    scratch = c * n * a * 8 * 4 + 8 * (4 * c * n + 2 * c * a)                    # E, G, U, D + scalars, written once
     line = dict(metric="sumprod_columns_per_s", columns=n_cols, nodes=n, components=c, alphabet=a, kernel_ms=ms,
                 columns_per_s_kernel=n_cols / (ms * 1e-3), columns_per_s_call=n_cols / wall,
-                gflops_kernel=flops * n_cols / (ms * 1e-3) / 1e9, flops_per_column=flops)
+                gflops_kernel=flops * n_cols / (ms * 1e-3) / 1e9, flops_per_column=flops,
+                scratch_bytes_per_column=scratch, scratch_write_gb_per_s=scratch * n_cols / (ms * 1e-3) / 1e9)
     try:
         from oracle import historian_oracle as ho
         from oracle import sumprod_oracle as so
@@ -68,7 +73,7 @@ def main():
         sample = 200
         t0 = time.perf_counter()
         for col in range(sample):
-            sp.init_column({r: model.alphabet[tok[col, r]] for r in range(n)})
+            sp.init_column({r: model.alphabet[tok[col, r]] if tok[col, r] >= 0 else "*" for r in range(n)})
             sp.fill_up()
             sp.fill_down()
             sp.accumulate_eigen_counts(root, eig)
