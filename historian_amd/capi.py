@@ -77,7 +77,8 @@ EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_cr
            "hx_quick_batch_create_on", "hx_batch_strip_windows", "hx_batch_total_cells", "hx_batch_last_kernel_ms", "hx_host_alloc",
            "hx_host_free", "hx_quick_batch_create", "hx_quick_batch_destroy", "hx_quick_batch_run",
            "hx_quick_batch_results", "hx_quick_batch_layout", "hx_quick_batch_read_matrix",
-           "hx_quick_batch_total_cells", "hx_quick_batch_last_kernel_ms", "hx_sumprod_columns", "hx_sumprod_last_kernel_ms"]
+           "hx_quick_batch_total_cells", "hx_quick_batch_last_kernel_ms", "hx_sumprod_columns", "hx_sumprod_last_kernel_ms",
+           "hx_batch_read_matrix_async", "hx_batch_wait_read"]
 
 
 class HxError(RuntimeError):
@@ -133,6 +134,8 @@ def load():
     lib.hx_sumprod_columns.argtypes = [C.POINTER(HxSumprodModel), C.POINTER(C.c_int8), _f64p, C.c_int64, _f64p, _f64p, _f64p, _f64p,
                                        _f64p, vp]
     lib.hx_sumprod_last_kernel_ms.argtypes = [C.POINTER(C.c_float)]
+    lib.hx_batch_read_matrix_async.argtypes = [vp, C.c_int32, C.c_int32, vp]
+    lib.hx_batch_wait_read.argtypes = [vp, C.c_int32, C.c_int32]
     _lib = lib
     return lib
 

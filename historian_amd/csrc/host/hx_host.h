@@ -58,6 +58,8 @@ struct FillTiming {
   double deviceInit = 0, flattenAndUpload = 0, forwardWait = 0, forwardKernel = 0, backwardWait = 0, readMatrix = 0;
   double deviceTrace = 0, cellGather = 0;
   double hostTraces = 0, hostMakeProfile = 0;      // host tracebacks (sampled, or best without the device kernel), makeProfile
+  double pinnedAlloc = 0; long pinnedAllocs = 0;   // page-locked buffers allocated for matrix copies (inside readMatrix)
+  double cellSets = 0, retain = 0;                 // sorting / merging the sampled cells; keeping their values (retainCells)
   long fills = 0, matrixReads = 0, deviceTraces = 0, cellGathers = 0;
   long long cells = 0;
 };
@@ -405,10 +407,18 @@ protected:
   mutable double* hostCells;     // lazy copy of the device matrix (strip-skewed layout), page-locked, pooled
   mutable size_t hostCellsCap;
   mutable bool haveHostCells;
+  mutable bool hostCopyInFlight;  // hx_batch_read_matrix_async issued into hostCells, not yet waited for
   // cells gathered from the device without copying the matrix (hx_batch_read_cells): used while the full
   // host copy does not exist, so that a best-path profile never moves 40 B/cell over PCIe
   mutable map<std::pair<ProfileStateIndex, ProfileStateIndex>, XYCell> sparseCells;
   void prefetchCells(const set<CellCoords>& cells) const;
+public:
+  // starts the device-to-host copy of the matrix without waiting for it; the first host access waits (ensureHostCells)
+  void startHostCopy() const;
+  // keeps the values of these cells and releases the host copy of the matrix (makeProfile reads only its chosen cells)
+  void retainCells(const set<CellCoords>& cells) const;
+  bool onHost() const { return haveHostCells; }
+protected:
   long long stripStride, planeStride, blockStride, matrixDoubles;   // hx_layout of this matrix
 
   void createBatchAndPrepare();  // flatten inputs -> hx_batch_create; run the fill; fetch the prepared vectors
@@ -480,6 +490,11 @@ public:
   Profile sampleProfile(random_engine& generator, size_t profileSamples, size_t maxCells = 0,
                         ProfilingStrategy strategy = CollapseChains, size_t minLen = 0,
                         size_t maxLen = std::numeric_limits<size_t>::max());
+  // the first half of sampleProfile: the cells of the best trace and of the sampled traces (all the generator draws);
+  // makeProfile(cells) is the second half and touches neither the generator nor the device once the matrix is on the host
+  set<CellCoords> sampleCells(random_engine& generator, size_t profileSamples, size_t maxCells = 0, ProfilingStrategy strategy = CollapseChains,
+                              size_t minLen = 0, size_t maxLen = (size_t)-1);
+  bool hostMatrixReady() const { return haveHostCells || !batch; }
   Profile bestProfile(ProfilingStrategy strategy = CollapseChains);
 
   map<CellCoords, LogProb> sourceTransitions(const CellCoords& destCell);
@@ -605,6 +620,7 @@ void ensureDevice();                  // the calling thread's device
 void ensureDevice(int ordinal);       // hx_init for that device, once per process
 int threadDevice();                   // the device this host thread creates its matrices on (HX_DEVICE or 0 by default)
 void setThreadDevice(int ordinal);
+void warmHostBuffers(size_t doubles, int count);   // page-lock `count` matrix buffers on a helper thread
 void mergeTiming(const FillTiming& from, FillTiming& into);
 double* pinnedTake(size_t doubles, size_t& capacity);
 void pinnedGive(double* p, size_t capacity);

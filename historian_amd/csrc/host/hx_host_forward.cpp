@@ -9,6 +9,7 @@
 #include <mutex>
 #include <iomanip>
 #include <sstream>
+#include <thread>
 
 #include "../../../include/historian_hip.h"
 
@@ -111,7 +112,7 @@ DPMatrix::DPMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, const
       xNearStart(xSize, false), yNearEnd(ySize, false),
       insx(x.size(), NEG_INF), insy(y.size(), NEG_INF), rootsubx(x.size(), NEG_INF), rootsuby(y.size(), NEG_INF),
       absorbScratch(hmm.components(), vguard<LogProb>(hmm.alphabetSize())),
-      batch(NULL), jobIndex(0), which(0), hostCells(NULL), hostCellsCap(0), haveHostCells(false), stripStride(0), planeStride(0), blockStride(128), matrixDoubles(0) {
+      batch(NULL), jobIndex(0), which(0), hostCells(NULL), hostCellsCap(0), haveHostCells(false), hostCopyInFlight(false), stripStride(0), planeStride(0), blockStride(128), matrixDoubles(0) {
   if (env.initialized()) {
     for (ProfileStateIndex i = 1; i < xSize; ++i) xClosestLeafPos[i] = x.state[i].seqCoords.at(env.row1);
     for (ProfileStateIndex j = 1; j < ySize; ++j) yClosestLeafPos[j] = y.state[j].seqCoords.at(env.row2);
@@ -128,7 +129,28 @@ DPMatrix::DPMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, const
 namespace {
 struct PinnedPool {
   std::vector<std::pair<size_t, double*> > freeList;   // (capacity in doubles, buffer)
+  std::thread warming;                                 // page-locks the first buffers while the first fill runs
+  std::mutex warmMutex;
+  void settle() {
+    std::lock_guard<std::mutex> lock(warmMutex);
+    if (warming.joinable()) warming.join();
+  }
+  // Page-locking memory costs ~12 ms per 40 MB buffer: do it on a helper thread, under the first fill, not in front of
+  // the first traceback.
+  void warm(size_t doubles, int count) {
+    settle();
+    std::lock_guard<std::mutex> lock(warmMutex);
+    warming = std::thread([this, doubles, count]() {
+      for (int k = 0; k < count; ++k) {
+        void* p = NULL;
+        if (hx_host_alloc(doubles * sizeof(double), &p) != HX_OK) return;
+        give(static_cast<double*>(p), doubles);
+      }
+    });
+  }
+  ~PinnedPool() { settle(); }
   double* take(size_t n, size_t& cap) {
+    settle();
     std::lock_guard<std::mutex> lock(g_deviceMutex);
     size_t best = freeList.size();
     for (size_t k = 0; k < freeList.size(); ++k)
@@ -139,7 +161,7 @@ struct PinnedPool {
       freeList.erase(freeList.begin() + (long)best);
       return p;
     }
-    if (freeList.size() >= 4) {                         // keep the pool small: drop the smallest buffer
+    if (freeList.size() >= 32) {                        // bound the pool: drop the smallest buffer
       size_t small = 0;
       for (size_t k = 1; k < freeList.size(); ++k)
         if (freeList[k].first < freeList[small].first) small = k;
@@ -148,7 +170,10 @@ struct PinnedPool {
     }
     void* p = NULL;
     cap = n + n / 8;
+    const double t0 = wallSeconds();
     hxCheck(hx_host_alloc(cap * sizeof(double), &p), "hx_host_alloc");
+    fillTiming.pinnedAlloc += wallSeconds() - t0;
+    fillTiming.pinnedAllocs += 1;
     return static_cast<double*>(p);
   }
   void give(double* p, size_t cap) {
@@ -160,10 +185,12 @@ PinnedPool g_pinned;
 }  // namespace
 
 DPMatrix::~DPMatrix() {
+  if (hostCopyInFlight && batch) (void)hx_batch_wait_read(batch, jobIndex, which);    // the copy writes into hostCells
   if (hostCells) g_pinned.give(hostCells, hostCellsCap);
 }
 
 namespace detail {
+void warmHostBuffers(size_t doubles, int count) { g_pinned.warm(doubles, count); }
 void ensureDevice() { historian::ensureDevice(); }
 void ensureDevice(int ordinal) { historian::ensureDevice(ordinal); }
 int threadDevice() { return historian::threadDevice(); }
@@ -171,7 +198,7 @@ void setThreadDevice(int ordinal) { t_device = ordinal; }
 void mergeTiming(const FillTiming& a, FillTiming& b) {
   b.deviceInit += a.deviceInit; b.flattenAndUpload += a.flattenAndUpload; b.forwardWait += a.forwardWait;
   b.forwardKernel += a.forwardKernel; b.backwardWait += a.backwardWait; b.readMatrix += a.readMatrix;
-  b.deviceTrace += a.deviceTrace; b.cellGather += a.cellGather; b.hostTraces += a.hostTraces; b.hostMakeProfile += a.hostMakeProfile;
+  b.deviceTrace += a.deviceTrace; b.cellGather += a.cellGather; b.hostTraces += a.hostTraces; b.hostMakeProfile += a.hostMakeProfile; b.cellSets += a.cellSets; b.retain += a.retain; b.pinnedAlloc += a.pinnedAlloc; b.pinnedAllocs += a.pinnedAllocs;
   b.fills += a.fills; b.matrixReads += a.matrixReads; b.deviceTraces += a.deviceTraces; b.cellGathers += a.cellGathers; b.cells += a.cells;
 }
 double* pinnedTake(size_t doubles, size_t& capacity) { return g_pinned.take(doubles, capacity); }
@@ -359,11 +386,25 @@ void DPMatrix::fetchPrepared() {
         for (size_t a = 0; a < A; ++a) suby.state[j].lpAbsorb[c][a] = sy[(j * C + c) * A + a];
 }
 
+void DPMatrix::startHostCopy() const {
+  if (haveHostCells || hostCopyInFlight || !batch) return;
+  const double t0 = wallSeconds();
+  hostCells = g_pinned.take((size_t)matrixDoubles, hostCellsCap);
+  hxCheck(hx_batch_read_matrix_async(batch, jobIndex, which, hostCells), "hx_batch_read_matrix_async");
+  hostCopyInFlight = true;
+  fillTiming.readMatrix += wallSeconds() - t0;
+}
+
 void DPMatrix::ensureHostCells() const {
   if (haveHostCells) return;
   const double t0 = wallSeconds();
-  hostCells = g_pinned.take((size_t)matrixDoubles, hostCellsCap);
-  hxCheck(hx_batch_read_matrix(batch, jobIndex, which, hostCells), "hx_batch_read_matrix");
+  if (hostCopyInFlight) {
+    hxCheck(hx_batch_wait_read(batch, jobIndex, which), "hx_batch_wait_read");
+    hostCopyInFlight = false;
+  } else {
+    hostCells = g_pinned.take((size_t)matrixDoubles, hostCellsCap);
+    hxCheck(hx_batch_read_matrix(batch, jobIndex, which, hostCells), "hx_batch_read_matrix");
+  }
   haveHostCells = true;
   fillTiming.readMatrix += wallSeconds() - t0;
   fillTiming.matrixReads += 1;
@@ -391,6 +432,26 @@ void DPMatrix::prefetchCells(const set<CellCoords>& cells) const {
   }
   fillTiming.cellGather += wallSeconds() - t0;
   fillTiming.cellGathers += 1;
+}
+
+// Keeps the values of `cells` (all five states of each (x, y)) and lets the page-locked copy of the matrix go: what
+// makeProfile reads afterwards is in sparseCells, so it needs neither the buffer nor the device.
+void DPMatrix::retainCells(const set<CellCoords>& cells) const {
+  if (!haveHostCells) return;
+  const double t0 = wallSeconds();
+  std::pair<ProfileStateIndex, ProfileStateIndex> last((ProfileStateIndex)-1, (ProfileStateIndex)-1);
+  for (const auto& c : cells) {
+    if (c.xpos + 1 >= xSize || c.ypos + 1 >= ySize) continue;
+    const std::pair<ProfileStateIndex, ProfileStateIndex> key(c.xpos, c.ypos);
+    if (key == last) continue;                     // the set is ordered by (x, y, state)
+    last = key;
+    sparseCells[key] = xyCell(c.xpos, c.ypos);
+  }
+  g_pinned.give(hostCells, hostCellsCap);
+  hostCells = NULL;
+  hostCellsCap = 0;
+  haveHostCells = false;
+  fillTiming.retain += wallSeconds() - t0;
 }
 
 LogProb DPMatrix::cell(ProfileStateIndex xpos, ProfileStateIndex ypos, PairHMM::State state) const {

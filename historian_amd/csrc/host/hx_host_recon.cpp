@@ -2,6 +2,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstdio>
+#include <exception>
 #include <mutex>
 #include <thread>
 // Progressive reconstruction loop of the host mirror (see hx_host.h): the part of
@@ -80,7 +81,7 @@ void Reconstructor::reconstruct(Dataset& dataset) {
   AlignPath path;
   map<int, Profile> prof;
   const bool timing = getenv("HX_TIMING") != NULL;
-  double tLeaf = 0, tHmm = 0, tFwd = 0, tProf = 0, tCheck = 0;
+  double tLeaf = 0, tHmm = 0, tFwd = 0, tProf = 0, tCheck = 0, tSample = 0, tBuild = 0;
 
   // per internal node: the branch models (the matrices keep references to them), the filled matrix, the band
   struct NodeWork {
@@ -101,6 +102,17 @@ void Reconstructor::reconstruct(Dataset& dataset) {
         done[node] = 1;
       }
     tLeaf += wallSeconds() - ta;
+  }
+  // sampled tracebacks read whole matrices on the host, through page-locked buffers (the node being walked, the copies
+  // in flight for the next two, one spare): have them page-locked by the time the first fill is done.
+  // An internal node's profile is a little longer than the longest sequence below it; buffers that turn out too small are
+  // replaced on demand.
+  if (!usePosteriorsForProfile && profileSamples > 0) {
+    size_t longest = 0;
+    for (TreeNodeIndex node = 0; node < N; ++node)
+      if (dataset.tree.isLeaf(node)) longest = std::max(longest, (size_t)dataset.seqs.at(node).length());
+    const size_t side = longest + longest / 4 + 130;
+    detail::warmHostBuffers(5 * side * side, 4);
   }
   auto envelopeFor = [&](TreeNodeIndex node, int maxDist) {
     return dataset.guide.empty() ? GuideAlignmentEnvelope()
@@ -156,6 +168,25 @@ void Reconstructor::reconstruct(Dataset& dataset) {
     tFwd += wallSeconds() - tb1;
 
     // ---- finish nodes in node order while their matrices are there ----
+    // Three passes over the nodes whose matrices are filled.  (1) In node order, everything that draws from the shared
+    // generator or talks to the device: refills of zero-likelihood bands, tracebacks, sampled traces.  (2) The profiles of
+    // the sampled cell sets - deterministic, host-only, independent between nodes - on as many host threads as there are
+    // nodes (up to the machine's cores).  (3) In node order again: the path-sum check and the clean-up.
+    struct Finishing { TreeNodeIndex node; ForwardMatrix* forward; set<ForwardMatrix::CellCoords> cells; bool deferred, checked; LogProb lpTrace; };
+    vguard<Finishing> finishing;
+    const double tp0 = wallSeconds();
+    // sampled tracebacks walk the whole matrix on the host: the copy of the next node's matrix is started before this
+    // node's traces are drawn, so that it runs underneath them (two page-locked buffers in use at a time)
+    const auto sampled = [&](TreeNodeIndex node) {
+      return !usePosteriorsForProfile && profileSamples > 0 && !dataset.tree.isLeaf(node) && node != dataset.tree.root() && work[node].forward &&
+             work[node].forward->lpEnd > NEG_INF;
+    };
+    const auto copyAhead = [&](TreeNodeIndex from) {
+      int started = 0;
+      for (TreeNodeIndex node = from; node < N && started < 2; ++node)
+        if (sampled(node)) { work[node].forward->startHostCopy(); ++started; }
+    };
+    copyAhead(next);
     while (next < N && (dataset.tree.isLeaf(next) || work[next].forward)) {
       const TreeNodeIndex node = next++;
       if (dataset.tree.isLeaf(node)) continue;
@@ -176,46 +207,96 @@ void Reconstructor::reconstruct(Dataset& dataset) {
       }
       ForwardMatrix* forward = w.forward;
       dataset.bandUsed[node] = w.maxDist;
-      const double tc = wallSeconds();
-      tFwd += tc - tc0;
+      tFwd += wallSeconds() - tc0;
 
-      BackwardMatrix* backward = NULL;
-      if (usePosteriorsForProfile && node != dataset.tree.root()) backward = new BackwardMatrix(*forward);
-
+      Finishing f;
+      f.node = node;
+      f.forward = forward;
+      f.deferred = f.checked = false;
+      f.lpTrace = NEG_INF;
       Profile& nodeProf = prof[node];
       if (node == dataset.tree.root()) {
         if (reconstructRoot) {
           path = forward->bestAlignPath();
           nodeProf = forward->bestProfile();
         }
-      } else if (usePosteriorsForProfile)
-        nodeProf = backward->postProbProfile(minPostProb, profileMaxStates, strategy);
-      else
-        nodeProf = forward->sampleProfile(generator, profileSamples, profileMaxStates, strategy);
-
-      if (backward) delete backward;
-      const double td = wallSeconds();
-      tProf += td - tc;
-      if (node == dataset.tree.root()) dataset.lpFinalFwd = forward->lpEnd;
-      if (nodeProf.size()) {
-        const LogProb lpTrace = nodeProf.calcSumPathAbsorbProbs(log_vector(model.cptWeight), logRootProb, NULL);
-        if (node == dataset.tree.root()) dataset.lpFinalTrace = lpTrace;
+        dataset.lpFinalFwd = forward->lpEnd;
+      } else if (usePosteriorsForProfile) {
+        BackwardMatrix backward(*forward);
+        nodeProf = backward.postProbProfile(minPostProb, profileMaxStates, strategy);
+      } else {
+        copyAhead(next);
+        f.cells = forward->sampleCells(generator, profileSamples, profileMaxStates, strategy);
+        forward->retainCells(f.cells);
+        f.deferred = !forward->onHost();
+        if (!f.deferred) nodeProf = forward->makeProfile(f.cells, strategy);
       }
-      delete forward;
+      finishing.push_back(std::move(f));
+    }
+    const double tp1 = wallSeconds();
+    tSample += tp1 - tp0;
+    {
+      vguard<size_t> todo;
+      for (size_t k = 0; k < finishing.size(); ++k)
+        if (finishing[k].deferred) todo.push_back(k);
+      const size_t cores = std::max(1u, std::thread::hardware_concurrency());
+      const size_t nThreads = std::min(todo.size(), cores);
+      const vguard<LogProb> logCptWeight = log_vector(model.cptWeight);
+      const auto build = [&](Finishing& f) {
+        Profile& p = prof[f.node];
+        p = f.forward->makeProfile(f.cells, strategy);
+        if (p.size()) f.lpTrace = p.calcSumPathAbsorbProbs(logCptWeight, logRootProb, NULL);
+        f.checked = true;
+      };
+      if (nThreads <= 1) {
+        for (size_t k : todo) build(finishing[k]);
+      } else {
+        std::atomic<size_t> cursor(0);
+        vguard<FillTiming> spent(nThreads);
+        vguard<std::exception_ptr> failed(nThreads);
+        vguard<std::thread> pool;
+        for (size_t t = 0; t < nThreads; ++t)
+          pool.emplace_back([&, t]() {
+            try {
+              for (size_t at = cursor++; at < todo.size(); at = cursor++) build(finishing[todo[at]]);
+            } catch (...) {
+              failed[t] = std::current_exception();
+            }
+            spent[t] = fillTiming;
+          });
+        for (auto& th : pool) th.join();
+        for (size_t t = 0; t < nThreads; ++t) {
+          if (failed[t]) std::rethrow_exception(failed[t]);
+          detail::mergeTiming(spent[t], fillTiming);
+        }
+      }
+    }
+    const double td = wallSeconds();
+    tProf += td - tp0;
+    tBuild += td - tp1;
+    if (timing && getenv("HX_TIMING_LEVELS"))
+      fprintf(stderr, "timing: level of %zu nodes: sampling %.4f s, profiles %.4f s\n", finishing.size(), tp1 - tp0, td - tp1);
+    for (Finishing& f : finishing) {
+      NodeWork& w = work[f.node];
+      Profile& nodeProf = prof[f.node];
+      if (!f.checked && nodeProf.size()) f.lpTrace = nodeProf.calcSumPathAbsorbProbs(log_vector(model.cptWeight), logRootProb, NULL);
+      if (f.node == dataset.tree.root() && nodeProf.size()) dataset.lpFinalTrace = f.lpTrace;
+      delete f.forward;
       w.forward = NULL;
       delete w.hmm;
       delete w.lProbs;
       delete w.rProbs;
       w.hmm = NULL;
       w.lProbs = w.rProbs = NULL;
-      done[node] = 1;
-      tCheck += wallSeconds() - td;
+      done[f.node] = 1;
     }
+    tCheck += wallSeconds() - td;
   }
   if (timing)
     fprintf(stderr, "timing: leaf profiles %.3f s, ProbModel+PairHMM %.3f s, ForwardMatrix fills %.3f s, traceback+profile %.3f s "
-                    "(host tracebacks %.3f s, makeProfile %.3f s), calcSumPathAbsorbProbs+delete %.3f s\n", tLeaf, tHmm, tFwd, tProf,
-            fillTiming.hostTraces, fillTiming.hostMakeProfile, tCheck);
+                    "(%.3f s tracebacks and sampling in node order, of which host tracebacks %.3f s; %.3f s profile building on host threads, "
+                    "makeProfile %.3f s summed over threads), path-sum check+delete %.3f s\n", tLeaf, tHmm, tFwd, tProf, tSample,
+            fillTiming.hostTraces, tBuild, fillTiming.hostMakeProfile, tCheck);
   dataset.path = path;
 }
 

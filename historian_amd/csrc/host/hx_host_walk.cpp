@@ -293,6 +293,7 @@ ForwardMatrix::Path ForwardMatrix::sampleTrace(random_engine& generator) {
 }
 
 ForwardMatrix::Path ForwardMatrix::bestTrace(const CellCoords& end) {
+  const double t0 = wallSeconds();
   Path path(1, end);
   Moves m;
   CellCoords at = end;
@@ -301,6 +302,7 @@ ForwardMatrix::Path ForwardMatrix::bestTrace(const CellCoords& end) {
     at = pickBest(m);
     path.push_front(at);
   }
+  fillTiming.hostTraces += wallSeconds() - t0;
   return path;
 }
 
@@ -558,6 +560,11 @@ Profile ForwardMatrix::makeProfile(const set<CellCoords>& cells, ProfilingStrate
 // sample takes draws from the shared generator; a sample whose ancestral length is out of bounds ends the sampling.
 Profile ForwardMatrix::sampleProfile(random_engine& generator, size_t profileSamples, size_t maxCells, ProfilingStrategy strategy,
                                      size_t minLen, size_t maxLen) {
+  return makeProfile(sampleCells(generator, profileSamples, maxCells, strategy, minLen, maxLen), strategy);
+}
+
+set<ForwardMatrix::CellCoords> ForwardMatrix::sampleCells(random_engine& generator, size_t profileSamples, size_t maxCells,
+                                                          ProfilingStrategy strategy, size_t minLen, size_t maxLen) {
   Require((strategy & IncludeBestTrace) || profileSamples > 0, "Must allow at least one sample path in the profile");
   const auto ancestralLength = [](const Path& p) {
     return (size_t)std::count_if(p.begin(), p.end(), [](const CellCoords& c) {
@@ -565,6 +572,9 @@ Profile ForwardMatrix::sampleProfile(random_engine& generator, size_t profileSam
     });
   };
   set<CellCoords> keep;
+  // sampled traces walk the matrix on the host, so it is coming over anyway: the best trace then walks it there too
+  // (a thousand-odd steps) instead of waiting for a device traceback kernel
+  if (profileSamples > 0 && batch) ensureHostCells();
   if (maxCells == 0) {
     // no cell budget: every visited cell stays, so the visits need not be counted - collect, sort, drop repeats
     vguard<CellCoords> seen;
@@ -578,10 +588,12 @@ Profile ForwardMatrix::sampleProfile(random_engine& generator, size_t profileSam
       if (ancestral < minLen || ancestral > maxLen) break;
       seen.insert(seen.end(), sampled.begin(), sampled.end());
     }
+    const double t0 = wallSeconds();
     std::sort(seen.begin(), seen.end());
     seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
     keep.insert(seen.begin(), seen.end());        // (sorted input: linear-time construction)
-    return makeProfile(keep, strategy);
+    fillTiming.cellSets += wallSeconds() - t0;
+    return keep;
   }
   map<CellCoords, size_t> visits;
   size_t traces = 0;
@@ -600,7 +612,7 @@ Profile ForwardMatrix::sampleProfile(random_engine& generator, size_t profileSam
   const size_t needed = (traces > 1 && visits.size() >= maxCells) ? 2 : 1;
   for (const auto& v : visits)
     if (v.second >= needed) keep.insert(keep.end(), v.first);
-  return makeProfile(keep, strategy);
+  return keep;
 }
 
 Profile ForwardMatrix::bestProfile(ProfilingStrategy strategy) {

@@ -114,10 +114,10 @@ int main(int argc, char** argv) {
     const double total = wallSeconds() - t0;
     const FillTiming& f = fillTiming;
     fprintf(stderr, "timing: reconstruct %.3f s = one-off HIP/device initialisation %.3f s + %.3f s; %ld fills over %lld lattice cells: "
-                    "flatten+upload %.3f s, forward (launch..lpEnd) %.3f s of which fill kernels %.3f s, matrix D2H %.3f s in %ld reads, "
-                    "device best-path tracebacks %.3f s in %ld calls, cell gathers %.3f s in %ld calls; host traceback/profile building/other %.3f s\n",
+                    "flatten+upload %.3f s, forward (launch..lpEnd) %.3f s of which fill kernels %.3f s, matrix D2H %.3f s in %ld reads (of which %.3f s allocating %ld page-locked buffers), "
+                    "device best-path tracebacks %.3f s in %ld calls, cell gathers %.3f s in %ld calls; sorting sampled cells %.3f s, keeping their values %.3f s; host traceback/profile building/other %.3f s\n",
             total, f.deviceInit, total - f.deviceInit, f.fills, f.cells, f.flattenAndUpload, f.forwardWait, f.forwardKernel, f.readMatrix,
-            f.matrixReads, f.deviceTrace, f.deviceTraces, f.cellGather, f.cellGathers,
+            f.matrixReads, f.pinnedAlloc, f.pinnedAllocs, f.deviceTrace, f.deviceTraces, f.cellGather, f.cellGathers, f.cellSets, f.retain,
             total - f.deviceInit - f.flattenAndUpload - f.forwardWait - f.readMatrix - f.backwardWait - f.deviceTrace - f.cellGather);
   }
   for (size_t k = 0; k < all.size(); ++k) {

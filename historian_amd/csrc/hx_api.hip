@@ -473,6 +473,8 @@ struct hx_batch {
   bool sub_scattered = false;        // subx / suby of table-emission jobs exist per state (k_scatter_sub, on demand)
   hipStream_t last_stream = nullptr;
   hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  hipStream_t copy_stream = nullptr;            // hx_batch_read_matrix_async
+  std::vector<hipEvent_t> copied[2];            // per job: the event behind its asynchronous matrix copy, or null
   int32_t* d_trace = nullptr;        // hx_batch_best_trace: path buffers, kept between calls
   int64_t* d_trace_n = nullptr;
   void* h_trace = nullptr;
@@ -890,6 +892,10 @@ int hx_batch_destroy(hx_batch* b) {
   for (int w = 0; w < 2; ++w)
     for (int e = 0; e < 2; ++e)
       if (b->ev[w][e]) (void)hipEventDestroy(b->ev[w][e]);
+  for (int w = 0; w < 2; ++w)
+    for (hipEvent_t e : b->copied[w])
+      if (e) (void)hipEventDestroy(e);
+  if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
   if (b->d_jobs) (void)hipFree(b->d_jobs);
   if (b->d_jobs_cls) (void)hipFree(b->d_jobs_cls);
   if (b->d_arena) (void)hipFree(b->d_arena);
@@ -1082,6 +1088,30 @@ int hx_batch_read_matrix(hx_batch* b, int32_t job, int32_t which, double* out) {
   { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
   HIP_TRY(hipStreamSynchronize(b->last_stream));
   HIP_TRY(hipMemcpy(out, matrix_of(b, job, which), sizeof(double) * (size_t)b->jobs[job].matrix_doubles, hipMemcpyDeviceToHost));
+  return HX_OK;
+}
+
+int hx_batch_read_matrix_async(hx_batch* b, int32_t job, int32_t which, double* out) {
+  if (!b || !out || which < 0 || which > 1) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
+  if (which == 0 ? !b->forward_done : !b->backward_done) return fail(HX_ERR_STATE, "fill has not been launched");
+  { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
+  HIP_TRY(hipStreamSynchronize(b->last_stream));
+  if (!b->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+  if (b->copied[which].empty()) b->copied[which].assign((size_t)b->n_jobs, nullptr);
+  hipEvent_t& e = b->copied[which][job];
+  if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_TRY(hipMemcpyAsync(out, matrix_of(b, job, which), sizeof(double) * (size_t)b->jobs[job].matrix_doubles, hipMemcpyDeviceToHost, b->copy_stream));
+  HIP_TRY(hipEventRecord(e, b->copy_stream));
+  return HX_OK;
+}
+
+int hx_batch_wait_read(hx_batch* b, int32_t job, int32_t which) {
+  if (!b || which < 0 || which > 1) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
+  if (b->copied[which].empty() || !b->copied[which][job]) return fail(HX_ERR_STATE, "no asynchronous read of job %d was started", job);
+  { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
+  HIP_TRY(hipEventSynchronize(b->copied[which][job]));
   return HX_OK;
 }
 

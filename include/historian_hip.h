@@ -203,6 +203,12 @@ int hx_batch_lp_start(hx_batch* b, double* out /* [n_jobs] BackwardMatrix::lpSta
 int hx_batch_layout(const hx_batch* b, int32_t job, int32_t which, hx_layout* out);
 /* which: 0 = Forward, 1 = Backward.  out holds hx_layout::matrix_doubles doubles. */
 int hx_batch_read_matrix(hx_batch* b, int32_t job, int32_t which, double* out);
+/* The same copy, started on the batch's own copy stream and not waited for: `out` must be page-locked (hx_host_alloc)
+ * and must not be read before hx_batch_wait_read(b, job, which) has returned.  Lets a caller that walks the jobs of a
+ * batch one after the other on the host (tracebacks in node order, reference src/recon.cpp:1006-1011) have the next
+ * matrices in flight while it works on the current one. */
+int hx_batch_read_matrix_async(hx_batch* b, int32_t job, int32_t which, double* out);
+int hx_batch_wait_read(hx_batch* b, int32_t job, int32_t which);
 /* Gather n cells (ij[2k], ij[2k+1]) -> out[5k..5k+4] without copying the matrix. */
 int hx_batch_read_cells(hx_batch* b, int32_t job, int32_t which, const int32_t* ij, int64_t n, double* out);
 /* Prepared per-state vectors of DPMatrix (src/forward.h:24-25,54): any pointer may be NULL.
