@@ -444,6 +444,7 @@ enum KernelClass {
   KC_COUNT
 };
 struct ClassRange {
+  int64_t agg_begin = 0, agg_doubles = 0;   // the class's part of hx_batch::d_agg (general-profile classes)
   int begin = 0, n = 0;       // positions in the class-ordered job table
   int max_rows = 0, max_cols = 0, max_cls = 0, yl_cols = 0, yl_emis = 0;
   int64_t mat_begin = 0, mat_doubles = 0;   // the class's matrices are contiguous: [mat_begin, mat_begin + mat_doubles)
@@ -473,6 +474,7 @@ struct hx_batch {
   bool sub_scattered = false;        // subx / suby of table-emission jobs exist per state (k_scatter_sub, on demand)
   hipStream_t last_stream = nullptr;
   hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  bool dag_linear = false;                      // general-profile classes run the scaled-probability fill (hx_daglin.hip)
   hipStream_t copy_stream = nullptr;            // hx_batch_read_matrix_async
   std::vector<hipEvent_t> copied[2];            // per job: the event behind its asynchronous matrix copy, or null
   int32_t* d_trace = nullptr;        // hx_batch_best_trace: path buffers, kept between calls
@@ -789,7 +791,14 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
   if (rc != HX_OK) { delete b; return rc; }
 
   // class-ordered job table and matrix allocation (stable within a class)
-  int64_t mat_total = 0, agg_begin = 0, agg_end = 0;
+  // The general-profile classes need scratch planes next to the matrices: the five outgoing sums of every cell
+  // (hx_dag.hip), or - HX_LSE_LINEAR, when every such job's planes fit 32-bit byte offsets - the cells in the
+  // scaled-probability fill's own format (hx_daglin.hip).
+  b->dag_linear = (flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && !(flags & HX_FORCE_GENERIC);
+  for (int k = 0; k < n_jobs && b->dag_linear; ++k)
+    if ((kclass[k] == KC_DAG || kclass[k] == KC_DAG_BANDED) && !dag_linear_fits(b->jobs[k].plane)) b->dag_linear = false;
+  int64_t mat_total = 0, agg_total = 0;
+  std::vector<int64_t> agg_off(n_jobs, -1);
   {
     int pos = 0;
     b->order.resize(n_jobs);
@@ -797,15 +806,19 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
       ClassRange& cr = b->cls[c];
       cr.begin = pos;
       cr.mat_begin = mat_total;
-      if (c == KC_DAG) agg_begin = mat_total;
+      cr.agg_begin = agg_total;
       for (int k = 0; k < n_jobs; ++k)
         if (kclass[k] == c) {
           b->order[pos++] = k;
           mat_off[k] = mat_total;
           mat_total += b->jobs[k].matrix_doubles;
+          if (c == KC_DAG || c == KC_DAG_BANDED) {
+            agg_off[k] = agg_total;
+            agg_total += b->dag_linear ? dag_linear_scratch_doubles(b->jobs[k].plane, offs[k].x.n, offs[k].y.n, jobs[k].x->in_off[jobs[k].x->n_states], jobs[k].y->in_off[jobs[k].y->n_states]) : b->jobs[k].matrix_doubles;
+          }
         }
       cr.mat_doubles = mat_total - cr.mat_begin;
-      if (c == KC_DAG_BANDED) agg_end = mat_total;
+      cr.agg_doubles = agg_total - cr.agg_begin;
     }
   }
   // lpEnd / lpStart of all jobs, contiguous (caller's order): one copy back per read
@@ -823,9 +836,9 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
   if (eplane_total > 0)
     if (hipMalloc(reinterpret_cast<void**>(&b->d_eplane), sizeof(double) * (size_t)eplane_total) != hipSuccess)
       return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld emission-plane bytes failed", (long long)(eplane_total * 8)));
-  if (agg_end > agg_begin)
-    if (hipMalloc(reinterpret_cast<void**>(&b->d_agg), sizeof(double) * (size_t)(agg_end - agg_begin)) != hipSuccess)
-      return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld scratch bytes failed", (long long)((agg_end - agg_begin) * 8)));
+  if (agg_total > 0)
+    if (hipMalloc(reinterpret_cast<void**>(&b->d_agg), sizeof(double) * (size_t)agg_total) != hipSuccess)
+      return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld scratch bytes failed", (long long)(agg_total * 8)));
   if (flags & HX_KEEP_BACKWARD)
     if (hipMalloc(reinterpret_cast<void**>(&b->d_bwd), sizeof(double) * (size_t)mat_total) != hipSuccess)
       return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld Backward-matrix bytes failed", (long long)(mat_total * 8)));
@@ -846,7 +859,7 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
     J.emis = jo.table_emission ? reinterpret_cast<double*>(base + jo.emis) : nullptr;
     J.emis_pad = jo.table_emission ? reinterpret_cast<double*>(base + jo.emis_pad) : nullptr;
     J.emis_plane = jo.eplane_off >= 0 ? b->d_eplane + jo.eplane_off : nullptr;
-    J.agg = (kclass[k] == KC_DAG || kclass[k] == KC_DAG_BANDED) ? b->d_agg + (mat_off[k] - agg_begin) : nullptr;
+    J.agg = agg_off[k] >= 0 ? b->d_agg + agg_off[k] : nullptr;
     J.fwd_windows = J.max_dist >= 0 ? reinterpret_cast<int32_t*>(base + jo.fwd_windows) : nullptr;
     J.bwd_windows = J.max_dist >= 0 ? reinterpret_cast<int32_t*>(base + jo.bwd_windows) : nullptr;
     J.strip_base = jo.compressed ? reinterpret_cast<int64_t*>(base + jo.strip_base) : nullptr;
@@ -958,9 +971,11 @@ int hx_batch_forward(hx_batch* b, void* stream) {
         // general profiles: the strip pipeline; with a band it only visits in-envelope windows, the rest is -inf
         if (banded) {
           launch_fill_neg_inf(b->d_fwd + cr.mat_begin, cr.mat_doubles, st);
-          launch_fill_neg_inf(b->d_agg + (cr.mat_begin - b->cls[KC_DAG].mat_begin), cr.mat_doubles, st);
+          if (b->dag_linear) launch_dag_linear_clear(jobs, cr.n, st);
+          else launch_fill_neg_inf(b->d_agg + cr.agg_begin, cr.agg_doubles, st);
         }
-        LAUNCH_TRY(launch_forward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, st));
+        if (b->dag_linear) LAUNCH_TRY(launch_forward_dag_linear(jobs, cr.n, cr.max_rows, Tab8{D.tab}, Tab16{D.log_tab}, st));
+        else LAUNCH_TRY(launch_forward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, st));
         break;
       default:
         LAUNCH_TRY(launch_forward_dag(jobs, cr.n, cr.max_rows, Tab8{D.tab}, st));

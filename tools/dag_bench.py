@@ -16,7 +16,7 @@ model = ho.RateModel.from_file(LG); model.sub_rate = [m.tolist() for m in model.
 closest = ho.closest_leaves(tree)
 capi.init(0, c_oracle.table())
 root = tree.root()
-for band in (20, -1):
+for band in ((-1,) if "unbanded" in sys.argv else (20, -1)):
     imgs = []
     for node in range(tree.nodes()):
         if tree.is_leaf(node): continue
@@ -31,7 +31,7 @@ for band in (20, -1):
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     if "perjob" in sys.argv:
         for k, img in enumerate(imgs):
-            b = capi.Batch([img], capi.HX_LSE_FAST)
+            b = capi.Batch([img], capi.HX_LSE_LINEAR if "linear" in sys.argv else capi.HX_LSE_FAST)
             b.forward(); b.sync(); b.forward(); b.sync()
             x, y = img[0], img[1]
             steps = (y.n_states - 1) + 63 + 72 * ((x.n_states - 1 + 63) // 64 - 1)
@@ -41,7 +41,7 @@ for band in (20, -1):
         continue
     sizes = [(x.n_states, y.n_states) for x, y, _, _ in imgs]
     print("band", band, "jobs", len(imgs) * reps, "sizes", sizes)
-    for name, flags in (("exact", capi.HX_LSE_EXACT), ("fast", capi.HX_LSE_FAST)) + (() if "fwdonly" in sys.argv else (("barrier-exact", capi.HX_FORCE_GENERIC),)):
+    for name, flags in (("exact", capi.HX_LSE_EXACT), ("fast", capi.HX_LSE_FAST), ("linear", capi.HX_LSE_LINEAR)) + (() if "fwdonly" in sys.argv else (("barrier-exact", capi.HX_FORCE_GENERIC),)):
         batch = capi.Batch(imgs * reps, flags)
         batch.forward(); batch.sync()
         batch.forward(); batch.sync()
