@@ -34,7 +34,7 @@ namespace {
 #define HXD_EMIN (-(1 << 28))      // exponent of a zero: loses every max()
 #define HXD_LOG_ENTRIES 1536       // the logarithm table of hx_linear.hip (build_log_table)
 #define HXD_EXP_ENTRIES 512
-#define HXD_EXTRA 3                // in-transitions beyond the inline three whose cells are fetched in one batch per step
+#define HXD_EXTRA 2                // in-transitions beyond the inline three whose cells are fetched in one batch per step
 
 typedef double d2v __attribute__((ext_vector_type(2)));
 
@@ -121,6 +121,13 @@ __device__ __forceinline__ void stg(HX_GLOBAL double* base, const unsigned byte_
 #endif
   *(HX_GLOBAL double*)((HX_GLOBAL char*)base + byte_off) = v;
 }
+
+// the cell a lane computed in the previous step: stored one step late (behind the next step's loads, so that those do not
+// queue behind fresh stores), and forwarded through registers to the two cells that may need it before it is in memory -
+// (i, j+1) of the lane itself and (i+1, j) of the next lane
+struct PrevCell { double v[V_PLANES]; int E; unsigned slot; };
+
+__device__ __forceinline__ int wave_shr1_int(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
 
 // byte offset (inside a plane of doubles) of the cell of row reference `rb` (strip base + 2 * lane, in bytes) at skewed
 // column t = column + lane-of-the-row
@@ -246,6 +253,8 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
     const unsigned xrB2 = (unsigned)(X.s2 >> 6) * ssB + ((unsigned)(X.s2 & 63) << 4);
     const int xl0 = X.s0 & 63, xl1 = X.s1 & 63, xl2 = X.s2 & 63;
     const unsigned vXa = (xnull ? V_IMD : V_G0) * planeB, vXb = (xnull ? V_IIW : V_G1) * planeB;
+    // a source in the row directly above, inside this strip, is the previous lane's cell of the previous step
+    const bool adjx0 = lane > 0 && xdeg > 0 && X.s0 == i - 1, adjx1 = lane > 0 && xdeg > 1 && X.s1 == i - 1, adjx2 = lane > 0 && xdeg > 2 && X.s2 == i - 1;
     // in-transitions 3 .. 7 of the row (rare: ~1 % of the states have more than three): kept for the whole strip, so that
     // a step fetches their cells in one batch
     unsigned xrx[HXD_EXTRA];
@@ -256,7 +265,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
       const int a = HX_DAG_INLINE + q;
       const int src = xdeg > a ? xin_src[X.in_b + a] : 0;
       xrx[q] = (unsigned)(src >> 6) * ssB + ((unsigned)(src & 63) << 4);
-      xlx[q] = src & 63;
+      xlx[q] = (src & 63) | ((lane > 0 && xdeg > a && src == i - 1) ? 64 : 0);     // bit 6: the row directly above
       xwx[q] = xdeg > a ? xin_w[X.in_b + a] : 0.;
     }
     const int above_base = ((s - 1) / W) * Cc;
@@ -277,6 +286,13 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
       int jn = wlo[w] - lane;
       jn = jn < 0 ? 0 : (jn >= Cc ? Cc - 1 : jn);
       ColRec Yn = load_col(ypk, ylp, jn);
+      PrevCell pv;
+#pragma unroll
+      for (int v = 0; v < V_PLANES; ++v) pv.v[v] = 0.;
+      pv.E = HXD_EMIN;
+      pv.slot = ownB + col_part(wlo[w]);      // (the first step's store goes to the slot that step's own cell overwrites one step later)
+      double up_imm = 0., up_imd = 0., up_iiw = 0., up_g0 = 0., up_g1 = 0.;
+      int up_E = HXD_EMIN;
       for (int t = wlo[w]; t < whi[w]; ++t) {
         if (s > 0) {
           const int need = above_base + (t + 1 < Cc ? t + 1 : Cc);
@@ -324,16 +340,18 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
         HXD_TR(1);     // column record, flags, addresses, emission load
         double m_imm = 0., m_imd = 0., m_idm = 0., m_imi = 0., m_iiw = 0.;
         int e_imm = HXD_EMIN, e_imd = HXD_EMIN, e_idm = HXD_EMIN, e_imi = HXD_EMIN, e_iiw = HXD_EMIN;
+        // ---- this step's loads, all issued before the first use: the first three transitions of the row and of the
+        // column, and the IMM sources that hang on them (pairs when both states emit, else the y or the x sources) ----
+        const unsigned sxs[3] = {sx0, sx1, sx2}, sys_[3] = {sy0, sy1, sy2};
+        const unsigned xr[3] = {xrB0, xrB1, xrB2};
+        const int xl[3] = {xl0, xl1, xl2};
+        const double wxs[3] = {X.w0, X.w1, X.w2}, wys[3] = {Y.w0, Y.w1, Y.w2};
+        const int ys[3] = {Y.s0, Y.s1, Y.s2};
+        double xa[3], xb[3], ya[3], yb[3], mv[9];
+        int xe[3], ye[3], me[9];
+        int ysx[HXD_EXTRA];
+        double ywx[HXD_EXTRA];
         if (act) {
-          // ---- this step's loads, all issued before the first use: the first three transitions of the row and of the
-          // column, and the IMM sources that hang on them (pairs when both states emit, else the y or the x sources) ----
-          const unsigned sxs[3] = {sx0, sx1, sx2}, sys_[3] = {sy0, sy1, sy2};
-          const unsigned xr[3] = {xrB0, xrB1, xrB2};
-          const int xl[3] = {xl0, xl1, xl2};
-          const double wxs[3] = {X.w0, X.w1, X.w2}, wys[3] = {Y.w0, Y.w1, Y.w2};
-          const int ys[3] = {Y.s0, Y.s1, Y.s2};
-          double xa[3], xb[3], ya[3], yb[3], mv[9];
-          int xe[3], ye[3], me[9];
 #pragma unroll
           for (int k = 0; k < 3; ++k) { xa[k] = xb[k] = ya[k] = yb[k] = 0.; xe[k] = ye[k] = HXD_EMIN; }
 #pragma unroll
@@ -363,12 +381,29 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
               if (xdeg > a) { mv[a] = ldg(LIN, sxs[a]); me[a] = xgo ? xe[a] : ldgi(EX, sxs[a] >> 1); }
           }
           // the column's in-transitions 3 .. 7 (CSR), fetched with the batch above
-          int ysx[HXD_EXTRA];
-          double ywx[HXD_EXTRA];
 #pragma unroll
           for (int q = 0; q < HXD_EXTRA; ++q) {
             ysx[q] = 0; ywx[q] = 0.;
             if (ydeg > HX_DAG_INLINE + q) { ysx[q] = yin_src[Y.in_b + HX_DAG_INLINE + q]; ywx[q] = yin_w[Y.in_b + HX_DAG_INLINE + q]; }
+          }
+        }
+        // ---- the previous step's cell goes to memory now, behind this step's loads (every lane: an idle lane's cell is
+        // all zeros, which is what padding and cells outside the envelope hold) ----
+#pragma unroll
+        for (int v = 0; v < V_PLANES; ++v) stg(LIN, v * planeB + pv.slot, pv.v[v]);
+        *(HX_GLOBAL int*)((HX_GLOBAL char*)EX + (pv.slot >> 1)) = pv.E;
+        if (act) {
+          // ---- values still on their way to memory: the previous step's cells of this lane and of the lane above ----
+          {
+            const bool ax3[3] = {adjx0, adjx1, adjx2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              if (ax3[k]) { xa[k] = xnull ? up_imd : up_g0; xb[k] = xnull ? up_iiw : up_g1; xe[k] = up_E; }
+              const bool ady = ydeg > k && ys[k] == j - 1;
+              if (ady) { ya[k] = ynull ? pv.v[V_IDM] : pv.v[V_G2]; yb[k] = ynull ? pv.v[V_IMI] : pv.v[V_G3]; ye[k] = pv.E; }
+              if (mode == 2 && ady) { mv[k] = pv.v[V_IMM]; me[k] = pv.E; }
+              if (mode == 3 && ax3[k]) { mv[k] = up_imm; me[k] = up_E; }
+            }
           }
           HXD_TR(5);     // (trace builds: the first batch of loads has landed)
           Acc2 ax = Acc2{0., 0., HXD_EMIN}, ay = Acc2{0., 0., HXD_EMIN};
@@ -396,58 +431,85 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
           }
           HXD_TR(6);     // (the inline transitions are summed)
           // ---- second batch: the cells of in-transitions 3 .. 7 of the row and of the column, all loads first ----
-          if (xdeg > HX_DAG_INLINE || ydeg > HX_DAG_INLINE) {
-            double xa2[HXD_EXTRA], xb2[HXD_EXTRA], ya2[HXD_EXTRA], yb2[HXD_EXTRA], mx2[HXD_EXTRA * 3], my2[HXD_EXTRA * 3];
-            int xe2[HXD_EXTRA], ye2[HXD_EXTRA], mxe[HXD_EXTRA * 3], mye[HXD_EXTRA * 3];
+          if (xdeg > HX_DAG_INLINE) {
+            // the row's further transitions: their cells at this column, and their pairs with the column's inline transitions
+            double xa2[HXD_EXTRA], xb2[HXD_EXTRA], mx2[HXD_EXTRA * 3];
+            int xe2[HXD_EXTRA], mxe[HXD_EXTRA * 3];
 #pragma unroll
             for (int q = 0; q < HXD_EXTRA; ++q) {
-              xa2[q] = xb2[q] = ya2[q] = yb2[q] = 0.; xe2[q] = ye2[q] = HXD_EMIN;
+              xa2[q] = xb2[q] = 0.; xe2[q] = HXD_EMIN;
 #pragma unroll
-              for (int k = 0; k < 3; ++k) { mx2[q * 3 + k] = my2[q * 3 + k] = 0.; mxe[q * 3 + k] = mye[q * 3 + k] = HXD_EMIN; }
+              for (int k = 0; k < 3; ++k) { mx2[q * 3 + k] = 0.; mxe[q * 3 + k] = HXD_EMIN; }
+              const bool hx = xdeg > HX_DAG_INLINE + q;
+              const unsigned slx = xrx[q] + col_part(jc + (xlx[q] & 63));
+              if (hx && (xgo || mode == 3)) xe2[q] = ldgi(EX, slx >> 1);
+              if (hx && xgo) { xa2[q] = ldg(LIN, vXa + slx); xb2[q] = ldg(LIN, vXb + slx); }
+              if (hx && mode == 3) mx2[q * 3] = ldg(LIN, slx);
+              if (mode == 1) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                  if (hx && ydeg > k) {                         // pair (row transition 3+q, column transition k)
+                    const unsigned sl = xrx[q] + col_part(ys[k] + (xlx[q] & 63));
+                    mx2[q * 3 + k] = ldg(LIN, V_G4 * planeB + sl); mxe[q * 3 + k] = ldgi(EX, sl >> 1);
+                  }
+              }
             }
 #pragma unroll
             for (int q = 0; q < HXD_EXTRA; ++q) {
-              const bool hx = xdeg > HX_DAG_INLINE + q, hy = ydeg > HX_DAG_INLINE + q;
-              const unsigned slx = xrx[q] + col_part(jc + xlx[q]), sly = ownB + col_part(ysx[q] + lane);
-              if (hx && (xgo || mode == 3)) xe2[q] = ldgi(EX, slx >> 1);
-              if (hx && xgo) { xa2[q] = ldg(LIN, vXa + slx); xb2[q] = ldg(LIN, vXb + slx); }
-              if (hy && (ygo || mode == 2)) ye2[q] = ldgi(EX, sly >> 1);
-              if (hy && ygo) { ya2[q] = ldg(LIN, vYa + sly); yb2[q] = ldg(LIN, vYb + sly); }
+              const bool hx = xdeg > HX_DAG_INLINE + q;
+              if (hx && (xlx[q] & 64)) {                        // the row directly above: still in registers
+                xa2[q] = xnull ? up_imd : up_g0; xb2[q] = xnull ? up_iiw : up_g1; xe2[q] = up_E;
+                if (mode == 3) mx2[q * 3] = up_imm;
+              }
+              if (hx && xgo) add2(ax, xa2[q], xb2[q], xe2[q], xwx[q]);
+              if (hx && mode == 3) add1(am, mx2[q * 3], xe2[q], xwx[q]);
               if (mode == 1) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                  if (hx && ydeg > k) {                         // pair (row transition 3+q, column transition k)
-                    const unsigned sl = xrx[q] + col_part(ys[k] + xlx[q]);
-                    mx2[q * 3 + k] = ldg(LIN, V_G4 * planeB + sl); mxe[q * 3 + k] = ldgi(EX, sl >> 1);
-                  }
+                for (int k = 0; k < 3; ++k)
+                  if (hx && ydeg > k) add1(am, mx2[q * 3 + k], mxe[q * 3 + k], xwx[q] * wys[k]);
+              }
+            }
+          }
+          if (ydeg > HX_DAG_INLINE) {
+            // the column's further transitions: their cells in this row, and their pairs with the row's inline transitions
+            double ya2[HXD_EXTRA], yb2[HXD_EXTRA], my2[HXD_EXTRA * 3];
+            int ye2[HXD_EXTRA], mye[HXD_EXTRA * 3];
+#pragma unroll
+            for (int q = 0; q < HXD_EXTRA; ++q) {
+              ya2[q] = yb2[q] = 0.; ye2[q] = HXD_EMIN;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) { my2[q * 3 + k] = 0.; mye[q * 3 + k] = HXD_EMIN; }
+              const bool hy = ydeg > HX_DAG_INLINE + q;
+              const unsigned sly = ownB + col_part(ysx[q] + lane);
+              if (hy && (ygo || mode == 2)) ye2[q] = ldgi(EX, sly >> 1);
+              if (hy && ygo) { ya2[q] = ldg(LIN, vYa + sly); yb2[q] = ldg(LIN, vYb + sly); }
+              if (hy && mode == 2) my2[q * 3] = ldg(LIN, sly);
+              if (mode == 1) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
                   if (hy && xdeg > k) {                         // pair (row transition k, column transition 3+q)
                     const unsigned sl = xr[k] + col_part(ysx[q] + xl[k]);
                     my2[q * 3 + k] = ldg(LIN, V_G4 * planeB + sl); mye[q * 3 + k] = ldgi(EX, sl >> 1);
                   }
-                }
-              } else if (mode == 2) {
-                if (hy) my2[q * 3] = ldg(LIN, sly);
-              } else if (mode == 3) {
-                if (hx) mx2[q * 3] = ldg(LIN, slx);
               }
             }
 #pragma unroll
             for (int q = 0; q < HXD_EXTRA; ++q) {
-              const bool hx = xdeg > HX_DAG_INLINE + q, hy = ydeg > HX_DAG_INLINE + q;
-              if (hx && xgo) add2(ax, xa2[q], xb2[q], xe2[q], xwx[q]);
+              const bool hy = ydeg > HX_DAG_INLINE + q;
+              if (hy && ysx[q] == j - 1) {                      // the lane's own previous cell
+                ya2[q] = ynull ? pv.v[V_IDM] : pv.v[V_G2]; yb2[q] = ynull ? pv.v[V_IMI] : pv.v[V_G3]; ye2[q] = pv.E;
+                if (mode == 2) my2[q * 3] = pv.v[V_IMM];
+              }
               if (hy && ygo) add2(ay, ya2[q], yb2[q], ye2[q], ywx[q]);
+              if (hy && mode == 2) add1(am, my2[q * 3], ye2[q], ywx[q]);
               if (mode == 1) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                  if (hx && ydeg > k) add1(am, mx2[q * 3 + k], mxe[q * 3 + k], xwx[q] * wys[k]);
+                for (int k = 0; k < 3; ++k)
                   if (hy && xdeg > k) add1(am, my2[q * 3 + k], mye[q * 3 + k], wxs[k] * ywx[q]);
-                }
-              } else if (mode == 2) {
-                if (hy) add1(am, my2[q * 3], ye2[q], ywx[q]);
-              } else if (mode == 3) {
-                if (hx) add1(am, mx2[q * 3], xe2[q], xwx[q]);
               }
             }
+          }
+          if (xdeg > HX_DAG_INLINE || ydeg > HX_DAG_INLINE) {
             // ---- what is left: pairs of two transitions beyond the inline ones, transitions beyond the eighth ----
             if (mode == 1 && xdeg > HX_DAG_INLINE && ydeg > HX_DAG_INLINE)
               for (int a = HX_DAG_INLINE; a < xdeg; ++a) {
@@ -464,8 +526,15 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
               const double wa = xin_w[X.in_b + a];
               const unsigned rb = (unsigned)(src >> 6) * ssB + ((unsigned)(src & 63) << 4);
               const unsigned sl = rb + col_part(jc + (src & 63));
-              if (xgo) add2(ax, ldg(LIN, vXa + sl), ldg(LIN, vXb + sl), ldgi(EX, sl >> 1), wa);
-              if (mode == 3) add1(am, ldg(LIN, sl), ldgi(EX, sl >> 1), wa);
+              const bool adj = lane > 0 && src == i - 1;
+              if (xgo) {
+                if (adj) add2(ax, xnull ? up_imd : up_g0, xnull ? up_iiw : up_g1, up_E, wa);
+                else add2(ax, ldg(LIN, vXa + sl), ldg(LIN, vXb + sl), ldgi(EX, sl >> 1), wa);
+              }
+              if (mode == 3) {
+                if (adj) add1(am, up_imm, up_E, wa);
+                else add1(am, ldg(LIN, sl), ldgi(EX, sl >> 1), wa);
+              }
               if (mode == 1)
                 for (int b = 0; b < (ydeg < HX_DAG_INLINE ? ydeg : HX_DAG_INLINE); ++b) {
                   const unsigned sp = rb + col_part((b == 0 ? Y.s0 : (b == 1 ? Y.s1 : Y.s2)) + (src & 63));
@@ -476,8 +545,15 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
               const int src = yin_src[Y.in_b + b];
               const double wb = yin_w[Y.in_b + b];
               const unsigned sl = ownB + col_part(src + lane);
-              if (ygo) add2(ay, ldg(LIN, vYa + sl), ldg(LIN, vYb + sl), ldgi(EX, sl >> 1), wb);
-              if (mode == 2) add1(am, ldg(LIN, sl), ldgi(EX, sl >> 1), wb);
+              const bool adj = src == j - 1;
+              if (ygo) {
+                if (adj) add2(ay, ynull ? pv.v[V_IDM] : pv.v[V_G2], ynull ? pv.v[V_IMI] : pv.v[V_G3], pv.E, wb);
+                else add2(ay, ldg(LIN, vYa + sl), ldg(LIN, vYb + sl), ldgi(EX, sl >> 1), wb);
+              }
+              if (mode == 2) {
+                if (adj) add1(am, pv.v[V_IMM], pv.E, wb);
+                else add1(am, ldg(LIN, sl), ldgi(EX, sl >> 1), wb);
+              }
               if (mode == 1)
                 for (int a = 0; a < (xdeg < HX_DAG_INLINE ? xdeg : HX_DAG_INLINE); ++a) {
                   const unsigned sp = (a == 0 ? xrB0 : (a == 1 ? xrB1 : xrB2)) + col_part(src + (a == 0 ? xl0 : (a == 1 ? xl1 : xl2)));
@@ -505,13 +581,13 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
           if (s == 0 && t == 0 && lane == 0) { m_imm = 1.; e_imm = 0; }    // cell (0,0): lpStart() = 0 (reference src/forward.cpp:73)
         }
         HXD_TR(2);     // source loads and accumulation
-        // ---- the reference's format: five logarithms ----
-        stg(M, own_slot, log_scaled(m_imm, e_imm, ltab));
+        // ---- the reference's format (five logarithms, stored at once) and the kernel's: a common exponent (that of the
+        // largest state), the five outgoing sums - kept in registers until the next step has issued its loads ----
+        stg(M, own_slot, log_scaled(m_imm, e_imm, ltab));                  // (nothing in this kernel reads these back)
         stg(M, planeB + own_slot, log_scaled(m_imd, e_imd, ltab));
         stg(M, 2 * planeB + own_slot, log_scaled(m_idm, e_idm, ltab));
         stg(M, 3 * planeB + own_slot, log_scaled(m_imi, e_imi, ltab));
         stg(M, 4 * planeB + own_slot, log_scaled(m_iiw, e_iiw, ltab));
-        // ---- the kernel's format: a common exponent (that of the largest state), the five outgoing sums ----
         {
           const int b0 = m_imm > 0. ? e_imm + __builtin_amdgcn_frexp_exp(m_imm) : HXD_EMIN;
           const int b1 = m_imd > 0. ? e_imd + __builtin_amdgcn_frexp_exp(m_imd) : HXD_EMIN;
@@ -525,31 +601,26 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
           const double imm = ldexp_fast(m_imm, (m_imm > 0. ? e_imm : HXD_EMIN) - E), imd = ldexp_fast(m_imd, (m_imd > 0. ? e_imd : HXD_EMIN) - E);
           const double idm = ldexp_fast(m_idm, (m_idm > 0. ? e_idm : HXD_EMIN) - E), imi = ldexp_fast(m_imi, (m_imi > 0. ? e_imi : HXD_EMIN) - E);
           const double iiw = ldexp_fast(m_iiw, (m_iiw > 0. ? e_iiw : HXD_EMIN) - E);
-          const double g0 = __builtin_fma(imi, P31, __builtin_fma(idm, P21, __builtin_fma(imd, P11, imm * P01)));
-          const double g1 = __builtin_fma(iiw, P44, __builtin_fma(imi, P34, imm * P04));
-          const double g2 = __builtin_fma(iiw, P42, __builtin_fma(idm, P22, __builtin_fma(imd, P12, imm * P02)));
-          const double g3 = __builtin_fma(imi, P33, imm * P03);
-          const double g4 = __builtin_fma(iiw, P40, __builtin_fma(imi, P30, __builtin_fma(idm, P20, __builtin_fma(imd, P10, imm * P00))));
-          stg(LIN, V_IMM * planeB + own_slot, imm);
-          stg(LIN, V_IMD * planeB + own_slot, imd);
-          stg(LIN, V_IDM * planeB + own_slot, idm);
-          stg(LIN, V_IMI * planeB + own_slot, imi);
-          stg(LIN, V_IIW * planeB + own_slot, iiw);
-          stg(LIN, V_G0 * planeB + own_slot, g0);
-          stg(LIN, V_G1 * planeB + own_slot, g1);
-          stg(LIN, V_G2 * planeB + own_slot, g2);
-          stg(LIN, V_G3 * planeB + own_slot, g3);
-          stg(LIN, V_G4 * planeB + own_slot, g4);
-          *(HX_GLOBAL int*)((HX_GLOBAL char*)EX + (own_slot >> 1)) = E;
+          pv.v[V_IMM] = imm; pv.v[V_IMD] = imd; pv.v[V_IDM] = idm; pv.v[V_IMI] = imi; pv.v[V_IIW] = iiw;
+          pv.v[V_G0] = __builtin_fma(imi, P31, __builtin_fma(idm, P21, __builtin_fma(imd, P11, imm * P01)));
+          pv.v[V_G1] = __builtin_fma(iiw, P44, __builtin_fma(imi, P34, imm * P04));
+          pv.v[V_G2] = __builtin_fma(iiw, P42, __builtin_fma(idm, P22, __builtin_fma(imd, P12, imm * P02)));
+          pv.v[V_G3] = __builtin_fma(imi, P33, imm * P03);
+          pv.v[V_G4] = __builtin_fma(iiw, P40, __builtin_fma(imi, P30, __builtin_fma(idm, P20, __builtin_fma(imd, P10, imm * P00))));
+          pv.E = E;
+          pv.slot = own_slot;
+          up_imm = wave_shr1(imm); up_imd = wave_shr1(imd); up_iiw = wave_shr1(iiw);
+          up_g0 = wave_shr1(pv.v[V_G0]); up_g1 = wave_shr1(pv.v[V_G1]);
+          up_E = wave_shr1_int(E);
         }
         HXD_TR(3);     // logarithms, alignment, sums, stores
-        // ---- publish, every 8th step: drain, then the cells of steps <= t are in memory, i.e. all 64 rows have
-        // completed the columns up to t - 63
+        // ---- publish, every 8th step: drain, then all stores issued so far (the cells of steps <= t - 1) are in memory,
+        // i.e. all 64 rows have completed the columns up to t - 1 - 63
         if ((t & 7) == 7) {
 #if HX_ABLATE != 31
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-          int done = t + 1 - 63;
+          int done = t - 63;
           done = done > Cc ? Cc : done;
           if (done > published) {
             published = done;
@@ -561,6 +632,10 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
         ++tr_steps;
 #endif
       }
+      // flush the last cell of the window
+#pragma unroll
+      for (int v = 0; v < V_PLANES; ++v) stg(LIN, v * planeB + pv.slot, pv.v[v]);
+      *(HX_GLOBAL int*)((HX_GLOBAL char*)EX + (pv.slot >> 1)) = pv.E;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // columns between / after the windows hold no in-envelope cell of this strip
       const int upto = (w == 0 && whi[1] > wlo[1]) ? wlo[1] - 63 : Cc;
