@@ -13,8 +13,11 @@ namespace hx {
 // Correctly rounded a / 1e-4 without the generic fp64 division sequence.
 // y = RN(1/1e-4) is exactly 1e4; q0 = RN(a*y) is a faithful quotient, the residual
 // r = a - 1e-4*q0 is exact in one FMA, and RN(q0 + r*y) is the correctly rounded
-// quotient (Markstein's theorem; checked against IEEE division on 4e8 inputs incl.
-// bin boundaries and tiny remainders -- tests/test_host_numerics.py).
+// quotient (Markstein's theorem; checked against IEEE division on every bin boundary and its
+// neighbours, random arguments, remainders and bit patterns -- tests/test_host_numerics.py,
+// tests/csrc/div1em4_check.c).  Holds while the residual does not underflow (|a| >= 1e-290):
+// the arguments here are differences of log-probabilities and remainders of them, zero or
+// many orders of magnitude above that.
 __device__ __forceinline__ double div_by_1em4(double a) {
   const double q0 = a * 1e4;
   const double r = __builtin_fma(-1e-4, q0, a);
