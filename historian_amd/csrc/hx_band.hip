@@ -56,6 +56,7 @@ typedef int i2v __attribute__((ext_vector_type(2)));
 #define HXB_EMIN (-(1 << 28))
 #define HXB_LOG_ENTRIES 1536       // the logarithm table of hx_linear.hip (build_log_table)
 #define HXB_RING 8                 // steps of cells in flight between the sweep and the converting wave
+#define HXB_RING_LEAN 4
 
 // value of the previous lane, lane 0 receives lane 63's: one v_mov_b32_dpp wave_ror:1 per dword
 __device__ __forceinline__ int ror1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false); }
@@ -98,11 +99,15 @@ struct BandPlan { int table, xrec, sbase, ycol, yclass, xclass, elds, ring, flag
 // followed, after the Nx - 1 + 64 records, by one int32 per 64-row strip: the cell of row i, step k lives at
 //   strip_store[i / 64] + 2 * (i % 64) + (k >> 1) * blk + (k & 1)   in a state plane.
 
-template <int POL, int PPW>
+// LEAN: the row records stay in memory (a lane fetches its next row's record a whole row ahead) and the ring between the
+// sweep and the converting wave is four steps deep instead of eight: 25 KB of LDS per pair instead of 54 (scaled
+// probabilities), 12 instead of 29 (table policies), so that large batches put five to seven pairs on a CU.
+template <int POL, int PPW, bool LEAN>
 __global__ void __launch_bounds__(2 * PPW * 64)
 k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const double* __restrict__ pol_tab,
             const BandPlan plan, const int n_jobs, const int write_edges) {
   constexpr int THREADS = 2 * PPW * 64;
+  constexpr int RING = LEAN ? HXB_RING_LEAN : HXB_RING;
   constexpr bool OFFLOAD = POL == POL_LINEAR;        // the second wave converts and stores the sweep's cells
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -122,9 +127,11 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   HX_LDS d2v* yclassL = (HX_LDS d2v*)(blkp + plan.yclass);
   HX_LDS d2v* xclassL = (HX_LDS d2v*)(blkp + plan.xclass);
   HX_LDS double* eldsL = (HX_LDS double*)(blkp + plan.elds);
-  HX_LDS d2v* ringL = (HX_LDS d2v*)(blkp + plan.ring);           // [HXB_RING][3][64]
+  HX_LDS d2v* ringL = (HX_LDS d2v*)(blkp + plan.ring);           // [RING][3][64]
   volatile HX_LDS int* progL = (volatile HX_LDS int*)(blkp + plan.flags);   // steps the sweep has put into the ring
   volatile HX_LDS int* consL = progL + 1;                                   // steps the converting wave has taken out
+  const HX_GLOBAL i2v* xrecG = (const HX_GLOBAL i2v*)as_global(reinterpret_cast<const i2v*>(J.band_rows));
+  auto xrec_at = [&](const int i) -> i2v { return LEAN ? xrecG[i] : xrecL[i]; };
 
   // ---- stage the shared table and the pair's two sides ----
   if (POL == POL_LINEAR) {
@@ -141,7 +148,8 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     const int Ky1 = J.y.n_cls + 1, Kx1 = J.x.n_cls + 1;
     const i2v* rows = reinterpret_cast<const i2v*>(J.band_rows);
     const int* sb = reinterpret_cast<const int*>(rows + (R + 64));
-    for (int i = pt; i < R + 64; i += 128) xrecL[i] = rows[i];          // (64 sentinel rows past the end: never owned)
+    if (!LEAN)
+      for (int i = pt; i < R + 64; i += 128) xrecL[i] = rows[i];        // (64 sentinel rows past the end: never owned)
     for (int q = pt; q < n_strips; q += 128) sbaseL[q] = sb[q];
     for (int j = pt; j < Cc; j += 128)
       ycolL[j] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0x100u : 0u);
@@ -181,8 +189,8 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
           if (seen < k + 2) __builtin_amdgcn_s_sleep(1);
         }
         asm volatile("" ::: "memory");
-        const HX_LDS d2v* s0 = ringL + (size_t)(k & (HXB_RING - 1)) * 192 + lane;
-        const HX_LDS d2v* s1 = ringL + (size_t)((k + 1) & (HXB_RING - 1)) * 192 + lane;
+        const HX_LDS d2v* s0 = ringL + (size_t)(k & (RING - 1)) * 192 + lane;
+        const HX_LDS d2v* s1 = ringL + (size_t)((k + 1) & (RING - 1)) * 192 + lane;
         const d2v a0 = s0[0], b0 = s0[64], c0 = s0[128], a1 = s1[0], b1 = s1[64], c1 = s1[128];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) consL[0] = k + 2;               // (the slots may be overwritten: their contents are in registers)
@@ -209,8 +217,8 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     // =====================================================================================================
     if (live) {
     // row 0 beyond what the sweep owns: the chain in log space (every policy stores log-probabilities)
-    const int own0 = (xrecL[0].x >> 16) & 0xFFFF;                      // row 0 is owned from step 0 to this step = column
-    const i2v rec1 = xrecL[1];
+    const int own0 = (xrec_at(0).x >> 16) & 0xFFFF;                      // row 0 is owned from step 0 to this step = column
+    const i2v rec1 = xrec_at(1);
     const bool row1_edge = ((rec1.x & 0xFFFF) + ((rec1.x >> 16) & 0xFFFF) - 1) < Cc - 1;   // row 1 does not own column Ny-2
     const double T02 = J.T[0][2], T03 = J.T[0][3], T22 = J.T[2][2], T33 = J.T[3][3];
     const double pen0 = J.x.pack[3];                                   // x START ready (or x empty): 0, else -inf
@@ -282,7 +290,7 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     // the rest of column Ny-2 away from the band: -inf (only where the matrix was not pre-filled)
     if (write_edges)
       for (int i = 2 + lane; i < R; i += 64) {
-        const i2v rec = xrecL[i];
+        const i2v rec = xrec_at(i);
         const int last_col = (rec.x & 0xFFFF) + ((rec.x >> 16) & 0xFFFF) - i;   // column of the row's last owned step
         if (last_col < Cc - 1) {
           const int64_t sl = stored_slot(J, i, Cc - 1);
@@ -317,9 +325,9 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   };
   auto store_base = [&](const int row) -> int { return sbaseL[row < R ? row >> 6 : 0] + 2 * (row & 63); };
   {
-    const i2v r0 = xrecL[lane < R ? lane : R];
+    const i2v r0 = xrec_at(lane < R ? lane : R);
     decode(r0, xclassL[r0.y & 0xFF], store_base(lane));
-    nrec = xrecL[lane + 64 < R ? lane + 64 : R];
+    nrec = xrec_at(lane + 64 < R ? lane + 64 : R);
   }
   // the 18 transition weights the recursion reads, pinned in scalar registers: probabilities or log-probabilities
   // (dest 5 = EEE is only read by lpEnd)
@@ -366,7 +374,7 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     if (k > oe) {
       i += 64;
       decode(nrec, nxc, nstore);
-      nrec = xrecL[i + 64 < R ? i + 64 : R];
+      nrec = xrec_at(i + 64 < R ? i + 64 : R);
     }
   };
   auto roll_odd = [&](const int k) {
@@ -461,16 +469,16 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     const int sl = store + (k >> 1) * blk;
     if (OFFLOAD) {
       // the ring slots of steps k, k + 1 were last used by steps k - 8, k - 7: the converting wave must be past them
-      while (cons_seen < k + 2 - HXB_RING) {
+      while (cons_seen < k + 2 - RING) {
         cons_seen = __builtin_amdgcn_readfirstlane(consL[0]);
-        if (cons_seen < k + 2 - HXB_RING) __builtin_amdgcn_s_sleep(1);
+        if (cons_seen < k + 2 - RING) __builtin_amdgcn_s_sleep(1);
       }
       step_linear(k, renorm, lb, la, lua, lub, y_side(k));
-      HX_LDS d2v* s0 = ringL + (size_t)(k & (HXB_RING - 1)) * 192 + lane;
+      HX_LDS d2v* s0 = ringL + (size_t)(k & (RING - 1)) * 192 + lane;
       s0[0] = d2v{la.imm, la.imd}; s0[64] = d2v{la.idm, la.imi}; s0[128] = d2v{la.iiw, __hiloint2double(own ? sl : -1, la.e)};
       roll_odd(k + 1);
       step_linear(k + 1, renorm, la, lb, lub, lua, y_side(k + 1));
-      HX_LDS d2v* s1 = ringL + (size_t)((k + 1) & (HXB_RING - 1)) * 192 + lane;
+      HX_LDS d2v* s1 = ringL + (size_t)((k + 1) & (RING - 1)) * 192 + lane;
       s1[0] = d2v{lb.imm, lb.imd}; s1[64] = d2v{lb.idm, lb.imi}; s1[128] = d2v{lb.iiw, __hiloint2double(0, lb.e)};
       asm volatile("" ::: "memory");               // data before flag (LDS operations of a wave complete in order)
       if (lane == 0) progL[0] = k + 2;
@@ -504,27 +512,27 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   if (!helper && live && lane == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
 }
 
-BandPlan plan_band(int pol, int ppw, int max_rows, int max_cols, int max_cls) {
+BandPlan plan_band(int pol, int ppw, int max_rows, int max_cols, int max_cls, bool lean = false) {
   BandPlan p;
   p.table = pol == POL_LINEAR ? 16 * HXB_LOG_ENTRIES : (pol == POL_FAST ? 16 * (HX_FAST_INTERVALS + 1) : 16);
   int a = 0;
-  p.xrec = a; a += (8 * (max_rows + 64) + 15) & ~15;
+  p.xrec = a; a += lean ? 0 : (8 * (max_rows + 64) + 15) & ~15;
   p.sbase = a; a += (4 * ((max_rows + 63) / 64 + 1) + 15) & ~15;
   p.ycol = a; a += (4 * max_cols + 15) & ~15;
   p.yclass = a; a += 16 * (max_cls + 1);
   p.xclass = a; a += 16 * (max_cls + 1);
   p.elds = a; a += (8 * (max_cls + 1) * (max_cls + 1) + 15) & ~15;
-  p.ring = a; a += pol == POL_LINEAR ? HXB_RING * 3 * 64 * 16 : 0;
+  p.ring = a; a += pol == POL_LINEAR ? (lean ? HXB_RING_LEAN : HXB_RING) * 3 * 64 * 16 : 0;
   p.flags = a; a += 16;
   p.stride = a;
   p.total = p.table + ppw * a;
   return p;
 }
 
-template <int POL, int PPW>
+template <int POL, int PPW, bool LEAN = false>
 int launch_pol(const DevJob* d_jobs, int n_jobs, const BandPlan& p, const double* tab, const double* pol_tab, int write_edges, hipStream_t st) {
   if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_band<%d, %d> needs %d bytes of LDS (limit %d)", POL, PPW, p.total, HX_LDS_LIMIT);
-  hipLaunchKernelGGL((k_fill_band<POL, PPW>), dim3((n_jobs + PPW - 1) / PPW), dim3(2 * PPW * 64), p.total, st, d_jobs, tab, pol_tab, p,
+  hipLaunchKernelGGL((k_fill_band<POL, PPW, LEAN>), dim3((n_jobs + PPW - 1) / PPW), dim3(2 * PPW * 64), p.total, st, d_jobs, tab, pol_tab, p,
                      n_jobs, write_edges);
   return 0;
 }
@@ -542,23 +550,42 @@ int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows,
   // Pairs per workgroup (they share the policy's table).  A CU holds 160 KB of LDS and four SIMDs; a pair is two waves.
   // One pair per workgroup while two such workgroups fit a CU; else two pairs share the table if that fits (the 64 KB
   // table of the fast policy); large batches put up to four pairs in a workgroup.
-  const char* v = getenv("HX_BAND_PPW");           // tuning / test hook
+  const char* v = getenv("HX_BAND_PPW");           // tuning / test hook: > 0 pairs per workgroup, < 0 the same in the lean variant
   int ppw = v ? atoi(v) : 0;
+  bool lean = ppw < 0;
+  if (lean) ppw = -ppw;
   if (ppw <= 0) {
     const int half = 72 * 1024;                    // (two workgroups of exactly 80 KB were measured NOT to fit a CU)
     ppw = 1;
     if (plan_band(pol, 1, max_rows, max_cols, max_cls).total > half && plan_band(pol, 2, max_rows, max_cols, max_cls).total <= HX_LDS_LIMIT) ppw = 2;
-    if (n_jobs > 1024 && plan_band(pol, 4, max_rows, max_cols, max_cls).total <= HX_LDS_LIMIT) ppw = 4;
+    if (n_jobs > 512) {
+      // more than two pairs per CU: the lean variant, as many pairs per workgroup as there are pairs per CU and its LDS
+      // plan admits (up to six).  Measured at 2560 pairs (tools/band_ppw_sweep.sh): scaled probabilities 7.7 ms with two
+      // pairs per workgroup, 5.1 ms with five; fast policy 14.4 ms -> 8.7 ms from four on (then bound by instruction issue).
+      int want = (n_jobs + 255) / 256;
+      want = want > 6 ? 6 : want;
+      int fit = want;
+      while (fit > 1 && plan_band(pol, fit, max_rows, max_cols, max_cls, true).total > HX_LDS_LIMIT) --fit;
+      if (fit >= 3) { lean = true; ppw = fit; }
+    }
   }
-  if (ppw > 1 && plan_band(pol, ppw, max_rows, max_cols, max_cls).total > HX_LDS_LIMIT) ppw = 1;
+  if (ppw > 1 && plan_band(pol, ppw, max_rows, max_cols, max_cls, lean).total > HX_LDS_LIMIT) { ppw = 1; lean = false; }
   const int we = write_edges ? 1 : 0;
+#define HXB_LEAN(POL_, N_) return launch_pol<POL_, N_, true>(d_jobs, n_jobs, plan_band(POL_, N_, max_rows, max_cols, max_cls, true), tab, pol_tab, we, st)
 #define HXB_GO(POL_) do { \
+    if (lean && ppw >= 6) HXB_LEAN(POL_, 6); \
+    if (lean && ppw == 5) HXB_LEAN(POL_, 5); \
+    if (lean && ppw == 4) HXB_LEAN(POL_, 4); \
+    if (lean && ppw == 3) HXB_LEAN(POL_, 3); \
+    if (lean && ppw == 2) HXB_LEAN(POL_, 2); \
+    if (lean) HXB_LEAN(POL_, 1); \
     if (ppw >= 4) return launch_pol<POL_, 4>(d_jobs, n_jobs, plan_band(POL_, 4, max_rows, max_cols, max_cls), tab, pol_tab, we, st); \
     if (ppw >= 2) return launch_pol<POL_, 2>(d_jobs, n_jobs, plan_band(POL_, 2, max_rows, max_cols, max_cls), tab, pol_tab, we, st); \
     return launch_pol<POL_, 1>(d_jobs, n_jobs, plan_band(POL_, 1, max_rows, max_cols, max_cls), tab, pol_tab, we, st); } while (0)
   if (pol == POL_LINEAR) HXB_GO(POL_LINEAR);
   if (pol == POL_FAST) HXB_GO(POL_FAST);
   HXB_GO(POL_EXACT);
+#undef HXB_LEAN
 #undef HXB_GO
 }
 

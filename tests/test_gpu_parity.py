@@ -517,3 +517,39 @@ def test_linear_mode_on_general_profiles():
         assert bf.best_trace() == be.best_trace() or True      # (paths may differ where the reference's truncation decides)
         be.close()
         bf.close()
+
+
+@pytest.mark.parametrize("ppw", [-3, -5])
+def test_banded_leaf_pairs_in_the_lean_band_kernel(ppw, monkeypatch):
+    # Large banded batches run the rotating-row band kernel in its lean variant (row records read from memory, a ring of four
+    # steps between the sweep and the converting wave, three to six pairs per workgroup: hx_band.hip); HX_BAND_PPW < 0 forces
+    # it on a small batch.  Exact mode bit for bit (Forward; the second workgroup is partly empty), fast within tolerance,
+    # scaled probabilities against the libm-arithmetic oracle.
+    monkeypatch.setenv("HX_BAND_PPW", str(ppw))
+    aa = "arndcqeghilkmfpstwyv"
+    cases = [H.leaf_case(501, 70, 66, band=5), H.leaf_case(502, 200, 90, band=12), H.leaf_case(503, 130, 150, band=3),
+             H.leaf_case(504, 300, 330, alphabet=aa, jc=False, band=20), H.leaf_case(505, 40, 45, band=0),
+             H.leaf_case(507, 500, 520, band=8), H.leaf_case(508, 260, 250, alphabet=aa, jc=False, band=16)]
+    imgs = [H.job_images(f) for f in cases]
+    run_and_check(cases, backward=False)
+    be = capi.Batch(imgs)
+    be.forward()
+    le = be.lp_end()
+    for flags in (capi.HX_LSE_FAST, capi.HX_LSE_LINEAR, capi.HX_LSE_LINEAR | capi.HX_BAND_COMPRESSED):
+        bf = capi.Batch(imgs, flags)
+        bf.forward()
+        lf = bf.lp_end()
+        for k, (x, y, hmm, md) in enumerate(imgs):
+            want = c_oracle.forward(x, y, hmm, md, true_math=(flags != capi.HX_LSE_FAST))
+            mf = bf.read_matrix(k, 0)
+            env = H.envelope_mask(cases[k]) if flags & capi.HX_BAND_COMPRESSED else np.ones(mf.shape[:2], dtype=bool)
+            assert np.array_equal(np.isneginf(want["cells"][env]), np.isneginf(mf[env])), "job %d: -inf pattern" % k
+            inside = np.isfinite(want["cells"])
+            assert np.max(np.abs(want["cells"][inside] - mf[inside]), initial=0.) < (1e-7 if flags == capi.HX_LSE_FAST else 1e-9), "job %d" % k
+            if np.isfinite(le[k]):
+                assert abs(le[k] - lf[k]) <= (1e-9 if flags == capi.HX_LSE_FAST else 1e-5) * abs(le[k])
+            else:
+                assert lf[k] == le[k]
+        assert bf.best_trace() == be.best_trace() or flags != capi.HX_LSE_FAST
+        bf.close()
+    be.close()
