@@ -78,7 +78,7 @@ EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_cr
            "hx_host_free", "hx_quick_batch_create", "hx_quick_batch_destroy", "hx_quick_batch_run",
            "hx_quick_batch_results", "hx_quick_batch_layout", "hx_quick_batch_read_matrix",
            "hx_quick_batch_total_cells", "hx_quick_batch_last_kernel_ms", "hx_sumprod_columns", "hx_sumprod_last_kernel_ms",
-           "hx_batch_read_matrix_async", "hx_batch_wait_read"]
+           "hx_batch_read_matrix_async", "hx_batch_wait_read", "hx_batch_indel_counts"]
 
 
 class HxError(RuntimeError):
@@ -136,6 +136,7 @@ def load():
     lib.hx_sumprod_last_kernel_ms.argtypes = [C.POINTER(C.c_float)]
     lib.hx_batch_read_matrix_async.argtypes = [vp, C.c_int32, C.c_int32, vp]
     lib.hx_batch_wait_read.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.hx_batch_indel_counts.argtypes = [vp, C.c_int32, _f64p, _f64p]
     _lib = lib
     return lib
 
@@ -318,6 +319,14 @@ class Batch:
         ii, jj = np.meshgrid(np.arange(l.n_rows), np.arange(l.n_cols), indexing="ij")
         slot = slot_index(l, ii, jj)
         return np.stack([buf[s * l.plane_stride + slot] for s in range(5)], axis=-1)
+
+    def indel_counts(self, job, branch_times):
+        """hx_batch_indel_counts: branch_times = (l.t, r.t, l.insWait, l.delWait, r.insWait, r.delWait)
+        -> dict ins, del, insExt, delExt, insTime, delTime"""
+        tm = np.ascontiguousarray(branch_times, dtype=np.float64)
+        out = np.zeros(6)
+        _check(load().hx_batch_indel_counts(self._h, job, _p(tm, _f64p), _p(out, _f64p)))
+        return dict(zip(("ins", "del", "insExt", "delExt", "insTime", "delTime"), out.tolist()))
 
     def strip_windows(self, job):
         l = self.layout(job)

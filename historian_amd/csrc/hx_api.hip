@@ -1432,6 +1432,29 @@ int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t*
   return HX_OK;
 }
 
+int hx_batch_indel_counts(hx_batch* b, int32_t job, const double* branch_times, double* out) {
+  if (!b || !branch_times || !out) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
+  if (!b->forward_done || !b->backward_done) return fail(HX_ERR_STATE, "hx_batch_indel_counts needs the Forward and the Backward fill");
+  { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
+  hipStream_t st = b->last_stream;
+  double* d = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d), 12 * sizeof(double)) != hipSuccess) return fail(HX_ERR_OUT_OF_MEMORY, "device allocation failed");
+  int rc = HX_OK;
+  double host[12];
+  for (int k = 0; k < 6; ++k) { host[k] = branch_times[k]; host[6 + k] = 0.; }
+  if (hipMemcpyAsync(d, host, sizeof(host), hipMemcpyHostToDevice, st) != hipSuccess) rc = HX_ERR_HIP;
+  if (rc == HX_OK) {
+    const DevJob& J = b->jobs[job];
+    launch_indel_counts(b->d_jobs, job, d, d + 6, (int64_t)J.n_rows * J.n_cols, Tab8{g_dev[b->device].tab}, !(b->flags & HX_FORCE_GENERIC), st);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d + 6, 6 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      rc = HX_ERR_HIP;
+  }
+  (void)hipFree(d);
+  return rc == HX_OK ? HX_OK : fail(rc, "indel-count kernel failed: %s", hipGetErrorString(hipGetLastError()));
+}
+
 int hx_batch_read_prepared(hx_batch* b, int32_t job, double* subx, double* suby, double* insx, double* rootsubx,
                            double* insy, double* rootsuby) {
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");

@@ -70,6 +70,8 @@ bool band_kernel_fits(int pol, int rows, int cols, int cls);
 int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, Tab8 tab,
                         Tab16 pol_tab, bool write_edges, hipStream_t st);
 
+void launch_indel_counts(const DevJob* d_jobs, int job, const double* d_tm, double* d_out, int64_t cells, Tab8 tab, bool plane_valid,
+                         hipStream_t st);
 void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, Tab8 tab,
                        bool plane_valid, hipStream_t st);
 

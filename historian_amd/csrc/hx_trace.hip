@@ -142,6 +142,128 @@ __global__ __launch_bounds__(64) void k_best_trace(const DevJob* __restrict__ jo
   if (lane == 0) n_cells[blockIdx.x] = status < 0 ? status : (int32_t)n;
 }
 
+// Expected indel events of a pair DP: BackwardMatrix::getCounts restricted to the IndelCounts members
+// (reference src/forward.cpp:1183-1214 with transitionEigenCounts, :579-652), for profiles whose transitions carry no
+// event counts of their own (leaf profiles).  A thread per matrix cell (i, j): for each of its five states, the source
+// transitions exactly as the traceback enumerates them, each weighted with exp(F(src) + lp + B(dest) - lpEnd); six sums
+// per thread, reduced over the workgroup, added to out[6] = {ins, del, insExt, delExt, insTime, delTime}.
+// tm[6] = {l.t, r.t, l.insWait, l.delWait, r.insWait, r.delWait} (ProbModel members of the pair HMM's two branches).
+__global__ __launch_bounds__(256) void k_indel_counts(const DevJob* __restrict__ jobs, const int job, const double* __restrict__ tm,
+                                                      double* __restrict__ out, const double* __restrict__ tab, const int plane_valid) {
+  const DevJob& J = jobs[job];
+  const int Nx = J.x.n, Ny = J.y.n, R = J.n_rows, Cc = J.n_cols;
+  const double lp_end = *J.lp_end;
+  const double l_t = tm[0], r_t = tm[1], l_iw = tm[2], l_dw = tm[3], r_iw = tm[4], r_dw = tm[5];
+  double c_ins = 0., c_del = 0., c_iext = 0., c_dext = 0., c_itime = 0., c_dtime = 0.;
+  for (int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; cell < (int64_t)R * Cc && lp_end > HX_NEG_INF; cell += (int64_t)gridDim.x * blockDim.x) {
+    const int dx = (int)(cell / Cc), dy = (int)(cell - (int64_t)dx * Cc);
+    if (!in_envelope(J, dx, dy)) continue;
+    const FwdPack xp = J.x.fpack[dx], yp = J.y.fpack[dy];
+    const int xf = xp.meta & 0xFF, yf = yp.meta & 0xFF;
+    const bool x_null = xf & F_NULL, y_null = yf & F_NULL;
+    const bool x_ready = (xf & F_READY) || J.x.empty, y_ready = (yf & F_READY) || J.y.empty;
+    const int64_t bslot = bwd_slot(J.strip_stride, R, Cc, dx, dy);
+    for (int ds = 0; ds < 5; ++ds) {
+      const double lp_dest = J.bwd[(int64_t)ds * J.plane + bslot];
+      if (!(lp_dest > HX_NEG_INF)) continue;
+      bool move_x = false, move_y = false, hmm = false, any = false;
+      double lp_abs = 0.;
+      if (ds == 1 || ds == 4) {
+        move_x = true;
+        if (x_null) any = y_ready && dx < Nx - 1;
+        else { any = y_ready; hmm = true; lp_abs = ds == 1 ? xp.rootsub : xp.ins; }
+      } else if (ds == 2 || ds == 3) {
+        move_y = true;
+        if (y_null) any = dy < Ny - 1;
+        else { any = x_ready; hmm = true; lp_abs = ds == 2 ? yp.rootsub : yp.ins; }
+      } else {
+        if (y_null && (xf & F_EMIT_OR_START)) { move_y = true; any = dy < Ny - 1; }
+        else if (x_null) { move_x = true; any = y_ready && dx < Nx - 1; }
+        else if (!y_null) {
+          move_x = move_y = hmm = any = true;
+          if (J.emis) {
+            const int cx = xp.cls, cy = yp.cls;
+            lp_abs = (cx < 0 || cy < 0) ? HX_NEG_INF : J.emis[(size_t)cx * J.y.n_cls + cy];
+          } else if (plane_valid)
+            lp_abs = J.emis_plane[cell_slot(J.strip_stride, dx, dy)];
+          else
+            lp_abs = emission(J, dx, dy, tab);
+        }
+      }
+      if (!any) continue;
+      const int nx = move_x ? (xp.meta >> 8) : 1, ny = move_y ? (yp.meta >> 8) : 1, ns = hmm ? 5 : 1;
+      for (int xi = 0; xi < nx; ++xi)
+        for (int yi = 0; yi < ny; ++yi) {
+          int sx = dx, sy = dy;
+          double xlp = 0., ylp = 0.;
+          if (move_x) {
+            if (xi < HX_DAG_INLINE) { sx = xi == 0 ? xp.s0 : xi == 1 ? xp.s1 : xp.s2; xlp = xi == 0 ? xp.lp0 : xi == 1 ? xp.lp1 : xp.lp2; }
+            else { sx = J.x.in_src[xp.in_b + xi]; xlp = J.x.in_lp[xp.in_b + xi]; }
+          }
+          if (move_y) {
+            if (yi < HX_DAG_INLINE) { sy = yi == 0 ? yp.s0 : yi == 1 ? yp.s1 : yp.s2; ylp = yi == 0 ? yp.lp0 : yi == 1 ? yp.lp1 : yp.lp2; }
+            else { sy = J.y.in_src[yp.in_b + yi]; ylp = J.y.in_lp[yp.in_b + yi]; }
+          }
+          for (int si = 0; si < ns; ++si) {
+            const int s = hmm ? si : ds;
+            const double h = hmm ? J.T[si][ds] : 0.;
+            const double f = forward_cell(J, sx, sy, s);
+            const double lw = (f + ((((h + xlp) + ylp) + lp_abs))) + lp_dest - lp_end;
+            if (!(lw > HX_NEG_INF)) continue;
+            const double w = exp(lw);
+            // transitionEigenCounts, dest.state switch (src/forward.cpp:585-649)
+            if (ds == 0) {
+              if (!x_null && !y_null) {
+                if (s == 0 || s == 1) { c_itime += w * l_t; c_dtime += w * l_t; }
+                if (s == 0 || s == 2) { c_itime += w * r_t; c_dtime += w * r_t; }
+              }
+            } else if (ds == 1) {
+              if (!x_null) {
+                if (s == 0 || s == 1) { c_itime += w * l_t; c_dtime += w * l_t; }
+                if (s == 1) c_dext += w;
+                else { c_del += w; c_dtime += w * r_dw; }
+              }
+            } else if (ds == 4) {
+              if (!x_null) {
+                if (s == 4) c_iext += w;
+                else { c_ins += w; c_itime += w * l_iw; }
+              }
+            } else if (ds == 2) {
+              if (!y_null) {
+                if (s == 0 || s == 2) { c_itime += w * r_t; c_dtime += w * r_t; }
+                if (s == 2) c_dext += w;
+                else { c_del += w; c_dtime += w * l_dw; }
+              }
+            } else {
+              if (!y_null) {
+                if (s == 3) c_iext += w;
+                else { c_ins += w; c_itime += w * r_iw; }
+              }
+            }
+          }
+        }
+    }
+  }
+  __shared__ double part[6][256];
+  part[0][threadIdx.x] = c_ins; part[1][threadIdx.x] = c_del; part[2][threadIdx.x] = c_iext;
+  part[3][threadIdx.x] = c_dext; part[4][threadIdx.x] = c_itime; part[5][threadIdx.x] = c_dtime;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if ((int)threadIdx.x < h)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) part[k][threadIdx.x] += part[k][threadIdx.x + h];
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) atomicAdd(&out[threadIdx.x], part[threadIdx.x][0]);
+}
+
+void launch_indel_counts(const DevJob* d_jobs, int job, const double* d_tm, double* d_out, int64_t cells, Tab8 tab8, bool plane_valid,
+                         hipStream_t st) {
+  int64_t blocks = (cells + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(k_indel_counts, dim3((unsigned)blocks), dim3(256), 0, st, d_jobs, job, d_tm, d_out, tab8.p, plane_valid ? 1 : 0);
+}
+
 // paths as walked (END cell first, [job][cap][3]) -> start-first, back to back at off[job]
 __global__ void k_reverse_paths(const int32_t* __restrict__ paths, int64_t cap, const int32_t* __restrict__ n_cells,
                                 const int64_t* __restrict__ off, int32_t* __restrict__ out) {

@@ -244,6 +244,14 @@ int64_t hx_batch_total_cells(const hx_batch* b);
  * fill kernel (HIP events recorded around that kernel on its stream). */
 int hx_batch_last_kernel_ms(hx_batch* b, int32_t which, float* ms);
 
+/* Expected indel events of pair `job` from its Forward and Backward matrices: BackwardMatrix::getCounts restricted to
+ * the IndelCounts members (reference src/forward.cpp:1183-1214, transitionEigenCounts :579-652) - every transition between
+ * two cells weighted with its posterior probability exp(F(src) + lp + B(dest) - lpEnd).  For profiles whose transitions
+ * carry no event counts of their own (leaf profiles; the x.getTrans(..)->counts terms of the reference are then zero).
+ * branch_times[6] = {l.t, r.t, l.insWait, l.delWait, r.insWait, r.delWait} (ProbModel members of the pair HMM's branches,
+ * src/model.cpp:374-391); out[6] = {ins, del, insExt, delExt, insTime, delTime}.  Needs both fills; synchronises. */
+int hx_batch_indel_counts(hx_batch* b, int32_t job, const double* branch_times, double* out);
+
 /* -- guide-alignment Viterbi (reference src/quickalign.cpp, src/diagenv.cpp) -------------------
  * The pairwise DP that builds the guide alignment the Forward fills are banded around: a batch of
  * independent QuickAlignMatrix fills.  Results are bit-identical to the reference (adds and maxima). */
