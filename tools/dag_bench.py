@@ -18,6 +18,7 @@ capi.init(0, c_oracle.table())
 root = tree.root()
 for band in ((-1,) if "unbanded" in sys.argv else (20, -1)):
     imgs = []
+    env_cells = 0
     for node in range(tree.nodes()):
         if tree.is_leaf(node): continue
         lc, rc = tree.child[node]
@@ -28,6 +29,16 @@ for band in ((-1,) if "unbanded" in sys.argv else (20, -1)):
         env = ho.GuideAlignmentEnvelope(guide, closest[lc], closest[rc], band) if band >= 0 else ho.GuideAlignmentEnvelope()
         f = ho.ForwardMatrix(res["prof"][lc], res["prof"][rc], hmm, node, env, fill=False)
         imgs.append(H.job_images(f))
+        if band >= 0:
+            # in-envelope cells of the pair (what a banded fill computes): vectorised |envelope coordinate difference| <= band,
+            # plus the always-stored edge row / column
+            img = imgs[-1]
+            ex, ey = np.asarray(img[0].env_pos[:f.x_size - 1]), np.asarray(img[1].env_pos[:f.y_size - 1])
+            inside = np.abs(ex[:, None] - ey[None, :]) <= band
+            inside |= np.asarray(f.x_near_start[:f.x_size - 1], dtype=bool)[:, None] | np.asarray(f.y_near_end[:f.y_size - 1], dtype=bool)[None, :]
+            env_cells += int(inside.sum())
+        else:
+            env_cells += (f.x_size - 1) * (f.y_size - 1)
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     if "perjob" in sys.argv:
         for k, img in enumerate(imgs):
@@ -46,14 +57,16 @@ for band in ((-1,) if "unbanded" in sys.argv else (20, -1)):
         batch.forward(); batch.sync()
         batch.forward(); batch.sync()
         cells = batch.total_cells()
+        in_env = env_cells * reps
         fms = batch.kernel_ms(0)
         if "fwdonly" in sys.argv:
-            print("  %-14s forward %8.3f ms %7.2f Gcell/s" % (name, fms, cells / fms / 1e6))
+            print("  %-14s forward %8.3f ms %7.2f Gcell/s over the lattice, %6.2f Gcell/s in-envelope (%d of %d cells)" %
+                  (name, fms, cells / fms / 1e6, in_env / fms / 1e6, in_env, cells))
             batch.close()
             continue
         batch.backward(); batch.sync()
         batch.backward(); batch.sync()
         bms = batch.kernel_ms(1)
-        print("  %-14s forward %8.3f ms %7.2f Gcell/s   backward %8.3f ms %7.2f Gcell/s (lattice cells %d)" %
-              (name, fms, cells / fms / 1e6, bms, cells / bms / 1e6, cells))
+        print("  %-14s forward %8.3f ms %7.2f Gcell/s   backward %8.3f ms %7.2f Gcell/s (lattice cells %d; in-envelope %d: forward %.2f, backward %.2f Gcell/s)" %
+              (name, fms, cells / fms / 1e6, bms, cells / bms / 1e6, cells, in_env, in_env / fms / 1e6, in_env / bms / 1e6))
         batch.close()
