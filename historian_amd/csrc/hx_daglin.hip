@@ -129,9 +129,13 @@ struct PrevCell { double v[V_PLANES]; int E; unsigned slot; };
 
 __device__ __forceinline__ int wave_shr1_int(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
 
-// byte offset (inside a plane of doubles) of the cell of row reference `rb` (strip base + 2 * lane, in bytes) at skewed
-// column t = column + lane-of-the-row
-__device__ __forceinline__ unsigned col_part(const int t) { return ((unsigned)(t >> 1) << 10) + ((unsigned)(t & 1) << 3); }
+// The scratch planes are private to this kernel and use their own layout inside a strip: cell (row lane l, skewed column
+// t = column + l) at byte (t * 64 + l) * 8 - a wavefront's store or load of one anti-diagonal is 512 contiguous bytes,
+// eight full 64-byte requests, where the matrix layout's step pairs (hx_device.h: (t / 2) * 128 + 2 l + t % 2) make it
+// sixteen half-used ones.  The fill is bound by the CU's vector-memory pipeline, so this halves its largest term.
+__device__ __forceinline__ unsigned col_part(const int t) { return (unsigned)t << 9; }
+// the Forward matrix itself (the five logarithms, the emission plane) keeps the matrix layout
+__device__ __forceinline__ unsigned m_col_part(const int t) { return ((unsigned)(t >> 1) << 10) + ((unsigned)(t & 1) << 3); }
 
 struct ColRec {            // what a step needs of its column: FwdPack's integer half and the LinPack
   int s0, s1, s2, in_b, meta, env, cls;
@@ -197,6 +201,10 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
   __shared__ volatile int prog[HXD_MAX_WAVES];
   __shared__ __attribute__((aligned(16))) double ltab_s[HXD_LOG_ENTRIES * 2];
   __shared__ double etab_s[HXD_EXP_ENTRIES];
+  // per wave: the column records (FwdPack's integer half + LinPack = five 16-byte quarters) of the 128 columns around the
+  // wave's position, refilled 64 columns at a time with one coalesced read: a step's record is five LDS reads instead of
+  // five vector loads of 64 different cache lines each (the fill is bound by the CU's vector-memory pipeline)
+  __shared__ d2v ycols[HXD_MAX_WAVES][5][128];
   const int threads = blockDim.x, W = threads >> 6;
   for (int k = threadIdx.x; k < HXD_LOG_ENTRIES * 2; k += threads) ltab_s[k] = log_tab[k];
   for (int k = threadIdx.x; k < HXD_EXP_ENTRIES; k += threads) etab_s[k] = exp2((double)k * (1.0 / HXD_EXP_ENTRIES));
@@ -239,6 +247,29 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
   const double P00 = PT(0, 0), P10 = PT(1, 0), P20 = PT(2, 0), P30 = PT(3, 0), P40 = PT(4, 0);
 #undef PT
 
+  HX_LDS d2v* ring = (HX_LDS d2v*)&ycols[wave][0][0];
+  auto stage = [&](const int c0) {       // columns c0 .. c0+63 (clamped into the profile) -> ring
+    int c = c0 + lane;
+    c = c < 0 ? 0 : (c >= Cc ? Cc - 1 : c);
+    const HX_GLOBAL d2v* q = (const HX_GLOBAL d2v*)(ypk + c);
+    const HX_GLOBAL d2v* l = (const HX_GLOBAL d2v*)(ylp + c);
+    const d2v q2 = q[2], q3 = q[3], l0 = l[0], l1 = l[1], l2 = l[2];
+    const int k = (c0 + lane) & 127;
+    ring[k] = q2; ring[128 + k] = q3; ring[256 + k] = l0; ring[384 + k] = l1; ring[512 + k] = l2;
+  };
+  auto column = [&](const int j) -> ColRec {
+    const int k = j & 127;
+    const d2v c2 = ring[k], c3 = ring[128 + k], l0 = ring[256 + k], l1 = ring[384 + k], l2 = ring[512 + k];
+    ColRec r;
+    r.s0 = __double2loint(c2.x); r.s1 = __double2hiint(c2.x);
+    r.in_b = __double2loint(c2.y); r.meta = __double2hiint(c2.y);
+    r.env = __double2loint(c3.x); r.cls = __double2hiint(c3.x);
+    r.s2 = __double2loint(c3.y);
+    r.w0 = l0.x; r.w1 = l0.y; r.w2 = l1.x; r.rs_m = l1.y; r.ins_m = l2.x;
+    r.rs_e = __double2loint(l2.y); r.ins_e = __double2hiint(l2.y);
+    return r;
+  };
+
   for (int s = wave; s < n_strips; s += W) {
     const int i = (s << 6) + lane;
     const bool rvalid = i < R;
@@ -246,11 +277,11 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
     const ColRec X = load_col(xpk, xlp, ir);
     const int xf = X.meta & 0xff, xdeg = X.meta >> 8;
     const bool xnull = xf & F_NULL, xok = (xf & F_READY) || xempty, xeos = xf & F_EMIT_OR_START;
-    const unsigned ownB = (unsigned)s * ssB + ((unsigned)lane << 4);
+    const unsigned ownB = (unsigned)s * ssB + ((unsigned)lane << 3), ownB_m = (unsigned)s * ssB + ((unsigned)lane << 4);
     // the rows of the first three in-transitions: byte offset of the row inside a plane, and the row's lane
-    const unsigned xrB0 = (unsigned)(X.s0 >> 6) * ssB + ((unsigned)(X.s0 & 63) << 4);
-    const unsigned xrB1 = (unsigned)(X.s1 >> 6) * ssB + ((unsigned)(X.s1 & 63) << 4);
-    const unsigned xrB2 = (unsigned)(X.s2 >> 6) * ssB + ((unsigned)(X.s2 & 63) << 4);
+    const unsigned xrB0 = (unsigned)(X.s0 >> 6) * ssB + ((unsigned)(X.s0 & 63) << 3);
+    const unsigned xrB1 = (unsigned)(X.s1 >> 6) * ssB + ((unsigned)(X.s1 & 63) << 3);
+    const unsigned xrB2 = (unsigned)(X.s2 >> 6) * ssB + ((unsigned)(X.s2 & 63) << 3);
     const int xl0 = X.s0 & 63, xl1 = X.s1 & 63, xl2 = X.s2 & 63;
     const unsigned vXa = (xnull ? V_IMD : V_G0) * planeB, vXb = (xnull ? V_IIW : V_G1) * planeB;
     // a source in the row directly above, inside this strip, is the previous lane's cell of the previous step
@@ -264,7 +295,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
     for (int q = 0; q < HXD_EXTRA; ++q) {
       const int a = HX_DAG_INLINE + q;
       const int src = xdeg > a ? xin_src[X.in_b + a] : 0;
-      xrx[q] = (unsigned)(src >> 6) * ssB + ((unsigned)(src & 63) << 4);
+      xrx[q] = (unsigned)(src >> 6) * ssB + ((unsigned)(src & 63) << 3);
       xlx[q] = (src & 63) | ((lane > 0 && xdeg > a && src == i - 1) ? 64 : 0);     // bit 6: the row directly above
       xwx[q] = xdeg > a ? xin_w[X.in_b + a] : 0.;
     }
@@ -283,9 +314,8 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
     }
     for (int w = 0; w < 2; ++w) {
       if (whi[w] <= wlo[w]) continue;
-      int jn = wlo[w] - lane;
-      jn = jn < 0 ? 0 : (jn >= Cc ? Cc - 1 : jn);
-      ColRec Yn = load_col(ypk, ylp, jn);
+      stage(wlo[w] - 64);
+      stage(wlo[w]);
       PrevCell pv;
 #pragma unroll
       for (int v = 0; v < V_PLANES; ++v) pv.v[v] = 0.;
@@ -305,13 +335,9 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
           }
         }
         HXD_TR(0);     // progress wait
-        const ColRec Y = Yn;
-        {
-          int c = t + 1 - lane;
-          c = c < 0 ? 0 : (c >= Cc ? Cc - 1 : c);
-          Yn = load_col(ypk, ylp, c);
-        }
+        if (t > wlo[w] && ((t - wlo[w]) & 63) == 0) stage(t);
         const int j = t - lane;
+        const ColRec Y = column(j);
         const int yf = Y.meta & 0xff, ydeg = Y.meta >> 8;
         bool act = rvalid && j >= 0 && j < Cc;
         if (banded) {
@@ -327,13 +353,13 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
         // slots (byte offsets inside a plane) of the source cells
         const unsigned sx0 = xrB0 + col_part(jc + xl0), sx1 = xrB1 + col_part(jc + xl1), sx2 = xrB2 + col_part(jc + xl2);
         const unsigned sy0 = ownB + col_part(Y.s0 + lane), sy1 = ownB + col_part(Y.s1 + lane), sy2 = ownB + col_part(Y.s2 + lane);
-        const unsigned own_slot = ownB + col_part(t);
+        const unsigned own_slot = ownB + col_part(t), own_slot_m = ownB_m + m_col_part(t);
 
         // ---- emission (log) of the cell ----
         double elog = HX_NEG_INF;
         if (act && mode == 1) {
           if (etab) elog = etab[(int64_t)(X.cls < 0 ? 0 : X.cls) * Ky + (Y.cls < 0 ? 0 : Y.cls)];
-          else elog = ldg(eplane, own_slot);
+          else elog = ldg(eplane, own_slot_m);
           if (X.cls < 0 || Y.cls < 0) elog = HX_NEG_INF;
         }
 
@@ -351,11 +377,22 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
         int xe[3], ye[3], me[9];
         int ysx[HXD_EXTRA];
         double ywx[HXD_EXTRA];
+#ifdef HX_DAG_TRACE
+        {   // latency probe: one source load by itself (the first transition of the row), then an old cell of the same row
+          volatile double probe = ldg(LIN, vXa + sx0);
+          (void)probe;
+          HXD_TR(7);
+          const int told = t - 40 < wlo[w] ? wlo[w] : t - 40;
+          volatile double probe2 = ldg(LIN, V_G2 * planeB + ownB + col_part(told));     // written 40 steps ago by this lane
+          (void)probe2;
+          HXD_TR(6);
+          volatile double probe3 = ldg(LIN, V_G2 * planeB + ownB + col_part(told));     // the same line again
+          (void)probe3;
+          HXD_TR(4);
+        }
+#endif
         if (act) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) { xa[k] = xb[k] = ya[k] = yb[k] = 0.; xe[k] = ye[k] = HXD_EMIN; }
-#pragma unroll
-          for (int k = 0; k < 9; ++k) { mv[k] = 0.; me[k] = HXD_EMIN; }
+          // (no initial values: every element is read under the predicate it was loaded under)
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             if (xgo && xdeg > k) { xa[k] = ldg(LIN, vXa + sxs[k]); xb[k] = ldg(LIN, vXb + sxs[k]); xe[k] = ldgi(EX, sxs[k] >> 1); }
@@ -515,7 +552,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
               for (int a = HX_DAG_INLINE; a < xdeg; ++a) {
                 const int srcx = xin_src[X.in_b + a];
                 const double wxa = xin_w[X.in_b + a];
-                const unsigned rb = (unsigned)(srcx >> 6) * ssB + ((unsigned)(srcx & 63) << 4);
+                const unsigned rb = (unsigned)(srcx >> 6) * ssB + ((unsigned)(srcx & 63) << 3);
                 for (int b = HX_DAG_INLINE; b < ydeg; ++b) {
                   const unsigned sl = rb + col_part(yin_src[Y.in_b + b] + (srcx & 63));
                   add1(am, ldg(LIN, V_G4 * planeB + sl), ldgi(EX, sl >> 1), wxa * yin_w[Y.in_b + b]);
@@ -524,7 +561,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
             for (int a = HX_DAG_INLINE + HXD_EXTRA; a < xdeg; ++a) {
               const int src = xin_src[X.in_b + a];
               const double wa = xin_w[X.in_b + a];
-              const unsigned rb = (unsigned)(src >> 6) * ssB + ((unsigned)(src & 63) << 4);
+              const unsigned rb = (unsigned)(src >> 6) * ssB + ((unsigned)(src & 63) << 3);
               const unsigned sl = rb + col_part(jc + (src & 63));
               const bool adj = lane > 0 && src == i - 1;
               if (xgo) {
@@ -583,11 +620,11 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
         HXD_TR(2);     // source loads and accumulation
         // ---- the reference's format (five logarithms, stored at once) and the kernel's: a common exponent (that of the
         // largest state), the five outgoing sums - kept in registers until the next step has issued its loads ----
-        stg(M, own_slot, log_scaled(m_imm, e_imm, ltab));                  // (nothing in this kernel reads these back)
-        stg(M, planeB + own_slot, log_scaled(m_imd, e_imd, ltab));
-        stg(M, 2 * planeB + own_slot, log_scaled(m_idm, e_idm, ltab));
-        stg(M, 3 * planeB + own_slot, log_scaled(m_imi, e_imi, ltab));
-        stg(M, 4 * planeB + own_slot, log_scaled(m_iiw, e_iiw, ltab));
+        stg(M, own_slot_m, log_scaled(m_imm, e_imm, ltab));                  // (nothing in this kernel reads these back)
+        stg(M, planeB + own_slot_m, log_scaled(m_imd, e_imd, ltab));
+        stg(M, 2 * planeB + own_slot_m, log_scaled(m_idm, e_idm, ltab));
+        stg(M, 3 * planeB + own_slot_m, log_scaled(m_imi, e_imi, ltab));
+        stg(M, 4 * planeB + own_slot_m, log_scaled(m_iiw, e_iiw, ltab));
         {
           const int b0 = m_imm > 0. ? e_imm + __builtin_amdgcn_frexp_exp(m_imm) : HXD_EMIN;
           const int b1 = m_imd > 0. ? e_imd + __builtin_amdgcn_frexp_exp(m_imd) : HXD_EMIN;
@@ -649,6 +686,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
     if (lane == 0 && tr_steps > 0)
       printf("trace job %d strip %d steps %d wait %lld setup %lld accumulate %lld finish %lld publish %lld loads1 %lld sums1 %lld\n", (int)blockIdx.x, s, tr_steps,
              tr_sum[0] / tr_steps, tr_sum[1] / tr_steps, tr_sum[2] / tr_steps, tr_sum[3] / tr_steps, tr_sum[4] / tr_steps, tr_sum[5] / tr_steps, tr_sum[6] / tr_steps);
+    if (lane == 0 && tr_steps > 0) printf("probe job %d strip %d one load %lld old line %lld\n", (int)blockIdx.x, s, tr_sum[7] / tr_steps, tr_sum[6] / tr_steps);
 #endif
     // (a strip without any window still has to release the strip below)
     if (published < Cc) {
