@@ -3,8 +3,8 @@
 // accumulateRootCounts and accumulateEigenCounts (src/sumprod.cpp:264-271, 294-372), for a BATCH of alignment columns.
 //
 // In the reference one SumProduct object walks the columns one after the other (AlignColSumProduct, and once per
-// posterior-weighted DP cell in BackwardMatrix::getCounts).  Columns are independent, so here a column is a thread
-// (k_sumprod_columns): every thread runs the tip-to-root and root-to-tip passes of its column - tiny tree recursions,
+// posterior-weighted DP cell in BackwardMatrix::getCounts).  Columns and mixture components are independent, so here a
+// (column, component) is a thread (k_sumprod_columns): every thread runs the tip-to-root and root-to-tip passes of its column - tiny tree recursions,
 // A x A matrix-vector products per branch and mixture component - with its messages E, F, G in a global scratch laid out
 // [.][column] so that the threads of a wavefront touch consecutive addresses, then turns the messages of every branch
 // into the eigen basis (D_k, U_l).  The reference adds weight x D_k J_kl U_l to the count matrix column by column; J_kl
@@ -23,6 +23,7 @@
 #include <vector>
 #include "../../include/historian_hip.h"
 #include "hx_lse.h"
+#include "hx_policy.h"
 #include "hx_kernels.h"
 
 namespace hx {
@@ -59,8 +60,11 @@ __device__ __forceinline__ CMat cmat(const double* p) { return (CMat)(unsigned l
 
 // TA: the alphabet size as a compile-time constant (message vectors live in registers, loops unrolled), or 0 for any
 // alphabet of up to 64 symbols (vectors in private memory).
-template <int TA>
-__global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const signed char* __restrict__ tok, const double* __restrict__ weight,
+// LM: a wave keeps the matrices it multiplies with in LDS - exp(R t) of the branch at hand (re-staged per node), the real
+// parts of the eigenvectors and of their inverse (per component) - and reads their entries as LDS broadcasts; without it
+// they come through the scalar cache, which the 3 KB per matrix-vector product overrun (2.9 TFLOP/s, one FMA per ~100 cycles).
+template <int TA, bool LM>
+__global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const signed char* __restrict__ tok, const double* __restrict__ weight,
                                                          const long long n_cols, const SpScratch s, const double* __restrict__ lse_tab,
                                                          double* __restrict__ col_log_like, double* __restrict__ root_post) {
   constexpr int AX = TA ? TA : 64;
@@ -71,7 +75,18 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
 #define LG(P, cpt, r) P[((long long)(cpt) * N + (r)) * stride + col]
 #define BS(cpt, r, part, l) s.basis[((((long long)(cpt) * N + (r)) * parts + (part)) * A + (l)) * stride + col]
 #define FR(cpt, a) s.Froot[((long long)(cpt) * A + (a)) * stride + col]
-  for (long long col = (long long)blockIdx.x * blockDim.x + threadIdx.x; col < n_cols; col += (long long)gridDim.x * blockDim.x) {
+  // a wavefront is 64 columns of one mixture component (the component is uniform over the wave, so the model's matrices
+  // still come through scalar loads); the waves of a workgroup share the columns and split the components.  They meet
+  // twice: for the column likelihood (through LDS) and for the root posterior (through the scratch).
+  extern __shared__ double sh_ll[];                 // [C][64], then per wave [3][A * A]: exp(R t), evecInv, evec (real parts)
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63, Wb = (int)blockDim.x >> 6;
+  HX_LDS double* Lsub = (HX_LDS double*)(sh_ll + 64 * C + (LM ? 3 * AA * wave : 0));
+  HX_LDS double* Linv = Lsub + AA;
+  HX_LDS double* Lvec = Linv + AA;
+  auto wave_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+  for (long long base = (long long)blockIdx.x * 64; base < n_cols; base += (long long)gridDim.x * 64) {
+    const bool busy = base + lane < n_cols;
+    const long long col = busy ? base + lane : 0;
     const signed char* t = tok + col * N;       // -2 gap, -1 wildcard, else the residue's token
     const double w = weight ? weight[col] : 1.;
     int root = -1;
@@ -79,10 +94,20 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
       if (t[r] != -2 && (m.parent[r] < 0 || t[m.parent[r]] == -2)) root = r;     // (one root per column: the caller's contract)
     double cll = HX_NEG_INF;
     // ---- tip-to-root (src/sumprod.cpp:99-161); U of every branch in the eigen basis on the way (src/sumprod.cpp:318-340) ----
-    for (int cpt = 0; cpt < C; ++cpt) {
+    for (int cpt = wave; cpt < C; cpt += Wb) {
       double cpt_ll = 0.;
       CMat ins = cmat(m.ins_prob + cpt * A);
+      if (LM) {
+        wave_sync();
+        for (int k = lane; k < AA; k += 64) { Linv[k] = m.einv_re[(long long)cpt * AA + k]; Lvec[k] = m.evec_re[(long long)cpt * AA + k]; }
+      }
       for (int r = 0; r < N; ++r) {
+        if (LM && m.parent[r] >= 0) {
+          wave_sync();                               // (the reads of the previous node's matrix are done)
+          for (int k = lane; k < AA; k += 64) Lsub[k] = m.branch_sub[((long long)cpt * N + r) * AA + k];
+          wave_sync();
+        }
+        if (!busy) continue;
         const int c0 = m.child[2 * r], c1 = m.child[2 * r + 1];
         double lf = (c0 >= 0 ? LG(s.logE, cpt, c0) : 0.) + (c1 >= 0 ? LG(s.logE, cpt, c1) : 0.);
         const int tk = t[r];
@@ -98,9 +123,11 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
             for (int l = 0; l < A; ++l) BS(cpt, r, 2, l) = 0.;
           continue;
         }
-        CMat sub = cmat(m.branch_sub + ((long long)cpt * N + r) * AA);
-        CMat ir = cmat(m.einv_re + (long long)cpt * AA);
+        CMat sub_s = cmat(m.branch_sub + ((long long)cpt * N + r) * AA);
+        CMat ir_s = cmat(m.einv_re + (long long)cpt * AA);
         CMat ii = cmat(m.einv_im + (long long)cpt * AA);
+        auto sub = [&](const int k) -> double { return LM ? Lsub[k] : sub_s[k]; };
+        auto ir = [&](const int k) -> double { return LM ? Linv[k] : ir_s[k]; };
         if (tk >= 0) {
           // a residue: F is one-hot, E and U are columns of the matrices
           double f = (c0 >= 0 ? AT(s.E, cpt, c0, tk) : 1.) * (c1 >= 0 ? AT(s.E, cpt, c1, tk) : 1.);
@@ -115,9 +142,9 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
             LG(s.maxU, cpt, r) = f;
             const double* subg = m.branch_sub + ((long long)cpt * N + r) * AA;
 #pragma unroll
-            for (int a = 0; a < A; ++a) AT(s.E, cpt, r, a) = subg[a * A + tk] * f;
+            for (int a = 0; a < A; ++a) AT(s.E, cpt, r, a) = (LM ? Lsub[a * A + tk] : subg[a * A + tk]) * f;
 #pragma unroll
-            for (int l = 0; l < A; ++l) BS(cpt, r, 0, l) = m.einv_re[(long long)cpt * AA + l * A + tk] * (f / f);
+            for (int l = 0; l < A; ++l) BS(cpt, r, 0, l) = (LM ? Linv[l * A + tk] : m.einv_re[(long long)cpt * AA + l * A + tk]) * (f / f);
             if (parts == 4)
               for (int l = 0; l < A; ++l) BS(cpt, r, 2, l) = m.einv_im[(long long)cpt * AA + l * A + tk] * (f / f);
           }
@@ -154,7 +181,7 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
         for (int a = 0; a < A; ++a) {
           double e = 0.;
 #pragma unroll
-          for (int b = 0; b < A; ++b) e += sub[a * A + b] * f[b];
+          for (int b = 0; b < A; ++b) e += sub(a * A + b) * f[b];
           AT(s.E, cpt, r, a) = e;
         }
 #pragma unroll
@@ -163,7 +190,7 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
         for (int l = 0; l < A; ++l) {
           double ur = 0.;
 #pragma unroll
-          for (int b = 0; b < A; ++b) ur += ir[l * A + b] * f[b];
+          for (int b = 0; b < A; ++b) ur += ir(l * A + b) * f[b];
           BS(cpt, r, 0, l) = ur;
         }
         if (parts == 4)
@@ -174,13 +201,25 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
             BS(cpt, r, 2, l) = ui;
           }
       }
-      cll = lse(cll, m.log_cpt_weight[cpt] + cpt_ll, lse_tab);
+      sh_ll[cpt * 64 + lane] = cpt_ll;
     }
-    col_log_like[col] = cll;
+    __syncthreads();
+    for (int cpt = 0; cpt < C; ++cpt) cll = lse(cll, m.log_cpt_weight[cpt] + sh_ll[cpt * 64 + lane], lse_tab);
+    if (wave == 0 && busy) col_log_like[col] = cll;
     // ---- root-to-tip (src/sumprod.cpp:163-198); D of every branch in the eigen basis on the way (src/sumprod.cpp:341-360) ----
-    for (int cpt = 0; cpt < C; ++cpt) {
+    for (int cpt = wave; cpt < C; cpt += Wb) {
       CMat ins = cmat(m.ins_prob + cpt * A);
+      if (LM && C > Wb) {                            // (with a wave per component the eigenvectors are still there)
+        wave_sync();
+        for (int k = lane; k < AA; k += 64) Lvec[k] = m.evec_re[(long long)cpt * AA + k];
+      }
       for (int r = N - 1; r >= 0; --r) {
+        if (LM && m.parent[r] >= 0) {
+          wave_sync();
+          for (int k = lane; k < AA; k += 64) Lsub[k] = m.branch_sub[((long long)cpt * N + r) * AA + k];
+          wave_sync();
+        }
+        if (!busy) continue;
         if (t[r] == -2 || r == root) {
           if (r == root) {
 #pragma unroll
@@ -201,9 +240,11 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
         const double le_sib = sib >= 0 ? LG(s.logE, cpt, sib) : 0.;
         const double lg_p = LG(s.logG, cpt, p);
         LG(s.logG, cpt, r) = lg_p + le_sib;
-        CMat sub = cmat(m.branch_sub + ((long long)cpt * N + r) * AA);
-        CMat vr = cmat(m.evec_re + (long long)cpt * AA);
+        CMat sub_s = cmat(m.branch_sub + ((long long)cpt * N + r) * AA);
+        CMat vr_s = cmat(m.evec_re + (long long)cpt * AA);
         CMat vi = cmat(m.evec_im + (long long)cpt * AA);
+        auto sub = [&](const int k) -> double { return LM ? Lsub[k] : sub_s[k]; };
+        auto vr = [&](const int k) -> double { return LM ? Lvec[k] : vr_s[k]; };
         // what flows down the branch: the parent's outside message times the sibling's subtree
         double d[AX];
         double max_d = 0.;
@@ -216,7 +257,7 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
         for (int b = 0; b < A; ++b) {
           double g = 0.;
 #pragma unroll
-          for (int a = 0; a < A; ++a) g += d[a] * sub[a * A + b];
+          for (int a = 0; a < A; ++a) g += d[a] * sub(a * A + b);
           AT(s.G, cpt, r, b) = g;
         }
         const double norm = exp(cll - m.log_cpt_weight[cpt] - LG(s.logF, cpt, r) - lg_p - le_sib) / (LG(s.maxU, cpt, r) * max_d);
@@ -227,7 +268,7 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
         for (int k = 0; k < A; ++k) {
           double dr = 0.;
 #pragma unroll
-          for (int a = 0; a < A; ++a) dr += vr[a * A + k] * d[a];
+          for (int a = 0; a < A; ++a) dr += vr(a * A + k) * d[a];
           BS(cpt, r, 1, k) = dr * scale;
         }
         if (parts == 4)
@@ -239,8 +280,9 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
           }
       }
     }
+    __syncthreads();            // (the other components' F, G at the root, written to the scratch by the neighbouring threads)
     // ---- posterior of the root's residue (src/sumprod.cpp:208-217) ----
-    if (root_post)
+    if (root_post && busy && wave == 0)
       for (int a = 0; a < A; ++a) {
         double lp = HX_NEG_INF;
         if (root >= 0)
@@ -250,11 +292,12 @@ __global__ void __launch_bounds__(128) k_sumprod_columns(const SpModel m, const 
         root_post[col * A + a] = lp < 0. ? lp : 0.;
       }
     // ---- this column's terms of the root counts (src/sumprod.cpp:264-271) ----
-    for (int cpt = 0; cpt < C; ++cpt) {
+    for (int cpt = wave; cpt < C && busy; cpt += Wb) {
       const double norm = root >= 0 ? exp(m.log_cpt_weight[cpt] + LG(s.logF, cpt, root) - cll) : 0.;
       for (int a = 0; a < A; ++a)
         s.rootc[((long long)cpt * A + a) * stride + col] = root >= 0 ? w * m.ins_prob[cpt * A + a] * FR(cpt, a) * norm : 0.;
     }
+    __syncthreads();
   }
 #undef AT
 #undef LG
@@ -366,6 +409,7 @@ int hx_sumprod_columns(const hx_sumprod_model* hm, const int8_t* tokens, const d
       !hm->evec_inv_re || !hm->evec_inv_im || !hm->esc_re || !hm->esc_im)
     return api_fail(HX_ERR_INVALID_ARG, "hx_sumprod_columns: incomplete model");
   if (AA > 256 * HX_SP_PAIRS) return api_fail(HX_ERR_INVALID_ARG, "hx_sumprod_columns: alphabets of more than 64 symbols are not supported");
+  if (C > 128) return api_fail(HX_ERR_INVALID_ARG, "hx_sumprod_columns: more than 128 mixture components are not supported");
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) return api_fail(HX_ERR_NO_DEVICE, "no HIP device");
   const double* lse_tab = device_lse_table(device);
@@ -453,18 +497,21 @@ int hx_sumprod_columns(const hx_sumprod_model* hm, const int8_t* tokens, const d
     s.Froot = s.maxU + lg;
     s.rootc = s.Froot + (size_t)C * A * nc;
     s.basis = s.rootc + (size_t)C * A * nc;
-    const int tpb = 128;
-    long long blocks = (nc + tpb - 1) / tpb;
+    const int tpb = 64 * (C < 8 ? C : 8);            // a wave per mixture component, up to eight
+    long long blocks = (nc + 63) / 64;
     if (blocks > 65535) blocks = 65535;
+    const size_t ll_lds = sizeof(double) * 64 * (size_t)C;
     const signed char* d_tok = static_cast<const signed char*>(b_tok.p) + first * N;
     const double* d_w = b_w.p ? static_cast<const double*>(b_w.p) + first : nullptr;
     double* d_p = d_post ? d_post + first * A : nullptr;
-    if (A == 4)
-      hipLaunchKernelGGL(k_sumprod_columns<4>, dim3((unsigned)blocks), dim3(tpb), 0, st, m, d_tok, d_w, nc, s, lse_tab, d_cll + first, d_p);
-    else if (A == 20)
-      hipLaunchKernelGGL(k_sumprod_columns<20>, dim3((unsigned)blocks), dim3(tpb), 0, st, m, d_tok, d_w, nc, s, lse_tab, d_cll + first, d_p);
-    else
-      hipLaunchKernelGGL(k_sumprod_columns<0>, dim3((unsigned)blocks), dim3(tpb), 0, st, m, d_tok, d_w, nc, s, lse_tab, d_cll + first, d_p);
+    const size_t mat_lds = sizeof(double) * 3 * (size_t)AA * (tpb / 64);
+    const bool lm = ll_lds + mat_lds <= 96 * 1024;
+    const size_t col_lds = ll_lds + (lm ? mat_lds : 0);
+#define HX_SP_GO(TA_, LM_) hipLaunchKernelGGL((k_sumprod_columns<TA_, LM_>), dim3((unsigned)blocks), dim3(tpb), col_lds, st, m, d_tok, d_w, nc, s, lse_tab, d_cll + first, d_p)
+    if (A == 4) { if (lm) HX_SP_GO(4, true); else HX_SP_GO(4, false); }
+    else if (A == 20) { if (lm) HX_SP_GO(20, true); else HX_SP_GO(20, false); }
+    else { if (lm) HX_SP_GO(0, true); else HX_SP_GO(0, false); }
+#undef HX_SP_GO
     const long long tiles = (nc + HX_SP_TILE - 1) / HX_SP_TILE;
     long long slices = 4096 / ((long long)C * N) + 1;
     if (slices > tiles) slices = tiles;
