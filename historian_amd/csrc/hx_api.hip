@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
@@ -586,6 +587,9 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
     return fail(HX_ERR_NOT_INITIALIZED, "hx_init has not been called for device %d", device);
   if (!jobs || n_jobs <= 0) return fail(HX_ERR_INVALID_ARG, "need at least one job");
   HIP_TRY(hipSetDevice(device));
+  const bool timing = getenv("HX_TIMING_CREATE") != nullptr;
+  const auto tick = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tc0 = tick();
 
   hx_batch* b = new (std::nothrow) hx_batch;
   if (!b) return fail(HX_ERR_OUT_OF_MEMORY, "host allocation failed");
@@ -826,6 +830,7 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
   b->lp_start_off = ar.reserve(sizeof(double) * n_jobs);
 
   auto cleanup = [&](int code) { hx_batch_destroy(b); return code; };
+  const double tc1 = tick();
   if (hipMalloc(reinterpret_cast<void**>(&b->d_arena), ar.host.size() + 256) != hipSuccess)
     return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %zu input bytes failed", ar.host.size()));
   if (hipMemcpy(b->d_arena, ar.host.data(), ar.host.size(), hipMemcpyHostToDevice) != hipSuccess)
@@ -874,7 +879,11 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
   if (hipMalloc(reinterpret_cast<void**>(&b->d_jobs), sizeof(DevJob) * n_jobs) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&b->d_jobs_cls), sizeof(DevJob) * n_jobs) != hipSuccess)
     return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of job table failed"));
+  const double tc2 = tick();
   if ((rc = publish_jobs(b)) != HX_OK) return cleanup(rc);
+  if (timing)
+    fprintf(stderr, "timing: hx_batch_create of %d jobs: host images and plans %.4f s, allocations and upload of %zu bytes %.4f s, job tables %.4f s\n",
+            n_jobs, tc1 - tc0, ar.host.size(), tc2 - tc1, tick() - tc2);
   for (int w = 0; w < 2; ++w)
     for (int e = 0; e < 2; ++e)
       if (hipEventCreate(&b->ev[w][e]) != hipSuccess) return cleanup(fail(HX_ERR_HIP, "hipEventCreate failed"));
