@@ -238,14 +238,30 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_strips = (R + 63) >> 6;
   const int prev_wave = (wave + W - 1) % W;
-  // transition probabilities of the pair HMM (uniform: kept in scalar registers)
-#define PT(s, d) __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(exp(J.T[s][d]))), __builtin_amdgcn_readfirstlane(__double2loint(exp(J.T[s][d]))))
-  const double P01 = PT(0, 1), P11 = PT(1, 1), P21 = PT(2, 1), P31 = PT(3, 1);
-  const double P04 = PT(0, 4), P34 = PT(3, 4), P44 = PT(4, 4);
-  const double P02 = PT(0, 2), P12 = PT(1, 2), P22 = PT(2, 2), P42 = PT(4, 2);
-  const double P03 = PT(0, 3), P33 = PT(3, 3);
-  const double P00 = PT(0, 0), P10 = PT(1, 0), P20 = PT(2, 0), P30 = PT(3, 0), P40 = PT(4, 0);
-#undef PT
+  // transition probabilities of the pair HMM: in LDS, read as broadcasts where the outgoing sums are formed (36 scalar
+  // registers on top of the plane bases and the control flow's saved masks made the compiler spill ~100 scalars per step)
+  __shared__ double Psh[5][5];
+  if (threadIdx.x < 25) Psh[threadIdx.x / 5][threadIdx.x % 5] = exp(J.T[threadIdx.x / 5][threadIdx.x % 5]);
+  __syncthreads();
+  const HX_LDS double* PL = (const HX_LDS double*)&Psh[0][0];
+#define P01 PL[0 * 5 + 1]
+#define P11 PL[1 * 5 + 1]
+#define P21 PL[2 * 5 + 1]
+#define P31 PL[3 * 5 + 1]
+#define P04 PL[0 * 5 + 4]
+#define P34 PL[3 * 5 + 4]
+#define P44 PL[4 * 5 + 4]
+#define P02 PL[0 * 5 + 2]
+#define P12 PL[1 * 5 + 2]
+#define P22 PL[2 * 5 + 2]
+#define P42 PL[4 * 5 + 2]
+#define P03 PL[0 * 5 + 3]
+#define P33 PL[3 * 5 + 3]
+#define P00 PL[0 * 5 + 0]
+#define P10 PL[1 * 5 + 0]
+#define P20 PL[2 * 5 + 0]
+#define P30 PL[3 * 5 + 0]
+#define P40 PL[4 * 5 + 0]
 
   HX_LDS d2v* ring = (HX_LDS d2v*)&ycols[wave][0][0];
   auto stage = [&](const int c0) {       // columns c0 .. c0+63 (clamped into the profile) -> ring
