@@ -128,3 +128,38 @@ def test_many_jobs_one_scalar_copy():
     want = c_oracle.forward(*img)["lp_end"]
     assert lp.shape == (n,) and np.all(np.abs(lp - want) < 1e-9)
     b.close()
+
+
+def test_asynchronous_matrix_reads_equal_the_synchronous_ones():
+    """hx_batch_read_matrix_async / hx_batch_wait_read: copies of several jobs in flight at once into page-locked buffers
+    (hx_host_alloc), waited for out of order; an unstarted read is refused."""
+    import ctypes as C
+    cases = [H.leaf_case(801, 120, 100), H.dag_case(33), H.leaf_case(802, 64, 200, band=8)]
+    imgs = [H.job_images(f) for f in cases]
+    b = capi.Batch(imgs, capi.HX_KEEP_BACKWARD)
+    b.forward()
+    b.backward()
+    lib = capi.load()
+    lib.hx_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.hx_host_free.argtypes = [C.c_void_p]
+    bufs = []
+    for k in range(len(cases)):
+        for which in (0, 1):
+            n = b.layout(k, which).matrix_doubles
+            p = C.c_void_p()
+            assert lib.hx_host_alloc(n * 8, C.byref(p)) == 0
+            assert lib.hx_batch_read_matrix_async(b._h, k, which, p) == 0
+            bufs.append((k, which, n, p))
+    assert lib.hx_batch_wait_read(b._h, 1, 0) == 0
+    for k, which, n, p in reversed(bufs):
+        assert lib.hx_batch_wait_read(b._h, k, which) == 0
+        got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(n,)).copy()
+        want = np.empty(n)
+        assert lib.hx_batch_read_matrix(b._h, k, which, want.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        H.assert_same_bits(got, want, "async read of job %d matrix %d" % (k, which))
+        lib.hx_host_free(p)
+    nb = capi.Batch(imgs[:1])
+    nb.forward()
+    assert lib.hx_batch_wait_read(nb._h, 0, 0) == -7          # nothing was started
+    nb.close()
+    b.close()
