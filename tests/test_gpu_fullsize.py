@@ -122,3 +122,40 @@ def test_four_component_mixture_5000_columns():
         bl.close()
     for b in (r["be"], r["bf"], r2["be"], r2["bf"]):
         b.close()
+
+
+def test_config4_batch_of_512_pairs_forward_equals_backward_in_every_policy():
+    """BASELINE configs[3] at size: 512 independent 2x2000-residue protein pairs (WAG) in ONE batch, Forward and Backward.
+    Size-independent properties over all 512 pairs - lpStart == lpEnd (1e-6 relative; to 1e-11 on scaled probabilities),
+    the fast and scaled-probability policies within north_star's 1e-4 of the exact one (they are within 1e-9 / 1e-5),
+    a second launch reproduces the first bit for bit - and the CPU oracle on three of the pairs: lpEnd bit for bit in
+    exact mode, the best path identical in exact and fast mode."""
+    import os
+    from historian_amd import hostmodel, workload
+    from oracle import trace_oracle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = hostmodel.RateModel.load(os.path.join(root, "tests", "golden", "models", "wag.json"))
+    hmm = hostmodel.make_hmm(model, .2, .3)
+    jobs = [workload.leaf_pair(np.random.default_rng(4000 + k), model, hmm, 2000) for k in range(512)]
+    lp = {}
+    for name, flags in (("exact", 0), ("fast", capi.HX_LSE_FAST), ("linear", capi.HX_LSE_LINEAR)):
+        b = capi.Batch(jobs, flags | capi.HX_KEEP_BACKWARD)
+        b.forward()
+        b.backward()
+        le, ls = b.lp_end().copy(), b.lp_start().copy()
+        assert np.all(np.isfinite(le)) and np.all(le < 0)
+        assert np.max(np.abs(ls - le) / np.abs(le)) <= (1e-11 if name == "linear" else 1e-6), name
+        b.forward()
+        H.assert_same_bits(b.lp_end(), le, "second launch, " + name)
+        lp[name] = le
+        if name != "linear":
+            paths = b.best_trace()
+            for k in (0, 255, 511):
+                x, y, h, md = jobs[k]
+                want = c_oracle.forward(x, y, h, md)
+                if name == "exact":
+                    H.assert_same_bits([le[k]], [want["lp_end"]], "lpEnd of pair %d" % k)
+                assert paths[k] == trace_oracle.best_trace(x, y, h, md, want), (name, k)
+        b.close()
+    assert np.max(np.abs(lp["fast"] - lp["exact"]) / np.abs(lp["exact"])) <= 1e-9
+    assert np.max(np.abs(lp["linear"] - lp["exact"]) / np.abs(lp["exact"])) <= 1e-5
