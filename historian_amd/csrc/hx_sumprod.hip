@@ -424,6 +424,9 @@ int hx_sumprod_columns(const hx_sumprod_model* hm, const int8_t* tokens, const d
     else if (child[2 * p + 1] < 0) child[2 * p + 1] = r;
     else return api_fail(HX_ERR_INVALID_ARG, "hx_sumprod_columns: a node has more than two children");
   }
+  // tokens index the alphabet on the device: refuse anything else here, not with a fault there
+  for (int64_t k = 0; k < n_cols * N; ++k)
+    if (tokens[k] < -2 || tokens[k] >= A) return api_fail(HX_ERR_RANGE, "hx_sumprod_columns: a token outside -2 .. alphabet size - 1");
   bool real_basis = true;
   for (size_t k = 0; k < (size_t)C * AA && real_basis; ++k) real_basis = hm->evec_im[k] == 0. && hm->evec_inv_im[k] == 0.;
   for (size_t k = 0; k < (size_t)C * N * AA && real_basis; ++k) real_basis = hm->esc_im[k] == 0.;

@@ -188,6 +188,11 @@ def test_refused_arguments():
     with pytest.raises(capi.HxError) as e:
         bad.run(tok)
     assert e.value.code == -5
+    bad_tok = tok.copy()
+    bad_tok[2, 1] = 4                                          # not a token of a four-letter alphabet
+    with pytest.raises(capi.HxError) as e:
+        cc.run(bad_tok)
+    assert e.value.code == -8
     three = counts.ColumnCounter(model, [3, 3, 3, -1], [.1, .2, .3, 0.])
     with pytest.raises(capi.HxError):
         three.run(np.zeros((4, 4), dtype=np.int8))
