@@ -357,15 +357,20 @@ __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_fill_dag(const DevJob
             m.M[4 * m.plane + sl] = c.iiw;
           }
         }
-        // drain this step's stores: the next step (and, through the counter, the strip below) reads them
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int done = t - 62;
-        done = done > Cc ? Cc : done;
-        if (done > published) {
-          published = done;
-          if (lane == 0) progp[wave] = my_base + done;
+        // The next step of this wave reads this step's cells back through memory: vector-memory operations of a wave
+        // take effect in issue order, so no wait is needed for that.  The strip below learns of them through the counter:
+        // every eighth step the wave drains its stores and publishes how many columns all of its rows have completed.
+        if ((t & 7) == 7) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          int done = t - 62;
+          done = done > Cc ? Cc : done;
+          if (done > published) {
+            published = done;
+            if (lane == 0) progp[wave] = my_base + done;
+          }
         }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // columns between / after the windows hold no in-envelope cell of this strip: they count as complete
       // once everything before them is
       const int upto = (w == 0 && whi[1] > wlo[1]) ? wlo[1] - 63 : Cc;
