@@ -74,7 +74,7 @@ EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_cr
            "hx_batch_forward", "hx_batch_backward", "hx_batch_sync", "hx_batch_lp_end", "hx_batch_lp_start",
            "hx_batch_layout", "hx_batch_read_matrix", "hx_batch_read_cells", "hx_batch_read_prepared",
            "hx_batch_posterior_scan", "hx_batch_best_trace", "hx_device_count", "hx_batch_create_on", "hx_batch_device",
-           "hx_quick_batch_create_on", "hx_batch_strip_windows", "hx_batch_total_cells", "hx_batch_last_kernel_ms", "hx_host_alloc",
+           "hx_quick_batch_create_on", "hx_batch_strip_windows", "hx_batch_total_cells", "hx_batch_job_kernel", "hx_batch_last_kernel_ms", "hx_host_alloc",
            "hx_host_free", "hx_quick_batch_create", "hx_quick_batch_destroy", "hx_quick_batch_run",
            "hx_quick_batch_results", "hx_quick_batch_layout", "hx_quick_batch_read_matrix",
            "hx_quick_batch_total_cells", "hx_quick_batch_last_kernel_ms", "hx_sumprod_columns", "hx_sumprod_last_kernel_ms",
@@ -119,6 +119,7 @@ def load():
                                             C.POINTER(C.c_int64)]
     lib.hx_batch_best_trace.argtypes = [vp, vp, C.c_int64, _i32p]
     lib.hx_batch_strip_windows.argtypes = [vp, C.c_int32, _i32p, C.POINTER(C.c_int64)]
+    lib.hx_batch_job_kernel.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.hx_batch_total_cells.argtypes = [vp]
     lib.hx_batch_total_cells.restype = C.c_int64
     lib.hx_batch_last_kernel_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
@@ -303,6 +304,12 @@ class Batch:
 
     def total_cells(self):
         return int(load().hx_batch_total_cells(self._h))
+
+    def job_kernel(self, job):
+        """(kernel class of the Forward fill, whether Backward runs the banded rotating-row sweep) of pair `job`."""
+        c, s = C.c_int32(0), C.c_int32(0)
+        _check(load().hx_batch_job_kernel(self._h, job, C.byref(c), C.byref(s)))
+        return c.value, bool(s.value)
 
     def kernel_ms(self, which=0):
         ms = C.c_float()

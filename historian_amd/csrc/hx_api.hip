@@ -285,7 +285,7 @@ void bind_profile(DevProfile& d, const ProfOff& o, char* base) {
 struct JobOff {
   ProfOff x, y;
   size_t log_root, log_sub_l, log_sub_r, log_ins_l, log_ins_r, log_cptw_l, log_cptw_r, emis, emis_pad;
-  size_t fwd_windows, bwd_windows, strip_base, yword, yword_bwd, band_rows;
+  size_t fwd_windows, bwd_windows, strip_base, yword, yword_bwd, band_rows, band_rows_bwd;
   bool compressed;
   int64_t compact_plane;
   int64_t eplane_off;     // into hx_batch::d_eplane, or -1
@@ -426,6 +426,65 @@ bool build_band_rows(const int32_t* xenv, const int32_t* yenv, const uint8_t* xf
   return true;
 }
 
+// The same for the Backward sweep of hx_band.hip, in mirrored coordinates i' = R-1-i, j' = Cc-1-j (the layout of the
+// Backward matrix).  What is always inside the envelope is now the LAST row (x START) and the FIRST column (the y state
+// feeding END): both are -inf away from the band (see below), written by the kernel's second wave; the sweep owns a row's band
+// cells, widened to column 0 where the band touches it, and on the last row from where the row above's band begins.
+//   x = first owned step | (owned steps - 1) << 16;  y = class of x state i + 1 | state i not ready << 8 | pads << 9, 10
+// followed by the per-strip store bases (dense planes only) and, last, one int: the first column the sweep owns on the last
+// row (0: the whole row).
+bool build_band_rows_bwd(const int32_t* xenv, const int32_t* yenv, const uint8_t* xf, const uint8_t* yf, const int32_t* xecls,
+                         bool x_empty, bool y_empty, int R, int Cc, int band, int64_t ss, int blk, std::vector<int32_t>& out, int& n_steps) {
+  if (R < 3 || Cc < 3 || R + Cc > 60000) return false;
+  // the y state that feeds END must not be ready (it has the null transition to END): then no x-absorbing move leaves a
+  // cell of its column (reference src/forward.cpp:1041-1049), and the column and the last row are -inf away from the band
+  if ((yf[Cc - 1] & F_READY) || y_empty) return false;
+  for (int i = 1; i <= R; ++i) if (xenv[i] < xenv[i - 1]) return false;
+  for (int j = 1; j <= Cc; ++j) if (yenv[j] < yenv[j - 1]) return false;
+  for (int i = 0; i < R; ++i) if (((xf[i] & F_EDGE) != 0) != (i == 0)) return false;
+  for (int j = 0; j < Cc; ++j) if (((yf[j] & F_EDGE) != 0) != (j == Cc - 1)) return false;
+  std::vector<int> lo(R), hi(R);          // mirrored rows, mirrored columns
+  {
+    int a = 0, b = -1;
+    for (int i = 0; i < R; ++i) {
+      while (a < Cc && (int64_t)yenv[a] < (int64_t)xenv[i] - band) ++a;
+      while (b + 1 < Cc && (int64_t)yenv[b + 1] <= (int64_t)xenv[i] + band) ++b;
+      if (b < a) return false;
+      lo[R - 1 - i] = Cc - 1 - b; hi[R - 1 - i] = Cc - 1 - a;
+    }
+  }
+  for (int i = 0; i < R; ++i) if (lo[i] <= 1) lo[i] = 0;            // the cells next to the band in the always-in column
+  hi[R - 1] = Cc - 1;
+  lo[R - 1] = std::min(lo[R - 1], lo[R - 2]);                       // the last row reads the row above from where its band begins
+  const int n_strips = (R + HX_STRIP - 1) / HX_STRIP;
+  out.assign(2 * (size_t)(R + 64) + (size_t)n_strips + 4, 0);
+  int32_t* strip_store = &out[2 * (size_t)(R + 64)];
+  std::vector<int> os(R), oe(R);
+  n_steps = 0;
+  for (int i = 0; i < R; ++i) {
+    const int as = i + lo[i], ae = i + hi[i];
+    os[i] = as & ~1; oe[i] = ae | 1;
+    const int q = i >> 6;
+    const int64_t A = (int64_t)q * ss - (int64_t)32 * q * blk;
+    if (A < INT32_MIN / 2 || A > INT32_MAX / 2) return false;
+    strip_store[q] = (int32_t)A;
+    const int ic = R - 1 - i;                                        // the actual x state of the row
+    const bool ready = (xf[ic] & F_READY) || x_empty;
+    int32_t* o = &out[2 * (size_t)i];
+    if (oe[i] - os[i] > 0xFFFF || os[i] >= 0xFFFF) return false;
+    o[0] = os[i] | ((oe[i] - os[i]) << 16);
+    o[1] = (xecls[ic + 1] & 0xFF) | (ready ? 0 : 0x100) | ((as - os[i]) << 9) | ((oe[i] - ae) << 10);
+    n_steps = std::max(n_steps, oe[i] + 1);
+  }
+  for (int i = 0; i + 63 < R; ++i) if (os[i + 63] < oe[i] + 1) return false;
+  for (int i = 0; i + 64 < R; ++i) if (os[i + 64] < oe[i] + 3) return false;
+  if ((int64_t)n_steps / 2 * blk + INT32_MAX / 2 > INT32_MAX) return false;
+  for (int i = R; i < R + 64; ++i) out[2 * (size_t)i] = 0xFFFF;
+  out[2 * (size_t)(R + 64) + n_strips] = lo[R - 1];
+  n_steps = (n_steps + 1) & ~1;
+  return true;
+}
+
 }  // namespace
 
 // Kernel classes: the jobs of a batch are grouped by the fill kernel that suits them, each class is launched on its own
@@ -446,6 +505,7 @@ enum KernelClass {
 };
 struct ClassRange {
   int64_t agg_begin = 0, agg_doubles = 0;   // the class's part of hx_batch::d_agg (general-profile classes)
+  bool bwd_band = false;      // KC_LEAF_ROT_BANDED: every pair of the class also has the Backward sweep's row records
   int begin = 0, n = 0;       // positions in the class-ordered job table
   int max_rows = 0, max_cols = 0, max_cls = 0, yl_cols = 0, yl_emis = 0;
   int64_t mat_begin = 0, mat_doubles = 0;   // the class's matrices are contiguous: [mat_begin, mat_begin + mat_doubles)
@@ -633,7 +693,7 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
     jo.table_emission = pairs > 0 && pairs <= (1 << 16);
     jo.emis = jo.table_emission ? ar.reserve(sizeof(double) * pairs) : 0;
     jo.emis_pad = jo.table_emission ? ar.reserve(sizeof(double) * (jo.x.n_cls + 1) * (jo.y.n_cls + 1)) : 0;
-    jo.fwd_windows = jo.bwd_windows = jo.strip_base = jo.yword = jo.yword_bwd = jo.band_rows = 0;
+    jo.fwd_windows = jo.bwd_windows = jo.strip_base = jo.yword = jo.yword_bwd = jo.band_rows = jo.band_rows_bwd = 0;
     jo.compressed = false;
     jo.compact_plane = 0;
 
@@ -763,6 +823,16 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
         jo.band_rows = ar.put(rows.data(), sizeof(int32_t) * rows.size());
         J.band_steps = n_steps;
         kc = kclass[k] = KC_LEAF_ROT_BANDED;
+        // the Backward sweep of the same kernel (table policies, dense planes); a pair it does not take keeps the strip pipeline
+        std::vector<int32_t> rows_b;
+        int n_steps_b = 0;
+        J.band_steps_bwd = 0;
+        if (!jo.compressed && !linear &&
+            build_band_rows_bwd(pj.x->env_pos, pj.y->env_pos, xf.data(), yf.data(), xecls.data(), jo.x.empty != 0, jo.y.empty != 0, J.n_rows, J.n_cols,
+                                pj.max_distance, J.strip_stride, J.blk, rows_b, n_steps_b)) {
+          jo.band_rows_bwd = ar.put(rows_b.data(), sizeof(int32_t) * rows_b.size());
+          J.band_steps_bwd = n_steps_b;
+        }
       }
     }
     L.strip_stride = J.strip_stride; L.plane_stride = J.plane;
@@ -848,6 +918,9 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
     if (hipMalloc(reinterpret_cast<void**>(&b->d_bwd), sizeof(double) * (size_t)mat_total) != hipSuccess)
       return cleanup(fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of %lld Backward-matrix bytes failed", (long long)(mat_total * 8)));
 
+  b->cls[KC_LEAF_ROT_BANDED].bwd_band = b->cls[KC_LEAF_ROT_BANDED].n > 0 && !getenv("HX_BAND_BWD_OLD");
+  for (int k = 0; k < n_jobs; ++k)
+    if (kclass[k] == KC_LEAF_ROT_BANDED && !offs[k].band_rows_bwd) b->cls[KC_LEAF_ROT_BANDED].bwd_band = false;
   for (int k = 0; k < n_jobs; ++k) {
     DevJob& J = b->jobs[k];
     const JobOff& jo = offs[k];
@@ -871,6 +944,7 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
     J.yword = jo.yword ? reinterpret_cast<uint32_t*>(base + jo.yword) : nullptr;
     J.yword_bwd = jo.yword_bwd ? reinterpret_cast<uint32_t*>(base + jo.yword_bwd) : nullptr;
     J.band_rows = jo.band_rows ? base + jo.band_rows : nullptr;
+    J.band_rows_bwd = jo.band_rows_bwd ? base + jo.band_rows_bwd : nullptr;
     J.lp_end = reinterpret_cast<double*>(base + b->lp_end_off) + k;
     J.lp_start = reinterpret_cast<double*>(base + b->lp_start_off) + k;
     J.fwd = b->d_fwd + mat_off[k];
@@ -1029,7 +1103,11 @@ int hx_batch_backward(hx_batch* b, void* stream) {
       case KC_LEAF_LDS: case KC_LEAF_LDS_BANDED: case KC_LEAF_ROT_BANDED: case KC_LEAF: case KC_LEAF_BANDED: {
         if (banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_bwd + cr.mat_begin, cr.mat_doubles, st);
         const int leaf = (c == KC_LEAF_LDS || c == KC_LEAF_LDS_BANDED || c == KC_LEAF_ROT_BANDED) ? 2 : 1;
-        if (linear && leaf == 2)
+        if (c == KC_LEAF_ROT_BANDED && cr.bwd_band && !linear)
+          // the rotating-row sweep in mirrored coordinates (hx_band.hip), table policies
+          LAUNCH_TRY(launch_backward_band(jobs, cr.n, fast ? 1 : 2, cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab}, lse_tab,
+                                          (b->flags & HX_SPARSE_ENVELOPE) != 0, st));
+        else if (linear && leaf == 2)
           LAUNCH_TRY(launch_backward_leaf_linear(jobs, cr.n, cr.max_rows, banded, Tab8{D.tab}, Tab16{D.log_tab}, cr.yl_cols, cr.yl_emis, cr.max_cls + 1, st));
         else
           LAUNCH_TRY(launch_backward_chain(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, st));
@@ -1100,6 +1178,21 @@ int hx_batch_strip_windows(const hx_batch* b, int32_t job, int32_t* windows, int
 }
 
 int64_t hx_batch_total_cells(const hx_batch* b) { return b ? b->total_cells : 0; }
+
+int hx_batch_job_kernel(const hx_batch* b, int32_t job, int32_t* forward_class, int32_t* backward_sweep) {
+  if (!b) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
+  for (int c = 0; c < KC_COUNT; ++c) {
+    const ClassRange& cr = b->cls[c];
+    for (int p = cr.begin; p < cr.begin + cr.n; ++p)
+      if (b->order[p] == job) {
+        if (forward_class) *forward_class = c;
+        if (backward_sweep) *backward_sweep = (c == KC_LEAF_ROT_BANDED && cr.bwd_band && (b->flags & HX_LSE_LINEAR) != HX_LSE_LINEAR) ? 1 : 0;
+        return HX_OK;
+      }
+  }
+  return fail(HX_ERR_INVALID_ARG, "job %d is in no kernel class", job);
+}
 
 static const double* matrix_of(hx_batch* b, int job, int which) {
   return which == 0 ? b->jobs[job].fwd : b->jobs[job].bwd;

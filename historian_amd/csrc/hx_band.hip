@@ -102,13 +102,19 @@ struct BandPlan { int table, xrec, sbase, ycol, yclass, xclass, elds, ring, flag
 // LEAN: the row records stay in memory (a lane fetches its next row's record a whole row ahead) and the ring between the
 // sweep and the converting wave is four steps deep instead of eight: 25 KB of LDS per pair instead of 54 (scaled
 // probabilities), 12 instead of 29 (table policies), so that large batches put five to seven pairs on a CU.
-template <int POL, int PPW, bool LEAN>
+// DIR = 1: the Backward fill (reference src/forward.cpp:975-1088 for leaf-like profiles) as the same sweep in mirrored
+// coordinates (row i' = R-1-i, column j' = Cc-1-j: the layout of the Backward matrix) with leaf_cell_bwd; table policies.
+// What is always inside the envelope is then the last row (x START) and the first column (the y state feeding END).  That
+// y state is never ready (it has the null transition to END), so away from the band both are -inf: the second wave only
+// writes them where the matrix was not pre-filled.
+template <int POL, int PPW, bool LEAN, int DIR = 0>
 __global__ void __launch_bounds__(2 * PPW * 64)
 k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const double* __restrict__ pol_tab,
             const BandPlan plan, const int n_jobs, const int write_edges) {
   constexpr int THREADS = 2 * PPW * 64;
   constexpr int RING = LEAN ? HXB_RING_LEAN : HXB_RING;
   constexpr bool OFFLOAD = POL == POL_LINEAR;        // the second wave converts and stores the sweep's cells
+  static_assert(DIR == 0 || POL != POL_LINEAR, "the Backward sweep exists for the table policies");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
@@ -130,7 +136,7 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   HX_LDS d2v* ringL = (HX_LDS d2v*)(blkp + plan.ring);           // [RING][3][64]
   volatile HX_LDS int* progL = (volatile HX_LDS int*)(blkp + plan.flags);   // steps the sweep has put into the ring
   volatile HX_LDS int* consL = progL + 1;                                   // steps the converting wave has taken out
-  const HX_GLOBAL i2v* xrecG = (const HX_GLOBAL i2v*)as_global(reinterpret_cast<const i2v*>(J.band_rows));
+  const HX_GLOBAL i2v* xrecG = (const HX_GLOBAL i2v*)as_global(reinterpret_cast<const i2v*>(DIR ? J.band_rows_bwd : J.band_rows));
   auto xrec_at = [&](const int i) -> i2v { return LEAN ? xrecG[i] : xrecL[i]; };
 
   // ---- stage the shared table and the pair's two sides ----
@@ -146,13 +152,17 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   {
     const int pt = lane + (helper ? 64 : 0);                            // the pair's two waves stage together
     const int Ky1 = J.y.n_cls + 1, Kx1 = J.x.n_cls + 1;
-    const i2v* rows = reinterpret_cast<const i2v*>(J.band_rows);
+    const i2v* rows = reinterpret_cast<const i2v*>(DIR ? J.band_rows_bwd : J.band_rows);
     const int* sb = reinterpret_cast<const int*>(rows + (R + 64));
     if (!LEAN)
       for (int i = pt; i < R + 64; i += 128) xrecL[i] = rows[i];        // (64 sentinel rows past the end: never owned)
     for (int q = pt; q < n_strips; q += 128) sbaseL[q] = sb[q];
-    for (int j = pt; j < Cc; j += 128)
-      ycolL[j] = (unsigned)J.y.ecls[j] | (J.y.pack[4 * (size_t)j + 3] < 0.0 ? 0x100u : 0u);
+    for (int j = pt; j < Cc; j += 128) {
+      // Backward: sweep column j is y state Cc-1-j; the class is that of the state an absorbing move leads to, the
+      // ready bit that of the state itself
+      const int jc = DIR ? Cc - 1 - j : j;
+      ycolL[j] = (unsigned)J.y.ecls[DIR ? jc + 1 : jc] | (J.y.pack[4 * (size_t)jc + 3] < 0.0 ? 0x100u : 0u);
+    }
     for (int c = pt; c < Ky1; c += 128) {
       const bool real = c < J.y.n_cls;
       const int rep = real ? J.y.cls_rep[c] : 0;
@@ -171,10 +181,10 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   __syncthreads();
   const int64_t plane = J.plane;
   const int blk = J.blk;
-  HX_GLOBAL double* __restrict__ M = as_global(J.fwd);
+  HX_GLOBAL double* __restrict__ M = as_global(DIR ? J.bwd : J.fwd);
   const int Ky1 = J.y.n_cls + 1;
   // anti-diagonal steps of the sweep, in whole blocks of eight (the extra steps own nothing)
-  const int n_steps = live ? (J.band_steps + 7) & ~7 : 0;
+  const int n_steps = live ? ((DIR ? J.band_steps_bwd : J.band_steps) + 7) & ~7 : 0;
   const HX_LDS double* lt = (const HX_LDS double*)ptab;
 
   if (helper) {
@@ -215,7 +225,37 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     // =====================================================================================================
     // (2) the envelope's one-dimensional edges (see the header comment).  Nothing here is read by the sweep.
     // =====================================================================================================
-    if (live) {
+    if (DIR == 1 && live) {
+      // Backward.  In mirrored coordinates the always-inside parts of the envelope are column 0 (the y state that feeds
+      // END) and the last row (x START).  The y state that feeds END has a null transition (to END), so it is not
+      // ready and no x-absorbing move leaves a cell of its column (reference src/forward.cpp:1041-1049; hx_api.hip admits
+      // a pair to this sweep only then): below the END-feeding cell the column is -inf, and so is the last row up to
+      // where the row above's band begins.  Those cells are written here; the sweep's idle lanes read them as -inf anyway.
+      const int64_t ssd = J.strip_stride;
+      const int lo_last = reinterpret_cast<const int*>(reinterpret_cast<const i2v*>(J.band_rows_bwd) + (R + 64))[n_strips];   // first column the sweep owns on the last row
+      auto put_inf = [&](const int ip, const int jp) {
+        const int64_t sl = cell_slot_blk(ssd, blk, ip, jp);
+        M[sl] = HX_NEG_INF; M[plane + sl] = HX_NEG_INF; M[2 * plane + sl] = HX_NEG_INF; M[3 * plane + sl] = HX_NEG_INF;
+        M[4 * plane + sl] = HX_NEG_INF;
+      };
+      if (write_edges) {
+        for (int ip = 1 + lane; ip < R; ip += 64) {
+          const i2v rec = xrec_at(ip);
+          if ((rec.x & 0xFFFF) + ((rec.y >> 9) & 1) - ip > 0) put_inf(ip, 0);      // (the sweep owns the row from a later column on)
+        }
+        for (int jp = 1 + lane; jp < lo_last; jp += 64) put_inf(R - 1, jp);
+      }
+      {
+        // a first row whose band does not reach column 0: the END-feeding cell itself (src/forward.cpp:981-995)
+        const i2v rec = xrec_at(0);
+        if (lane == 0 && (rec.x & 0xFFFF) + ((rec.y >> 9) & 1) > 0) {
+          const double lpe = J.x.pack[4 * (size_t)R] + J.y.pack[4 * (size_t)Cc];
+          const int64_t sl = cell_slot_blk(ssd, blk, 0, 0);
+          for (int st = 0; st < 5; ++st) M[st * plane + sl] = lpe + J.T[st][5];
+        }
+      }
+    }
+    if (DIR == 0 && live) {
     // row 0 beyond what the sweep owns: the chain in log space (every policy stores log-probabilities)
     const int own0 = (xrec_at(0).x >> 16) & 0xFFFF;                      // row 0 is owned from step 0 to this step = column
     const i2v rec1 = xrec_at(1);
@@ -349,6 +389,12 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     }
   const FastLse LF = FastLse::make(ptab);
   const ExactLse3 LE = ExactLse3::make(pol_tab);
+  // Backward: the cell feeding END
+  C5 end_cell = c5_neg_inf();
+  if (DIR == 1) {
+    const double lpe = J.x.pack[4 * (size_t)R] + J.y.pack[4 * (size_t)Cc];
+    end_cell = C5{lpe + J.T[0][5], lpe + J.T[1][5], lpe + J.T[2][5], lpe + J.T[3][5], lpe + J.T[4][5]};
+  }
 
   // cell registers, ping-ponged: at an even step the lane's previous cell is in cb (the one before in ca, which the new
   // cell overwrites), the previous lane's cells of one / two steps ago in ua / ub
@@ -454,9 +500,15 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     X.lp = 0.0; X.rootsub = xc_rs; X.ins = xc_in; X.pen = xpen; X.eoff = eoff; X.valid = true;
     const d4v Y = d4v{0.0, rc.x, rc.y, ypen};
     C5 nw;
-    if (POL == POL_FAST) nw = leaf_cell(P, LF, X, Y, em, pj, u1, left, u2);
-    else nw = leaf_cell(P, LE, X, Y, em, pj, u1, left, u2);
-    if (k == 0 && lane == 0) nw.imm = 0.0;         // cell (0,0): lpStart() = 0 (src/forward.cpp:73)
+    if (DIR == 0) {
+      if (POL == POL_FAST) nw = leaf_cell(P, LF, X, Y, em, pj, u1, left, u2);
+      else nw = leaf_cell(P, LE, X, Y, em, pj, u1, left, u2);
+      if (k == 0 && lane == 0) nw.imm = 0.0;         // cell (0,0): lpStart() = 0 (src/forward.cpp:73)
+    } else {
+      if (POL == POL_FAST) nw = leaf_cell_bwd(P, LF, X, Y, em, pj, u1, left, u2);
+      else nw = leaf_cell_bwd(P, LE, X, Y, em, pj, u1, left, u2);
+      if (k == 0 && lane == 0) nw = end_cell;        // the cell feeding END (src/forward.cpp:981-995)
+    }
     out = nw;
     u2 = ror1(nw);
   };
@@ -509,7 +561,12 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   // lpEnd reads cell (Nx-2, Ny-2): the sweep's last cell (stored by either wave), or - a one-row band - an edge cell
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (!helper && live && lane == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
+  if (DIR == 0) {
+    if (!helper && live && lane == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
+  } else {
+    // B(START, START).IMM: the sweep's last cell
+    if (!helper && live && lane == 0) *J.lp_start = J.bwd[cell_slot_blk(J.strip_stride, J.blk, R - 1, Cc - 1)];
+  }
 }
 
 BandPlan plan_band(int pol, int ppw, int max_rows, int max_cols, int max_cls, bool lean = false) {
@@ -529,10 +586,10 @@ BandPlan plan_band(int pol, int ppw, int max_rows, int max_cols, int max_cls, bo
   return p;
 }
 
-template <int POL, int PPW, bool LEAN = false>
+template <int POL, int PPW, bool LEAN = false, int DIR = 0>
 int launch_pol(const DevJob* d_jobs, int n_jobs, const BandPlan& p, const double* tab, const double* pol_tab, int write_edges, hipStream_t st) {
   if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_band<%d, %d> needs %d bytes of LDS (limit %d)", POL, PPW, p.total, HX_LDS_LIMIT);
-  hipLaunchKernelGGL((k_fill_band<POL, PPW, LEAN>), dim3((n_jobs + PPW - 1) / PPW), dim3(2 * PPW * 64), p.total, st, d_jobs, tab, pol_tab, p,
+  hipLaunchKernelGGL((k_fill_band<POL, PPW, LEAN, DIR>), dim3((n_jobs + PPW - 1) / PPW), dim3(2 * PPW * 64), p.total, st, d_jobs, tab, pol_tab, p,
                      n_jobs, write_edges);
   return 0;
 }
@@ -543,8 +600,10 @@ int launch_pol(const DevJob* d_jobs, int n_jobs, const BandPlan& p, const double
 // workgroup: hx_api.hip admits a pair to this kernel's class only below it
 bool band_kernel_fits(int pol, int rows, int cols, int cls) { return plan_band(pol, 1, rows, cols, cls).total <= HX_LDS_LIMIT; }
 
-int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, Tab8 tab8,
-                        Tab16 tab16, bool write_edges, hipStream_t st) {
+namespace {
+template <int DIR>
+int launch_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, Tab8 tab8,
+                Tab16 tab16, bool write_edges, hipStream_t st) {
   const double* tab = tab8.p;
   const double* pol_tab = tab16.p;
   // Pairs per workgroup (they share the policy's table).  A CU holds 160 KB of LDS and four SIMDs; a pair is two waves.
@@ -571,7 +630,7 @@ int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows,
   }
   if (ppw > 1 && plan_band(pol, ppw, max_rows, max_cols, max_cls, lean).total > HX_LDS_LIMIT) { ppw = 1; lean = false; }
   const int we = write_edges ? 1 : 0;
-#define HXB_LEAN(POL_, N_) return launch_pol<POL_, N_, true>(d_jobs, n_jobs, plan_band(POL_, N_, max_rows, max_cols, max_cls, true), tab, pol_tab, we, st)
+#define HXB_LEAN(POL_, N_) return launch_pol<POL_, N_, true, DIR>(d_jobs, n_jobs, plan_band(POL_, N_, max_rows, max_cols, max_cls, true), tab, pol_tab, we, st)
 #define HXB_GO(POL_) do { \
     if (lean && ppw >= 6) HXB_LEAN(POL_, 6); \
     if (lean && ppw == 5) HXB_LEAN(POL_, 5); \
@@ -579,14 +638,27 @@ int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows,
     if (lean && ppw == 3) HXB_LEAN(POL_, 3); \
     if (lean && ppw == 2) HXB_LEAN(POL_, 2); \
     if (lean) HXB_LEAN(POL_, 1); \
-    if (ppw >= 4) return launch_pol<POL_, 4>(d_jobs, n_jobs, plan_band(POL_, 4, max_rows, max_cols, max_cls), tab, pol_tab, we, st); \
-    if (ppw >= 2) return launch_pol<POL_, 2>(d_jobs, n_jobs, plan_band(POL_, 2, max_rows, max_cols, max_cls), tab, pol_tab, we, st); \
-    return launch_pol<POL_, 1>(d_jobs, n_jobs, plan_band(POL_, 1, max_rows, max_cols, max_cls), tab, pol_tab, we, st); } while (0)
-  if (pol == POL_LINEAR) HXB_GO(POL_LINEAR);
+    if (ppw >= 4) return launch_pol<POL_, 4, false, DIR>(d_jobs, n_jobs, plan_band(POL_, 4, max_rows, max_cols, max_cls), tab, pol_tab, we, st); \
+    if (ppw >= 2) return launch_pol<POL_, 2, false, DIR>(d_jobs, n_jobs, plan_band(POL_, 2, max_rows, max_cols, max_cls), tab, pol_tab, we, st); \
+    return launch_pol<POL_, 1, false, DIR>(d_jobs, n_jobs, plan_band(POL_, 1, max_rows, max_cols, max_cls), tab, pol_tab, we, st); } while (0)
+  if constexpr (DIR == 0) if (pol == POL_LINEAR) HXB_GO(POL_LINEAR);
   if (pol == POL_FAST) HXB_GO(POL_FAST);
   HXB_GO(POL_EXACT);
 #undef HXB_LEAN
 #undef HXB_GO
+}
+}  // namespace
+
+int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, Tab8 tab8,
+                        Tab16 tab16, bool write_edges, hipStream_t st) {
+  return launch_band<0>(d_jobs, n_jobs, pol, max_rows, max_cols, max_cls, tab8, tab16, write_edges, st);
+}
+
+// The Backward sweep (table policies; the class's pairs all carry band_rows_bwd: hx_api.hip ClassRange::bwd_band)
+int launch_backward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, Tab8 tab8,
+                         Tab16 tab16, bool write_edges, hipStream_t st) {
+  if (pol == POL_LINEAR) return launch_fail("the Backward band sweep has no scaled-probability variant");
+  return launch_band<1>(d_jobs, n_jobs, pol, max_rows, max_cols, max_cls, tab8, tab16, write_edges, st);
 }
 
 }  // namespace hx

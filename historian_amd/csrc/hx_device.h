@@ -107,7 +107,8 @@ struct DevJob {
   // anti-diagonal steps of the sweep; nullptr when the pair does not run on that kernel
   const void* band_rows;
   int32_t band_steps;
-  int32_t pad4_;
+  int32_t band_steps_bwd;     // the same for the Backward sweep (mirrored rows and columns), 0 when band_rows_bwd is null
+  const void* band_rows_bwd;
 };
 
 // One pair of the guide-alignment Viterbi batch (hx_quick.hip)

@@ -69,6 +69,9 @@ int launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, 
 bool band_kernel_fits(int pol, int rows, int cols, int cls);
 int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, Tab8 tab,
                         Tab16 pol_tab, bool write_edges, hipStream_t st);
+// the Backward sweep of the same kernel (mirrored coordinates; pol 1 fast, 2 exact; DevJob::band_rows_bwd)
+int launch_backward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, Tab8 tab, Tab16 pol_tab,
+                         bool write_edges, hipStream_t st);
 
 void launch_indel_counts(const DevJob* d_jobs, int job, const double* d_tm, double* d_out, int64_t cells, Tab8 tab, bool plane_valid,
                          hipStream_t st);

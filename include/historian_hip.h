@@ -240,6 +240,12 @@ int hx_batch_strip_windows(const hx_batch* b, int32_t job, int32_t* windows, int
 /* Total in-envelope-or-not lattice cells of the batch, sum (Nx-1)(Ny-1). */
 int64_t hx_batch_total_cells(const hx_batch* b);
 
+/* Diagnostics: which fill kernel takes pair `job`.  *forward_class = the kernel class of DESIGN.md section 5 (0 leaf pairs in
+ * LDS, 1 the same banded, 2 the banded rotating-row sweep, 3/4 other leaf pairs, 5/6 in-degree-1 profiles, 7/8 general
+ * profiles, 9 the barrier-per-diagonal kernels); *backward_sweep = 1 when hx_batch_backward also runs the rotating-row
+ * sweep for it (class 2, table policies, dense planes), 0 when it runs the class's strip pipeline.  Either may be NULL. */
+int hx_batch_job_kernel(const hx_batch* b, int32_t job, int32_t* forward_class, int32_t* backward_sweep);
+
 /* Duration in milliseconds of the most recent hx_batch_forward / hx_batch_backward
  * fill kernel (HIP events recorded around that kernel on its stream). */
 int hx_batch_last_kernel_ms(hx_batch* b, int32_t which, float* ms);

@@ -553,3 +553,50 @@ def test_banded_leaf_pairs_in_the_lean_band_kernel(ppw, monkeypatch):
         assert bf.best_trace() == be.best_trace() or flags != capi.HX_LSE_FAST
         bf.close()
     be.close()
+
+
+@pytest.mark.parametrize("ppw", [0, -3])
+def test_banded_backward_in_the_rotating_row_sweep(ppw, monkeypatch):
+    # Backward of banded leaf pairs (table policies, dense planes) runs the rotating-row sweep in mirrored coordinates:
+    # the envelope's always-inside column and last row are chains of the second wave, handed to the sweep through LDS
+    # (hx_band.hip, DIR = 1).  Exact mode bit for bit against the oracle, whole matrix and in the sparse-envelope storage;
+    # both policies bit for bit against the strip pipeline they replace (HX_BAND_BWD_OLD); shapes where the band of the last
+    # x state does not reach the y state that feeds END, a band of zero, more rows than columns and the reverse.
+    if ppw:
+        monkeypatch.setenv("HX_BAND_PPW", str(ppw))
+    aa = "arndcqeghilkmfpstwyv"
+    cases = [H.leaf_case(801, 70, 66, band=5), H.leaf_case(802, 200, 90, band=12), H.leaf_case(803, 130, 150, band=3),
+             H.leaf_case(804, 300, 330, alphabet=aa, jc=False, band=20), H.leaf_case(805, 40, 45, band=0),
+             H.leaf_case(806, 90, 210, band=7), H.leaf_case(807, 500, 520, band=8), H.leaf_case(808, 3, 3, band=1),
+             H.leaf_case(809, 2, 9, band=2), H.leaf_case(810, 260, 250, alphabet=aa, jc=False, band=16)]
+    imgs = [H.job_images(f) for f in cases]
+    probe = capi.Batch(imgs, capi.HX_KEEP_BACKWARD)
+    taken = [probe.job_kernel(k) for k in range(len(cases))]
+    probe.close()
+    assert sum(1 for c, s in taken if c == 2 and s) >= 6, taken       # (pairs whose band has an empty row keep the strip pipeline)
+    run_and_check(cases, backward=True)
+    for flags in (0, capi.HX_LSE_FAST, capi.HX_SPARSE_ENVELOPE):
+        got = []
+        for old in (False, True):
+            if old:
+                monkeypatch.setenv("HX_BAND_BWD_OLD", "1")
+            else:
+                monkeypatch.delenv("HX_BAND_BWD_OLD", raising=False)
+            b = capi.Batch(imgs, capi.HX_KEEP_BACKWARD | flags)
+            kern = [b.job_kernel(k) for k in range(len(cases))]
+            assert all(s != old for c, s in kern if c == 2), (flags, old, kern)
+            b.forward()
+            b.backward()
+            mats = [b.read_matrix(k, 1) for k in range(len(cases))]
+            if flags & capi.HX_SPARSE_ENVELOPE:       # cells outside the envelope are undefined
+                for k, (x, y, hmm, md) in enumerate(imgs):
+                    wb = c_oracle.backward(x, y, hmm, md)["cells"]
+                    wf = c_oracle.forward(x, y, hmm, md)["cells"]
+                    inside = np.isfinite(wb).any(axis=2) | np.isfinite(wf).any(axis=2)
+                    mats[k] = np.where(inside[:, :, None], mats[k], 0.0)
+            got.append((mats, b.lp_start()))
+            b.close()
+        monkeypatch.delenv("HX_BAND_BWD_OLD", raising=False)
+        for k in range(len(cases)):
+            H.assert_same_bits(got[0][0][k], got[1][0][k], "job %d backward cells, sweep vs strip pipeline (flags %d)" % (k, flags))
+        H.assert_same_bits(got[0][1], got[1][1], "lpStart")
