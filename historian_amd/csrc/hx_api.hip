@@ -823,11 +823,11 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
         jo.band_rows = ar.put(rows.data(), sizeof(int32_t) * rows.size());
         J.band_steps = n_steps;
         kc = kclass[k] = KC_LEAF_ROT_BANDED;
-        // the Backward sweep of the same kernel (table policies, dense planes); a pair it does not take keeps the strip pipeline
+        // the Backward sweep of the same kernel (dense planes); a pair it does not take keeps the strip pipeline
         std::vector<int32_t> rows_b;
         int n_steps_b = 0;
         J.band_steps_bwd = 0;
-        if (!jo.compressed && !linear &&
+        if (!jo.compressed &&
             build_band_rows_bwd(pj.x->env_pos, pj.y->env_pos, xf.data(), yf.data(), xecls.data(), jo.x.empty != 0, jo.y.empty != 0, J.n_rows, J.n_cols,
                                 pj.max_distance, J.strip_stride, J.blk, rows_b, n_steps_b)) {
           jo.band_rows_bwd = ar.put(rows_b.data(), sizeof(int32_t) * rows_b.size());
@@ -1103,10 +1103,10 @@ int hx_batch_backward(hx_batch* b, void* stream) {
       case KC_LEAF_LDS: case KC_LEAF_LDS_BANDED: case KC_LEAF_ROT_BANDED: case KC_LEAF: case KC_LEAF_BANDED: {
         if (banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_bwd + cr.mat_begin, cr.mat_doubles, st);
         const int leaf = (c == KC_LEAF_LDS || c == KC_LEAF_LDS_BANDED || c == KC_LEAF_ROT_BANDED) ? 2 : 1;
-        if (c == KC_LEAF_ROT_BANDED && cr.bwd_band && !linear)
-          // the rotating-row sweep in mirrored coordinates (hx_band.hip), table policies
-          LAUNCH_TRY(launch_backward_band(jobs, cr.n, fast ? 1 : 2, cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab}, lse_tab,
-                                          (b->flags & HX_SPARSE_ENVELOPE) != 0, st));
+        if (c == KC_LEAF_ROT_BANDED && cr.bwd_band)
+          // the rotating-row sweep in mirrored coordinates (hx_band.hip)
+          LAUNCH_TRY(launch_backward_band(jobs, cr.n, linear ? 0 : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab},
+                                          linear ? Tab16{D.log_tab} : lse_tab, (b->flags & HX_SPARSE_ENVELOPE) != 0, st));
         else if (linear && leaf == 2)
           LAUNCH_TRY(launch_backward_leaf_linear(jobs, cr.n, cr.max_rows, banded, Tab8{D.tab}, Tab16{D.log_tab}, cr.yl_cols, cr.yl_emis, cr.max_cls + 1, st));
         else
@@ -1187,7 +1187,7 @@ int hx_batch_job_kernel(const hx_batch* b, int32_t job, int32_t* forward_class, 
     for (int p = cr.begin; p < cr.begin + cr.n; ++p)
       if (b->order[p] == job) {
         if (forward_class) *forward_class = c;
-        if (backward_sweep) *backward_sweep = (c == KC_LEAF_ROT_BANDED && cr.bwd_band && (b->flags & HX_LSE_LINEAR) != HX_LSE_LINEAR) ? 1 : 0;
+        if (backward_sweep) *backward_sweep = (c == KC_LEAF_ROT_BANDED && cr.bwd_band) ? 1 : 0;
         return HX_OK;
       }
   }

@@ -103,7 +103,7 @@ struct BandPlan { int table, xrec, sbase, ycol, yclass, xclass, elds, ring, flag
 // sweep and the converting wave is four steps deep instead of eight: 25 KB of LDS per pair instead of 54 (scaled
 // probabilities), 12 instead of 29 (table policies), so that large batches put five to seven pairs on a CU.
 // DIR = 1: the Backward fill (reference src/forward.cpp:975-1088 for leaf-like profiles) as the same sweep in mirrored
-// coordinates (row i' = R-1-i, column j' = Cc-1-j: the layout of the Backward matrix) with leaf_cell_bwd; table policies.
+// coordinates (row i' = R-1-i, column j' = Cc-1-j: the layout of the Backward matrix), every policy.
 // What is always inside the envelope is then the last row (x START) and the first column (the y state feeding END).  That
 // y state is never ready (it has the null transition to END), so away from the band both are -inf: the second wave only
 // writes them where the matrix was not pre-filled.
@@ -114,7 +114,6 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   constexpr int THREADS = 2 * PPW * 64;
   constexpr int RING = LEAN ? HXB_RING_LEAN : HXB_RING;
   constexpr bool OFFLOAD = POL == POL_LINEAR;        // the second wave converts and stores the sweep's cells
-  static_assert(DIR == 0 || POL != POL_LINEAR, "the Backward sweep exists for the table policies");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
@@ -394,6 +393,7 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   if (DIR == 1) {
     const double lpe = J.x.pack[4 * (size_t)R] + J.y.pack[4 * (size_t)Cc];
     end_cell = C5{lpe + J.T[0][5], lpe + J.T[1][5], lpe + J.T[2][5], lpe + J.T[3][5], lpe + J.T[4][5]};
+    if (POL == POL_LINEAR) end_cell = C5{exp(end_cell.imm), exp(end_cell.imd), exp(end_cell.idm), exp(end_cell.imi), exp(end_cell.iiw)};
   }
 
   // cell registers, ping-ponged: at an even step the lane's previous cell is in cb (the one before in ca, which the new
@@ -446,6 +446,28 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     const d2v rc = ys.rc;
     const int y_wait = (int)((ys.w & 0x100u) << 21);        // y state not ready: 2^29, else 0
     const double em = ys.em;
+    if (DIR == 1) {
+      // Backward (src/forward.cpp:1018-1065 for leaf-like profiles): the five destination terms - the xy-absorbing move into
+      // (i+1,j+1), the x-absorbing moves into (i+1,j) as IMD / IIW, the y-absorbing moves into (i,j+1) as IDM / IMI - brought
+      // to the cell's exponent (a move that may not be made, a cell outside the envelope: shifted out of range), then 18
+      // multiply-adds.  Same arithmetic as the strip pipeline's (hx_linear.hip).
+      const double tD = u2.imm * em;
+      const double t1x = u1.imd * xc_rs, t2x = u1.iiw * xc_in;
+      const double t1y = left.idm * rc.x, t2y = left.imi * rc.y;
+      int E = left.e > u1.e ? left.e : u1.e;
+      E = E > u2.e ? E : u2.e;
+      const int outside = (k >= as && k <= ae) ? 0 : (1 << 29);
+      const int du = ((u1.e - E) - y_wait) - outside, dl = ((left.e - E) - x_wait) - outside, dd = (u2.e - E) - outside;
+      const double D = __builtin_ldexp(tD, dd);
+      const double d1x = __builtin_ldexp(t1x, du), d2x = __builtin_ldexp(t2x, du);
+      const double d1y = __builtin_ldexp(t1y, dl), d2y = __builtin_ldexp(t2y, dl);
+      out.imm = __builtin_fma(P[0][3], d2y, __builtin_fma(P[0][2], d1y, __builtin_fma(P[0][4], d2x, __builtin_fma(P[0][1], d1x, P[0][0] * D))));
+      out.imd = __builtin_fma(P[1][2], d1y, __builtin_fma(P[1][1], d1x, P[1][0] * D));
+      out.idm = __builtin_fma(P[2][2], d1y, __builtin_fma(P[2][1], d1x, P[2][0] * D));
+      out.imi = __builtin_fma(P[3][3], d2y, __builtin_fma(P[3][4], d2x, __builtin_fma(P[3][1], d1x, P[3][0] * D)));
+      out.iiw = __builtin_fma(P[4][2], d1y, __builtin_fma(P[4][4], d2x, P[4][0] * D));
+      out.e = E;
+    } else {
     // the five sums of src/forward.cpp:103-115,139-150,171-180 on probabilities
     double s_imd = u1.imm * P[0][1];
     double s_iiw = u1.imm * P[0][4];
@@ -477,8 +499,15 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     out.imi = __builtin_ldexp(s_imi * rc.y, dl);
     out.imm = __builtin_ldexp(s_imm * em, dd);
     out.e = E;
+    }
     if (renorm) {                                  // (compile-time: the first two steps of every block of eight)
-      if (k == 0 && lane == 0) { out.imm = 1.0; out.e = 0; }     // cell (0,0): lpStart() = 0 (src/forward.cpp:73)
+      if (DIR == 0) {
+        if (k == 0 && lane == 0) { out.imm = 1.0; out.e = 0; }   // cell (0,0): lpStart() = 0 (src/forward.cpp:73)
+      } else if (k == 0 && lane == 0) {
+        // the cell feeding END is initialised by assignment (src/forward.cpp:981-995)
+        out.imm = end_cell.imm; out.imd = end_cell.imd; out.idm = end_cell.idm; out.imi = end_cell.imi; out.iiw = end_cell.iiw;
+        out.e = 0;
+      }
       const double mx = vmax(vmax(vmax(out.imm, out.imd), vmax(out.idm, out.imi)), out.iiw);
       const int kk = __builtin_amdgcn_frexp_exp(mx);
       out.imm = __builtin_ldexp(out.imm, -kk);
@@ -641,7 +670,7 @@ int launch_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max
     if (ppw >= 4) return launch_pol<POL_, 4, false, DIR>(d_jobs, n_jobs, plan_band(POL_, 4, max_rows, max_cols, max_cls), tab, pol_tab, we, st); \
     if (ppw >= 2) return launch_pol<POL_, 2, false, DIR>(d_jobs, n_jobs, plan_band(POL_, 2, max_rows, max_cols, max_cls), tab, pol_tab, we, st); \
     return launch_pol<POL_, 1, false, DIR>(d_jobs, n_jobs, plan_band(POL_, 1, max_rows, max_cols, max_cls), tab, pol_tab, we, st); } while (0)
-  if constexpr (DIR == 0) if (pol == POL_LINEAR) HXB_GO(POL_LINEAR);
+  if (pol == POL_LINEAR) HXB_GO(POL_LINEAR);
   if (pol == POL_FAST) HXB_GO(POL_FAST);
   HXB_GO(POL_EXACT);
 #undef HXB_LEAN
@@ -654,10 +683,9 @@ int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows,
   return launch_band<0>(d_jobs, n_jobs, pol, max_rows, max_cols, max_cls, tab8, tab16, write_edges, st);
 }
 
-// The Backward sweep (table policies; the class's pairs all carry band_rows_bwd: hx_api.hip ClassRange::bwd_band)
+// The Backward sweep (the class's pairs all carry band_rows_bwd: hx_api.hip ClassRange::bwd_band)
 int launch_backward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, Tab8 tab8,
                          Tab16 tab16, bool write_edges, hipStream_t st) {
-  if (pol == POL_LINEAR) return launch_fail("the Backward band sweep has no scaled-probability variant");
   return launch_band<1>(d_jobs, n_jobs, pol, max_rows, max_cols, max_cls, tab8, tab16, write_edges, st);
 }
 

@@ -243,7 +243,7 @@ int64_t hx_batch_total_cells(const hx_batch* b);
 /* Diagnostics: which fill kernel takes pair `job`.  *forward_class = the kernel class of DESIGN.md section 5 (0 leaf pairs in
  * LDS, 1 the same banded, 2 the banded rotating-row sweep, 3/4 other leaf pairs, 5/6 in-degree-1 profiles, 7/8 general
  * profiles, 9 the barrier-per-diagonal kernels); *backward_sweep = 1 when hx_batch_backward also runs the rotating-row
- * sweep for it (class 2, table policies, dense planes), 0 when it runs the class's strip pipeline.  Either may be NULL. */
+ * sweep for it (class 2, dense planes), 0 when it runs the class's strip pipeline.  Either may be NULL. */
 int hx_batch_job_kernel(const hx_batch* b, int32_t job, int32_t* forward_class, int32_t* backward_sweep);
 
 /* Duration in milliseconds of the most recent hx_batch_forward / hx_batch_backward

@@ -557,11 +557,12 @@ def test_banded_leaf_pairs_in_the_lean_band_kernel(ppw, monkeypatch):
 
 @pytest.mark.parametrize("ppw", [0, -3])
 def test_banded_backward_in_the_rotating_row_sweep(ppw, monkeypatch):
-    # Backward of banded leaf pairs (table policies, dense planes) runs the rotating-row sweep in mirrored coordinates:
-    # the envelope's always-inside column and last row are chains of the second wave, handed to the sweep through LDS
-    # (hx_band.hip, DIR = 1).  Exact mode bit for bit against the oracle, whole matrix and in the sparse-envelope storage;
-    # both policies bit for bit against the strip pipeline they replace (HX_BAND_BWD_OLD); shapes where the band of the last
-    # x state does not reach the y state that feeds END, a band of zero, more rows than columns and the reverse.
+    # Backward of banded leaf pairs (dense planes) runs the rotating-row sweep in mirrored coordinates (hx_band.hip, DIR = 1):
+    # the envelope's always-inside column and last row are -inf away from the band and only written by the second wave.
+    # Exact mode bit for bit against the oracle, whole matrix and in the sparse-envelope storage; both table policies bit for
+    # bit against the strip pipeline they replace (HX_BAND_BWD_OLD); scaled probabilities against the libm-arithmetic oracle;
+    # shapes where the band has an empty row (those pairs keep the strip pipeline), a band of zero, more rows than columns
+    # and the reverse.
     if ppw:
         monkeypatch.setenv("HX_BAND_PPW", str(ppw))
     aa = "arndcqeghilkmfpstwyv"
@@ -600,3 +601,26 @@ def test_banded_backward_in_the_rotating_row_sweep(ppw, monkeypatch):
         for k in range(len(cases)):
             H.assert_same_bits(got[0][0][k], got[1][0][k], "job %d backward cells, sweep vs strip pipeline (flags %d)" % (k, flags))
         H.assert_same_bits(got[0][1], got[1][1], "lpStart")
+    # scaled probabilities: the libm-arithmetic oracle, and Forward == Backward to rounding
+    for flags in (0, capi.HX_SPARSE_ENVELOPE):
+        b = capi.Batch(imgs, capi.HX_KEEP_BACKWARD | capi.HX_LSE_LINEAR | flags)
+        assert sum(1 for c, s in (b.job_kernel(k) for k in range(len(cases))) if c == 2 and s) >= 6
+        b.forward()
+        b.backward()
+        lf, sf = b.lp_end(), b.lp_start()
+        for k, (x, y, hmm, md) in enumerate(imgs):
+            want = c_oracle.backward(x, y, hmm, md, true_math=True)
+            mb = b.read_matrix(k, 1)
+            inside = np.isfinite(want["cells"])
+            if not flags:
+                assert np.array_equal(np.isneginf(want["cells"]), np.isneginf(mb)), "job %d: backward -inf pattern" % k
+            else:
+                env = H.envelope_mask(cases[k])
+                assert np.array_equal(np.isneginf(want["cells"][env]), np.isneginf(mb[env])), "job %d: backward -inf pattern" % k
+            assert np.max(np.abs(want["cells"][inside] - mb[inside]), initial=0.) < 1e-9, "job %d backward" % k
+            if np.isfinite(want["lp_start"]):
+                assert abs(want["lp_start"] - sf[k]) <= 1e-12 * abs(sf[k])
+                assert abs(sf[k] - lf[k]) <= 1e-11 * abs(lf[k])
+            else:
+                assert sf[k] == want["lp_start"]
+        b.close()
