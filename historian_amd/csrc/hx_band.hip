@@ -59,7 +59,7 @@ typedef int i2v __attribute__((ext_vector_type(2)));
 #define HXB_RING_LEAN 4
 
 // value of the previous lane, lane 0 receives lane 63's: one v_mov_b32_dpp wave_ror:1 per dword
-__device__ __forceinline__ int ror1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ int ror1(int v) { return __builtin_amdgcn_mov_dpp(v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false); }   // (every lane is written: no tied "old" operand, no copy)
 __device__ __forceinline__ double ror1(double v) {
   return __hiloint2double(ror1(__double2hiint(v)), ror1(__double2loint(v)));
 }
