@@ -132,6 +132,7 @@ struct PinnedPool {
   std::vector<std::pair<size_t, double*> > freeList;   // (capacity in doubles, buffer)
   std::thread warming;                                 // page-locks the first buffers while the first fill runs
   std::mutex warmMutex;
+  bool hostReadsExpected = false;                      // warm() was called: the caller walks matrices on the host
   void settle() {
     std::lock_guard<std::mutex> lock(warmMutex);
     if (warming.joinable()) warming.join();
@@ -140,6 +141,7 @@ struct PinnedPool {
   // the first traceback.
   void warm(size_t doubles, int count) {
     settle();
+    hostReadsExpected = true;
     std::lock_guard<std::mutex> lock(warmMutex);
     warming = std::thread([this, doubles, count]() {
       for (int k = 0; k < count; ++k) {
@@ -180,6 +182,20 @@ struct PinnedPool {
   void give(double* p, size_t cap) {
     std::lock_guard<std::mutex> lock(g_deviceMutex);
     freeList.push_back(std::make_pair(cap, p));
+  }
+  // makes sure a free buffer of n doubles exists; called while a fill kernel runs, so that page-locking a buffer for a
+  // matrix larger than any before it is not paid in front of its traceback
+  void reserve(size_t n) {
+    if (!hostReadsExpected) return;
+    settle();
+    {
+      std::lock_guard<std::mutex> lock(g_deviceMutex);
+      for (const auto& f : freeList)
+        if (f.first >= n) return;
+    }
+    size_t cap = 0;
+    double* p = take(n, cap);
+    give(p, cap);
   }
 };
 PinnedPool g_pinned;
@@ -356,6 +372,19 @@ vguard<ForwardMatrix*> ForwardMatrix::fillBatch(const vguard<JobSpec>& jobs, con
     fprintf(stderr, "timing: fill batch of %zu jobs: matrices and POD images %.4f s, hx_batch_create %.4f s\n", n, t0b - t0, t1 - t0b);
   for (auto& h : handles)
     if (h) hxCheck(hx_batch_forward(h->b, NULL), "hx_batch_forward");
+  // while the fills run: a page-locked buffer for the largest matrix of the batch, if the pool has none
+  {
+    size_t largest = 0;
+    for (auto& h : handles) {
+      if (!h) continue;
+      for (int j = 0; j < h->nJobs; ++j) {
+        hx_layout lay;
+        hxCheck(hx_batch_layout(h->b, j, 0, &lay), "hx_batch_layout");
+        largest = std::max(largest, (size_t)lay.matrix_doubles);
+      }
+    }
+    if (largest) g_pinned.reserve(largest);
+  }
   for (auto& h : handles) {
     if (!h) continue;
     vguard<double> lp((size_t)h->nJobs, NEG_INF);

@@ -14,6 +14,7 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/historian_hip.h"
@@ -34,6 +35,10 @@ struct DeviceTables {
   double* fast_tab = nullptr; // quadratic pieces of the fast fill mode (FastPiece, 16 bytes each)
   double* log_tab = nullptr;  // {c, -log c} entries of the scaled-probability fills' logarithm (hx_linear.hip)
   double* pair_tab = nullptr; // {lookup[n], lookup[n+1]-lookup[n]} pairs, 16-byte aligned (exact fill mode)
+  // the stream of hx_batch_read_matrix_async, shared by the device's batches: a stream's queue is set up at its first use,
+  // which costs a caller that makes a batch per fill (a reconstruction's internal nodes) a millisecond or two per matrix
+  hipStream_t copy_stream = nullptr;
+  std::mutex copy_mutex;
   bool ready = false;
 };
 DeviceTables g_dev[HX_MAX_DEVICES];
@@ -536,7 +541,7 @@ struct hx_batch {
   hipStream_t last_stream = nullptr;
   hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   bool dag_linear = false;                      // general-profile classes run the scaled-probability fill (hx_daglin.hip)
-  hipStream_t copy_stream = nullptr;            // hx_batch_read_matrix_async
+  hipStream_t copy_stream = nullptr;            // hx_batch_read_matrix_async: the device's copy stream (DeviceTables)
   std::vector<hipEvent_t> copied[2];            // per job: the event behind its asynchronous matrix copy, or null
   int32_t* d_trace = nullptr;        // hx_batch_best_trace: path buffers, kept between calls
   int64_t* d_trace_n = nullptr;
@@ -581,7 +586,10 @@ void free_tables(DeviceTables& t) {
   if (t.fast_tab) (void)hipFree(t.fast_tab);
   if (t.log_tab) (void)hipFree(t.log_tab);
   if (t.pair_tab) (void)hipFree(t.pair_tab);
-  t = DeviceTables();
+  if (t.copy_stream) (void)hipStreamDestroy(t.copy_stream);
+  t.tab = t.fast_tab = t.log_tab = t.pair_tab = nullptr;
+  t.copy_stream = nullptr;
+  t.ready = false;
 }
 int upload(double** dst, const std::vector<double>& src) {
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), src.size() * sizeof(double)));
@@ -991,7 +999,6 @@ int hx_batch_destroy(hx_batch* b) {
   for (int w = 0; w < 2; ++w)
     for (hipEvent_t e : b->copied[w])
       if (e) (void)hipEventDestroy(e);
-  if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
   if (b->d_jobs) (void)hipFree(b->d_jobs);
   if (b->d_jobs_cls) (void)hipFree(b->d_jobs_cls);
   if (b->d_arena) (void)hipFree(b->d_arena);
@@ -1214,7 +1221,12 @@ int hx_batch_read_matrix_async(hx_batch* b, int32_t job, int32_t which, double* 
   if (which == 0 ? !b->forward_done : !b->backward_done) return fail(HX_ERR_STATE, "fill has not been launched");
   { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
   HIP_TRY(hipStreamSynchronize(b->last_stream));
-  if (!b->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+  if (!b->copy_stream) {
+    DeviceTables& D = g_dev[b->device];
+    std::lock_guard<std::mutex> lock(D.copy_mutex);
+    if (!D.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&D.copy_stream, hipStreamNonBlocking));
+    b->copy_stream = D.copy_stream;
+  }
   if (b->copied[which].empty()) b->copied[which].assign((size_t)b->n_jobs, nullptr);
   hipEvent_t& e = b->copied[which][job];
   if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
