@@ -6,7 +6,7 @@
 // posterior-weighted DP cell in BackwardMatrix::getCounts).  Columns and mixture components are independent, so here a
 // (column, component) is a thread (k_sumprod_columns): every thread runs the tip-to-root and root-to-tip passes of its column - tiny tree recursions,
 // A x A matrix-vector products per branch and mixture component - with its messages E, F, G in a global scratch laid out
-// [.][column] so that the threads of a wavefront touch consecutive addresses, then turns the messages of every branch
+// in blocks of 64 columns ([block][.][64 lanes], two vector entries per lane and access), then turns the messages of every branch
 // into the eigen basis (D_k, U_l).  The reference adds weight x D_k J_kl U_l to the count matrix column by column; J_kl
 // (eigenSubCount of the branch) does not depend on the column, so the sum over columns is an outer-product sum
 // J_kl x sum_col D_k(col) U_l(col): a second kernel (k_outer_counts) reduces the columns of one (component, branch) per
@@ -49,14 +49,85 @@ struct SpModel {
   const double* esc_im;
 };
 
-// scratch of one chunk of columns: messages E, G [cpt][node][a][column]; scale factors and max U [cpt][node][column];
-// F at the column's root and the root-count terms [cpt][a][column]; bases [cpt][node][Ur, Dr, (Ui, Di)][a][column]
+// scratch of one chunk of columns, in blocks of 64 columns: messages E, G [block][cpt][node][a][64]; scale factors and max U
+// [block][cpt][node][64]; F at the column's root and the root-count terms [block][cpt][a][64]; bases
+// [block][cpt][node][Ur, Dr, (Ui, Di)][a][64]
 struct SpScratch { double* E; double* G; double* logE; double* logF; double* logG; double* maxU; double* Froot; double* rootc; double* basis; };
 
 // Model matrices are read through the constant address space: their addresses are uniform over the wavefront and
 // nothing writes them, so the compiler fetches them with scalar loads and feeds the FMAs from SGPRs.
 typedef const __attribute__((address_space(4))) double* CMat;
 __device__ __forceinline__ CMat cmat(const double* p) { return (CMat)(unsigned long long)p; }
+
+// Matrix-vector products with a matrix that a wave keeps in LDS (row-major, A x A, 16-byte aligned rows: A even).  Every
+// lane reads the same entries (broadcast reads, two entries per ds_read_b128); a row is fetched a whole row ahead of its
+// use into registers of its own, so that no read is waited for - written the plain way the compiler, short of registers,
+// reused one register pair for every read and waited for each (one multiply-add per ~50 cycles).
+typedef double sp_d2 __attribute__((ext_vector_type(2)));
+template <int A>
+struct LdsRow {
+  sp_d2 v[A / 2];
+  __device__ __forceinline__ void fetch(const HX_LDS double* row) {
+#pragma unroll
+    for (int q = 0; q < A / 2; ++q) v[q] = reinterpret_cast<const HX_LDS sp_d2*>(row)[q];
+  }
+  __device__ __forceinline__ double at(const int b) const { return (b & 1) ? v[b >> 1].y : v[b >> 1].x; }
+};
+// y[a] = sum_b M[a][b] x[b]   (four partial sums per row: the additions of a row do not wait for one another); the results
+// are handed out two rows at a time (A even), the way the scratch stores them
+template <int A, class Emit>
+__device__ __forceinline__ void lds_mat_vec(const HX_LDS double* M, const double (&x)[A], const Emit& emit) {
+  LdsRow<A> r0, r1;
+  r0.fetch(M);
+#pragma unroll
+  for (int a = 0; a < A; a += 2) {
+    r1.fetch(M + (a + 1) * A);
+    double ya, yb;
+    {
+      double p0 = 0., p1 = 0., p2 = 0., p3 = 0.;
+#pragma unroll
+      for (int b = 0; b < A; b += 4) {
+        p0 = __builtin_fma(r0.at(b), x[b], p0);
+        if (b + 1 < A) p1 = __builtin_fma(r0.at(b + 1), x[b + 1], p1);
+        if (b + 2 < A) p2 = __builtin_fma(r0.at(b + 2), x[b + 2], p2);
+        if (b + 3 < A) p3 = __builtin_fma(r0.at(b + 3), x[b + 3], p3);
+      }
+      ya = (p0 + p1) + (p2 + p3);
+    }
+    if (a + 2 < A) r0.fetch(M + (a + 2) * A);
+    {
+      double p0 = 0., p1 = 0., p2 = 0., p3 = 0.;
+#pragma unroll
+      for (int b = 0; b < A; b += 4) {
+        p0 = __builtin_fma(r1.at(b), x[b], p0);
+        if (b + 1 < A) p1 = __builtin_fma(r1.at(b + 1), x[b + 1], p1);
+        if (b + 2 < A) p2 = __builtin_fma(r1.at(b + 2), x[b + 2], p2);
+        if (b + 3 < A) p3 = __builtin_fma(r1.at(b + 3), x[b + 3], p3);
+      }
+      yb = (p0 + p1) + (p2 + p3);
+    }
+    emit(a >> 1, ya, yb);
+  }
+}
+// y[b] = sum_a x[a] M[a][b]   (A independent accumulators)
+template <int A>
+__device__ __forceinline__ void lds_vec_mat(const HX_LDS double* M, const double (&x)[A], double (&y)[A]) {
+  LdsRow<A> r0, r1;
+  r0.fetch(M);
+#pragma unroll
+  for (int b = 0; b < A; ++b) y[b] = 0.;
+#pragma unroll
+  for (int a = 0; a < A; a += 2) {
+    if (a + 1 < A) r1.fetch(M + (a + 1) * A);
+#pragma unroll
+    for (int b = 0; b < A; ++b) y[b] = __builtin_fma(x[a], r0.at(b), y[b]);
+    if (a + 2 < A) r0.fetch(M + (a + 2) * A);
+    if (a + 1 < A) {
+#pragma unroll
+      for (int b = 0; b < A; ++b) y[b] = __builtin_fma(x[a + 1], r1.at(b), y[b]);
+    }
+  }
+}
 
 // TA: the alphabet size as a compile-time constant (message vectors live in registers, loops unrolled), or 0 for any
 // alphabet of up to 64 symbols (vectors in private memory).
@@ -68,13 +139,18 @@ __global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const 
                                                          const long long n_cols, const SpScratch s, const double* __restrict__ lse_tab,
                                                          double* __restrict__ col_log_like, double* __restrict__ root_post) {
   constexpr int AX = TA ? TA : 64;
-  const int A = TA ? TA : m.A, C = m.C, N = m.N, AA = A * A;
-  const long long stride = n_cols;
+  const int A = TA ? TA : m.A, C = m.C, N = m.N, AA = A * A, AP = (A + 1) & ~1;
   const int parts = m.real_basis ? 2 : 4;
-#define AT(P, cpt, r, a) P[(((long long)(cpt) * N + (r)) * A + (a)) * stride + col]
-#define LG(P, cpt, r) P[((long long)(cpt) * N + (r)) * stride + col]
-#define BS(cpt, r, part, l) s.basis[((((long long)(cpt) * N + (r)) * parts + (part)) * A + (l)) * stride + col]
-#define FR(cpt, a) s.Froot[((long long)(cpt) * A + (a)) * stride + col]
+  // Scratch layout: blocks of 64 columns, [block][.][64] - everything a wavefront touches in a pass lies in one
+  // contiguous stretch (a few hundred KB) instead of one 512-byte piece per row of a [.][all columns] array, rows
+  // n_cols * 8 bytes apart (two thousand pages per wavefront).  `cb`: this wave's block, `cl` = the lane.
+  // Inside a block a message vector is stored two entries per lane and row, [a / 2][64][2]: a lane moves 16 bytes per
+  // memory instruction (8-byte accesses run at 0.5-0.7 of the 16-byte rate).  AP = A rounded up to even.
+#define ROWP(P, idx) ((P) + (idx) * (long long)(AP * 64) + cl * 2)
+#define AT(P, cpt, r, a) ROWP(P, (cb * C + (cpt)) * N + (r))[((a) >> 1) * 128 + ((a) & 1)]
+#define LG(P, cpt, r) P[((cb * C + (cpt)) * N + (r)) * 64 + cl]
+#define BS(cpt, r, part, l) ROWP(s.basis, ((cb * C + (cpt)) * N + (r)) * parts + (part))[((l) >> 1) * 128 + ((l) & 1)]
+#define FR(cpt, a) s.Froot[((cb * C + (cpt)) * A + (a)) * 64 + cl]
   // a wavefront is 64 columns of one mixture component (the component is uniform over the wave, so the model's matrices
   // still come through scalar loads); the waves of a workgroup share the columns and split the components.  They meet
   // twice: for the column likelihood (through LDS) and for the root posterior (through the scratch).
@@ -87,6 +163,30 @@ __global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const 
   for (long long base = (long long)blockIdx.x * 64; base < n_cols; base += (long long)gridDim.x * 64) {
     const bool busy = base + lane < n_cols;
     const long long col = busy ? base + lane : 0;
+    const long long cb = base >> 6;
+    const int cl = lane;
+    // a whole row of the scratch, 16 bytes per access when the alphabet size is a compile-time even number
+    auto put_row = [&](double* rp, auto&& gen) {
+      if constexpr (TA != 0 && TA % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < TA / 2; ++q) *reinterpret_cast<sp_d2*>(rp + q * 128) = sp_d2{gen(2 * q), gen(2 * q + 1)};
+      } else {
+        for (int a = 0; a < A; ++a) rp[(a >> 1) * 128 + (a & 1)] = gen(a);
+      }
+    };
+    auto get_row = [&](const double* rp, double (&v)[AX]) {
+      if constexpr (TA != 0 && TA % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < TA / 2; ++q) {
+          const sp_d2 t2 = *reinterpret_cast<const sp_d2*>(rp + q * 128);
+          v[2 * q] = t2.x; v[2 * q + 1] = t2.y;
+        }
+      } else {
+        for (int a = 0; a < A; ++a) v[a] = rp[(a >> 1) * 128 + (a & 1)];
+      }
+    };
+#define EROW(P, cpt, r) ROWP(P, (cb * C + (cpt)) * N + (r))
+#define BROW(cpt, r, part) ROWP(s.basis, ((cb * C + (cpt)) * N + (r)) * parts + (part))
     const signed char* t = tok + col * N;       // -2 gap, -1 wildcard, else the residue's token
     const double w = weight ? weight[col] : 1.;
     int root = -1;
@@ -113,12 +213,10 @@ __global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const 
         const int tk = t[r];
         if (tk == -2) {
           // a gap: its message to the parent is all ones, and no counts on the branch above it
-#pragma unroll
-          for (int a = 0; a < A; ++a) AT(s.E, cpt, r, a) = 1.;
+          put_row(EROW(s.E, cpt, r), [](int) { return 1.; });
           LG(s.logE, cpt, r) = 0.;
           LG(s.logF, cpt, r) = lf;
-#pragma unroll
-          for (int l = 0; l < A; ++l) BS(cpt, r, 0, l) = 0.;
+          put_row(BROW(cpt, r, 0), [](int) { return 0.; });
           if (parts == 4)
             for (int l = 0; l < A; ++l) BS(cpt, r, 2, l) = 0.;
           continue;
@@ -141,10 +239,8 @@ __global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const 
             LG(s.logE, cpt, r) = lf;
             LG(s.maxU, cpt, r) = f;
             const double* subg = m.branch_sub + ((long long)cpt * N + r) * AA;
-#pragma unroll
-            for (int a = 0; a < A; ++a) AT(s.E, cpt, r, a) = (LM ? Lsub[a * A + tk] : subg[a * A + tk]) * f;
-#pragma unroll
-            for (int l = 0; l < A; ++l) BS(cpt, r, 0, l) = (LM ? Linv[l * A + tk] : m.einv_re[(long long)cpt * AA + l * A + tk]) * (f / f);
+            put_row(EROW(s.E, cpt, r), [&](const int a) { return (LM ? Lsub[a * A + tk] : subg[a * A + tk]) * f; });
+            put_row(BROW(cpt, r, 0), [&](const int l) { return (LM ? Linv[l * A + tk] : m.einv_re[(long long)cpt * AA + l * A + tk]) * (f / f); });
             if (parts == 4)
               for (int l = 0; l < A; ++l) BS(cpt, r, 2, l) = m.einv_im[(long long)cpt * AA + l * A + tk] * (f / f);
           }
@@ -153,10 +249,17 @@ __global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const 
         // a wildcard: the full vector
         double f[AX];
         double fmax = 0.;
+        {
+          double e1[AX];
 #pragma unroll
-        for (int a = 0; a < A; ++a) {
-          f[a] = (c0 >= 0 ? AT(s.E, cpt, c0, a) : 1.) * (c1 >= 0 ? AT(s.E, cpt, c1, a) : 1.);
-          fmax = f[a] > fmax ? f[a] : fmax;
+          for (int a = 0; a < A; ++a) f[a] = e1[a] = 1.;
+          if (c0 >= 0) get_row(EROW(s.E, cpt, c0), f);
+          if (c1 >= 0) get_row(EROW(s.E, cpt, c1), e1);
+#pragma unroll
+          for (int a = 0; a < A; ++a) {
+            f[a] *= e1[a];
+            fmax = f[a] > fmax ? f[a] : fmax;
+          }
         }
         if (fmax < HX_SP_RESCALE) {
 #pragma unroll
@@ -177,21 +280,35 @@ __global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const 
         }
         LG(s.logE, cpt, r) = lf;
         LG(s.maxU, cpt, r) = fmax;
+        if constexpr (LM && TA != 0 && TA % 2 == 0) {
+          {
+            double* rp = EROW(s.E, cpt, r);
+            lds_mat_vec<AX>(Lsub, f, [&](const int q, const double ea, const double eb) { *reinterpret_cast<sp_d2*>(rp + q * 128) = sp_d2{ea, eb}; });
+          }
+          const double inv_fmax = 1. / fmax;
 #pragma unroll
-        for (int a = 0; a < A; ++a) {
-          double e = 0.;
+          for (int a = 0; a < A; ++a) f[a] *= inv_fmax;
+          {
+            double* rp = BROW(cpt, r, 0);
+            lds_mat_vec<AX>(Linv, f, [&](const int q, const double ua, const double ub) { *reinterpret_cast<sp_d2*>(rp + q * 128) = sp_d2{ua, ub}; });
+          }
+        } else {
 #pragma unroll
-          for (int b = 0; b < A; ++b) e += sub(a * A + b) * f[b];
-          AT(s.E, cpt, r, a) = e;
-        }
+          for (int a = 0; a < A; ++a) {
+            double e = 0.;
 #pragma unroll
-        for (int a = 0; a < A; ++a) f[a] /= fmax;
+            for (int b = 0; b < A; ++b) e += sub(a * A + b) * f[b];
+            AT(s.E, cpt, r, a) = e;
+          }
 #pragma unroll
-        for (int l = 0; l < A; ++l) {
-          double ur = 0.;
+          for (int a = 0; a < A; ++a) f[a] /= fmax;
 #pragma unroll
-          for (int b = 0; b < A; ++b) ur += ir(l * A + b) * f[b];
-          BS(cpt, r, 0, l) = ur;
+          for (int l = 0; l < A; ++l) {
+            double ur = 0.;
+#pragma unroll
+            for (int b = 0; b < A; ++b) ur += ir(l * A + b) * f[b];
+            BS(cpt, r, 0, l) = ur;
+          }
         }
         if (parts == 4)
           for (int l = 0; l < A; ++l) {
@@ -222,15 +339,13 @@ __global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const 
         if (!busy) continue;
         if (t[r] == -2 || r == root) {
           if (r == root) {
-#pragma unroll
-            for (int a = 0; a < A; ++a) AT(s.G, cpt, r, a) = ins[a];
+            put_row(EROW(s.G, cpt, r), [&](const int a) { return ins[a]; });
             LG(s.logG, cpt, r) = 0.;
-            for (int l = 0; l < A; ++l) BS(cpt, r, 0, l) = 0.;        // no branch above the root: U was not written on the way up
+            put_row(BROW(cpt, r, 0), [](int) { return 0.; });         // no branch above the root: U was not written on the way up
             if (parts == 4)
               for (int l = 0; l < A; ++l) BS(cpt, r, 2, l) = 0.;
           }
-#pragma unroll
-          for (int l = 0; l < A; ++l) BS(cpt, r, 1, l) = 0.;
+          put_row(BROW(cpt, r, 1), [](int) { return 0.; });
           if (parts == 4)
             for (int l = 0; l < A; ++l) BS(cpt, r, 3, l) = 0.;
           continue;
@@ -248,28 +363,50 @@ __global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const 
         // what flows down the branch: the parent's outside message times the sibling's subtree
         double d[AX];
         double max_d = 0.;
+        {
+          double es[AX];
 #pragma unroll
-        for (int a = 0; a < A; ++a) {
-          d[a] = AT(s.G, cpt, p, a) * (sib >= 0 ? AT(s.E, cpt, sib, a) : 1.);
-          max_d = d[a] > max_d ? d[a] : max_d;
+          for (int a = 0; a < A; ++a) es[a] = 1.;
+          get_row(EROW(s.G, cpt, p), d);
+          if (sib >= 0) get_row(EROW(s.E, cpt, sib), es);
+#pragma unroll
+          for (int a = 0; a < A; ++a) {
+            d[a] *= es[a];
+            max_d = d[a] > max_d ? d[a] : max_d;
+          }
         }
+        if constexpr (LM && TA != 0 && TA % 2 == 0) {
+          double g[AX];
+          lds_vec_mat<AX>(Lsub, d, g);
+          put_row(EROW(s.G, cpt, r), [&](const int b) { return g[b]; });
+        } else {
 #pragma unroll
-        for (int b = 0; b < A; ++b) {
-          double g = 0.;
+          for (int b = 0; b < A; ++b) {
+            double g = 0.;
 #pragma unroll
-          for (int a = 0; a < A; ++a) g += d[a] * sub(a * A + b);
-          AT(s.G, cpt, r, b) = g;
+            for (int a = 0; a < A; ++a) g += d[a] * sub(a * A + b);
+            AT(s.G, cpt, r, b) = g;
+          }
         }
         const double norm = exp(cll - m.log_cpt_weight[cpt] - LG(s.logF, cpt, r) - lg_p - le_sib) / (LG(s.maxU, cpt, r) * max_d);
         const double scale = w / norm;
+        if constexpr (LM && TA != 0 && TA % 2 == 0) {
+          const double inv_max = 1. / max_d;
 #pragma unroll
-        for (int a = 0; a < A; ++a) d[a] /= max_d;
+          for (int a = 0; a < A; ++a) d[a] *= inv_max;
+          double dr[AX];
+          lds_vec_mat<AX>(Lvec, d, dr);
+          put_row(BROW(cpt, r, 1), [&](const int k) { return dr[k] * scale; });
+        } else {
 #pragma unroll
-        for (int k = 0; k < A; ++k) {
-          double dr = 0.;
+          for (int a = 0; a < A; ++a) d[a] /= max_d;
 #pragma unroll
-          for (int a = 0; a < A; ++a) dr += vr(a * A + k) * d[a];
-          BS(cpt, r, 1, k) = dr * scale;
+          for (int k = 0; k < A; ++k) {
+            double dr = 0.;
+#pragma unroll
+            for (int a = 0; a < A; ++a) dr += vr(a * A + k) * d[a];
+            BS(cpt, r, 1, k) = dr * scale;
+          }
         }
         if (parts == 4)
           for (int k = 0; k < A; ++k) {
@@ -295,11 +432,14 @@ __global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const 
     for (int cpt = wave; cpt < C && busy; cpt += Wb) {
       const double norm = root >= 0 ? exp(m.log_cpt_weight[cpt] + LG(s.logF, cpt, root) - cll) : 0.;
       for (int a = 0; a < A; ++a)
-        s.rootc[((long long)cpt * A + a) * stride + col] = root >= 0 ? w * m.ins_prob[cpt * A + a] * FR(cpt, a) * norm : 0.;
+        s.rootc[((cb * C + cpt) * A + a) * 64 + cl] = root >= 0 ? w * m.ins_prob[cpt * A + a] * FR(cpt, a) * norm : 0.;
     }
     __syncthreads();
   }
 #undef AT
+#undef ROWP
+#undef EROW
+#undef BROW
 #undef LG
 #undef BS
 #undef FR
@@ -315,7 +455,9 @@ __global__ void __launch_bounds__(256) k_outer_counts(const SpModel m, const dou
   const int A = m.A, AA = A * A, N = m.N;
   const int branch = blockIdx.x, cpt = branch / N, r = branch - cpt * N;
   if (m.parent[r] < 0) return;
-  const double* bs = basis + (long long)branch * PARTS * A * n_cols;
+  const int AP = (A + 1) & ~1;
+  const long long blk_doubles = (long long)m.C * N * PARTS * AP * 64;     // one 64-column block of the scratch (see k_sumprod_columns)
+  const double* bs = basis + (long long)branch * PARTS * AP * 64;
   double acc_re[HX_SP_PAIRS], acc_im[HX_SP_PAIRS];
 #pragma unroll
   for (int q = 0; q < HX_SP_PAIRS; ++q) acc_re[q] = acc_im[q] = 0.;
@@ -324,7 +466,9 @@ __global__ void __launch_bounds__(256) k_outer_counts(const SpModel m, const dou
     const long long c0 = tl * HX_SP_TILE;
     for (int e = threadIdx.x; e < PARTS * A * HX_SP_TILE; e += 256) {
       const int row = e / HX_SP_TILE, c = e - row * HX_SP_TILE;
-      tile[row * TS + c] = c0 + c < n_cols ? bs[(long long)row * n_cols + c0 + c] : 0.;
+      const long long cc = c0 + c;
+      const int part = row / A, l = row - part * A;      // (rows of a part are stored in pairs: [l / 2][64][2])
+      tile[row * TS + c] = cc < n_cols ? bs[(cc >> 6) * blk_doubles + (long long)part * AP * 64 + ((l >> 1) * 64 + (cc & 63)) * 2 + (l & 1)] : 0.;
     }
     __syncthreads();
 #pragma unroll
@@ -366,12 +510,100 @@ __global__ void __launch_bounds__(256) k_outer_counts(const SpModel m, const dou
   }
 }
 
+// The same sum for real bases on the matrix cores: sum_col D_k(col) U_l(col) is the product D (A x columns) times U^T
+// (columns x A).  A workgroup takes one (component, branch) and a slice of the 64-column blocks; a block's 2 A rows of 64
+// columns are one contiguous piece of the scratch (see k_sumprod_columns), copied to LDS with rows padded to 65 entries; the
+// four waves share the 16 x 16 tiles of the A x A result, sixteen v_mfma_f64_16x16x4_f64 per tile and block (k = the block's
+// columns, four at a time).  Operand maps of that instruction: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; result
+// register q of lane l is C[(l >> 4) + 4 q][l & 15].  Rows past A are zero in LDS.
+typedef double sp_d4 __attribute__((ext_vector_type(4)));
+#define HX_SP_MAX_TILES 4          // tiles per wave: A <= 64 -> (A / 16)^2 <= 16 tiles over four waves
+__global__ void __launch_bounds__(256) k_outer_counts_mfma(const SpModel m, const double* __restrict__ basis, const long long n_cols,
+                                                           double* __restrict__ eig_re) {
+  extern __shared__ double tile[];                 // [2][Mp][65]: U rows, then D rows
+  const int A = m.A, AA = A * A, N = m.N;
+  const int tm = (A + 15) >> 4, Mp = tm << 4, n_tiles = tm * tm;
+  const int branch = blockIdx.x, cpt = branch / N, r = branch - cpt * N;
+  if (m.parent[r] < 0) return;
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int AP = (A + 1) & ~1;
+  const long long blk_doubles = (long long)m.C * N * 2 * AP * 64;
+  const double* bs = basis + (long long)branch * 2 * AP * 64;
+  for (int e = threadIdx.x; e < 2 * Mp * 65; e += 256) tile[e] = 0.;
+  sp_d4 acc[HX_SP_MAX_TILES];
+#pragma unroll
+  for (int q = 0; q < HX_SP_MAX_TILES; ++q) acc[q] = sp_d4{0., 0., 0., 0.};
+  const long long n_blocks = (n_cols + 63) >> 6;
+  // a block's entries travel through registers: the next block is fetched while this one is multiplied
+  constexpr int PER = (64 * 64) / 256;              // 16-byte entries per thread at the largest alphabet
+  sp_d2 next[PER];
+  const int total = AP * 64;                        // a block's U and D rows: AP / 2 row pairs of 64 lanes each, 16 bytes per entry
+  auto fetch = [&](const long long b) {
+    const sp_d2* src = reinterpret_cast<const sp_d2*>(bs + b * blk_doubles);
+    const long long c0 = b << 6;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = q * 256 + (int)threadIdx.x;
+      if (q * 256 < total) {
+        sp_d2 v = e < total ? src[e] : sp_d2{0., 0.};
+        if (c0 + (e & 63) >= n_cols) v = sp_d2{0., 0.};
+        next[q] = v;
+      }
+    }
+  };
+  if ((long long)blockIdx.y < n_blocks) fetch(blockIdx.y);
+  for (long long b = blockIdx.y; b < n_blocks; b += gridDim.y) {
+    __syncthreads();                               // (the previous block's products are done; the first time: the zero fill)
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int e = q * 256 + (int)threadIdx.x;
+      if (q * 256 < total && e < total) {
+        // entry e: row pair e / 64 (pairs 0 .. AP/2 - 1: U, then D), column e % 64; its two values are rows 2 p and 2 p + 1
+        const int pr = e >> 6, c = e & 63;
+        const int part = pr >= AP / 2, l0 = 2 * (pr - part * (AP / 2));
+        const int trow = part * Mp + l0;
+        tile[trow * 65 + c] = next[q].x;
+        if (l0 + 1 < A) tile[(trow + 1) * 65 + c] = next[q].y;
+      }
+    }
+    __syncthreads();
+    if (b + gridDim.y < n_blocks) fetch(b + gridDim.y);
+#pragma unroll
+    for (int q = 0; q < HX_SP_MAX_TILES; ++q) {
+      const int t = wave + 4 * q;
+      if (t >= n_tiles) break;
+      const int tk = t / tm, tl = t - tk * tm;
+      const double* drow = tile + (Mp + 16 * tk + (lane & 15)) * 65 + (lane >> 4);
+      const double* urow = tile + (16 * tl + (lane & 15)) * 65 + (lane >> 4);
+      sp_d4 c = acc[q];
+#pragma unroll
+      for (int s4 = 0; s4 < 16; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(drow[4 * s4], urow[4 * s4], c, 0, 0, 0);
+      acc[q] = c;
+    }
+  }
+  const double* jr = m.esc_re + (long long)branch * AA;
+#pragma unroll
+  for (int q = 0; q < HX_SP_MAX_TILES; ++q) {
+    const int t = wave + 4 * q;
+    if (t >= n_tiles) break;
+    const int tk = t / tm, tl = t - tk * tm;
+    const int l = 16 * tl + (lane & 15);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int k = 16 * tk + (lane >> 4) + 4 * g;
+      if (k < A && l < A) atomicAdd(&eig_re[(long long)cpt * AA + k * A + l], acc[q][g] * jr[k * A + l]);
+    }
+  }
+}
+
 // out[row] += sum of the row's n_cols entries; one workgroup per row
 __global__ void __launch_bounds__(256) k_row_sums(const double* __restrict__ rows, const long long n_cols, double* __restrict__ out) {
   __shared__ double part[256];
-  const double* row = rows + (long long)blockIdx.x * n_cols;
+  // rows are laid out in blocks of 64 columns: [block][row][64]
+  const double* row = rows + (long long)blockIdx.x * 64;
+  const long long blk_doubles = (long long)gridDim.x * 64;
   double sum = 0.;
-  for (long long c = threadIdx.x; c < n_cols; c += 256) sum += row[c];
+  for (long long c = threadIdx.x; c < n_cols; c += 256) sum += row[(c >> 6) * blk_doubles + (c & 63)];
   part[threadIdx.x] = sum;
   __syncthreads();
   for (int h = 128; h > 0; h >>= 1) {
@@ -468,14 +700,16 @@ int hx_sumprod_columns(const hx_sumprod_model* hm, const int8_t* tokens, const d
   }
 #undef UP
   // columns per chunk: the scratch of a chunk stays within the budget (HX_SUMPROD_SCRATCH_MB, default 16 GiB)
-  const size_t per_col = (2 + (size_t)parts) * C * N * A + 4 * (size_t)C * N + 2 * (size_t)C * A;
+  const int AP = (A + 1) & ~1;                     // message vectors are stored in pairs of entries
+  const size_t per_col = (2 + (size_t)parts) * C * N * AP + 4 * (size_t)C * N + 2 * (size_t)C * A;
   size_t budget = (size_t)16 << 30;
   if (const char* e = getenv("HX_SUMPROD_SCRATCH_MB")) budget = (size_t)atoll(e) << 20;
   long long chunk = (long long)(budget / (per_col * sizeof(double)));
-  if (chunk < 1) chunk = 1;
+  chunk &= ~63LL;                                   // whole blocks of 64 columns
+  if (chunk < 64) chunk = 64;
   if (chunk > n_cols) chunk = n_cols;
   const size_t n_out = (size_t)n_cols * (1 + (root_post ? A : 0)) + (size_t)C * A + 2 * (size_t)C * AA;
-  if (hipMalloc(&b_scr.p, per_col * chunk * sizeof(double)) != hipSuccess || hipMalloc(&b_out.p, n_out * sizeof(double)) != hipSuccess)
+  if (hipMalloc(&b_scr.p, per_col * (((size_t)chunk + 63) & ~(size_t)63) * sizeof(double)) != hipSuccess || hipMalloc(&b_out.p, n_out * sizeof(double)) != hipSuccess)
     return api_fail(HX_ERR_OUT_OF_MEMORY, "hx_sumprod_columns: device allocation failed");
   double* out = static_cast<double*>(b_out.p);
   double* d_cll = out;
@@ -494,12 +728,13 @@ int hx_sumprod_columns(const hx_sumprod_model* hm, const int8_t* tokens, const d
     const long long nc = n_cols - first < chunk ? n_cols - first : chunk;
     double* scr = static_cast<double*>(b_scr.p);
     SpScratch s;
-    const size_t msg = (size_t)C * N * A * nc, lg = (size_t)C * N * nc;
+    const size_t nc64 = ((size_t)nc + 63) & ~(size_t)63;         // the scratch holds whole blocks of 64 columns
+    const size_t msg = (size_t)C * N * AP * nc64, lg = (size_t)C * N * nc64;
     s.E = scr; s.G = scr + msg;
     s.logE = scr + 2 * msg; s.logF = s.logE + lg; s.logG = s.logF + lg; s.maxU = s.logG + lg;
     s.Froot = s.maxU + lg;
-    s.rootc = s.Froot + (size_t)C * A * nc;
-    s.basis = s.rootc + (size_t)C * A * nc;
+    s.rootc = s.Froot + (size_t)C * A * nc64;
+    s.basis = s.rootc + (size_t)C * A * nc64;
     const int tpb = 64 * (C < 8 ? C : 8);            // a wave per mixture component, up to eight
     long long blocks = (nc + 63) / 64;
     if (blocks > 65535) blocks = 65535;
@@ -518,7 +753,15 @@ int hx_sumprod_columns(const hx_sumprod_model* hm, const int8_t* tokens, const d
     const long long tiles = (nc + HX_SP_TILE - 1) / HX_SP_TILE;
     long long slices = 4096 / ((long long)C * N) + 1;
     if (slices > tiles) slices = tiles;
-    if (real_basis)
+    if (real_basis && sizeof(double) * 2 * (((A + 15) / 16) * 16) * 65 <= 64 * 1024 && !getenv("HX_SUMPROD_NO_MFMA")) {
+      const int mp = ((A + 15) / 16) * 16;
+      const long long blocks64 = (nc + 63) / 64;
+      long long sl = 4096 / ((long long)C * N) + 1;
+      if (const char* e = getenv("HX_SUMPROD_SLICES")) sl = atoll(e);
+      if (sl < 1) sl = 1;
+      if (sl > blocks64) sl = blocks64;
+      hipLaunchKernelGGL(k_outer_counts_mfma, dim3((unsigned)(C * N), (unsigned)sl), dim3(256), sizeof(double) * 2 * mp * 65, st, m, s.basis, nc, d_re);
+    } else if (real_basis)
       hipLaunchKernelGGL(k_outer_counts<true>, dim3((unsigned)(C * N), (unsigned)slices), dim3(256), lds, st, m, s.basis, nc, d_re, d_im);
     else
       hipLaunchKernelGGL(k_outer_counts<false>, dim3((unsigned)(C * N), (unsigned)slices), dim3(256), lds, st, m, s.basis, nc, d_re, d_im);
