@@ -344,7 +344,7 @@ public:
 
   const Profile& x, y;
   const bool xEmpty, yEmpty;
-  Profile subx, suby;           // x, y with lpAbsorb left-multiplied by the branch matrices (device result)
+  Profile subx, suby;           // lpAbsorb of x, y left-multiplied by the branch matrices (device result); shells: states carry lpAbsorb only
   const PairHMM& hmm;
   const AlphTok alphSize;
   const ProfileStateIndex xSize, ySize;

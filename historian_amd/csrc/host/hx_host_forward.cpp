@@ -105,8 +105,21 @@ struct FlatProfile {
 };
 }  // namespace
 
+// subx / suby: the reference multiplies a copy of the whole profile (src/profile.cpp:78-91 - states with their
+// alignment paths, sequence coordinates, names).  All a matrix ever reads of them is lpAbsorb, so here they are
+// shells: as many states, emitting where the profile's are, nothing else copied (building and tearing down the
+// full copies was 3-4 ms per internal node, tens of thousands of small allocations).
+static Profile absorbShell(const Profile& p) {
+  Profile s(p.components, p.alphSize, p.rootRowIndex);
+  s.name = p.name;
+  s.state.resize(p.size());
+  for (ProfileStateIndex i = 0; i < p.size(); ++i)
+    if (!p.state[i].isNull()) s.state[i].lpAbsorb.assign(p.components, vguard<LogProb>(p.alphSize, NEG_INF));
+  return s;
+}
+
 DPMatrix::DPMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, const GuideAlignmentEnvelope& env)
-    : x(x), y(y), xEmpty(x.isEmpty()), yEmpty(y.isEmpty()), subx(x), suby(y), hmm(hmm),
+    : x(x), y(y), xEmpty(x.isEmpty()), yEmpty(y.isEmpty()), subx(absorbShell(x)), suby(absorbShell(y)), hmm(hmm),
       alphSize((AlphTok)hmm.alphabetSize()), xSize(x.size()), ySize(y.size()),
       startCell(0, 0, PairHMM::SSS), endCell(xSize - 1, ySize - 1, PairHMM::EEE),
       lpEnd(NEG_INF), envelope(env), xClosestLeafPos(xSize, 0), yClosestLeafPos(ySize, 0),
