@@ -287,6 +287,7 @@ struct Profile {
   void assertAllStatesWaitOrReady() const;
   void assertPathToEndExists() const;
   Profile addReadyStates() const;
+  static Profile withReadyStates(Profile&& src);   // addReadyStates of a profile that is not needed afterwards (moves its states)
   bool isEmpty() const;
   vguard<ProfileStateIndex> examplePathToEnd() const;
 };

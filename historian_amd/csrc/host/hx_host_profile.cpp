@@ -281,25 +281,30 @@ void Profile::assertPathToEndExists() const { (void)examplePathToEnd(); }
 // takes over its absorbing transitions, joined by a null transition of log-weight 0.  States keep their relative order;
 // the new joining transitions are appended to the transition list in state order.
 // ------------------------------------------------------------------------------------------------------------------
-Profile Profile::addReadyStates() const {
-  const ProfileStateIndex n = size();
+Profile Profile::addReadyStates() const { return withReadyStates(Profile(*this)); }
+
+// The same, consuming the profile: states and transitions (with their alignment paths and coordinate maps) are moved into
+// the result, not copied - makeProfile builds a profile only to pass it through here.
+Profile Profile::withReadyStates(Profile&& src) {
+  const ProfileStateIndex n = src.size();
+  const ProfileTransitionIndex nTrans = src.trans.size();
   vguard<char> mixed(n, 0);
   vguard<ProfileStateIndex> moved(n);                // new index of every old state
   ProfileStateIndex next = 0;
   for (ProfileStateIndex s = 0; s < n; ++s) {
-    mixed[s] = !state[s].isReady() && !state[s].isWait();
+    mixed[s] = !src.state[s].isReady() && !src.state[s].isWait();
     moved[s] = next;
     next += mixed[s] ? 2 : 1;
   }
 
-  Profile out(components, alphSize, rootRowIndex);
-  out.name = name;
-  out.meta = meta;
-  out.seq = seq;
-  out.trans = trans;
+  Profile out(src.components, src.alphSize, src.rootRowIndex);
+  out.name = std::move(src.name);
+  out.meta = std::move(src.meta);
+  out.seq = std::move(src.seq);
+  out.trans = std::move(src.trans);
   out.state.reserve(next);
   for (ProfileStateIndex s = 0; s < n; ++s) {
-    out.state.push_back(state[s]);
+    out.state.push_back(std::move(src.state[s]));
     if (!mixed[s]) continue;
     const ProfileTransitionIndex joinIdx = out.trans.size();
     ProfileState& wait = out.state.back();
@@ -313,7 +318,7 @@ Profile Profile::addReadyStates() const {
     wait.nullOut.push_back(joinIdx);
     ProfileTransition join;
     join.src = s;                                     // (old numbering; renumbered with all the others below)
-    join.dest = n + (joinIdx - trans.size());         // a provisional index past the old states: the k-th twin
+    join.dest = n + (joinIdx - nTrans);               // a provisional index past the old states: the k-th twin
     join.lpTrans = 0;
     out.trans.push_back(join);
     out.state.push_back(ready);
@@ -325,13 +330,16 @@ Profile Profile::addReadyStates() const {
   const auto renumber = [&](ProfileStateIndex old) { return old < n ? moved[old] : twin[old - n]; };
   for (ProfileTransitionIndex t = 0; t < out.trans.size(); ++t) {
     ProfileTransition& tr = out.trans[t];
-    // an absorbing transition of a split state now leaves its Ready twin
-    const bool leavesTwin = t < trans.size() && mixed[tr.src] &&
-                            std::find(state[tr.src].absorbOut.begin(), state[tr.src].absorbOut.end(), t) != state[tr.src].absorbOut.end();
+    // an absorbing transition of a split state now leaves its Ready twin (which took over the state's absorbOut list)
+    bool leavesTwin = false;
+    if (t < nTrans && mixed[tr.src]) {
+      const vguard<ProfileTransitionIndex>& taken = out.state[moved[tr.src] + 1].absorbOut;
+      leavesTwin = std::find(taken.begin(), taken.end(), t) != taken.end();
+    }
     tr.src = leavesTwin ? moved[tr.src] + 1 : renumber(tr.src);
     tr.dest = renumber(tr.dest);
   }
-  for (const auto& eq : equivAbsorbState) out.equivAbsorbState[moved[eq.first]] = moved[eq.second];
+  for (const auto& eq : src.equivAbsorbState) out.equivAbsorbState[moved[eq.first]] = moved[eq.second];
   out.assertTransitionsConsistent();
   out.assertAllStatesWaitOrReady();
   out.assertPathToEndExists();

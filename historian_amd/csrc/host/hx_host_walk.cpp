@@ -550,7 +550,7 @@ Profile ForwardMatrix::makeProfile(const set<CellCoords>& cells, ProfilingStrate
   prof.seq.insert(y.seq.begin(), y.seq.end());
   prof.assertTransitionsConsistent();
   prof.assertPathToEndExists();
-  prof = prof.addReadyStates();
+  prof = Profile::withReadyStates(std::move(prof));
   prof.assertSeqCoordsConsistent();
   fillTiming.hostMakeProfile += wallSeconds() - tStart;
   return prof;
