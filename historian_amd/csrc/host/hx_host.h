@@ -56,6 +56,7 @@ void Fail(const char* error, ...);    // message + exit(EXIT_FAILURE)
 // when HX_TIMING is set.  Not part of the reference's interface.
 struct FillTiming {
   double deviceInit = 0, flattenAndUpload = 0, forwardWait = 0, forwardKernel = 0, backwardWait = 0, readMatrix = 0;
+  double construct = 0, readPrepared = 0;      // DPMatrix constructor (host-side vectors, envelope coordinates); hx_batch_read_prepared + lpAbsorb fill
   double deviceTrace = 0, cellGather = 0;
   double hostTraces = 0, hostMakeProfile = 0;      // host tracebacks (sampled, or best without the device kernel), makeProfile
   double pinnedAlloc = 0; long pinnedAllocs = 0;   // page-locked buffers allocated for matrix copies (inside readMatrix)

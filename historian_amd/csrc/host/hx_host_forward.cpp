@@ -185,7 +185,7 @@ struct PinnedPool {
       freeList.erase(freeList.begin() + (long)small);
     }
     void* p = NULL;
-    cap = n + n / 8;
+    cap = n + n / 2;                                    // (profiles grow towards the root: leave room for the next few matrices)
     const double t0 = wallSeconds();
     hxCheck(hx_host_alloc(cap * sizeof(double), &p), "hx_host_alloc");
     fillTiming.pinnedAlloc += wallSeconds() - t0;
@@ -228,6 +228,7 @@ void setThreadDevice(int ordinal) { t_device = ordinal; }
 void mergeTiming(const FillTiming& a, FillTiming& b) {
   b.deviceInit += a.deviceInit; b.flattenAndUpload += a.flattenAndUpload; b.forwardWait += a.forwardWait;
   b.forwardKernel += a.forwardKernel; b.backwardWait += a.backwardWait; b.readMatrix += a.readMatrix;
+  b.construct += a.construct; b.readPrepared += a.readPrepared;
   b.deviceTrace += a.deviceTrace; b.cellGather += a.cellGather; b.hostTraces += a.hostTraces; b.hostMakeProfile += a.hostMakeProfile; b.cellSets += a.cellSets; b.retain += a.retain; b.pinnedAlloc += a.pinnedAlloc; b.pinnedAllocs += a.pinnedAllocs;
   b.fills += a.fills; b.matrixReads += a.matrixReads; b.deviceTraces += a.deviceTraces; b.cellGathers += a.cellGathers; b.cells += a.cells;
 }
@@ -304,6 +305,12 @@ void DPMatrix::createBatchAndPrepare() {
   std::shared_ptr<BatchHandle> h(new BatchHandle(b, 1));
   const double t1 = wallSeconds();
   hxCheck(hx_batch_forward(b, NULL), "hx_batch_forward");
+  {
+    // while the fill runs: a page-locked buffer for this matrix, if the pool has none large enough
+    hx_layout lay;
+    hxCheck(hx_batch_layout(b, 0, 0, &lay), "hx_batch_layout");
+    g_pinned.reserve((size_t)lay.matrix_doubles);
+  }
   double lp = NEG_INF;
   hxCheck(hx_batch_lp_end(b, &lp), "hx_batch_lp_end");
   const double t2 = wallSeconds();
@@ -418,6 +425,7 @@ vguard<ForwardMatrix*> ForwardMatrix::fillBatch(const vguard<JobSpec>& jobs, con
 }
 
 void DPMatrix::fetchPrepared() {
+  const double tPrep = wallSeconds();
   const size_t C = hmm.components(), A = hmm.alphabetSize();
   vguard<double> sx(xSize * C * A), sy(ySize * C * A);
   hxCheck(hx_batch_read_prepared(batch, jobIndex, sx.data(), sy.data(), insx.data(), rootsubx.data(), insy.data(), rootsuby.data()),
@@ -430,6 +438,7 @@ void DPMatrix::fetchPrepared() {
     if (!suby.state[j].isNull())
       for (size_t c = 0; c < C; ++c)
         for (size_t a = 0; a < A; ++a) suby.state[j].lpAbsorb[c][a] = sy[(j * C + c) * A + a];
+  fillTiming.readPrepared += wallSeconds() - tPrep;
 }
 
 void DPMatrix::startHostCopy() const {

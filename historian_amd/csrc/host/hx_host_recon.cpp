@@ -115,6 +115,7 @@ void Reconstructor::reconstruct(Dataset& dataset) {
     detail::warmHostBuffers(5 * side * side, 4);
   }
   auto envelopeFor = [&](TreeNodeIndex node, int maxDist) {
+    struct Timed { double t0; ~Timed() { fillTiming.construct += wallSeconds() - t0; } } timed{wallSeconds()};
     return dataset.guide.empty() ? GuideAlignmentEnvelope()
                                  : GuideAlignmentEnvelope(dataset.guide, dataset.closestLeaf[dataset.tree.getChild(node, 0)],
                                                           dataset.closestLeaf[dataset.tree.getChild(node, 1)], maxDist);
