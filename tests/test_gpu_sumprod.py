@@ -105,7 +105,11 @@ def _random_columns(rng, parent, alphabet, n_cols):
     return ["".join(r) for r in rows]
 
 
-def test_protein_mixture_columns_on_a_nine_leaf_tree():
+@pytest.mark.parametrize("outer", ["matrix cores", "vector units"])
+def test_protein_mixture_columns_on_a_nine_leaf_tree(outer, monkeypatch):
+    # (the outer-product sums of real eigen bases run on the f64 matrix cores; HX_SUMPROD_NO_MFMA keeps the vector-ALU kernel)
+    if outer == "vector units":
+        monkeypatch.setenv("HX_SUMPROD_NO_MFMA", "1")
     with open(PROT4) as f:
         omodel = ho.RateModel(json.load(f))
     model = hostmodel.RateModel.load(PROT4)
