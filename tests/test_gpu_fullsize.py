@@ -159,3 +159,46 @@ def test_config4_batch_of_512_pairs_forward_equals_backward_in_every_policy():
         b.close()
     assert np.max(np.abs(lp["fast"] - lp["exact"]) / np.abs(lp["exact"])) <= 1e-9
     assert np.max(np.abs(lp["linear"] - lp["exact"]) / np.abs(lp["exact"])) <= 1e-5
+
+
+def test_config4_batch_banded_as_the_reference_runs_it(monkeypatch):
+    """The same batch in the reference's default mode - every fill inside a band of 20 around the guide alignment
+    (src/forward.h:92-98, src/alignpath.cpp:282-310) - at size: 512 pairs of 2x2000 residues, Forward and Backward in the
+    banded rotating-row sweep (hx_band.hip), every policy.  Properties over all 512 pairs: both fills run the sweep
+    (hx_batch_job_kernel), lpStart == lpEnd, fast / scaled probabilities within 1e-9 / 1e-5 of exact, the Backward sweep's
+    lpStart bit for bit that of the strip pipeline it replaces (table policies); and the CPU oracle on three of the pairs:
+    lpEnd and lpStart bit for bit in exact mode."""
+    import os
+    from historian_amd import hostmodel, workload
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = hostmodel.RateModel.load(os.path.join(root, "tests", "golden", "models", "wag.json"))
+    hmm = hostmodel.make_hmm(model, .2, .3)
+    jobs = [workload.leaf_pair(np.random.default_rng(4000 + k), model, hmm, 2000, band=20) for k in range(512)]
+    lp = {}
+    for name, flags in (("exact", 0), ("fast", capi.HX_LSE_FAST), ("linear", capi.HX_LSE_LINEAR)):
+        b = capi.Batch(jobs, flags | capi.HX_KEEP_BACKWARD | capi.HX_SPARSE_ENVELOPE)
+        kern = [b.job_kernel(k) for k in range(len(jobs))]
+        assert all(c == 2 and s for c, s in kern), "every pair in the rotating-row sweep, both directions"
+        b.forward()
+        b.backward()
+        le, ls = b.lp_end().copy(), b.lp_start().copy()
+        assert np.all(np.isfinite(le)) and np.all(le < 0)
+        assert np.max(np.abs(ls - le) / np.abs(le)) <= (1e-11 if name == "linear" else 1e-6), name
+        lp[name] = le
+        if name == "exact":
+            for k in (0, 255, 511):
+                x, y, h, md = jobs[k]
+                H.assert_same_bits([le[k]], [c_oracle.forward(x, y, h, md)["lp_end"]], "lpEnd of pair %d" % k)
+                H.assert_same_bits([ls[k]], [c_oracle.backward(x, y, h, md)["lp_start"]], "lpStart of pair %d" % k)
+        b.close()
+        if name != "linear":
+            monkeypatch.setenv("HX_BAND_BWD_OLD", "1")
+            o = capi.Batch(jobs, flags | capi.HX_KEEP_BACKWARD | capi.HX_SPARSE_ENVELOPE)
+            assert not any(s for c, s in (o.job_kernel(k) for k in range(len(jobs))))
+            o.forward()
+            o.backward()
+            H.assert_same_bits(o.lp_start(), ls, "lpStart, sweep vs strip pipeline, " + name)
+            o.close()
+            monkeypatch.delenv("HX_BAND_BWD_OLD")
+    assert np.max(np.abs(lp["fast"] - lp["exact"]) / np.abs(lp["exact"])) <= 1e-9
+    assert np.max(np.abs(lp["linear"] - lp["exact"]) / np.abs(lp["exact"])) <= 1e-5
