@@ -169,6 +169,50 @@ def test_complex_eigenvectors_and_column_chunks(monkeypatch):
     np.testing.assert_array_equal(whole["col_log_like"], got["col_log_like"])
 
 
+def _random_model(rng, alphabet, reversible):
+    a = len(alphabet)
+    pi = rng.dirichlet(np.ones(a) * 3.)
+    if reversible:
+        sym = rng.uniform(.05, 1.5, (a, a))
+        sym = (sym + sym.T) / 2.
+        rate = sym * pi[None, :]                              # detailed balance: pi_i R_ij = pi_j R_ji (real eigenvectors)
+    else:
+        rate = rng.uniform(.02, 1.5, (a, a))
+        for k in range(a):
+            rate[k, (k + 1) % a] += 2.                            # a cyclic drift: complex eigenvalues
+    return {"alphabet": alphabet, "insrate": .02, "delrate": .02, "insextprob": .4, "delextprob": .4,
+            "rootprob": {alphabet[i]: float(pi[i]) for i in range(a)},
+            "subrate": {alphabet[i]: {alphabet[j]: float(rate[i, j]) for j in range(a) if j != i} for i in range(a)}}
+
+
+@pytest.mark.parametrize("alphabet,reversible", [("acgtu", True), ("acgtu", False), ("abcdefghijklmnopqrstu", True),
+                                                 ("abcdefghijklmnopqrstuvwyz012345678", True), ("ab", True)])
+def test_alphabets_without_a_kernel_of_their_own(alphabet, reversible):
+    """Alphabet sizes other than 4 and 20 take the any-alphabet instantiation (message vectors in private memory): an odd
+    size (the scratch stores vector entries in pairs: one padding entry), 21 and 34 symbols (two and three 16 x 16 tiles per
+    side of the matrix-core product, rows past the alphabet zero), 2 symbols; real and complex eigenvectors.  Column
+    likelihoods, root counts and substitution counts against the oracle."""
+    rng = np.random.default_rng(len(alphabet) * 2 + reversible)
+    js = _random_model(rng, alphabet, reversible)
+    omodel, model = ho.RateModel(js), hostmodel.RateModel(js)
+    parent, length = _random_tree(rng, 7)
+    tree = so.Tree(parent, length, ["n%d" % k for k in range(len(parent))])
+    rows = _random_columns(rng, parent, alphabet, 333)                # (not a multiple of 64: a partly filled block)
+    cc = counts.ColumnCounter(model, parent, length)
+    assert (np.abs(np.asarray(cc.eigen.evec).imag).max() > 1e-6) == (not reversible)
+    got = cc.run(counts.tokenize_columns(alphabet, rows))
+    want_root, want, eig, sp = so.counts_for_alignment(omodel, tree, dict(enumerate(rows)))
+    np.testing.assert_allclose(got["root_counts"][0], want_root[0], rtol=1e-9)
+    np.testing.assert_allclose(got["eigen_counts"][0], eig[0], rtol=0, atol=1e-9 * np.abs(eig[0]).max())
+    np.testing.assert_allclose(got["counts"][0], want[0], rtol=0, atol=1e-8 * np.abs(want[0]).max())
+    for col, seq in enumerate(so.columns_of(tree, dict(enumerate(rows)))):
+        if col % 37:
+            continue
+        sp.init_column(seq)
+        sp.fill_up()
+        assert abs(got["col_log_like"][col] - sp.col_log_like) <= 1e-11 * abs(sp.col_log_like) + 1e-13, col      # (an all-wildcard column: 0)
+
+
 @pytest.mark.parametrize("model_file,fasta,newick,expected", [
     ("testcount.jukescantor.json", "testcount.fa", "testcount.nh", "testcount.out.json"),
     ("testcount.jukescantor.json", "testcount.historian.fa", "testcount.nh", "testcount.count.json"),
