@@ -260,6 +260,10 @@ def test_error_codes():
     b.forward()
     b.backward()                                 # Backward matrix is allocated on demand
     assert abs(b.lp_start()[0] - b.lp_end()[0]) < 1e-6
+    assert b.job_kernel(0) == (0, False)         # an unbanded leaf pair whose y side fits LDS; Backward in the strip pipeline
+    with pytest.raises(capi.HxError) as e:
+        b.job_kernel(1)                          # no such pair
+    assert e.value.code == -8                    # HX_ERR_RANGE
     b.close()
     # non-toposorted transition
     bad = capi.ProfileImage(x.trans_src.copy(), x.trans_dst.copy(), x.trans_lp,
