@@ -32,6 +32,10 @@ namespace {
 
 #define HX_SP_RESCALE 1e-30        // SUMPROD_RESCALE_THRESHOLD (src/sumprod.cpp:8)
 #define HX_SP_TILE 32              // columns per LDS tile of k_outer_counts
+#ifndef HX_SP_WAVES_PER_SIMD
+#define HX_SP_WAVES_PER_SIMD 2    // the column kernel's register budget: 512 / this.  Four waves per SIMD (128 registers, 49 spilled doubles)
+                                  // run at the same rate: the kernel is bound by the traffic it moves, not by the latency it hides
+#endif
 #define HX_SP_PAIRS 16             // (k,l) pairs per thread of k_outer_counts: A*A <= 256 * 16, A <= 64
 
 struct SpModel {
@@ -60,72 +64,51 @@ typedef const __attribute__((address_space(4))) double* CMat;
 __device__ __forceinline__ CMat cmat(const double* p) { return (CMat)(unsigned long long)p; }
 
 // Matrix-vector products with a matrix that a wave keeps in LDS (row-major, A x A, 16-byte aligned rows: A even).  Every
-// lane reads the same entries (broadcast reads, two entries per ds_read_b128); a row is fetched a whole row ahead of its
-// use into registers of its own, so that no read is waited for - written the plain way the compiler, short of registers,
-// reused one register pair for every read and waited for each (one multiply-add per ~50 cycles).
+// lane reads the same entries (broadcast reads, two entries per ds_read_b128); half a row is fetched half a row ahead of
+// its use into registers of its own, so that no read is waited for - written the plain way the compiler, short of
+// registers, reused one register pair for every read and waited for each (one multiply-add per ~50 cycles).  Products
+// with the transposed matrix (y = x M) use the same routine on a transposed LDS copy: one vector in registers, results
+// handed out as they are complete - the kernel stays within 128 registers, four waves per SIMD.
 typedef double sp_d2 __attribute__((ext_vector_type(2)));
-template <int A>
-struct LdsRow {
-  sp_d2 v[A / 2];
-  __device__ __forceinline__ void fetch(const HX_LDS double* row) {
+template <int H>                                    // H entries (H even)
+struct LdsPiece {
+  sp_d2 v[H / 2];
+  __device__ __forceinline__ void fetch(const HX_LDS double* p) {
 #pragma unroll
-    for (int q = 0; q < A / 2; ++q) v[q] = reinterpret_cast<const HX_LDS sp_d2*>(row)[q];
+    for (int q = 0; q < H / 2; ++q) v[q] = reinterpret_cast<const HX_LDS sp_d2*>(p)[q];
   }
   __device__ __forceinline__ double at(const int b) const { return (b & 1) ? v[b >> 1].y : v[b >> 1].x; }
 };
-// y[a] = sum_b M[a][b] x[b]   (four partial sums per row: the additions of a row do not wait for one another); the results
-// are handed out two rows at a time (A even), the way the scratch stores them
+// y[a] = sum_b M[a][b] x[b], handed out two rows at a time (A even), the way the scratch stores them; two partial sums per
+// row and half (the additions do not wait for one another)
 template <int A, class Emit>
 __device__ __forceinline__ void lds_mat_vec(const HX_LDS double* M, const double (&x)[A], const Emit& emit) {
-  LdsRow<A> r0, r1;
-  r0.fetch(M);
+  constexpr int H0 = ((A / 2) + 1) & ~1, H1 = A - H0;      // a row in two pieces of even length (20 = 10 + 10, 4 = 2 + 2)
+  static_assert(H1 >= 0 && (H1 & 1) == 0, "even alphabet sizes");
+  LdsPiece<H0> lo;
+  LdsPiece<(H1 > 0 ? H1 : 2)> hi;
+  lo.fetch(M);
+  double ya = 0.;
 #pragma unroll
-  for (int a = 0; a < A; a += 2) {
-    r1.fetch(M + (a + 1) * A);
-    double ya, yb;
-    {
-      double p0 = 0., p1 = 0., p2 = 0., p3 = 0.;
+  for (int a = 0; a < A; ++a) {
+    if (H1 > 0) hi.fetch(M + a * A + H0);
+    double p0 = 0., p1 = 0.;
 #pragma unroll
-      for (int b = 0; b < A; b += 4) {
-        p0 = __builtin_fma(r0.at(b), x[b], p0);
-        if (b + 1 < A) p1 = __builtin_fma(r0.at(b + 1), x[b + 1], p1);
-        if (b + 2 < A) p2 = __builtin_fma(r0.at(b + 2), x[b + 2], p2);
-        if (b + 3 < A) p3 = __builtin_fma(r0.at(b + 3), x[b + 3], p3);
+    for (int b = 0; b < H0; b += 2) {
+      p0 = __builtin_fma(lo.at(b), x[b], p0);
+      p1 = __builtin_fma(lo.at(b + 1), x[b + 1], p1);
+    }
+    if (a + 1 < A) lo.fetch(M + (a + 1) * A);
+    if (H1 > 0) {
+#pragma unroll
+      for (int b = 0; b < H1; b += 2) {
+        p0 = __builtin_fma(hi.at(b), x[H0 + b], p0);
+        p1 = __builtin_fma(hi.at(b + 1), x[H0 + b + 1], p1);
       }
-      ya = (p0 + p1) + (p2 + p3);
     }
-    if (a + 2 < A) r0.fetch(M + (a + 2) * A);
-    {
-      double p0 = 0., p1 = 0., p2 = 0., p3 = 0.;
-#pragma unroll
-      for (int b = 0; b < A; b += 4) {
-        p0 = __builtin_fma(r1.at(b), x[b], p0);
-        if (b + 1 < A) p1 = __builtin_fma(r1.at(b + 1), x[b + 1], p1);
-        if (b + 2 < A) p2 = __builtin_fma(r1.at(b + 2), x[b + 2], p2);
-        if (b + 3 < A) p3 = __builtin_fma(r1.at(b + 3), x[b + 3], p3);
-      }
-      yb = (p0 + p1) + (p2 + p3);
-    }
-    emit(a >> 1, ya, yb);
-  }
-}
-// y[b] = sum_a x[a] M[a][b]   (A independent accumulators)
-template <int A>
-__device__ __forceinline__ void lds_vec_mat(const HX_LDS double* M, const double (&x)[A], double (&y)[A]) {
-  LdsRow<A> r0, r1;
-  r0.fetch(M);
-#pragma unroll
-  for (int b = 0; b < A; ++b) y[b] = 0.;
-#pragma unroll
-  for (int a = 0; a < A; a += 2) {
-    if (a + 1 < A) r1.fetch(M + (a + 1) * A);
-#pragma unroll
-    for (int b = 0; b < A; ++b) y[b] = __builtin_fma(x[a], r0.at(b), y[b]);
-    if (a + 2 < A) r0.fetch(M + (a + 2) * A);
-    if (a + 1 < A) {
-#pragma unroll
-      for (int b = 0; b < A; ++b) y[b] = __builtin_fma(x[a + 1], r1.at(b), y[b]);
-    }
+    const double y = p0 + p1;
+    if (a & 1) emit(a >> 1, ya, y);
+    else ya = y;
   }
 }
 
@@ -135,7 +118,7 @@ __device__ __forceinline__ void lds_vec_mat(const HX_LDS double* M, const double
 // parts of the eigenvectors and of their inverse (per component) - and reads their entries as LDS broadcasts; without it
 // they come through the scalar cache, which the 3 KB per matrix-vector product overrun (2.9 TFLOP/s, one FMA per ~100 cycles).
 template <int TA, bool LM>
-__global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const signed char* __restrict__ tok, const double* __restrict__ weight,
+__global__ void __launch_bounds__(512, HX_SP_WAVES_PER_SIMD) k_sumprod_columns(const SpModel m, const signed char* __restrict__ tok, const double* __restrict__ weight,
                                                          const long long n_cols, const SpScratch s, const double* __restrict__ lse_tab,
                                                          double* __restrict__ col_log_like, double* __restrict__ root_post) {
   constexpr int AX = TA ? TA : 64;
@@ -199,7 +182,12 @@ __global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const 
       CMat ins = cmat(m.ins_prob + cpt * A);
       if (LM) {
         wave_sync();
-        for (int k = lane; k < AA; k += 64) { Linv[k] = m.einv_re[(long long)cpt * AA + k]; Lvec[k] = m.evec_re[(long long)cpt * AA + k]; }
+        for (int k = lane; k < AA; k += 64) {
+          Linv[k] = m.einv_re[(long long)cpt * AA + k];
+          // (the root-to-tip pass multiplies with the transposed matrices: staged transposed where the row routine is used)
+          if constexpr (TA != 0 && TA % 2 == 0) Lvec[(k % A) * A + k / A] = m.evec_re[(long long)cpt * AA + k];
+          else Lvec[k] = m.evec_re[(long long)cpt * AA + k];
+        }
       }
       for (int r = 0; r < N; ++r) {
         if (LM && m.parent[r] >= 0) {
@@ -328,12 +316,18 @@ __global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const 
       CMat ins = cmat(m.ins_prob + cpt * A);
       if (LM && C > Wb) {                            // (with a wave per component the eigenvectors are still there)
         wave_sync();
-        for (int k = lane; k < AA; k += 64) Lvec[k] = m.evec_re[(long long)cpt * AA + k];
+        for (int k = lane; k < AA; k += 64) {
+          if constexpr (TA != 0 && TA % 2 == 0) Lvec[(k % A) * A + k / A] = m.evec_re[(long long)cpt * AA + k];
+          else Lvec[k] = m.evec_re[(long long)cpt * AA + k];
+        }
       }
       for (int r = N - 1; r >= 0; --r) {
         if (LM && m.parent[r] >= 0) {
           wave_sync();
-          for (int k = lane; k < AA; k += 64) Lsub[k] = m.branch_sub[((long long)cpt * N + r) * AA + k];
+          for (int k = lane; k < AA; k += 64) {
+            if constexpr (TA != 0 && TA % 2 == 0) Lsub[(k % A) * A + k / A] = m.branch_sub[((long long)cpt * N + r) * AA + k];
+            else Lsub[k] = m.branch_sub[((long long)cpt * N + r) * AA + k];
+          }
           wave_sync();
         }
         if (!busy) continue;
@@ -376,9 +370,8 @@ __global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const 
           }
         }
         if constexpr (LM && TA != 0 && TA % 2 == 0) {
-          double g[AX];
-          lds_vec_mat<AX>(Lsub, d, g);
-          put_row(EROW(s.G, cpt, r), [&](const int b) { return g[b]; });
+          double* rp = EROW(s.G, cpt, r);
+          lds_mat_vec<AX>(Lsub, d, [&](const int q, const double ga, const double gb) { *reinterpret_cast<sp_d2*>(rp + q * 128) = sp_d2{ga, gb}; });
         } else {
 #pragma unroll
           for (int b = 0; b < A; ++b) {
@@ -394,9 +387,8 @@ __global__ void __launch_bounds__(512) k_sumprod_columns(const SpModel m, const 
           const double inv_max = 1. / max_d;
 #pragma unroll
           for (int a = 0; a < A; ++a) d[a] *= inv_max;
-          double dr[AX];
-          lds_vec_mat<AX>(Lvec, d, dr);
-          put_row(BROW(cpt, r, 1), [&](const int k) { return dr[k] * scale; });
+          double* rp = BROW(cpt, r, 1);
+          lds_mat_vec<AX>(Lvec, d, [&](const int q, const double da, const double db) { *reinterpret_cast<sp_d2*>(rp + q * 128) = sp_d2{da * scale, db * scale}; });
         } else {
 #pragma unroll
           for (int a = 0; a < A; ++a) d[a] /= max_d;
