@@ -510,6 +510,7 @@ __global__ void __launch_bounds__(256) k_outer_counts(const SpModel m, const dou
 // register q of lane l is C[(l >> 4) + 4 q][l & 15].  Rows past A are zero in LDS.
 typedef double sp_d4 __attribute__((ext_vector_type(4)));
 #define HX_SP_MAX_TILES 4          // tiles per wave: A <= 64 -> (A / 16)^2 <= 16 tiles over four waves
+template <int PER>                                  // 16-byte entries of a block per thread: >= ceil(A / 2) * 2 * 64 / 256
 __global__ void __launch_bounds__(256) k_outer_counts_mfma(const SpModel m, const double* __restrict__ basis, const long long n_cols,
                                                            double* __restrict__ eig_re) {
   extern __shared__ double tile[];                 // [2][Mp][65]: U rows, then D rows
@@ -526,11 +527,11 @@ __global__ void __launch_bounds__(256) k_outer_counts_mfma(const SpModel m, cons
 #pragma unroll
   for (int q = 0; q < HX_SP_MAX_TILES; ++q) acc[q] = sp_d4{0., 0., 0., 0.};
   const long long n_blocks = (n_cols + 63) >> 6;
-  // a block's entries travel through registers: the next block is fetched while this one is multiplied
-  constexpr int PER = (64 * 64) / 256;              // 16-byte entries per thread at the largest alphabet
-  sp_d2 next[PER];
+  // a block's entries travel through registers, two blocks ahead: the blocks after this one are in flight while it is multiplied
+  sp_d2 bufA[PER], bufB[PER];
   const int total = AP * 64;                        // a block's U and D rows: AP / 2 row pairs of 64 lanes each, 16 bytes per entry
-  auto fetch = [&](const long long b) {
+  const auto fetch = [&](sp_d2 (&buf)[PER], const long long b) {
+    if (b >= n_blocks) return;
     const sp_d2* src = reinterpret_cast<const sp_d2*>(bs + b * blk_doubles);
     const long long c0 = b << 6;
 #pragma unroll
@@ -539,12 +540,11 @@ __global__ void __launch_bounds__(256) k_outer_counts_mfma(const SpModel m, cons
       if (q * 256 < total) {
         sp_d2 v = e < total ? src[e] : sp_d2{0., 0.};
         if (c0 + (e & 63) >= n_cols) v = sp_d2{0., 0.};
-        next[q] = v;
+        buf[q] = v;
       }
     }
   };
-  if ((long long)blockIdx.y < n_blocks) fetch(blockIdx.y);
-  for (long long b = blockIdx.y; b < n_blocks; b += gridDim.y) {
+  const auto multiply = [&](const sp_d2 (&buf)[PER]) {
     __syncthreads();                               // (the previous block's products are done; the first time: the zero fill)
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
@@ -554,12 +554,13 @@ __global__ void __launch_bounds__(256) k_outer_counts_mfma(const SpModel m, cons
         const int pr = e >> 6, c = e & 63;
         const int part = pr >= AP / 2, l0 = 2 * (pr - part * (AP / 2));
         const int trow = part * Mp + l0;
-        tile[trow * 65 + c] = next[q].x;
-        if (l0 + 1 < A) tile[(trow + 1) * 65 + c] = next[q].y;
+        tile[trow * 65 + c] = buf[q].x;
+        if (l0 + 1 < A) tile[(trow + 1) * 65 + c] = buf[q].y;
       }
     }
     __syncthreads();
-    if (b + gridDim.y < n_blocks) fetch(b + gridDim.y);
+  };
+  const auto products = [&]() {
 #pragma unroll
     for (int q = 0; q < HX_SP_MAX_TILES; ++q) {
       const int t = wave + 4 * q;
@@ -572,6 +573,18 @@ __global__ void __launch_bounds__(256) k_outer_counts_mfma(const SpModel m, cons
       for (int s4 = 0; s4 < 16; ++s4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(drow[4 * s4], urow[4 * s4], c, 0, 0, 0);
       acc[q] = c;
     }
+  };
+  const long long step = gridDim.y;
+  fetch(bufA, blockIdx.y);
+  fetch(bufB, blockIdx.y + step);
+  for (long long b = blockIdx.y; b < n_blocks; b += 2 * step) {
+    multiply(bufA);
+    fetch(bufA, b + 2 * step);
+    products();
+    if (b + step >= n_blocks) break;
+    multiply(bufB);
+    fetch(bufB, b + 3 * step);
+    products();
   }
   const double* jr = m.esc_re + (long long)branch * AA;
 #pragma unroll
@@ -595,14 +608,16 @@ __global__ void __launch_bounds__(256) k_row_sums(const double* __restrict__ row
   const double* row = rows + (long long)blockIdx.x * 64;
   const long long blk_doubles = (long long)gridDim.x * 64;
   double sum = 0.;
-  for (long long c = threadIdx.x; c < n_cols; c += 256) sum += row[(c >> 6) * blk_doubles + (c & 63)];
+  // grid (rows, slices of the columns): a slice's partial sum is added with one atomic
+  for (long long c = (long long)blockIdx.y * 256 + threadIdx.x; c < n_cols; c += (long long)gridDim.y * 256)
+    sum += row[(c >> 6) * blk_doubles + (c & 63)];
   part[threadIdx.x] = sum;
   __syncthreads();
   for (int h = 128; h > 0; h >>= 1) {
     if ((int)threadIdx.x < h) part[threadIdx.x] += part[threadIdx.x + h];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[blockIdx.x] += part[0];
+  if (threadIdx.x == 0) atomicAdd(&out[blockIdx.x], part[0]);
 }
 
 thread_local float g_sp_ms = 0.f;
@@ -748,16 +763,24 @@ int hx_sumprod_columns(const hx_sumprod_model* hm, const int8_t* tokens, const d
     if (real_basis && sizeof(double) * 2 * (((A + 15) / 16) * 16) * 65 <= 64 * 1024 && !getenv("HX_SUMPROD_NO_MFMA")) {
       const int mp = ((A + 15) / 16) * 16;
       const long long blocks64 = (nc + 63) / 64;
-      long long sl = 4096 / ((long long)C * N) + 1;
+      long long sl = 8192 / ((long long)C * N) + 1;          // (measured: 4.46 / 4.35 / 4.23 ms per 100 000 columns at 8 / 34 / 68 slices)
       if (const char* e = getenv("HX_SUMPROD_SLICES")) sl = atoll(e);
       if (sl < 1) sl = 1;
       if (sl > blocks64) sl = blocks64;
-      hipLaunchKernelGGL(k_outer_counts_mfma, dim3((unsigned)(C * N), (unsigned)sl), dim3(256), sizeof(double) * 2 * mp * 65, st, m, s.basis, nc, d_re);
+      const size_t tile_lds = sizeof(double) * 2 * mp * 65;
+      const dim3 og((unsigned)(C * N), (unsigned)sl);
+      if (AP <= 4) hipLaunchKernelGGL(k_outer_counts_mfma<1>, og, dim3(256), tile_lds, st, m, s.basis, nc, d_re);
+      else if (AP <= 20) hipLaunchKernelGGL(k_outer_counts_mfma<5>, og, dim3(256), tile_lds, st, m, s.basis, nc, d_re);
+      else hipLaunchKernelGGL(k_outer_counts_mfma<16>, og, dim3(256), tile_lds, st, m, s.basis, nc, d_re);
     } else if (real_basis)
       hipLaunchKernelGGL(k_outer_counts<true>, dim3((unsigned)(C * N), (unsigned)slices), dim3(256), lds, st, m, s.basis, nc, d_re, d_im);
     else
       hipLaunchKernelGGL(k_outer_counts<false>, dim3((unsigned)(C * N), (unsigned)slices), dim3(256), lds, st, m, s.basis, nc, d_re, d_im);
-    hipLaunchKernelGGL(k_row_sums, dim3((unsigned)(C * A)), dim3(256), 0, st, s.rootc, nc, d_root);
+    {
+      long long rs = (nc + 4095) / 4096;                      // at least 4 096 columns per slice
+      if (rs > 64) rs = 64;
+      hipLaunchKernelGGL(k_row_sums, dim3((unsigned)(C * A), (unsigned)rs), dim3(256), 0, st, s.rootc, nc, d_root);
+    }
   }
   (void)hipEventRecord(e1, st);
   int rc = HX_OK;
