@@ -828,18 +828,23 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
           build_band_rows(pj.x->env_pos, pj.y->env_pos, xf.data(), yf.data(), xecls.data(), jo.x.empty != 0, J.n_rows, J.n_cols,
                           pj.max_distance, J.strip_stride, J.blk, jo.compressed ? cwin_keep.data() : nullptr,
                           jo.compressed ? cbase_keep.data() : nullptr, rows, n_steps)) {
-        jo.band_rows = ar.put(rows.data(), sizeof(int32_t) * rows.size());
-        J.band_steps = n_steps;
-        kc = kclass[k] = KC_LEAF_ROT_BANDED;
-        // the Backward sweep of the same kernel (dense planes); a pair it does not take keeps the strip pipeline
+        // the Backward sweep of the same kernel (dense planes: band-compressed batches have no Backward).  A pair the
+        // Backward sweep cannot take (fewer than three rows or columns) stays out of the class altogether, so that the
+        // class never falls back to the strip pipeline because of one such pair.
         std::vector<int32_t> rows_b;
         int n_steps_b = 0;
-        J.band_steps_bwd = 0;
-        if (!jo.compressed &&
+        const bool bwd_ok = jo.compressed ||
             build_band_rows_bwd(pj.x->env_pos, pj.y->env_pos, xf.data(), yf.data(), xecls.data(), jo.x.empty != 0, jo.y.empty != 0, J.n_rows, J.n_cols,
-                                pj.max_distance, J.strip_stride, J.blk, rows_b, n_steps_b)) {
-          jo.band_rows_bwd = ar.put(rows_b.data(), sizeof(int32_t) * rows_b.size());
-          J.band_steps_bwd = n_steps_b;
+                                pj.max_distance, J.strip_stride, J.blk, rows_b, n_steps_b);
+        if (bwd_ok) {
+          jo.band_rows = ar.put(rows.data(), sizeof(int32_t) * rows.size());
+          J.band_steps = n_steps;
+          kc = kclass[k] = KC_LEAF_ROT_BANDED;
+          J.band_steps_bwd = 0;
+          if (!jo.compressed) {
+            jo.band_rows_bwd = ar.put(rows_b.data(), sizeof(int32_t) * rows_b.size());
+            J.band_steps_bwd = n_steps_b;
+          }
         }
       }
     }

@@ -630,13 +630,13 @@ def test_banded_backward_in_the_rotating_row_sweep(ppw, monkeypatch):
         b.close()
 
 
-def test_banded_backward_keeps_the_strip_pipeline_when_a_pair_cannot_take_the_sweep():
-    # The Backward sweep needs at least three rows and columns; the Forward sweep two.  A one-residue sequence in a banded batch
-    # is in the sweep's class for Forward, and the class as a whole then runs Backward in the strip pipeline: same cells.
+def test_a_pair_too_small_for_the_backward_sweep_stays_out_of_its_class():
+    # The Backward sweep needs at least three rows and columns.  A one-residue sequence in a banded batch keeps the strip
+    # pipelines for both fills (class 1), so that the other pairs' class runs both directions in the rotating-row sweep.
     cases = [H.leaf_case(901, 1, 4, band=3), H.leaf_case(902, 120, 110, band=6), H.leaf_case(903, 60, 64, band=2)]
     imgs = [H.job_images(f) for f in cases]
     b = capi.Batch(imgs, capi.HX_KEEP_BACKWARD)
     kern = [b.job_kernel(k) for k in range(len(cases))]
     b.close()
-    assert kern == [(2, False)] * 3, kern
+    assert kern == [(1, False), (2, True), (2, True)], kern
     run_and_check(cases, backward=True)
