@@ -9,7 +9,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_INST_CYCLES_VMEM"; do
   i=$((i+1))
-  timeout -k 5 240 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmcd_${tag}_$i -- python tools/dag_bench.py 32 fwdonly unbanded > gpurun_out/pmcd_${tag}_$i.log 2>&1 || { echo "pass $i failed"; tail -3 gpurun_out/pmcd_${tag}_$i.log; exit 1; }
+  timeout -k 5 240 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmcd_${tag}_$i -- python tools/dag_bench.py 32 ${DAG_BENCH_ARGS:-fwdonly unbanded} > gpurun_out/pmcd_${tag}_$i.log 2>&1 || { echo "pass $i failed"; tail -3 gpurun_out/pmcd_${tag}_$i.log; exit 1; }
 done
 python - <<PY
 import csv,glob,collections
