@@ -203,7 +203,7 @@ int hx_batch_lp_start(hx_batch* b, double* out /* [n_jobs] BackwardMatrix::lpSta
 int hx_batch_layout(const hx_batch* b, int32_t job, int32_t which, hx_layout* out);
 /* which: 0 = Forward, 1 = Backward.  out holds hx_layout::matrix_doubles doubles. */
 int hx_batch_read_matrix(hx_batch* b, int32_t job, int32_t which, double* out);
-/* The same copy, started on the batch's own copy stream and not waited for: `out` must be page-locked (hx_host_alloc)
+/* The same copy, started on the device's copy stream (one per device, shared by its batches) and not waited for: `out` must be page-locked (hx_host_alloc)
  * and must not be read before hx_batch_wait_read(b, job, which) has returned.  Lets a caller that walks the jobs of a
  * batch one after the other on the host (tracebacks in node order, reference src/recon.cpp:1006-1011) have the next
  * matrices in flight while it works on the current one. */
