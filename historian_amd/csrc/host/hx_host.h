@@ -48,9 +48,9 @@ using std::vector;
 template <class T> using vguard = std::vector<T>;
 
 // ---- src/util.h:30-37, src/util.cpp:37-54 -------------------------------------------------
-void Abort(const char* error, ...);   // message + terminate (reference: `throw;` with no active exception)
-void Warn(const char* warning, ...);
-void Fail(const char* error, ...);    // message + exit(EXIT_FAILURE)
+void Abort(const char* format, ...);   // message + terminate (reference: `throw;` with no active exception)
+void Warn(const char* format, ...);
+void Fail(const char* format, ...);    // message + exit(EXIT_FAILURE)
 
 // wall-clock accounting of the device-backed constructors (seconds, whole process); printed by hxrecon
 // when HX_TIMING is set.  Not part of the reference's interface.
@@ -75,14 +75,14 @@ double wallSeconds();
 #define LOG_SUM_EXP_LOOKUP_PRECISION .0001
 #define LOG_SUM_EXP_LOOKUP_ENTRIES (((int)(LOG_SUM_EXP_LOOKUP_MAX / LOG_SUM_EXP_LOOKUP_PRECISION)) + 1)
 
-typedef double LogProb;
+using LogProb = double;
 
-double log_sum_exp_unary_slow(double x);
+double log_sum_exp_unary_slow(double gap);
 
-struct LogSumExpLookupTable {
+struct LogSumExpLookupTable final {
   double* lookup;   // LOG_SUM_EXP_LOOKUP_ENTRIES + 1 entries (the guard entry the reference reads past its end)
-  LogSumExpLookupTable();
   ~LogSumExpLookupTable();
+  LogSumExpLookupTable();                           // fills the table with the host's libm (reference src/logsumexp.cpp:8-16)
 };
 extern LogSumExpLookupTable logSumExpLookupTable;
 
@@ -104,214 +104,219 @@ inline double log_sum_exp_unary(double gap) {
   return entry[0] + (entry[1] - entry[0]) * within;
 }
 
-inline double log_sum_exp(double a, double b) {
+inline double log_sum_exp(double p, double q) {
   // (equal operands first: -inf and -inf must not reach the subtraction)
-  if (a == b) return a + log_sum_exp_unary(0);
-  return a < b ? b + log_sum_exp_unary(b - a) : a + log_sum_exp_unary(a - b);
+  if (p == q) return p + log_sum_exp_unary(0);
+  return p < q ? q + log_sum_exp_unary(q - p) : p + log_sum_exp_unary(p - q);
 }
 // more operands: folded from the left, as the reference's overloads are
 inline double log_sum_exp(double a, double b, double c) { return log_sum_exp(log_sum_exp(a, b), c); }
 inline double log_sum_exp(double a, double b, double c, double d) { return log_sum_exp(log_sum_exp(a, b, c), d); }
 inline double log_sum_exp(double a, double b, double c, double d, double e) { return log_sum_exp(log_sum_exp(a, b, c, d), e); }
 inline void log_accum_exp(double& a, double b) { a = log_sum_exp(a, b); }
-double log_sum_exp_slow(double a, double b);
-double log_sum_exp_slow(double a, double b, double c);
-double log_sum_exp_slow(double a, double b, double c, double d);
-void log_accum_exp_slow(double& a, double b);
+double log_sum_exp_slow(double p, double q);
+double log_sum_exp_slow(double p, double q, double r);
+double log_sum_exp_slow(double p, double q, double r, double s);
+void log_accum_exp_slow(double& total, double term);
 
 // log of sum_k exp(v1[k] + v2[k]), accumulated from -inf in index order (src/logsumexp.h:132-151); the nested form
 // sums the inner products of the rows the same way
-inline LogProb logInnerProduct(const vguard<LogProb>& v1, const vguard<LogProb>& v2) {
+inline LogProb logInnerProduct(const vguard<LogProb>& left, const vguard<LogProb>& right) {
   LogProb total = -std::numeric_limits<double>::infinity();
-  auto q = v2.begin();
-  for (auto p = v1.begin(); p != v1.end(); ++p, ++q) log_accum_exp(total, *p + *q);
+  auto q = right.begin();
+  for (auto p = left.begin(); p != left.end(); ++p, ++q) log_accum_exp(total, *p + *q);
   return total;
 }
-inline LogProb logInnerProduct(const vguard<vguard<LogProb> >& v1, const vguard<vguard<LogProb> >& v2) {
+inline LogProb logInnerProduct(const vguard<vguard<LogProb>>& left, const vguard<vguard<LogProb>>& right) {
   LogProb total = -std::numeric_limits<double>::infinity();
-  auto q = v2.begin();
-  for (auto p = v1.begin(); p != v1.end(); ++p, ++q) log_accum_exp(total, logInnerProduct(*p, *q));
+  auto q = right.begin();
+  for (auto p = left.begin(); p != left.end(); ++p, ++q) log_accum_exp(total, logInnerProduct(*p, *q));
   return total;
 }
-vguard<LogProb> log_vector(const vguard<double>& v);
+vguard<LogProb> log_vector(const vguard<double>& probabilities);
 
 // ---- src/fastseq.h (subset) -----------------------------------------------------------------
-typedef unsigned int SeqIdx;
-typedef unsigned int AlphTok;
-typedef int UnvalidatedAlphTok;
-#define InvalidAlphabetToken -1
+using SeqIdx = unsigned int;              // position in a sequence
+using AlphTok = unsigned int;             // index of a symbol in the alphabet
+using UnvalidatedAlphTok = int;           // ... or InvalidAlphabetToken
+constexpr UnvalidatedAlphTok InvalidAlphabetToken = -1;
 
-UnvalidatedAlphTok tokenize(char c, const string& alphabet);
+UnvalidatedAlphTok tokenize(char symbol, const string& alphabet);
 
 struct FastSeq {
-  string name, comment, seq, qual;
-  SeqIdx length() const { return (SeqIdx)seq.size(); }
+  string name, comment;
+  string seq, qual;
+  SeqIdx length() const { return static_cast<SeqIdx>(seq.size()); }
 };
-vguard<FastSeq> readFastSeqs(const char* filename);
+vguard<FastSeq> readFastSeqs(const char* fastaFile);
 
 // ---- src/alignpath.h ------------------------------------------------------------------------
-typedef size_t AlignRowIndex;
-typedef size_t AlignColIndex;
-typedef vguard<bool> AlignRowPath;
-typedef map<AlignRowIndex, AlignRowPath> AlignPath;
+using AlignRowIndex = size_t;
+using AlignColIndex = size_t;
+using AlignRowPath = vguard<bool>;                       // per column: does the row have a residue there?
+using AlignPath = map<AlignRowIndex, AlignRowPath>;
 
-AlignColIndex alignPathColumns(const AlignPath& a);
-SeqIdx alignPathResiduesInRow(const AlignRowPath& r);
-AlignPath alignPathUnion(const AlignPath& a1, const AlignPath& a2);
-AlignPath alignPathConcat(const AlignPath& a1, const AlignPath& a2);
-AlignPath alignPathConcat(const AlignPath& a1, const AlignPath& a2, const AlignPath& a3);
-void ensureAlignPathHasRow(AlignPath&, AlignRowIndex);
-string alignPathString(const AlignPath& a);
+AlignColIndex alignPathColumns(const AlignPath& path);
+SeqIdx alignPathResiduesInRow(const AlignRowPath& row);
+AlignPath alignPathUnion(const AlignPath& left, const AlignPath& right);
+AlignPath alignPathConcat(const AlignPath& first, const AlignPath& second);
+AlignPath alignPathConcat(const AlignPath& first, const AlignPath& second, const AlignPath& third);
+void ensureAlignPathHasRow(AlignPath& path, AlignRowIndex row);
+string alignPathString(const AlignPath& path);
 
-AlignPath alignPathMerge(const vguard<AlignPath>& alignments);   // synchronized merge of multiple alignments
+AlignPath alignPathMerge(const vguard<AlignPath>& paths);   // one alignment out of several that share rows
 
 struct Alignment {
-  static const char gapChar, wildcardChar;
-  vguard<FastSeq> ungapped;
   AlignPath path;
-  Alignment() {}
-  Alignment(const vguard<FastSeq>& gapped);
-  Alignment(const vguard<FastSeq>& ungapped, const AlignPath& path);
+  vguard<FastSeq> ungapped;
+  static const char gapChar, wildcardChar;
+  Alignment() = default;
+  explicit Alignment(const vguard<FastSeq>& gappedRows);
+  Alignment(const vguard<FastSeq>& ungappedRows, const AlignPath& rowPaths);
   vguard<FastSeq> gapped() const;
-  static inline bool isGap(char c) { return c == '-' || c == '.'; }
-  static inline bool isWildcard(char c) { return c == wildcardChar; }
+  static bool isGap(char symbol) { return symbol == '-' || symbol == '.'; }
+  static bool isWildcard(char symbol) { return symbol == wildcardChar; }
 };
 
 struct GuideAlignmentEnvelope {
-  vguard<int> cumulativeMatches;
-  vguard<AlignColIndex> row1PosToCol, row2PosToCol;
-  AlignRowIndex row1, row2;
-  int maxDistance;
-  GuideAlignmentEnvelope() : row1(0), row2(0), maxDistance(-1) {}
-  GuideAlignmentEnvelope(const AlignPath& guide, AlignRowIndex row1, AlignRowIndex row2, int maxDistance);
-  inline bool initialized() const { return maxDistance >= 0; }
-  inline bool inRange(SeqIdx pos1, SeqIdx pos2) const {
-    if (!initialized()) return true;
-    const int d = cumulativeMatches[row1PosToCol[pos1]] - cumulativeMatches[row2PosToCol[pos2]];
-    return abs(d) <= maxDistance;
+  AlignRowIndex row1 = 0, row2 = 0;                          // the two rows of the guide the envelope is about
+  int maxDistance = -1;                                      // < 0: no envelope
+  vguard<AlignColIndex> row1PosToCol, row2PosToCol;          // sequence position -> guide column
+  vguard<int> cumulativeMatches;                             // per guide column: columns so far in which both rows have a residue
+  GuideAlignmentEnvelope() = default;
+  GuideAlignmentEnvelope(const AlignPath& guide, AlignRowIndex firstRow, AlignRowIndex secondRow, int band);
+  bool initialized() const { return maxDistance >= 0; }
+  bool inRange(SeqIdx pos1, SeqIdx pos2) const {
+    if (maxDistance < 0) return true;
+    const int apart = cumulativeMatches[row1PosToCol[pos1]] - cumulativeMatches[row2PosToCol[pos2]];
+    return (apart < 0 ? -apart : apart) <= maxDistance;
   }
 };
 
 // ---- src/model.h (subset) -------------------------------------------------------------------
-typedef vguard<double> Vec;            // stands in for gsl_vector*
-typedef vguard<vguard<double> > Mat;   // stands in for gsl_matrix*
+using Vec = vguard<double>;             // stands in for gsl_vector*
+using Mat = vguard<vguard<double>>;    // stands in for gsl_matrix*
 
 struct AlphabetOwner {
+  char wildcard = '*';
   string alphabet;
-  char wildcard;
-  AlphabetOwner() : wildcard('*') {}
-  inline size_t alphabetSize() const { return alphabet.size(); }
+  size_t alphabetSize() const { return alphabet.size(); }
 };
 
 struct RateModel : AlphabetOwner {
-  double insRate, delRate, insExtProb, delExtProb;
-  vguard<Mat> subRate;
+  double insRate = 0, delRate = 0;           // indel rates and extension probabilities
+  double insExtProb = 0, delExtProb = 0;
+  vguard<double> cptWeight;                  // mixture components: weight, root / insertion distribution, rate matrix
   vguard<Vec> insProb;
-  vguard<double> cptWeight;
-  RateModel() : insRate(0), delRate(0), insExtProb(0), delExtProb(0) {}
-  inline int components() const { return (int)subRate.size(); }
-  void readFile(const char* filename);     // JSON, reference src/model.cpp:172-232
+  vguard<Mat> subRate;
+  int components() const { return static_cast<int>(subRate.size()); }
+  void readFile(const char* jsonFile);       // JSON, reference src/model.cpp:172-232
   void read(const string& jsonText);
-  static Vec getEqmProbVector(const Mat& sr);   // src/model.cpp:282-320
-  vguard<Mat> getSubProbMatrix(double t) const; // src/model.cpp:322-334 (own scaling-and-squaring exp(Rt))
+  static Vec getEqmProbVector(const Mat& rates);       // src/model.cpp:282-320
+  vguard<Mat> getSubProbMatrix(double time) const;     // src/model.cpp:322-334 (own scaling-and-squaring exp(Rt))
 };
 
 struct ProbModel : AlphabetOwner {
-  double t, ins, del, insExt, delExt;
-  vguard<double> cptWeight;
-  vguard<Vec> insVec;
+  double t;                                  // branch length, and what the rates come to over it
+  double ins, del, insExt, delExt;
   vguard<Mat> subMat;
-  ProbModel(const RateModel& model, double t);
-  inline int components() const { return (int)subMat.size(); }
+  vguard<Vec> insVec;
+  vguard<double> cptWeight;
+  ProbModel(const RateModel& model, double branchLength);
+  int components() const { return static_cast<int>(subMat.size()); }
 };
 
 struct LogProbModel {
+  vguard<vguard<LogProb>> logInsProb;
   vguard<LogProb> logCptWeight;
-  vguard<vguard<LogProb> > logInsProb;
-  LogProbModel(const ProbModel& pm);
-  inline int components() const { return (int)logCptWeight.size(); }
+  explicit LogProbModel(const ProbModel& probs);
+  int components() const { return static_cast<int>(logCptWeight.size()); }
 };
 
 // ---- src/profile.h --------------------------------------------------------------------------
-typedef size_t ProfileStateIndex;
-typedef size_t ProfileTransitionIndex;
+using ProfileStateIndex = size_t;
+using ProfileTransitionIndex = size_t;
 
 struct ProfileTransition {
   ProfileStateIndex src, dest;
+  AlignPath alignPath;               // the alignment columns the transition steps over
   LogProb lpTrans;
-  AlignPath alignPath;
   ProfileTransition();
 };
 
 struct ProfileState {
-  typedef map<AlignRowIndex, SeqIdx> SeqCoords;
-  string name;
-  map<string, string> meta;
-  vguard<ProfileTransitionIndex> in, nullOut, absorbOut;
-  vguard<vguard<LogProb> > lpAbsorb;
-  AlignPath alignPath;
+  using SeqCoords = map<AlignRowIndex, SeqIdx>;     // per alignment row: residues of that row absorbed so far
+  vguard<vguard<LogProb>> lpAbsorb;                // [component][symbol]; empty: a null state
+  vguard<ProfileTransitionIndex> in;                // transitions into the state, and out of it by kind of destination
+  vguard<ProfileTransitionIndex> nullOut, absorbOut;
   SeqCoords seqCoords;
+  AlignPath alignPath;
+  map<string, string> meta;
+  string name;
   ProfileState();
-  ProfileState(size_t components, AlphTok alphSize);
-  inline bool isNull() const { return lpAbsorb.empty(); }
-  inline bool isEmit() const { return !lpAbsorb.empty(); }
-  inline bool isStart() const { return in.empty(); }
-  inline bool isEmitOrStart() const { return isEmit() || isStart(); }
-  inline bool isReady() const { return nullOut.empty(); }
-  inline bool isWait() const { return absorbOut.empty(); }
-  static void assertSeqCoordsConsistent(const SeqCoords& srcCoords, const ProfileState& dest, const AlignPath& transPath);
-  static void assertSeqCoordsConsistent(const SeqCoords& srcCoords, const SeqCoords& destCoords, const AlignPath& transPath, const AlignPath& destPath);
+  ProfileState(size_t nComponents, AlphTok nSymbols);
+  bool isNull() const { return lpAbsorb.empty(); }
+  bool isEmit() const { return !isNull(); }
+  bool isStart() const { return in.empty(); }
+  bool isEmitOrStart() const { return !isNull() || in.empty(); }
+  bool isReady() const { return nullOut.empty(); }
+  bool isWait() const { return absorbOut.empty(); }
+  static void assertSeqCoordsConsistent(const SeqCoords& before, const ProfileState& after, const AlignPath& step);
+  static void assertSeqCoordsConsistent(const SeqCoords& before, const SeqCoords& after, const AlignPath& step, const AlignPath& atDest);
 };
 
 struct Profile {
-  AlphTok alphSize;
-  size_t components;
-  string name;
-  map<string, string> meta;
-  vguard<ProfileState> state;
+  vguard<ProfileState> state;                       // START first, END last, topologically sorted
   vguard<ProfileTransition> trans;
-  map<AlignRowIndex, string> seq;
+  size_t components = 0;
+  AlphTok alphSize = 0;
+  AlignRowIndex rootRowIndex = 0;
+  map<AlignRowIndex, string> seq;                   // the sequences below this node
   map<ProfileStateIndex, ProfileStateIndex> equivAbsorbState;
-  AlignRowIndex rootRowIndex;
-  Profile() : alphSize(0), components(0), rootRowIndex(0) {}
-  Profile(size_t components, AlphTok alphSize, AlignRowIndex rowIndex) : alphSize(alphSize), components(components), rootRowIndex(rowIndex) {}
-  Profile(size_t components, const string& alphabet, const FastSeq& seq, AlignRowIndex rowIndex);
+  map<string, string> meta;
+  string name;
+  Profile() = default;
+  Profile(size_t nComponents, AlphTok nSymbols, AlignRowIndex row) : components(nComponents), alphSize(nSymbols), rootRowIndex(row) {}
+  Profile(size_t nComponents, const string& alphabet, const FastSeq& leaf, AlignRowIndex row);
   ProfileStateIndex size() const { return state.size(); }
-  const ProfileState& start() const { return state.front(); }
-  const ProfileState& end() const { return state.back(); }
-  const ProfileTransition* getTrans(ProfileStateIndex src, ProfileStateIndex dest) const;
-  LogProb calcSumPathAbsorbProbs(const vguard<LogProb>& logCptWeight, const vguard<vguard<LogProb> >& logInsProb, const char* tag = "cumLogProb");
-  void writeJson(std::ostream& out) const;
+  const ProfileState& start() const { return state[0]; }
+  const ProfileState& end() const { return state[state.size() - 1]; }
+  const ProfileTransition* getTrans(ProfileStateIndex from, ProfileStateIndex to) const;
+  LogProb calcSumPathAbsorbProbs(const vguard<LogProb>& logWeightOfComponent, const vguard<vguard<LogProb>>& logInsertProb,
+                                 const char* tag = "cumLogProb");
   string toJson() const;
-  void assertTransitionsConsistent() const;
-  void assertSeqCoordsConsistent() const;
-  void assertAllStatesWaitOrReady() const;
-  void assertPathToEndExists() const;
+  void writeJson(std::ostream& to) const;
+  // consistency checks (abort with a message): every state Wait or Ready; END reachable; coordinates; transition indices
+  void assertAllStatesWaitOrReady() const;   void assertPathToEndExists() const;
+  void assertSeqCoordsConsistent() const;    void assertTransitionsConsistent() const;
   Profile addReadyStates() const;
   static Profile withReadyStates(Profile&& src);   // addReadyStates of a profile that is not needed afterwards (moves its states)
-  bool isEmpty() const;
   vguard<ProfileStateIndex> examplePathToEnd() const;
+  bool isEmpty() const;                             // no emitting state
 };
 
 // ---- src/pairhmm.h --------------------------------------------------------------------------
 struct PairHMM : AlphabetOwner {
-  const ProbModel& l;
+  enum State { IMM = 0, IMD = 1, IDM = 2, IMI = 3, IIW = 4, TotalStates = 5,
+               SSS = 0, SSI = 3, SIW = 4, EEE = 5 };      // (start aliases of IMM, IMI, IIW; END)
+  const ProbModel& l;                                    // the two branches: probabilities and their logarithms
   const ProbModel& r;
   const LogProbModel logl, logr;
-  vguard<vguard<LogProb> > logRoot;
-  typedef enum { IMM = 0, IMD = 1, IDM = 2, IMI = 3, IIW = 4, TotalStates = 5, SSS = 0, SSI = 3, SIW = 4, EEE = 5 } State;
-  inline int components() const { return (int)logRoot.size(); }
-  static const char* stateName(State s, bool xAtStart, bool yAtStart);
-  LogProb imm_imi, imm_iiw, imm_imm, imm_imd, imm_idm, imm_eee;
-  LogProb imd_imm, imd_imd, imd_idm, imd_eee;
-  LogProb idm_imm, idm_imd, idm_idm, idm_eee;
-  LogProb imi_imi, imi_iiw, imi_imm, imi_imd, imi_eee;
-  LogProb iiw_iiw, iiw_imm, iiw_idm, iiw_eee;
-  PairHMM(const ProbModel& l, const ProbModel& r, const vguard<Vec>& root);
+  vguard<vguard<LogProb>> logRoot;
+  int components() const { return static_cast<int>(logRoot.size()); }
+  static const char* stateName(State state, bool xAtStart, bool yAtStart);
+  // one weight per move of the composite machine, named <source>_<destination>; listed by destination
+  LogProb imm_imm, imd_imm, idm_imm, imi_imm, iiw_imm;
+  LogProb imm_imd, imd_imd, idm_imd, imi_imd;
+  LogProb imm_idm, imd_idm, idm_idm, iiw_idm;
+  LogProb imm_imi, imi_imi;
+  LogProb imm_iiw, imi_iiw, iiw_iiw;
+  LogProb imm_eee, imd_eee, idm_eee, imi_eee, iiw_eee;
+  PairHMM(const ProbModel& left, const ProbModel& right, const vguard<Vec>& rootDistribution);
   LogProb weight[TotalStates][TotalStates + 1];   // the same weights as a table [src][dest], -inf where there is no such move
+  LogProb lpTrans(State from, State to) const;
+  static vguard<State> sources(State to);
   static vguard<State> states();
-  static vguard<State> sources(State dest);
-  LogProb lpTrans(State src, State dest) const;
 };
 
 // ---- src/forward.h --------------------------------------------------------------------------
@@ -322,59 +327,65 @@ public:
   struct XYCell {
     LogProb lp[PairHMM::TotalStates];
     XYCell() { for (size_t s = 0; s < PairHMM::TotalStates; ++s) lp[s] = -std::numeric_limits<double>::infinity(); }
-    LogProb operator()(PairHMM::State s) const { return lp[s]; }
+    LogProb operator()(PairHMM::State which) const { return lp[which]; }
   };
   struct CellCoords {
-    ProfileStateIndex xpos, ypos;
     PairHMM::State state;
-    CellCoords() : xpos(0), ypos(0), state(PairHMM::EEE) {}
-    CellCoords(ProfileStateIndex xpos, ProfileStateIndex ypos, PairHMM::State state) : xpos(xpos), ypos(ypos), state(state) {}
+    ProfileStateIndex xpos, ypos;
+    CellCoords() : state(PairHMM::EEE), xpos(0), ypos(0) {}
+    CellCoords(ProfileStateIndex x, ProfileStateIndex y, PairHMM::State s) : state(s), xpos(x), ypos(y) {}
     bool operator<(const CellCoords& c) const { return xpos == c.xpos ? ypos == c.ypos ? state < c.state : ypos < c.ypos : xpos < c.xpos; }
     bool operator==(const CellCoords& c) const { return xpos == c.xpos && ypos == c.ypos && state == c.state; }
   };
   enum ProfilingStrategy { KeepAll = 0, CollapseChains = 1, DontCountSubstEvents = 0, CountSubstEvents = 2,
                            DontCountIndelEvents = 0, CountIndelEvents = 4, DontIncludeBestTrace = 0, IncludeBestTrace = 8,
                            DontKeepGapsOpen = 0, KeepGapsOpen = 16 };
-  typedef list<CellCoords> Path;
+  using Path = list<CellCoords>;
   // (hx_host_walk.cpp) the cells next to a cell with the log-weight of the move between them, as a flat list: sorted by
   // cell, one entry per cell.  Tracebacks and profile construction work on these; the map-returning members of the
   // reference's interface are adapters.
   typedef std::pair<CellCoords, LogProb> Move;
   typedef vguard<Move> Moves;
   typedef std::mt19937 random_engine;
-  static const char* random_engine_name() { return "mt19937"; }
+  static const char* random_engine_name() { return "mt" "19937"; }
 
-  const Profile& x, y;
-  const bool xEmpty, yEmpty;
+  const Profile& x;
+  const Profile& y;
+  const bool xEmpty;
+  const bool yEmpty;
   Profile subx, suby;           // lpAbsorb of x, y left-multiplied by the branch matrices (device result); shells: states carry lpAbsorb only
   const PairHMM& hmm;
   const AlphTok alphSize;
-  const ProfileStateIndex xSize, ySize;
-  const CellCoords startCell, endCell;
+  const ProfileStateIndex xSize;
+  const ProfileStateIndex ySize;
+  const CellCoords startCell;
+  const CellCoords endCell;
   LogProb lpEnd;
   const GuideAlignmentEnvelope envelope;
-  vguard<SeqIdx> xClosestLeafPos, yClosestLeafPos;
-  vguard<bool> xNearStart, yNearEnd;
+  vguard<SeqIdx> xClosestLeafPos;
+  vguard<SeqIdx> yClosestLeafPos;
+  vguard<bool> xNearStart;
+  vguard<bool> yNearEnd;
 
-  DPMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, const GuideAlignmentEnvelope& env);
+  DPMatrix(const Profile& xProfile, const Profile& yProfile, const PairHMM& pairHmm, const GuideAlignmentEnvelope& band);
   virtual ~DPMatrix();
 
   // cell accessors: -inf outside storage (src/forward.h:68-88)
   LogProb cell(ProfileStateIndex xpos, ProfileStateIndex ypos, PairHMM::State state) const;
-  inline LogProb cell(const CellCoords& c) const { return cell(c.xpos, c.ypos, c.state); }
+  LogProb cell(const CellCoords& c) const { return cell(c.xpos, c.ypos, c.state); }
   XYCell xyCell(ProfileStateIndex xpos, ProfileStateIndex ypos) const;
-  inline LogProb lpStart() const { return cell(0, 0, PairHMM::IMM); }
+  LogProb lpStart() const { return cell(0, 0, PairHMM::IMM); }
 
-  inline bool atEdge(ProfileStateIndex xpos, ProfileStateIndex ypos) const { return xNearStart[xpos] || yNearEnd[ypos]; }
-  inline bool inEnvelope(ProfileStateIndex xpos, ProfileStateIndex ypos) const {
+  bool atEdge(ProfileStateIndex xpos, ProfileStateIndex ypos) const { return xNearStart[xpos] || yNearEnd[ypos]; }
+  bool inEnvelope(ProfileStateIndex xpos, ProfileStateIndex ypos) const {
     return atEdge(xpos, ypos) || envelope.inRange(xClosestLeafPos[xpos], yClosestLeafPos[ypos]);
   }
   void write(std::ostream& out, bool edgeOnly = false) const;
-  string toString(bool edgeOnly = false) const;
-  string cellName(const CellCoords& cell) const;
+  string cellName(const CellCoords& which) const;
+  string toString(bool onlyEdges = false) const;
+  static size_t cellSize() { return sizeof(LogProb) * PairHMM::TotalStates; }
   static random_engine newRNG();
-  static size_t cellSize() { return sizeof(XYCell); }
-  inline int components() const { return hmm.components(); }
+  int components() const { return hmm.components(); }
 
   // log-sum-exp policy of the device fills: 0 = exact (bit-identical to the reference, default), 1 = fast
   static void setFillMode(unsigned hxFlags);
@@ -386,7 +397,7 @@ public:
 
 protected:
   vguard<LogProb> insx, insy, rootsubx, rootsuby;
-  vguard<vguard<LogProb> > absorbScratch;
+  vguard<vguard<LogProb>> absorbScratch;
   // device-resident batch this matrix is one job of (shared by the ForwardMatrix objects of one
   // ForwardMatrix::fillBatch call and by their BackwardMatrix objects; destroyed with the last of them)
   struct BatchHandle {
@@ -427,14 +438,14 @@ protected:
   void attach(const std::shared_ptr<BatchHandle>& h, int job, double lpEndOfJob);   // adopt job `job` of a filled batch
   void fetchPrepared();
   void ensureHostCells() const;
-  inline void initAbsorbScratch(ProfileStateIndex xpos, ProfileStateIndex ypos) {
+  void initAbsorbScratch(ProfileStateIndex xpos, ProfileStateIndex ypos) {
     for (int cpt = 0; cpt < components(); ++cpt)
       for (size_t n = 0; n < hmm.alphabetSize(); ++n)
         absorbScratch[cpt][n] = subx.state[xpos].lpAbsorb[cpt][n] + suby.state[ypos].lpAbsorb[cpt][n];
   }
   // (memoised per cell: sampled tracebacks revisit the same cells, and the sum is C x (A + 1) table look-ups)
   std::unordered_map<unsigned long long, LogProb> absorbMemo;
-  inline LogProb computeLogProbAbsorb(ProfileStateIndex xpos, ProfileStateIndex ypos) {
+  LogProb computeLogProbAbsorb(ProfileStateIndex xpos, ProfileStateIndex ypos) {
     const unsigned long long key = ((unsigned long long)xpos << 32) | (unsigned long long)ypos;
     const auto hit = absorbMemo.find(key);
     if (hit != absorbMemo.end()) return hit->second;
@@ -444,24 +455,24 @@ protected:
   static void settle(Moves& m);
   static CellCoords pickBest(const Moves& m);
   CellCoords pickSampled(const Moves& m, random_engine& generator) const;
-  LogProb lpCellEmitOrAbsorb(const CellCoords& c);
-  bool isAbsorbing(const CellCoords& c) const;
-  bool changesX(const CellCoords& c) const;
-  bool changesY(const CellCoords& c) const;
-  list<CellCoords> equivAbsorbCells(const CellCoords& c) const;
-  CellCoords sampleCell(const map<CellCoords, LogProb>& cellLogProb, random_engine& generator) const;
-  static CellCoords bestCell(const map<CellCoords, LogProb>& cellLogProb);
+  bool isAbsorbing(const CellCoords& at) const;
+  bool changesX(const CellCoords& at) const;
+  bool changesY(const CellCoords& at) const;
+  LogProb lpCellEmitOrAbsorb(const CellCoords& at);
+  list<CellCoords> equivAbsorbCells(const CellCoords& at) const;
+  static CellCoords bestCell(const map<CellCoords, LogProb>& scored);
+  CellCoords sampleCell(const map<CellCoords, LogProb>& scored, random_engine& rng) const;
   friend class BackwardMatrix;
 };
 
 class ForwardMatrix : public DPMatrix {
 public:
+  SumProduct* sumProd;                     // always NULL here
   const AlignRowIndex parentRowIndex;
-  SumProduct* sumProd;
 
   struct EffectiveTransition {
-    LogProb lpPath, lpBestAlignPath;
     AlignPath bestAlignPath;
+    LogProb lpBestAlignPath, lpPath;
     EffectiveTransition();
   };
 
@@ -483,12 +494,12 @@ public:
   // (lptAssign); one device batch per device, all launched before the first result is awaited.  Same results.
   static vguard<ForwardMatrix*> fillBatch(const vguard<JobSpec>& jobs, const vguard<int>& devices);
 
-  Path sampleTrace(random_engine& generator);
   Path bestTrace();
-  Path bestTrace(const CellCoords& end);
+  Path bestTrace(const CellCoords& from);
+  Path sampleTrace(random_engine& rng);
   AlignPath bestAlignPath();
 
-  Profile makeProfile(const set<CellCoords>& cells, ProfilingStrategy strategy = CollapseChains);
+  Profile makeProfile(const set<CellCoords>& chosen, ProfilingStrategy how = CollapseChains);
   Profile sampleProfile(random_engine& generator, size_t profileSamples, size_t maxCells = 0,
                         ProfilingStrategy strategy = CollapseChains, size_t minLen = 0,
                         size_t maxLen = std::numeric_limits<size_t>::max());
@@ -497,21 +508,21 @@ public:
   set<CellCoords> sampleCells(random_engine& generator, size_t profileSamples, size_t maxCells = 0, ProfilingStrategy strategy = CollapseChains,
                               size_t minLen = 0, size_t maxLen = (size_t)-1);
   bool hostMatrixReady() const { return haveHostCells || !batch; }
-  Profile bestProfile(ProfilingStrategy strategy = CollapseChains);
+  Profile bestProfile(ProfilingStrategy how = CollapseChains);
 
-  map<CellCoords, LogProb> sourceTransitions(const CellCoords& destCell);
-  map<CellCoords, LogProb> sourceTransitionsWithoutEmitOrAbsorb(const CellCoords& destCell);
-  void slowFillTest();
+  map<CellCoords, LogProb> sourceTransitionsWithoutEmitOrAbsorb(const CellCoords& into);
+  map<CellCoords, LogProb> sourceTransitions(const CellCoords& into);
+  void slowFillTest();   // (Forward)
 
 private:
   void movesInto(const CellCoords& dest, Moves& out) const;     // sourceTransitionsWithoutEmitOrAbsorb as a flat list
   void scoredSources(const CellCoords& dest, Moves& out);       // ... + the destination's emission + the source's Forward cell
-  map<CellCoords, LogProb> sourceCells(const CellCoords& destCell);
-  LogProb eliminatedLogProbInsert(const CellCoords& cell) const;
-  AlignPath cellAlignPath(const CellCoords& cell) const;
-  AlignPath transitionAlignPath(const CellCoords& src, const CellCoords& dest) const;
-  AlignPath traceAlignPath(const Path& path) const;
-  ProfileState::SeqCoords cellSeqCoords(const CellCoords& cell) const;
+  map<CellCoords, LogProb> sourceCells(const CellCoords& into);
+  AlignPath cellAlignPath(const CellCoords& at) const;
+  AlignPath transitionAlignPath(const CellCoords& from, const CellCoords& to) const;
+  AlignPath traceAlignPath(const Path& cells) const;
+  ProfileState::SeqCoords cellSeqCoords(const CellCoords& at) const;
+  LogProb eliminatedLogProbInsert(const CellCoords& at) const;
   friend class BackwardMatrix;
 
 private:
@@ -529,24 +540,24 @@ public:
   };
   ForwardMatrix& fwd;
 
-  BackwardMatrix(ForwardMatrix& fwd);
+  explicit BackwardMatrix(ForwardMatrix& forward);
 
-  double cellPostProb(const CellCoords& cell) const;
-  double transPostProb(const CellCoords& src, const CellCoords& dest) const;
-  Path bestTrace(const CellCoords& start);
+  double transPostProb(const CellCoords& from, const CellCoords& to) const;
+  double cellPostProb(const CellCoords& at) const;
+  Path bestTrace(const CellCoords& from);
   std::priority_queue<CellPostProb> cellsAbovePostProbThreshold(double minPostProb) const;
-  Profile postProbProfile(double minPostProb, size_t maxCells = 0, ProfilingStrategy strategy = CollapseChains);
-  Profile bestProfile(ProfilingStrategy strategy = CollapseChains);
-  map<CellCoords, LogProb> destTransitions(const CellCoords& srcCell);
-  void slowFillTest();
+  Profile bestProfile(ProfilingStrategy how = CollapseChains);
+  Profile postProbProfile(double minPostProb, size_t cellBudget = 0, ProfilingStrategy how = CollapseChains);
+  map<CellCoords, LogProb> destTransitions(const CellCoords& outOf);
   void sourceDestTransTest();
+  void slowFillTest();   // (Backward)
 
 private:
   void movesOutOf(const CellCoords& src, Moves& out);           // destTransitions as a flat list
   void scoredDestinations(const CellCoords& src, Moves& out);   // ... + the destination's Backward cell
-  map<CellCoords, LogProb> destCells(const CellCoords& srcCell);
+  map<CellCoords, LogProb> destCells(const CellCoords& outOf);
   bool addCells(set<CellCoords>& cells, size_t maxCells, const list<CellCoords>& fwdTrace, const list<CellCoords>& backTrace, bool keepGapsOpen);
-  bool addTrace(const CellCoords& cell, set<CellCoords>& cells, size_t maxCells, bool keepGapsOpen);
+  bool addTrace(const CellCoords& through, set<CellCoords>& chosen, size_t cellBudget, bool gapsOpen);
 };
 
 string pairParentName(const string& lChildName, double lTime, const string& rChildName, double rTime);  // Tree::pairParentName
@@ -563,14 +574,14 @@ struct ReconTree {
   vguard<TreeNodeIndex> parent;          // -1 for the root (last node)
   vguard<double> branchLen;              // length of the branch above each node
   vguard<string> nodeName;
-  vguard<vguard<TreeNodeIndex> > child;
+  vguard<vguard<TreeNodeIndex>> child;
   void addNode(TreeNodeIndex parentNode, double len, const string& name);
   void finish();                         // builds child lists, asserts post-order and binary
-  inline TreeNodeIndex nodes() const { return (TreeNodeIndex)parent.size(); }
-  inline bool isLeaf(TreeNodeIndex n) const { return child[n].empty(); }
-  inline TreeNodeIndex root() const { return nodes() - 1; }
-  inline TreeNodeIndex getChild(TreeNodeIndex n, size_t k) const { return child[n][k]; }
-  inline double branchLength(TreeNodeIndex n) const { return branchLen[n]; }
+  TreeNodeIndex nodes() const { return (TreeNodeIndex)parent.size(); }
+  bool isLeaf(TreeNodeIndex n) const { return child[n].empty(); }
+  TreeNodeIndex root() const { return nodes() - 1; }
+  TreeNodeIndex getChild(TreeNodeIndex n, size_t k) const { return child[n][k]; }
+  double branchLength(TreeNodeIndex n) const { return branchLen[n]; }
 };
 
 struct Reconstructor {
@@ -590,9 +601,8 @@ struct Reconstructor {
   struct Dataset {
     ReconTree tree;
     map<TreeNodeIndex, FastSeq> seqs;    // ungapped sequence of every leaf node
-    AlignPath guide;                     // rows = leaf node indices; empty = no band
     vguard<TreeNodeIndex> closestLeaf;
-    AlignPath path;                      // result: root alignment path
+    AlignPath guide, path;               // guide: rows = leaf node indices, empty = no band; path: the result (root alignment)
     LogProb lpFinalFwd, lpFinalTrace;
     map<TreeNodeIndex, int> bandUsed;
     void prepareRecon();
@@ -607,8 +617,8 @@ struct Reconstructor {
   vguard<int> devices;
 
   Reconstructor();
+  void reconstruct(Dataset& family);
   void seedGenerator();
-  void reconstruct(Dataset& dataset);
   void reconstructAll(vguard<Dataset*>& datasets);   // reference src/recon.cpp:1368-1372: every family
   static double familyCost(const Dataset& dataset);   // estimated lattice cells of a family's pair DPs
 };
@@ -634,42 +644,42 @@ void check(int rc, const char* what);
 // members and methods that callers use (the storage-index bookkeeping is the reference's CPU
 // layout and has no counterpart here: the matrix lives in the device layout); QuickAlignMatrix
 // keeps the reference's interface with the fill running on the device.
-typedef unsigned long long Kmer;
-typedef vguard<UnvalidatedAlphTok> UnvalidatedTokSeq;
+using Kmer = unsigned long long;
+using UnvalidatedTokSeq = vguard<UnvalidatedAlphTok>;
 UnvalidatedTokSeq unvalidatedTokens(const FastSeq& seq, const string& alphabet);
 bool kmerValid(SeqIdx k, vguard<int>::const_iterator tok);
 Kmer makeKmer(SeqIdx k, vguard<int>::const_iterator tok, AlphTok alphabetSize);
 void writeFastaSeqs(std::ostream& out, const vguard<FastSeq>& fastSeqs);
 
 struct KmerIndex {
-  const FastSeq& seq;
-  const string& alphabet;
   const SeqIdx kmerLen;
-  map<Kmer, vguard<SeqIdx> > kmerLocations;
-  KmerIndex(const FastSeq& seq, const string& alphabet, SeqIdx kmerLen);
+  const string& alphabet;
+  const FastSeq& seq;
+  map<Kmer, vguard<SeqIdx>> kmerLocations;
+  KmerIndex(const FastSeq& sequence, const string& symbols, SeqIdx k);
 };
 
-#define DEFAULT_KMER_LENGTH 6
-#define DEFAULT_KMER_THRESHOLD -1
-#define DEFAULT_BAND_SIZE 64
+enum { DEFAULT_KMER_LENGTH = 6, DEFAULT_BAND_SIZE = 64, DEFAULT_KMER_THRESHOLD = -1 };
 
 struct DiagonalEnvelope {
-  const FastSeq *px, *py;
-  const SeqIdx xLen, yLen;
+  const FastSeq* px;
+  const FastSeq* py;
+  const SeqIdx xLen;
+  const SeqIdx yLen;
   vguard<int> diagonals;   // sorted ascending; (i,j) is on diagonal d if i-j=d
   bool full;               // set by initFull (lets the device skip the per-cell membership test)
   DiagonalEnvelope(const FastSeq& x, const FastSeq& y) : px(&x), py(&y), xLen(x.length()), yLen(y.length()), full(false) {}
   void initFull();
   void initSparse(const KmerIndex& yKmerIndex, unsigned int bandSize = DEFAULT_BAND_SIZE,
                   int kmerThreshold = DEFAULT_KMER_THRESHOLD, size_t cellSize = sizeof(double), size_t maxSize = 0);
-  inline int minDiagonal() const { return 1 - (int)yLen; }
-  inline int maxDiagonal() const { return (int)xLen - 1; }
+  int minDiagonal() const { return 1 - static_cast<int>(yLen); }
+  int maxDiagonal() const { return (int)xLen - 1; }
   bool contains(SeqIdx i, SeqIdx j) const;
-  static inline SeqIdx get_i(SeqIdx j, int diag) { return (SeqIdx)(diag + j); }
-  static inline int get_diag(SeqIdx i, SeqIdx j) { return (int)i - (int)j; }
-  inline bool intersects(SeqIdx j, int diag) const { const int i = diag + (int)j; return i > 0 && i <= (int)xLen; }
-  vguard<SeqIdx> forward_i(SeqIdx j) const;
-  vguard<SeqIdx> reverse_i(SeqIdx j) const;
+  static SeqIdx get_i(SeqIdx j, int diagonal) { return static_cast<SeqIdx>(diagonal + (int)j); }
+  static int get_diag(SeqIdx i, SeqIdx j) { return static_cast<int>(i) - static_cast<int>(j); }
+  bool intersects(SeqIdx j, int diag) const { const int i = diag + (int)j; return i > 0 && i <= (int)xLen; }
+  vguard<SeqIdx> forward_i(SeqIdx column) const;
+  vguard<SeqIdx> reverse_i(SeqIdx column) const;
 };
 
 class QuickAlignMatrix {
@@ -678,15 +688,19 @@ public:
   const DiagonalEnvelope* penv;
   const FastSeq *px, *py;
   UnvalidatedTokSeq xTok, yTok;
-  SeqIdx xLen, yLen, xEnd, yEnd;
-  LogProb start, end, result;
+  SeqIdx xLen, yLen;
+  SeqIdx xEnd, yEnd;                // where the best local alignment ends
+  LogProb start, end;
+  LogProb result;
   const RateModel& model;
   const double time;
-  vguard<vguard<LogProb> > submat;  // log odds-ratio
-  LogProb m2m, m2i, m2d, i2i, i2m, i2d, i2e, d2d, d2m, d2e;
-  LogProb gapOpen, gapExtend, noGap;
+  vguard<vguard<LogProb>> submat;  // log odds-ratio
+  LogProb m2m, m2i, m2d;           // affine-gap transition scores by source state
+  LogProb i2i, i2m, i2d, i2e;
+  LogProb d2d, d2m, d2e;
+  LogProb noGap, gapOpen, gapExtend;
 
-  QuickAlignMatrix(const DiagonalEnvelope& env, const RateModel& model, double time);
+  QuickAlignMatrix(const DiagonalEnvelope& envelope, const RateModel& rates, double branchLength);
   ~QuickAlignMatrix();
   // Not in the reference: n independent fills as one device batch (the pairs of an alignment graph)
   static vguard<QuickAlignMatrix*> fillBatch(const vguard<const DiagonalEnvelope*>& envs, const RateModel& model, double time);
@@ -694,17 +708,17 @@ public:
   LogProb mat(SeqIdx i, SeqIdx j) const { return getCell(i, j, 0); }
   LogProb ins(SeqIdx i, SeqIdx j) const { return getCell(i, j, 1); }
   LogProb del(SeqIdx i, SeqIdx j) const { return getCell(i, j, 2); }
-  inline double matchEmitScore(SeqIdx i, SeqIdx j) const {
+  double matchEmitScore(SeqIdx i, SeqIdx j) const {
     Assert(i > 0 && j > 0 && i <= xLen && j <= yLen, "Out of range: (i,j)=(%u,%u) (xLen,yLen)=(%u,%u)", i, j, xLen, yLen);
     const UnvalidatedAlphTok xt = xTok[i - 1], yt = yTok[j - 1];
     return (xt < 0 || yt < 0) ? 0 : submat[xt][yt];
   }
-  LogProb cellScore(SeqIdx i, SeqIdx j, State state) const;
-  static const char* stateToString(State state);
-  static size_t cellSize() { return 3 * sizeof(double); }
+  static const char* stateToString(State which);
+  static size_t cellSize() { return sizeof(double) * 3; }
+  LogProb cellScore(SeqIdx row, SeqIdx column, State which) const;
   bool resultIsFinite() const { return result > -std::numeric_limits<double>::infinity(); }
+  AlignPath alignPath(AlignRowIndex xRow, AlignRowIndex yRow) const;
   AlignPath alignPath() const;
-  AlignPath alignPath(AlignRowIndex row1, AlignRowIndex row2) const;
   vguard<FastSeq> gappedSeq() const;   // Alignment(seqs, alignPath()).gapped()
 
 protected:
@@ -713,11 +727,11 @@ protected:
   void computeScores();
   void fillJob(hx_quick_job& job, vguard<double>& flatSub) const;
   LogProb getCell(SeqIdx i, SeqIdx j, unsigned int offset) const;   // -inf outside the envelope / the lattice
-  static void updateMax(LogProb& currentMax, State& currentMaxIdx, double candidateMax, State candidateMaxIdx);
-  inline LogProb startGapScore(SeqIdx i, SeqIdx j) const {
+  static void updateMax(LogProb& best, State& bestState, double candidate, State candidateState);
+  LogProb startGapScore(SeqIdx i, SeqIdx j) const {
     return (i == 1 ? noGap : (gapOpen + (i - 2) * gapExtend)) + (j == 1 ? noGap : (gapOpen + (j - 2) * gapExtend));
   }
-  inline LogProb endGapScore(SeqIdx i, SeqIdx j) const {
+  LogProb endGapScore(SeqIdx i, SeqIdx j) const {
     return (i == xLen ? noGap : (gapOpen + (xLen - i - 2) * gapExtend)) + (j == yLen ? noGap : (gapOpen + (yLen - j - 2) * gapExtend));
   }
   struct QuickHandle {
@@ -735,11 +749,11 @@ protected:
 
 // ---- src/diagenv.h (parameters), src/span.h ---------------------------------------------------
 struct DiagEnvParams {
-  bool sparse, autoMemSize;
   int kmerLen, kmerThreshold, bandSize;
+  bool sparse, autoMemSize;
   size_t maxSize;
-  DiagEnvParams();
   size_t effectiveMaxSize() const;
+  DiagEnvParams();
 };
 
 // The alignment graph of the guide alignment: which pairs are aligned, the pair farm (one device batch
@@ -747,38 +761,38 @@ struct DiagEnvParams {
 // spanning tree of the pairwise alignments and their merge.
 struct AlignGraph {
   struct TrialEdge {
-    AlignRowIndex row1, row2;
-    TrialEdge() {}
+    AlignRowIndex row1 = 0, row2 = 0;
+    TrialEdge() = default;
     TrialEdge(AlignRowIndex src, AlignRowIndex dest) : row1(src), row2(dest) {}
   };
   struct Edge : TrialEdge {
     LogProb lp;
     Edge() : lp(-std::numeric_limits<double>::infinity()) {}
-    bool operator<(const Edge& e) const { return lp < e.lp; }
+    bool operator<(const Edge& other) const { return lp < other.lp; }
   };
   struct Partition {
-    vguard<size_t> seqSetIdx;
-    vguard<set<size_t> > seqSet;
     size_t nSets;
-    Partition(size_t n);
-    bool inSameSet(const TrialEdge& e) const;
-    void merge(const TrialEdge& e);
+    vguard<set<size_t>> seqSet;
+    vguard<size_t> seqSetIdx;
+    explicit Partition(size_t nSequences);
+    void merge(const TrialEdge& edge);
+    bool inSameSet(const TrialEdge& edge) const;
   };
 
-  const vguard<FastSeq>& seqs;
   const RateModel& model;
   const double time;
+  const vguard<FastSeq>& seqs;
   const DiagEnvParams& diagEnvParams;
-  vguard<std::priority_queue<Edge> > edges;
-  vguard<map<AlignRowIndex, AlignPath> > edgePath;
+  vguard<std::priority_queue<Edge>> edges;
+  vguard<map<AlignRowIndex, AlignPath>> edgePath;
 
   AlignGraph(const vguard<FastSeq>& seqs, const RateModel& model, const double time, const DiagEnvParams& diagEnvParams,
              ForwardMatrix::random_engine& generator);
-  AlignGraph(const vguard<FastSeq>& seqs, const RateModel& model, const double time, const DiagEnvParams& diagEnvParams);
-  void buildSparseRandomGraph(ForwardMatrix::random_engine& generator);
+  AlignGraph(const vguard<FastSeq>& sequences, const RateModel& rates, double branchLength, const DiagEnvParams& envelopeParams);
   void buildDenseGraph();
-  void buildGraph(const list<TrialEdge>& trialEdges, const string& graphDescription);
-  list<AlignPath> minSpanTree();
+  void buildSparseRandomGraph(ForwardMatrix::random_engine& rng);
+  void buildGraph(const list<TrialEdge>& candidates, const string& description);
+  list<AlignPath> minSpanTree();            // the spanning tree's pairwise alignments; then merged, as rows, as gapped sequences
   AlignPath mstPath();
   Alignment mstAlign();
   vguard<FastSeq> mstGapped();

@@ -444,10 +444,10 @@ vguard<Mat> RateModel::getSubProbMatrix(double t) const {
 
 ProbModel::ProbModel(const RateModel& model, double t)
     : AlphabetOwner(model), t(t), ins(1 - exp(-model.insRate * t)), del(1 - exp(-model.delRate * t)),
-      insExt(model.insExtProb), delExt(model.delExtProb), cptWeight(model.cptWeight), insVec(model.insProb),
-      subMat(model.getSubProbMatrix(t)) {}
+      insExt(model.insExtProb), delExt(model.delExtProb), subMat(model.getSubProbMatrix(t)), insVec(model.insProb),
+      cptWeight(model.cptWeight) {}
 
-LogProbModel::LogProbModel(const ProbModel& pm) : logCptWeight(pm.components()), logInsProb(pm.components()) {
+LogProbModel::LogProbModel(const ProbModel& pm) : logInsProb(pm.components()), logCptWeight(pm.components()) {
   for (int c = 0; c < pm.components(); ++c) {
     logCptWeight[c] = log(pm.cptWeight[c]);
     logInsProb[c] = log_vector(pm.insVec[c]);

@@ -535,13 +535,13 @@ DPMatrix::XYCell DPMatrix::xyCell(ProfileStateIndex xpos, ProfileStateIndex ypos
 // ---- ForwardMatrix: construction = the device fill (traceback, profiles, posteriors: hx_host_walk.cpp) ----------
 ForwardMatrix::ForwardMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, AlignRowIndex parentRowIndex,
                              const GuideAlignmentEnvelope& env, SumProduct* sumProd)
-    : DPMatrix(x, y, hmm, env), parentRowIndex(parentRowIndex), sumProd(sumProd) {
+    : DPMatrix(x, y, hmm, env), sumProd(sumProd), parentRowIndex(parentRowIndex) {
   Require(sumProd == NULL, "substitution counts (SumProduct) are outside this build's scope");
   createBatchAndPrepare();
 }
 
 ForwardMatrix::ForwardMatrix(const Profile& x, const Profile& y, const PairHMM& hmm, AlignRowIndex parentRowIndex,
                              const GuideAlignmentEnvelope& env, Deferred)
-    : DPMatrix(x, y, hmm, env), parentRowIndex(parentRowIndex), sumProd(NULL) {}
+    : DPMatrix(x, y, hmm, env), sumProd(NULL), parentRowIndex(parentRowIndex) {}
 
 }  // namespace historian

@@ -29,7 +29,7 @@ ProfileState::ProfileState(size_t components, AlphTok alphSize) : lpAbsorb(compo
 // transitions of log-weight 0; the move into END is a null move, every other one absorbs a residue
 // ------------------------------------------------------------------------------------------------------------------
 Profile::Profile(size_t components, const string& alphabet, const FastSeq& seq, AlignRowIndex rowIndex)
-    : alphSize((AlphTok)alphabet.size()), components(components), name(seq.name), rootRowIndex(rowIndex) {
+    : components(components), alphSize((AlphTok)alphabet.size()), rootRowIndex(rowIndex), name(seq.name) {
   const size_t len = seq.seq.size();
   state.assign(len + 2, ProfileState());
   ProfileState& first = state.front();

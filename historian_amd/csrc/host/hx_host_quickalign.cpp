@@ -42,7 +42,7 @@ Kmer makeKmer(SeqIdx k, vguard<int>::const_iterator tok, AlphTok alphabetSize) {
   return kmer;
 }
 
-KmerIndex::KmerIndex(const FastSeq& seq, const string& alphabet, SeqIdx kmerLen) : seq(seq), alphabet(alphabet), kmerLen(kmerLen) {
+KmerIndex::KmerIndex(const FastSeq& seq, const string& alphabet, SeqIdx kmerLen) : kmerLen(kmerLen), alphabet(alphabet), seq(seq) {
   const UnvalidatedTokSeq tok = unvalidatedTokens(seq, alphabet);
   const AlphTok alphabetSize = (AlphTok)alphabet.size();
   const SeqIdx seqLen = seq.length();

@@ -30,7 +30,7 @@ Alignment::Alignment(const vguard<FastSeq>& gapped) : ungapped(gapped.size()) {
   }
 }
 
-Alignment::Alignment(const vguard<FastSeq>& ungapped, const AlignPath& path) : ungapped(ungapped), path(path) {}
+Alignment::Alignment(const vguard<FastSeq>& ungapped, const AlignPath& path) : path(path), ungapped(ungapped) {}
 
 vguard<FastSeq> Alignment::gapped() const {
   vguard<FastSeq> rows(ungapped.size());
@@ -160,8 +160,8 @@ AlignPath alignPathMerge(const vguard<AlignPath>& alignments) {
 
 // ---- src/diagenv.cpp:12-20,92-102 --------------------------------------------------------------
 DiagEnvParams::DiagEnvParams()
-    : sparse(true), autoMemSize(true), kmerLen(DEFAULT_KMER_LENGTH), kmerThreshold(DEFAULT_KMER_THRESHOLD),
-      bandSize(DEFAULT_BAND_SIZE), maxSize(0) {}
+    : kmerLen(DEFAULT_KMER_LENGTH), kmerThreshold(DEFAULT_KMER_THRESHOLD), bandSize(DEFAULT_BAND_SIZE), sparse(true),
+      autoMemSize(true), maxSize(0) {}
 
 size_t DiagEnvParams::effectiveMaxSize() const {
   size_t ms = 0;
@@ -177,7 +177,7 @@ size_t DiagEnvParams::effectiveMaxSize() const {
 // ---- src/span.cpp --------------------------------------------------------------------------------
 // Disjoint sets of sequence indices; the union keeps the smaller set index, so seqSet.front() is always the
 // component of sequence 0 (the spanning tree below grows from it).
-AlignGraph::Partition::Partition(size_t n) : seqSetIdx(n), seqSet(n), nSets(n) {
+AlignGraph::Partition::Partition(size_t n) : nSets(n), seqSet(n), seqSetIdx(n) {
   for (size_t k = 0; k < n; ++k) {
     seqSetIdx[k] = k;
     seqSet[k].insert(k);
@@ -200,12 +200,12 @@ void AlignGraph::Partition::merge(const AlignGraph::TrialEdge& e) {
 
 AlignGraph::AlignGraph(const vguard<FastSeq>& seqs, const RateModel& model, const double time, const DiagEnvParams& diagEnvParams,
                        ForwardMatrix::random_engine& generator)
-    : seqs(seqs), model(model), time(time), diagEnvParams(diagEnvParams), edges(seqs.size()), edgePath(seqs.size()) {
+    : model(model), time(time), seqs(seqs), diagEnvParams(diagEnvParams), edges(seqs.size()), edgePath(seqs.size()) {
   buildSparseRandomGraph(generator);
 }
 
 AlignGraph::AlignGraph(const vguard<FastSeq>& seqs, const RateModel& model, const double time, const DiagEnvParams& diagEnvParams)
-    : seqs(seqs), model(model), time(time), diagEnvParams(diagEnvParams), edges(seqs.size()), edgePath(seqs.size()) {
+    : model(model), time(time), seqs(seqs), diagEnvParams(diagEnvParams), edges(seqs.size()), edgePath(seqs.size()) {
   buildDenseGraph();
 }
 

@@ -419,7 +419,7 @@ AlignPath ForwardMatrix::traceAlignPath(const Path& path) const {
 // eliminated cells between them, and the alignment columns of the best such path.  Cells are handled in reverse cell
 // order, so that when a cell is processed the effective transitions leaving it are complete.
 // ---------------------------------------------------------------------------------------------------------------------
-ForwardMatrix::EffectiveTransition::EffectiveTransition() : lpPath(kNegInf), lpBestAlignPath(kNegInf) {}
+ForwardMatrix::EffectiveTransition::EffectiveTransition() : lpBestAlignPath(kNegInf), lpPath(kNegInf) {}
 
 Profile ForwardMatrix::makeProfile(const set<CellCoords>& cells, ProfilingStrategy strategy) {
   Assert(cells.count(startCell), "Missing SSS");
