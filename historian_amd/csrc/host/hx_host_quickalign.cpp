@@ -153,29 +153,22 @@ QuickAlignMatrix::QuickAlignMatrix(const DiagonalEnvelope& env, const RateModel&
 
 // scores: src/quickalign.cpp:25-54
 void QuickAlignMatrix::computeScores() {
-  ProbModel pm(model, time);
-  LogProbModel lpm(pm);
+  const ProbModel branch(model, time);
+  const LogProbModel logBranch(branch);
   const size_t A = model.alphabetSize();
+  // substitution log-odds against the insertion distribution, first mixture component
   submat.assign(A, vguard<LogProb>(A));
   for (AlphTok i = 0; i < A; ++i)
-    for (AlphTok j = 0; j < A; ++j) submat[i][j] = log(pm.subMat.front()[i][j]) - lpm.logInsProb.front()[j];
-  const double gapProb = pm.ins + (1 - pm.ins) * pm.del;
-  const double noGapProb = 1 - gapProb;
-  const double gapExt = 1 / ((pm.ins / gapProb) / pm.insExt + (1 - pm.ins / gapProb) / pm.delExt);
-  const double noGapExt = 1 - gapExt;
-  noGap = log(noGapProb);
-  gapOpen = log(gapProb) + log(noGapExt);
-  gapExtend = log(gapExt);
-  m2i = log(gapProb);
-  m2d = log(noGapProb * gapProb);
-  m2m = log(noGapProb * noGapProb);
-  i2i = log(gapExt);
-  i2d = log(noGapExt * gapProb);
-  i2m = log(noGapExt * noGapProb);
-  i2e = i2m;
-  d2d = log(gapExt);
-  d2m = log(noGapExt);
-  d2e = d2m;
+    for (AlphTok j = 0; j < A; ++j) submat[i][j] = log(branch.subMat.front()[i][j]) - logBranch.logInsProb.front()[j];
+  // one gap state for insertions and deletions: probability of opening a gap, and of extending one (the harmonic mix of the
+  // two extension probabilities, weighted by how often a gap is an insertion)
+  const double open = branch.ins + (1 - branch.ins) * branch.del, stay = 1 - open;
+  const double insShare = branch.ins / open;
+  const double extend = 1 / (insShare / branch.insExt + (1 - insShare) / branch.delExt), close = 1 - extend;
+  noGap = log(stay); gapOpen = log(open) + log(close); gapExtend = log(extend);
+  m2m = log(stay * stay);  m2i = log(open);   m2d = log(stay * open);
+  i2m = log(close * stay); i2i = log(extend); i2d = log(close * open); i2e = i2m;
+  d2m = log(close);        d2d = log(extend); d2e = d2m;
   static bool dumped = false;
   if (!dumped && getenv("HX_DEBUG_SPAN")) {   // test hook: the inputs of the DP, exactly (tests/test_host_mirror.py)
     dumped = true;
