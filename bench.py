@@ -83,11 +83,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # HX_BENCH_REHEARSE=1: the multi-rank flow (dealing, broadcast, barriers, reductions, rank 0's line) on a box with ONE
+    # GPU - every rank on device 0, collectives over gloo on host tensors.  For checking the N > 1 path, not for numbers.
+    rehearse = bool(os.environ.get("HX_BENCH_REHEARSE"))
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    coll_dev = None if rehearse else dev      # where the collectives' tensors live (nccl: on the rank's GPU)
 
     from historian_amd import capi, farm, hostmodel, workload
 
@@ -95,10 +103,10 @@ def main():
     model = hostmodel.RateModel.load(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json"))
     a, c = len(model.alphabet), model.components()
     block = farm.constant_block(model, args.tl, args.tr) if rank == 0 else None
-    block = farm.broadcast_block(block, farm.block_len(model), rank, world, dev)
+    block = farm.broadcast_block(block, farm.block_len(model), rank, world, coll_dev)
     table, sub_l, sub_r = farm.split_block(model, block)
 
-    capi.init(local_rank, table)
+    capi.init(dev_index, table)
     hmm = hostmodel.make_hmm(model, args.tl, args.tr, sub_l, sub_r)
     pi = np.asarray(model.root[0], dtype=float)
     pi = pi / pi.sum()
@@ -146,7 +154,7 @@ def main():
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-        dt = farm.max_over_ranks(dt, world, dev)
+        dt = farm.max_over_ranks(dt, world, coll_dev)
         lp = batch.lp_end()
         # outside the timed region: the device-side best-path traceback of every pair (hx_batch_best_trace); the first
         # few paths are compared with the CPU oracle's below
@@ -172,9 +180,9 @@ def main():
     if rank == 0:
         if args.band >= 0:
             cells = env_cells          # the metric counts in-envelope cells
-        gcells = farm.sum_over_ranks(cells, world, dev) if strong else cells * world
+        gcells = farm.sum_over_ranks(cells, world, coll_dev) if strong else cells * world
     elif strong:
-        farm.sum_over_ranks(env_cells if args.band >= 0 else cells, world, dev)
+        farm.sum_over_ranks(env_cells if args.band >= 0 else cells, world, coll_dev)
     if rank == 0:
         total_cells = gcells * args.steps
         value = total_cells / dt
