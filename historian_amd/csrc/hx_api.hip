@@ -1127,7 +1127,13 @@ int hx_batch_backward(hx_batch* b, void* stream) {
       }
       case KC_CHAIN: case KC_CHAIN_BANDED: case KC_DAG: case KC_DAG_BANDED:
         if (banded) launch_fill_neg_inf(b->d_bwd + cr.mat_begin, cr.mat_doubles, st);
-        LAUNCH_TRY(launch_backward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, st));
+        {
+          // the state-record formulation needs the pair's scratch planes (general-profile classes have them: five planes
+          // per pair, of no use once the Forward fill is done); in the scaled-probability mode the planes hold per-state
+          // packs that a later Forward launch does not rebuild, so that mode keeps the CSR walk
+          const bool records = (c == KC_DAG || c == KC_DAG_BANDED) && !b->dag_linear && !getenv("HX_DAG_BWD_OLD");
+          LAUNCH_TRY(launch_backward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, records, st));
+        }
         break;
       default:
         LAUNCH_TRY(launch_backward_dag(jobs, cr.n, cr.max_rows, Tab8{D.tab}, st));

@@ -281,10 +281,151 @@ __device__ __forceinline__ C5 backward_cell_dag(const Mat& m, const Side& x, con
   return r;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward with state records (round 2).  The recursion above walks a state's out-transitions through the CSR arrays:
+// offsets, then destinations and weights, then the destinations' constants, then the matrix - four loads deep, sixty-four
+// loads per wave-step.  A 64-byte record per state holds the CSR ranges, the flags and envelope coordinate and the FIRST
+// absorbing out-transition in full (nine states in ten have exactly one); the workgroup builds the records of its two
+// profiles into the pair's scratch planes (free after the Forward fill) before it starts.  A row's record stays in
+// registers for the strip, a column's is four 16-byte loads; the matrix loads of the first transitions follow at once.
+// Same operations on the same operands in the same order as backward_cell_dag: bit-identical.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef double bw_d2 __attribute__((ext_vector_type(2)));
+struct BwdRec {
+  int ab, ae, nb, ne;                  // absorbing / null out-transitions (CSR ranges)
+  int d0, flags, env, pad;             // destination of the first absorbing transition; the state's flags and envelope coordinate
+  double lp0, rs0, ins0, spare;        // its weight, rootsub and ins of its destination
+};
+__device__ __forceinline__ void build_bwd_recs(const Side& s, HX_GLOBAL BwdRec* out, bool banded, int tid, int threads) {
+  for (int i = tid; i < s.n; i += threads) {
+    BwdRec r;
+    r.ab = s.ao_off[i]; r.ae = s.ao_off[i + 1];
+    r.nb = s.no_off[i]; r.ne = s.no_off[i + 1];
+    r.flags = s.flags[i];
+    r.env = banded ? s.env[i] : 0;
+    r.pad = 0; r.spare = 0.;
+    r.d0 = 0; r.lp0 = r.rs0 = r.ins0 = HX_NEG_INF;
+    if (r.ae > r.ab) {
+      r.d0 = s.ao_dst[r.ab];
+      r.lp0 = s.ao_lp[r.ab];
+      r.rs0 = s.rootsub[r.d0];
+      r.ins0 = s.ins[r.d0];
+    }
+    HX_GLOBAL i4v* q = (HX_GLOBAL i4v*)(out + i);
+    q[0] = i4v{r.ab, r.ae, r.nb, r.ne};
+    q[1] = i4v{r.d0, r.flags, r.env, 0};
+    ((HX_GLOBAL bw_d2*)q)[2] = bw_d2{r.lp0, r.rs0};
+    ((HX_GLOBAL bw_d2*)q)[3] = bw_d2{r.ins0, 0.};
+  }
+}
+__device__ __forceinline__ BwdRec load_bwd_rec(const HX_GLOBAL BwdRec* p) {
+  const HX_GLOBAL i4v* q = (const HX_GLOBAL i4v*)p;
+  const i4v a = q[0], b = q[1];
+  const bw_d2 c = ((const HX_GLOBAL bw_d2*)q)[2], d = ((const HX_GLOBAL bw_d2*)q)[3];
+  BwdRec r;
+  r.ab = a.x; r.ae = a.y; r.nb = a.z; r.ne = a.w;
+  r.d0 = b.x; r.flags = b.y; r.env = b.z; r.pad = 0;
+  r.lp0 = c.x; r.rs0 = c.y; r.ins0 = d.x; r.spare = 0.;
+  return r;
+}
+
+template <class LSE>
+__device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, const Side& y, const double (*T)[6],
+                                                const LSE& L, int i, int j, const BwdRec& rx, const BwdRec& ry) {
+  const HX_GLOBAL double* M = m.M;
+  const int64_t plane = m.plane, ss = m.ss;
+  const int R = m.R, Cc = m.Cc;
+  const uint8_t xf = (uint8_t)rx.flags, yf = (uint8_t)ry.flags;
+#define BS(a, b) bwd_slot(ss, R, Cc, (a), (b))
+  C5 r = c5_neg_inf();
+  // cells that feed END are initialised by assignment (src/forward.cpp:981-995)
+  if ((xf & F_TO_END) && (yf & F_TO_END)) {
+    const int xe = x.n - 1, ye = y.n - 1;
+    for (int tx = x.in_off[xe]; tx < x.in_off[xe + 1]; ++tx)
+      for (int ty = y.in_off[ye]; ty < y.in_off[ye + 1]; ++ty)
+        if (x.in_src[tx] == i && y.in_src[ty] == j) {
+          const double lp = x.in_lp[tx] + y.in_lp[ty];
+          r = C5{lp + T[0][5], lp + T[1][5], lp + T[2][5], lp + T[3][5], lp + T[4][5]};
+        }
+  }
+  const bool yok = (yf & F_READY) || y.empty;
+  const bool xok = (xf & F_READY) || x.empty;
+  const int xab = rx.ab, xae = rx.ae, yab = ry.ab, yae = ry.ae;
+  const int xnb = rx.nb, xne = rx.ne, ynb = ry.nb, yne = ry.ne;
+
+  for (int tx = xab; tx < xae; ++tx) {
+    const int dx = tx == xab ? rx.d0 : x.ao_dst[tx];
+    const double lpx = tx == xab ? rx.lp0 : x.ao_lp[tx];
+    for (int ty = yab; ty < yae; ++ty) {
+      const int dy = ty == yab ? ry.d0 : y.ao_dst[ty];
+      const double lpy = ty == yab ? ry.lp0 : y.ao_lp[ty];
+      const double d = lpx + lpy + emis_at(m, x, y, dx, dy) + M[BS(dx, dy)];
+      r.imm = L(r.imm, T[0][0] + d);
+      r.imd = L(r.imd, T[1][0] + d);
+      r.idm = L(r.idm, T[2][0] + d);
+      r.imi = L(r.imi, T[3][0] + d);
+      r.iiw = L(r.iiw, T[4][0] + d);
+    }
+  }
+  if (yok)
+    for (int tx = xab; tx < xae; ++tx) {
+      const bool first = tx == xab;
+      const int dx = first ? rx.d0 : x.ao_dst[tx];
+      const double lpx = first ? rx.lp0 : x.ao_lp[tx];
+      const int64_t sl = BS(dx, j);
+      const double d1 = lpx + (first ? rx.rs0 : x.rootsub[dx]) + M[plane + sl];
+      const double d2 = lpx + (first ? rx.ins0 : x.ins[dx]) + M[4 * plane + sl];
+      r.imm = L(r.imm, T[0][1] + d1);
+      r.imd = L(r.imd, T[1][1] + d1);
+      r.idm = L(r.idm, T[2][1] + d1);
+      r.imi = L(r.imi, T[3][1] + d1);
+      r.imm = L(r.imm, T[0][4] + d2);
+      r.imi = L(r.imi, T[3][4] + d2);
+      r.iiw = L(r.iiw, T[4][4] + d2);
+    }
+  if (xok)
+    for (int ty = yab; ty < yae; ++ty) {
+      const bool first = ty == yab;
+      const int dy = first ? ry.d0 : y.ao_dst[ty];
+      const double lpy = first ? ry.lp0 : y.ao_lp[ty];
+      const int64_t sl = BS(i, dy);
+      const double d1 = lpy + (first ? ry.rs0 : y.rootsub[dy]) + M[2 * plane + sl];
+      const double d2 = lpy + (first ? ry.ins0 : y.ins[dy]) + M[3 * plane + sl];
+      r.imm = L(r.imm, T[0][2] + d1);
+      r.imd = L(r.imd, T[1][2] + d1);
+      r.idm = L(r.idm, T[2][2] + d1);
+      r.iiw = L(r.iiw, T[4][2] + d1);
+      r.imm = L(r.imm, T[0][3] + d2);
+      r.imi = L(r.imi, T[3][3] + d2);
+    }
+  if (yok)
+    for (int tx = xnb; tx < xne; ++tx) {
+      const int dx = x.no_dst[tx];
+      if (dx >= R) continue;   // END is not stored: xyCell(END,.) is the empty cell
+      const double lpx = x.no_lp[tx];
+      const int64_t sl = BS(dx, j);
+      r.imd = L(r.imd, lpx + M[plane + sl]);
+      r.iiw = L(r.iiw, lpx + M[4 * plane + sl]);
+      r.imm = L(r.imm, lpx + M[sl]);
+    }
+  for (int ty = ynb; ty < yne; ++ty) {
+    const int dy = y.no_dst[ty];
+    if (dy >= Cc) continue;
+    const double lpy = y.no_lp[ty];
+    const int64_t sl = BS(i, dy);
+    r.idm = L(r.idm, lpy + M[2 * plane + sl]);
+    r.imi = L(r.imi, lpy + M[3 * plane + sl]);
+    if (xf & F_EMIT_OR_START) r.imm = L(r.imm, lpy + M[sl]);
+  }
+#undef BS
+  return r;
+}
+
 #define HX_DAG_MAX_WAVES 16
 
 // DIR 0: Forward, DIR 1: Backward (swept in mirrored coordinates)
-template <int DIR, class LSE, bool FAST>
+template <int DIR, class LSE, bool FAST, bool REC = false>
 __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_fill_dag(const DevJob* __restrict__ jobs,
                                                                       const double* __restrict__ exact_tab,
                                                                       const double* __restrict__ fast_tab) {
@@ -312,6 +453,18 @@ __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_fill_dag(const DevJob
   const int prev_wave = (wave + W - 1) % W;
   const bool banded = J.max_dist >= 0;
   const HX_GLOBAL int32_t* win = as_global(DIR ? J.bwd_windows : J.fwd_windows);
+  // REC: the state records of both profiles, built here into the pair's scratch planes (the caller launches this
+  // instantiation only for pairs that have them, and only after the Forward fill is done with them)
+  HX_GLOBAL BwdRec* xrec = nullptr;
+  HX_GLOBAL BwdRec* yrec = nullptr;
+  if (REC) {
+    xrec = (HX_GLOBAL BwdRec*)as_global(J.agg);
+    yrec = xrec + x.n;
+    build_bwd_recs(x, xrec, banded, (int)threadIdx.x, threads);
+    build_bwd_recs(y, yrec, banded, (int)threadIdx.x, threads);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 
   for (int s = wave; s < n_strips; s += W) {
     const int im = (s << 6) + lane;              // row in sweep coordinates
@@ -319,6 +472,8 @@ __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_fill_dag(const DevJob
     const int i = rvalid ? (DIR ? R - 1 - im : im) : 0;
     const uint8_t xf = x.flags[i];
     const int xenv = banded ? x.env[i] : 0;
+    BwdRec rx;
+    if (REC) rx = load_bwd_rec(xrec + i);
     const int above_base = ((s - 1) / W) * Cc;   // columns the wave above published in its earlier strips
     const int my_base = (s / W) * Cc;
     const int64_t store_base = (int64_t)s * m.ss + (lane << 1);
@@ -345,9 +500,12 @@ __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_fill_dag(const DevJob
         const int jm = t - lane;
         if (rvalid && jm >= 0 && jm < Cc) {
           const int j = DIR ? Cc - 1 - jm : jm;
-          const uint8_t yf = y.flags[j];
-          if (in_env(m, xf, yf, xenv, banded ? y.env[j] : 0)) {
-            const C5 c = DIR ? backward_cell_dag(m, x, y, J.T, L, i, j, xf, yf)
+          BwdRec ry;
+          if (REC) ry = load_bwd_rec(yrec + j);
+          const uint8_t yf = REC ? (uint8_t)ry.flags : y.flags[j];
+          if (in_env(m, xf, yf, xenv, banded ? (REC ? ry.env : y.env[j]) : 0)) {
+            const C5 c = REC ? backward_cell_rec(m, x, y, J.T, L, i, j, rx, ry)
+                       : DIR ? backward_cell_dag(m, x, y, J.T, L, i, j, xf, yf)
                              : forward_cell_dag(m, x, y, J.T, L, i, j, xf, yf);
             const int64_t sl = store_base + ((int64_t)(t >> 1) << 7) + (t & 1);
             m.M[sl] = c.imm;
@@ -888,11 +1046,18 @@ int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8
   return 0;
 }
 
+// `records`: every pair of the launch has scratch planes (DevJob::agg) that the Forward fill no longer needs and that hold
+// at least 8 doubles per state of its two profiles: the state-record formulation (backward_cell_rec)
 int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 tab16,
-                             bool fast, hipStream_t st) {
+                             bool fast, bool records, hipStream_t st) {
   const double* tab = tab8.p;
   const double* fast_tab = tab16.p;
   const dim3 g(n_jobs), b(dag_waves(max_rows, HX_DAG_MAX_WAVES) * 64);
+  if (records) {
+    if (fast) hipLaunchKernelGGL((k_fill_dag<1, FastLse, true, true>), g, b, 0, st, d_jobs, tab, fast_tab);
+    else hipLaunchKernelGGL((k_fill_dag<1, ExactLse3, false, true>), g, b, 0, st, d_jobs, tab, fast_tab);
+    return 0;
+  }
   if (fast) hipLaunchKernelGGL((k_fill_dag<1, FastLse, true>), g, b, 0, st, d_jobs, tab, fast_tab);
   else hipLaunchKernelGGL((k_fill_dag<1, ExactLse3, false>), g, b, 0, st, d_jobs, tab, fast_tab);
   return 0;
