@@ -635,6 +635,7 @@ void setThreadDevice(int ordinal);
 void warmHostBuffers(size_t doubles, int count);   // page-lock `count` matrix buffers on a helper thread
 void mergeTiming(const FillTiming& from, FillTiming& into);
 double* pinnedTake(size_t doubles, size_t& capacity);
+void pinnedReserve(size_t doubles, int count);     // make sure `count` free page-locked buffers of that size exist (call while the device is busy)
 void pinnedGive(double* p, size_t capacity);
 void check(int rc, const char* what);
 }  // namespace detail

@@ -198,17 +198,16 @@ struct PinnedPool {
   }
   // makes sure a free buffer of n doubles exists; called while a fill kernel runs, so that page-locking a buffer for a
   // matrix larger than any before it is not paid in front of its traceback
-  void reserve(size_t n) {
-    if (!hostReadsExpected) return;
+  void reserve(size_t n, int count = 1, bool certain = false) {
+    if (!hostReadsExpected && !certain) return;
     settle();
-    {
-      std::lock_guard<std::mutex> lock(g_deviceMutex);
-      for (const auto& f : freeList)
-        if (f.first >= n) return;
+    std::vector<std::pair<size_t, double*> > held;
+    for (int k = 0; k < count; ++k) {              // (take() picks the smallest free buffer that fits, or locks a new one)
+      size_t cap = 0;
+      double* p = take(n, cap);
+      held.push_back(std::make_pair(cap, p));
     }
-    size_t cap = 0;
-    double* p = take(n, cap);
-    give(p, cap);
+    for (const auto& h : held) give(h.second, h.first);
   }
 };
 PinnedPool g_pinned;
@@ -233,6 +232,7 @@ void mergeTiming(const FillTiming& a, FillTiming& b) {
   b.fills += a.fills; b.matrixReads += a.matrixReads; b.deviceTraces += a.deviceTraces; b.cellGathers += a.cellGathers; b.cells += a.cells;
 }
 double* pinnedTake(size_t doubles, size_t& capacity) { return g_pinned.take(doubles, capacity); }
+void pinnedReserve(size_t doubles, int count) { g_pinned.reserve(doubles, count, true); }
 void pinnedGive(double* p, size_t capacity) { g_pinned.give(p, capacity); }
 void check(int rc, const char* what) { hxCheck(rc, what); }
 }  // namespace detail

@@ -720,12 +720,16 @@ BackwardMatrix::BackwardMatrix(ForwardMatrix& fwd) : DPMatrix(fwd.x, fwd.y, fwd.
   suby = fwd.suby;
   insx = fwd.insx; insy = fwd.insy; rootsubx = fwd.rootsubx; rootsuby = fwd.rootsuby;
   lpEnd = 0;
+  const double tBack = wallSeconds();
   if (!handle->backwardDone) {      // one launch fills the Backward matrices of every job of the batch
     detail::check(hx_batch_backward(batch, NULL), "hx_batch_backward");
     handle->backwardDone = true;
+    // posterior decoding walks both matrices on the host: their page-locked buffers, while the Backward fill runs
+    detail::pinnedReserve((size_t)matrixDoubles, 2);
   }
   vguard<double> lpStarts((size_t)handle->nJobs, kNegInf);
   detail::check(hx_batch_lp_start(batch, lpStarts.data()), "hx_batch_lp_start");
+  fillTiming.backwardWait += wallSeconds() - tBack;
   const double lpStartDev = lpStarts[(size_t)jobIndex];
   if (!nearlyEqual(lpStartDev, fwd.lpEnd, FWD_BACK_ERROR_TOLERANCE)) {
     // the two fills disagree by more than 1 %: find the cells and moves that do not add up (reference src/forward.cpp:1091-1096)

@@ -114,9 +114,9 @@ int main(int argc, char** argv) {
     const double total = wallSeconds() - t0;
     const FillTiming& f = fillTiming;
     fprintf(stderr, "timing: reconstruct %.3f s = one-off HIP/device initialisation %.3f s + %.3f s; %ld fills over %lld lattice cells: "
-                    "flatten+upload %.3f s, forward (launch..lpEnd) %.3f s of which fill kernels %.3f s, matrix D2H %.3f s in %ld reads (page-locking beyond the warmed buffers: %.3f s for %ld buffers, while a fill runs where the size is known by then), "
+                    "flatten+upload %.3f s, forward (launch..lpEnd) %.3f s of which fill kernels %.3f s, backward (launch..lpStart) %.3f s, matrix D2H %.3f s in %ld reads (page-locking beyond the warmed buffers: %.3f s for %ld buffers, while a fill runs where the size is known by then), "
                     "device best-path tracebacks %.3f s in %ld calls, cell gathers %.3f s in %ld calls; sorting sampled cells %.3f s, keeping their values %.3f s; envelopes %.3f s, prepared vectors (read + lpAbsorb) %.3f s; host traceback/profile building/other %.3f s\n",
-            total, f.deviceInit, total - f.deviceInit, f.fills, f.cells, f.flattenAndUpload, f.forwardWait, f.forwardKernel, f.readMatrix,
+            total, f.deviceInit, total - f.deviceInit, f.fills, f.cells, f.flattenAndUpload, f.forwardWait, f.forwardKernel, f.backwardWait, f.readMatrix,
             f.matrixReads, f.pinnedAlloc, f.pinnedAllocs, f.deviceTrace, f.deviceTraces, f.cellGather, f.cellGathers, f.cellSets, f.retain, f.construct, f.readPrepared,
             total - f.deviceInit - f.flattenAndUpload - f.forwardWait - f.readMatrix - f.backwardWait - f.deviceTrace - f.cellGather);
   }
