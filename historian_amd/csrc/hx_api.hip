@@ -1132,7 +1132,18 @@ int hx_batch_backward(hx_batch* b, void* stream) {
           // per pair, of no use once the Forward fill is done); in the scaled-probability mode the planes hold per-state
           // packs that a later Forward launch does not rebuild, so that mode keeps the CSR walk
           const bool records = (c == KC_DAG || c == KC_DAG_BANDED) && !b->dag_linear && !getenv("HX_DAG_BWD_OLD");
-          LAUNCH_TRY(launch_backward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, records, st));
+          // a lone pair (or two) of more than sixteen strips: its strips dealt to two to four workgroups (hx_dag.hip
+          // k_backward_dag_multi); their progress counters - the last 256 ints of each pair's scratch planes - start at zero
+          int multi = 1;
+          if (records && cr.n <= 2 && cr.max_rows > 16 * HX_STRIP && !getenv("HX_DAG_BWD_SINGLE")) {
+            const int strips = (cr.max_rows + HX_STRIP - 1) / HX_STRIP;
+            multi = std::min(4, (strips + 15) / 16);
+            for (int q = 0; q < cr.n && multi > 1; ++q) {
+              const DevJob& Jh = b->jobs[b->order[cr.begin + q]];
+              HIP_TRY(hipMemsetAsync(reinterpret_cast<int*>(Jh.agg + 5 * Jh.plane) - 256, 0, 256 * sizeof(int), st));
+            }
+          }
+          LAUNCH_TRY(launch_backward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, records, multi, st));
         }
         break;
       default:
@@ -1174,7 +1185,15 @@ static int read_scalars(hx_batch* b, double* out, int which) {
 }
 
 int hx_batch_lp_end(hx_batch* b, double* out) { return read_scalars(b, out, 0); }
-int hx_batch_lp_start(hx_batch* b, double* out) { return read_scalars(b, out, 1); }
+int hx_batch_lp_start(hx_batch* b, double* out) {
+  const int rc = read_scalars(b, out, 1);
+  if (rc != HX_OK) return rc;
+  // a Backward fill dealt to several workgroups marks a pair whose waves gave up waiting for one another (hx_dag.hip
+  // k_backward_dag_multi: a bounded number of polls, never a hang) with NaN; no fill produces NaN otherwise
+  for (int k = 0; k < b->n_jobs; ++k)
+    if (out[k] != out[k]) return fail(HX_ERR_HIP, "the Backward fill of pair %d did not complete (workgroups lost one another)", k);
+  return HX_OK;
+}
 
 int hx_batch_layout(const hx_batch* b, int32_t job, int32_t which, hx_layout* out) {
   if (!b || !out || which < 0 || which > 1) return fail(HX_ERR_INVALID_ARG, "bad arguments");

@@ -330,10 +330,21 @@ __device__ __forceinline__ BwdRec load_bwd_rec(const HX_GLOBAL BwdRec* p) {
   return r;
 }
 
-template <class LSE>
+// COH: the matrix is being written by other workgroups too (k_backward_dag_multi): every load of a cell bypasses the L1
+// (`sc1`, a relaxed agent-scope load) - the producing wave stored it `sc1` and published its progress behind its own
+// s_waitcnt vmcnt(0), the form MI355X_MICROARCH.md lists as valid without an L2 write-back.
+template <bool COH>
+struct CellLoads {
+  const HX_GLOBAL double* p;
+  __device__ __forceinline__ double operator[](int64_t k) const {
+    if (COH) return __hip_atomic_load((double*)(p + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return p[k];
+  }
+};
+template <class LSE, bool COH = false>
 __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, const Side& y, const double (*T)[6],
                                                 const LSE& L, int i, int j, const BwdRec& rx, const BwdRec& ry) {
-  const HX_GLOBAL double* M = m.M;
+  const CellLoads<COH> M{m.M};
   const int64_t plane = m.plane, ss = m.ss;
   const int R = m.R, Cc = m.Cc;
   const uint8_t xf = (uint8_t)rx.flags, yf = (uint8_t)ry.flags;
@@ -543,6 +554,127 @@ __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_fill_dag(const DevJob
   if (threadIdx.x == 0) {
     if (DIR == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
     else *J.lp_start = J.bwd[cell_slot(m.ss, R - 1, Cc - 1)];   // B(0,0).IMM in mirrored coordinates
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward for ONE pair (or two) on several CUs: the pair's strips are dealt to the 16 G waves of G workgroups instead of the
+// 16 waves of one, so that a pair of thirty strips needs one pass instead of two and its waves share SIMDs less.  What the
+// strips hand each other - the matrix itself - travels write-through: every cell is stored `sc1`, every cell is loaded `sc1`
+// (CellLoads), a wave's progress counter lives in global memory (zeroed by the host before the launch), is stored `sc1`
+// behind the wave's own s_waitcnt vmcnt(0) and polled with `sc1` loads.  A poll gives up after HX_MULTI_PATIENCE rounds: the
+// pair's lpStart then reads NaN and the host reports an error - never a hang.  All workgroups of the launch must be resident
+// at once (the caller launches at most sixteen).  State records as in k_fill_dag<.., REC>.
+// ---------------------------------------------------------------------------------------------------------------------
+#define HX_MULTI_PATIENCE (1 << 22)
+template <class LSE, bool FAST, int G>
+__global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_backward_dag_multi(const DevJob* __restrict__ jobs,
+                                                                                const double* __restrict__ exact_tab,
+                                                                                const double* __restrict__ fast_tab) {
+  __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : 2];
+  const int threads = blockDim.x, W = threads >> 6, WT = W * G;
+  if (FAST)
+    for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 2; k += threads) ftab[k] = fast_tab[k];
+  __syncthreads();
+  const LSE L = LSE::make(FAST ? (const double*)ftab : fast_tab);
+  const int job = (int)blockIdx.x / G, grp = (int)blockIdx.x % G;
+  const DevJob& J = jobs[job];
+  const Side x = make_side(J.x), y = make_side(J.y);
+  Mat m;
+  m.M = as_global(J.bwd);
+  m.etab = as_global((const double*)J.emis);
+  m.eplane = as_global((const double*)J.emis_plane);
+  m.plane = J.plane; m.ss = J.strip_stride;
+  m.R = J.n_rows; m.Cc = J.n_cols; m.max_dist = J.max_dist;
+  const int R = m.R, Cc = m.Cc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gw = grp * W + wave;                   // this wave among the pair's WT waves
+  const int n_strips = (R + 63) >> 6;
+  const int prev_gw = (gw + WT - 1) % WT;
+  const bool banded = J.max_dist >= 0;
+  const HX_GLOBAL int32_t* win = as_global(J.bwd_windows);
+  // records: every workgroup builds them (the same bytes at the same addresses), its own waves read them after its barrier
+  HX_GLOBAL BwdRec* xrec = (HX_GLOBAL BwdRec*)as_global(J.agg);
+  HX_GLOBAL BwdRec* yrec = xrec + x.n;
+  build_bwd_recs(x, xrec, banded, (int)threadIdx.x, threads);
+  build_bwd_recs(y, yrec, banded, (int)threadIdx.x, threads);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // progress counters of the pair's waves: the last 256 ints of its scratch planes
+  HX_GLOBAL int* gprog = (HX_GLOBAL int*)as_global(reinterpret_cast<int*>(J.agg + 5 * J.plane) - 256);
+  bool dead = false;
+  HX_GLOBAL double* Mw = as_global(J.bwd);       // (global, not flat, instructions: the hand-off is only measured valid for those)
+  const auto put = [&](int64_t k, double v) { __hip_atomic_store(Mw + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  const auto publish = [&](int value) {
+    if (lane == 0) __hip_atomic_store(gprog + gw, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  for (int s = gw; s < n_strips; s += WT) {
+    const int im = (s << 6) + lane;
+    const bool rvalid = im < R;
+    const int i = rvalid ? R - 1 - im : 0;
+    const uint8_t xf = x.flags[i];
+    const int xenv = banded ? x.env[i] : 0;
+    const BwdRec rx = load_bwd_rec(xrec + i);
+    const int above_base = ((s - 1) / WT) * Cc;
+    const int my_base = (s / WT) * Cc;
+    const int64_t store_base = (int64_t)s * m.ss + (lane << 1);
+    int seen = 0;
+    int wlo[2] = {0, 0}, whi[2] = {Cc + 63, 0};
+    if (banded) {
+      wlo[0] = win[4 * s]; whi[0] = win[4 * s + 1];
+      wlo[1] = win[4 * s + 2]; whi[1] = win[4 * s + 3];
+    }
+    int published = 0;
+    for (int w = 0; w < 2; ++w) {
+      for (int t = wlo[w]; t < whi[w]; ++t) {
+        if (s > 0 && !dead) {
+          const int need = above_base + (t + 1 < Cc ? t + 1 : Cc);
+          int polls = 0;
+          while (seen < need) {
+            seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(gprog + prev_gw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (seen < need) {
+              if (++polls > HX_MULTI_PATIENCE) { dead = true; break; }
+              __builtin_amdgcn_s_sleep(2);
+            }
+          }
+        }
+        const int jm = t - lane;
+        if (!dead && rvalid && jm >= 0 && jm < Cc) {
+          const int j = Cc - 1 - jm;
+          const BwdRec ry = load_bwd_rec(yrec + j);
+          const uint8_t yf = (uint8_t)ry.flags;
+          if (in_env(m, xf, yf, xenv, banded ? ry.env : 0)) {
+            const C5 c = backward_cell_rec<LSE, true>(m, x, y, J.T, L, i, j, rx, ry);
+            const int64_t sl = store_base + ((int64_t)(t >> 1) << 7) + (t & 1);
+            put(sl, c.imm); put(m.plane + sl, c.imd); put(2 * m.plane + sl, c.idm); put(3 * m.plane + sl, c.imi); put(4 * m.plane + sl, c.iiw);
+          }
+        }
+        if ((t & 7) == 7) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          int done = t - 62;
+          done = done > Cc ? Cc : done;
+          if (dead) done = Cc;                     // (let everyone below run out as well)
+          if (done > published) {
+            published = done;
+            publish(my_base + done);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int upto = (w == 0 && whi[1] > wlo[1]) ? wlo[1] - 63 : Cc;
+      int done = upto > Cc ? Cc : upto;
+      if (dead) done = Cc;
+      if (done > published) {
+        published = done;
+        publish(my_base + done);
+      }
+    }
+    // the wave of the last strip reports B(START, START).IMM (its own store, read back past the L1)
+    if (s == n_strips - 1 && lane == 0) {
+      const double v = __hip_atomic_load(Mw + cell_slot(m.ss, R - 1, Cc - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *J.lp_start = dead ? __builtin_nan("") : v;
+    }
   }
 }
 
@@ -1049,10 +1181,23 @@ int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8
 // `records`: every pair of the launch has scratch planes (DevJob::agg) that the Forward fill no longer needs and that hold
 // at least 8 doubles per state of its two profiles: the state-record formulation (backward_cell_rec)
 int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 tab16,
-                             bool fast, bool records, hipStream_t st) {
+                             bool fast, bool records, int multi, hipStream_t st) {
   const double* tab = tab8.p;
   const double* fast_tab = tab16.p;
   const dim3 g(n_jobs), b(dag_waves(max_rows, HX_DAG_MAX_WAVES) * 64);
+  // one or two pairs of more than sixteen strips: several workgroups per pair (k_backward_dag_multi); the caller has zeroed
+  // the progress counters
+  if (records && multi > 1) {
+    const dim3 gm(n_jobs * multi), bm(HX_DAG_MAX_WAVES * 64);
+#define HX_MULTI_GO(G_) do { \
+      if (fast) hipLaunchKernelGGL((k_backward_dag_multi<FastLse, true, G_>), gm, bm, 0, st, d_jobs, tab, fast_tab); \
+      else hipLaunchKernelGGL((k_backward_dag_multi<ExactLse3, false, G_>), gm, bm, 0, st, d_jobs, tab, fast_tab); \
+      return 0; } while (0)
+    if (multi == 2) HX_MULTI_GO(2);
+    if (multi == 3) HX_MULTI_GO(3);
+    if (multi == 4) HX_MULTI_GO(4);
+#undef HX_MULTI_GO
+  }
   if (records) {
     if (fast) hipLaunchKernelGGL((k_fill_dag<1, FastLse, true, true>), g, b, 0, st, d_jobs, tab, fast_tab);
     else hipLaunchKernelGGL((k_fill_dag<1, ExactLse3, false, true>), g, b, 0, st, d_jobs, tab, fast_tab);
