@@ -1134,16 +1134,20 @@ int hx_batch_backward(hx_batch* b, void* stream) {
           const bool records = (c == KC_DAG || c == KC_DAG_BANDED) && !b->dag_linear && !getenv("HX_DAG_BWD_OLD");
           // a lone pair (or two) of more than sixteen strips: its strips dealt to two to four workgroups (hx_dag.hip
           // k_backward_dag_multi); their progress counters - the last 256 ints of each pair's scratch planes - start at zero
-          int multi = 1;
-          if (records && cr.n <= 2 && cr.max_rows > 16 * HX_STRIP && !getenv("HX_DAG_BWD_SINGLE")) {
+          int multi = 1, multi_waves = 4;
+          const char* min_strips = getenv("HX_DAG_MULTI_MIN_STRIPS");      // tuning hook
+          if (records && cr.n <= 2 && cr.max_rows > (min_strips ? atoi(min_strips) : 16) * HX_STRIP && !getenv("HX_DAG_BWD_SINGLE")) {
             const int strips = (cr.max_rows + HX_STRIP - 1) / HX_STRIP;
-            multi = std::min(4, (strips + 15) / 16);
+            if (const char* e = getenv("HX_DAG_MULTI_WAVES")) multi_waves = atoi(e);      // tuning hook: waves per workgroup (default 4: measured 1.24 / 1.13 / 1.02 / 1.01 s at one workgroup / 16 / 8 / 4 waves)
+            if (multi_waves != 16 && multi_waves != 8 && multi_waves != 2) multi_waves = 4;
+            multi = std::min(256 / multi_waves, (strips + multi_waves - 1) / multi_waves);   // (progress counters: 256 per pair)
+            if (multi > 32) multi = 32;
             for (int q = 0; q < cr.n && multi > 1; ++q) {
               const DevJob& Jh = b->jobs[b->order[cr.begin + q]];
               HIP_TRY(hipMemsetAsync(reinterpret_cast<int*>(Jh.agg + 5 * Jh.plane) - 256, 0, 256 * sizeof(int), st));
             }
           }
-          LAUNCH_TRY(launch_backward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, records, multi, st));
+          LAUNCH_TRY(launch_backward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, records, multi, multi_waves, st));
         }
         break;
       default:

@@ -567,10 +567,10 @@ __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_fill_dag(const DevJob
 // at once (the caller launches at most sixteen).  State records as in k_fill_dag<.., REC>.
 // ---------------------------------------------------------------------------------------------------------------------
 #define HX_MULTI_PATIENCE (1 << 22)
-template <class LSE, bool FAST, int G>
+template <class LSE, bool FAST>
 __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_backward_dag_multi(const DevJob* __restrict__ jobs,
                                                                                 const double* __restrict__ exact_tab,
-                                                                                const double* __restrict__ fast_tab) {
+                                                                                const double* __restrict__ fast_tab, const int G) {
   __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : 2];
   const int threads = blockDim.x, W = threads >> 6, WT = W * G;
   if (FAST)
@@ -1181,22 +1181,17 @@ int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8
 // `records`: every pair of the launch has scratch planes (DevJob::agg) that the Forward fill no longer needs and that hold
 // at least 8 doubles per state of its two profiles: the state-record formulation (backward_cell_rec)
 int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 tab16,
-                             bool fast, bool records, int multi, hipStream_t st) {
+                             bool fast, bool records, int multi, int multi_waves, hipStream_t st) {
   const double* tab = tab8.p;
   const double* fast_tab = tab16.p;
   const dim3 g(n_jobs), b(dag_waves(max_rows, HX_DAG_MAX_WAVES) * 64);
   // one or two pairs of more than sixteen strips: several workgroups per pair (k_backward_dag_multi); the caller has zeroed
   // the progress counters
   if (records && multi > 1) {
-    const dim3 gm(n_jobs * multi), bm(HX_DAG_MAX_WAVES * 64);
-#define HX_MULTI_GO(G_) do { \
-      if (fast) hipLaunchKernelGGL((k_backward_dag_multi<FastLse, true, G_>), gm, bm, 0, st, d_jobs, tab, fast_tab); \
-      else hipLaunchKernelGGL((k_backward_dag_multi<ExactLse3, false, G_>), gm, bm, 0, st, d_jobs, tab, fast_tab); \
-      return 0; } while (0)
-    if (multi == 2) HX_MULTI_GO(2);
-    if (multi == 3) HX_MULTI_GO(3);
-    if (multi == 4) HX_MULTI_GO(4);
-#undef HX_MULTI_GO
+    const dim3 gm(n_jobs * multi), bm((multi_waves > 0 ? multi_waves : HX_DAG_MAX_WAVES) * 64);
+if (fast) hipLaunchKernelGGL((k_backward_dag_multi<FastLse, true>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi);
+    else hipLaunchKernelGGL((k_backward_dag_multi<ExactLse3, false>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi);
+    return 0;
   }
   if (records) {
     if (fast) hipLaunchKernelGGL((k_fill_dag<1, FastLse, true, true>), g, b, 0, st, d_jobs, tab, fast_tab);

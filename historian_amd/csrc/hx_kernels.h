@@ -49,7 +49,7 @@ void launch_dag_linear_clear(const DevJob* d_jobs, int n_jobs, hipStream_t st);
 int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 fast_tab,
                              bool fast, hipStream_t st);
 int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 fast_tab,
-                             bool fast, bool records, int multi, hipStream_t st);
+                             bool fast, bool records, int multi, int multi_waves, hipStream_t st);
 int launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, hipStream_t st);
 void launch_posterior_scan(const DevJob* d_jobs, int job, double lpp_threshold, PostCell* out,
                            unsigned long long cap, unsigned long long* counter, hipStream_t st);

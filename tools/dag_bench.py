@@ -46,8 +46,10 @@ for band in ((-1,) if "unbanded" in sys.argv else (20, -1)):
             b.forward(); b.sync(); b.forward(); b.sync()
             x, y = img[0], img[1]
             steps = (y.n_states - 1) + 63 + 72 * ((x.n_states - 1 + 63) // 64 - 1)
-            print("  job %d  %4d x %4d  fast forward %7.3f ms   %5.2f us/step over %d critical-path steps" %
-                  (k, x.n_states, y.n_states, b.kernel_ms(0), b.kernel_ms(0) * 1e3 / steps, steps))
+            fwd_ms = b.kernel_ms(0)
+            b.backward(); b.sync(); b.backward(); b.sync()
+            print("  job %d  %4d x %4d  fast forward %7.3f ms   %5.2f us/step over %d critical-path steps | backward %7.3f ms" %
+                  (k, x.n_states, y.n_states, fwd_ms, fwd_ms * 1e3 / steps, steps, b.kernel_ms(1)))
             b.close()
         continue
     sizes = [(x.n_states, y.n_states) for x, y, _, _ in imgs]
