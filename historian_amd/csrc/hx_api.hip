@@ -542,6 +542,7 @@ struct hx_batch {
   hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   bool dag_linear = false;                      // general-profile classes run the scaled-probability fill (hx_daglin.hip)
   hipStream_t copy_stream = nullptr;            // hx_batch_read_matrix_async: the device's copy stream (DeviceTables)
+  int* d_multi = nullptr;                       // progress counters of a pair dealt to several workgroups (hx_dag.hip MULTI)
   std::vector<hipEvent_t> copied[2];            // per job: the event behind its asynchronous matrix copy, or null
   int32_t* d_trace = nullptr;        // hx_batch_best_trace: path buffers, kept between calls
   int64_t* d_trace_n = nullptr;
@@ -1004,6 +1005,7 @@ int hx_batch_destroy(hx_batch* b) {
   for (int w = 0; w < 2; ++w)
     for (hipEvent_t e : b->copied[w])
       if (e) (void)hipEventDestroy(e);
+  if (b->d_multi) (void)hipFree(b->d_multi);
   if (b->d_jobs) (void)hipFree(b->d_jobs);
   if (b->d_jobs_cls) (void)hipFree(b->d_jobs_cls);
   if (b->d_arena) (void)hipFree(b->d_arena);
@@ -1070,7 +1072,21 @@ int hx_batch_forward(hx_batch* b, void* stream) {
           else launch_fill_neg_inf(b->d_agg + cr.agg_begin, cr.agg_doubles, st);
         }
         if (b->dag_linear) LAUNCH_TRY(launch_forward_dag_linear(jobs, cr.n, cr.max_rows, Tab8{D.tab}, Tab16{D.log_tab}, st));
-        else LAUNCH_TRY(launch_forward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, st));
+        else {
+          // a lone pair (or two) of more than sixteen strips: dealt to several workgroups, as the Backward fill is (below)
+          int multi = 1, multi_waves = 4;
+          const char* min_strips = getenv("HX_DAG_MULTI_MIN_STRIPS");
+          if (cr.n <= 2 && cr.max_rows > (min_strips ? atoi(min_strips) : 16) * HX_STRIP && !getenv("HX_DAG_FWD_SINGLE")) {
+            const int strips = (cr.max_rows + HX_STRIP - 1) / HX_STRIP;
+            if (const char* e = getenv("HX_DAG_MULTI_WAVES")) multi_waves = atoi(e);
+            if (multi_waves != 8 && multi_waves != 2) multi_waves = 4;
+            multi = std::min(32, (strips + multi_waves - 1) / multi_waves);
+            if (!b->d_multi && hipMalloc(reinterpret_cast<void**>(&b->d_multi), 2 * 256 * sizeof(int)) != hipSuccess)
+              return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of the progress counters failed");
+            HIP_TRY(hipMemsetAsync(b->d_multi, 0, 2 * 256 * sizeof(int), st));
+          }
+          LAUNCH_TRY(launch_forward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, multi, multi_waves, b->d_multi, st));
+        }
         break;
       default:
         LAUNCH_TRY(launch_forward_dag(jobs, cr.n, cr.max_rows, Tab8{D.tab}, st));
@@ -1188,7 +1204,13 @@ static int read_scalars(hx_batch* b, double* out, int which) {
   return HX_OK;
 }
 
-int hx_batch_lp_end(hx_batch* b, double* out) { return read_scalars(b, out, 0); }
+int hx_batch_lp_end(hx_batch* b, double* out) {
+  const int rc = read_scalars(b, out, 0);
+  if (rc != HX_OK) return rc;
+  for (int k = 0; k < b->n_jobs; ++k)      // (a fill dealt to several workgroups marks a pair it could not finish with NaN: hx_batch_lp_start)
+    if (out[k] != out[k]) return fail(HX_ERR_HIP, "the Forward fill of pair %d did not complete (workgroups lost one another)", k);
+  return HX_OK;
+}
 int hx_batch_lp_start(hx_batch* b, double* out) {
   const int rc = read_scalars(b, out, 1);
   if (rc != HX_OK) return rc;

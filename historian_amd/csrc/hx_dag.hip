@@ -741,12 +741,35 @@ __device__ __forceinline__ int64_t slot_at(const RowRef& r, int c) {
 #endif
 
 // what the next step may need from the cell a lane has just computed
+// The matrix (and the scratch planes addressed relative to it) as the Forward pipeline reads and writes it.  COH: other
+// workgroups fill other strips of the same pair (the MULTI launch of k_forward_dag_pipe): every access is `sc1` - stores
+// write through, loads bypass the L1 - the hand-off of k_backward_dag_multi.
+template <bool COH>
+struct PairPlanes {
+  HX_GLOBAL double* p;
+  struct Ref {
+    HX_GLOBAL double* q;
+    __device__ __forceinline__ operator double() const {
+      if (COH) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return *q;
+    }
+    __device__ __forceinline__ void operator=(double v) const {
+      if (COH) __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *q = v;
+    }
+  };
+  __device__ __forceinline__ Ref operator[](int64_t k) const { return Ref{p + k}; }
+};
+
 struct Fwd10 { double imm, imd, idm, imi, iiw, g0, g1, g2, g3, g4; };
 
-template <class LSE, bool FAST>
+// MULTI: one pair's strips dealt to `groups` workgroups (one or two pairs of many strips: see k_backward_dag_multi for the
+// hand-off; the progress counters - 256 ints per pair - are a region the host passes in, zeroed before the launch).
+template <class LSE, bool FAST, bool MULTI = false>
 __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(const DevJob* __restrict__ jobs,
                                                                                const double* __restrict__ exact_tab,
-                                                                               const double* __restrict__ fast_tab) {
+                                                                               const double* __restrict__ fast_tab,
+                                                                               const int groups = 1, int* const counters = nullptr) {
   __shared__ volatile int prog[HX_DAGF_MAX_WAVES];
   __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : 2];
   // per wave: the column constants (FwdPack) of the 128 columns around the wave's position, as four
@@ -760,11 +783,14 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
   const LSE L = LSE::make(FAST ? (const double*)ftab : fast_tab)   /* exact mode: fast_tab is the pair table */;
   volatile HX_LDS int* progp = (volatile HX_LDS int*)prog;
 
-  const DevJob& J = jobs[blockIdx.x];
+  const int G = MULTI ? groups : 1;
+  const int job = MULTI ? (int)blockIdx.x / G : (int)blockIdx.x, grp = MULTI ? (int)blockIdx.x % G : 0;
+  const DevJob& J = jobs[job];
   const double (*T)[6] = J.T;
   const int R = J.n_rows, Cc = J.n_cols;
   const int64_t plane = J.plane, ss = J.strip_stride;
-  HX_GLOBAL double* M = as_global(J.fwd);
+  const PairPlanes<MULTI> M{as_global(J.fwd)};
+  HX_GLOBAL int* gprog = MULTI ? (HX_GLOBAL int*)as_global(counters + 256 * job) : nullptr;
   const int64_t aggoff = J.agg - J.fwd;          // the outgoing-sum planes, addressed relative to the matrix
   const HX_GLOBAL double* etab = as_global((const double*)J.emis);
   const HX_GLOBAL double* eplane = as_global((const double*)J.emis_plane);
@@ -781,7 +807,18 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
   const HX_GLOBAL int32_t* win = as_global(J.fwd_windows);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_strips = (R + 63) >> 6;
-  const int prev_wave = (wave + W - 1) % W;
+  const int WT = W * G, gw = grp * W + wave;      // the pair's waves, and this one among them
+  const int prev_wave = (gw + WT - 1) % WT;
+  bool dead = false;                              // MULTI: a poll ran out of patience - run out without computing
+  const auto read_progress = [&](const int of) -> int {
+    if (MULTI) return __hip_atomic_load(gprog + of, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return progp[of];
+  };
+  const auto publish = [&](const int value) {
+    if (lane != 0) return;
+    if (MULTI) __hip_atomic_store(gprog + gw, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else progp[wave] = value;
+  };
   const double NI = HX_NEG_INF;
   HX_LDS d2v* ring = (HX_LDS d2v*)&ycols[wave][0][0];
   // columns c0 .. c0+63 (clamped into the profile) -> ring; one coalesced 4 KiB read per call
@@ -798,7 +835,7 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
     return unpack(ring[k], ring[128 + k], ring[256 + k], ring[384 + k], ring[512 + k]);
   };
 
-  for (int s = wave; s < n_strips; s += W) {
+  for (int s = gw; s < n_strips; s += WT) {
     const int i = (s << 6) + lane;
     const bool rvalid = i < R;
     const PackRegs X = load_pack(xpk + (rvalid ? i : 0));
@@ -816,8 +853,8 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
       adjx[k] = lane > 0 && xdeg > k && X.s[k] == i - 1;
     }
     const int64_t offXa = xnull ? plane : aggoff, offXb = xnull ? 4 * plane : aggoff + plane;
-    const int above_base = ((s - 1) / W) * Cc;
-    const int my_base = (s / W) * Cc;
+    const int above_base = ((s - 1) / WT) * Cc;
+    const int my_base = (s / WT) * Cc;
     int seen = 0, published = 0;
 #ifdef HX_DAG_TRACE
     long long tr_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -844,10 +881,14 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
       for (int t = wlo[w]; t < whi[w]; ++t) {
         if (s > 0) {
           const int need = above_base + (t + 1 < Cc ? t + 1 : Cc);
-          if (seen < need) {
+          if (seen < need && !dead) {
+            int polls = 0;
             do {
-              seen = __builtin_amdgcn_readfirstlane(progp[prev_wave]);
-              if (seen < need) __builtin_amdgcn_s_sleep(1);
+              seen = __builtin_amdgcn_readfirstlane(read_progress(prev_wave));
+              if (seen < need) {
+                if (MULTI && ++polls > HX_MULTI_PATIENCE) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+              }
             } while (seen < need);
             asm volatile("" ::: "memory");
           }
@@ -857,7 +898,7 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
         const int j = t - lane;
         const PackRegs Y = column(j);
         const int yf = Y.meta & 0xff, ydeg = Y.meta >> 8;
-        bool act = rvalid && j >= 0 && j < Cc;
+        bool act = rvalid && j >= 0 && j < Cc && !dead;
         if (banded) {
           int dd = X.env - Y.env;
           dd = dd < 0 ? -dd : dd;
@@ -1064,9 +1105,10 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           int done = t - 63;
           done = done > Cc ? Cc : done;
+          if (dead) done = Cc;
           if (done > published) {
             published = done;
-            if (lane == 0) progp[wave] = my_base + done;
+            publish(my_base + done);
           }
         }
         HX_TR(5);      // rotate, drain + publish
@@ -1090,10 +1132,10 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // columns between / after the windows hold no in-envelope cell of this strip
       const int upto = (w == 0 && whi[1] > wlo[1]) ? wlo[1] - 63 : Cc;
-      const int done = upto > Cc ? Cc : upto;
+      const int done = (dead || upto > Cc) ? Cc : upto;
       if (done > published) {
         published = done;
-        if (lane == 0) progp[wave] = my_base + done;
+        publish(my_base + done);
       }
     }
 #ifdef HX_DAG_TRACE
@@ -1104,9 +1146,17 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
     // (a strip without any window still has to release the strip below)
     if (published < Cc) {
       published = Cc;
-      if (lane == 0) progp[wave] = my_base + Cc;
+      publish(my_base + Cc);
+    }
+    if (MULTI && s == n_strips - 1) {
+      // the last strip finishes last (every strip follows the one above): all of the pair's cells are in memory.  What END
+      // reads may lie in other workgroups' strips: drop this CU's L1 first (agent-scope acquire = buffer_inv sc1).
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) *J.lp_end = dead ? __builtin_nan("") : forward_lp_end(J, ExactLse{exact_tab});
     }
   }
+  if (MULTI) return;
   __syncthreads();
   if (threadIdx.x == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
 }
@@ -1163,17 +1213,25 @@ static int dag_waves(int max_rows, int cap) {
   return w;
 }
 
+// multi > 1: one or two pairs of many strips, each dealt to `multi` workgroups of `multi_waves` waves (MULTI instantiation);
+// `counters`: 256 zeroed ints per pair
 int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 tab16,
-                            bool fast, hipStream_t st) {
+                            bool fast, int multi, int multi_waves, int* counters, hipStream_t st) {
   const double* tab = tab8.p;
   const double* fast_tab = tab16.p;
+  if (multi > 1) {
+    const dim3 gm(n_jobs * multi), bm(multi_waves * 64);
+    if (fast) hipLaunchKernelGGL((k_forward_dag_pipe<FastLse, true, true>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi, counters);
+    else hipLaunchKernelGGL((k_forward_dag_pipe<ExactLse3, false, true>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi, counters);
+    return 0;
+  }
   const dim3 g(n_jobs), b(dag_waves(max_rows, HX_DAGF_MAX_WAVES) * 64);
   if (fast) {
     HX_CHECK_LDS((k_forward_dag_pipe<FastLse, true>), 0, "k_forward_dag_pipe<fast>");
-    hipLaunchKernelGGL((k_forward_dag_pipe<FastLse, true>), g, b, 0, st, d_jobs, tab, fast_tab);
+    hipLaunchKernelGGL((k_forward_dag_pipe<FastLse, true>), g, b, 0, st, d_jobs, tab, fast_tab, 1, nullptr);
   } else {
     HX_CHECK_LDS((k_forward_dag_pipe<ExactLse3, false>), 0, "k_forward_dag_pipe<exact>");
-    hipLaunchKernelGGL((k_forward_dag_pipe<ExactLse3, false>), g, b, 0, st, d_jobs, tab, fast_tab);
+    hipLaunchKernelGGL((k_forward_dag_pipe<ExactLse3, false>), g, b, 0, st, d_jobs, tab, fast_tab, 1, nullptr);
   }
   return 0;
 }

@@ -47,7 +47,7 @@ bool dag_linear_fits(int64_t plane);
 int launch_forward_dag_linear(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 log_tab, hipStream_t st);
 void launch_dag_linear_clear(const DevJob* d_jobs, int n_jobs, hipStream_t st);
 int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 fast_tab,
-                             bool fast, hipStream_t st);
+                            bool fast, int multi, int multi_waves, int* counters, hipStream_t st);
 int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 fast_tab,
                              bool fast, bool records, int multi, int multi_waves, hipStream_t st);
 int launch_backward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, hipStream_t st);

@@ -104,17 +104,20 @@ def test_internal_node_pair_of_sampled_four_component_profiles():
         else:
             assert abs(lp_end - wf["lp_end"]) <= 1e-9 * abs(wf["lp_end"])
         assert abs(lp_start - lp_end) <= 1e-6 * abs(lp_end)              # Forward == Backward
-        # a lone pair of more than sixteen strips: the Backward fill dealt its strips to several workgroups
-        # (k_backward_dag_multi: write-through hand-off between CUs).  One workgroup gives the same bits.
+        # a lone pair of more than sixteen strips: both fills dealt its strips to several workgroups (the MULTI launch of
+        # k_forward_dag_pipe, k_backward_dag_multi: write-through hand-off between CUs).  One workgroup gives the same bits.
         several = b.read_matrix(0, 1)
+        several_fwd = b.read_matrix(0, 0)
         b.close()
-        os.environ["HX_DAG_BWD_SINGLE"] = "1"
+        os.environ["HX_DAG_BWD_SINGLE"] = os.environ["HX_DAG_FWD_SINGLE"] = "1"
         try:
             one = capi.Batch([img], flags | capi.HX_KEEP_BACKWARD)
             one.forward()
             one.backward()
+            H.assert_same_bits(one.read_matrix(0, 0), several_fwd, "Forward cells: one workgroup vs several")
+            H.assert_same_bits([one.lp_end()[0]], [lp_end], "lpEnd: one workgroup vs several")
             H.assert_same_bits(one.read_matrix(0, 1), several, "Backward cells: one workgroup vs several")
             H.assert_same_bits([one.lp_start()[0]], [lp_start], "lpStart: one workgroup vs several")
             one.close()
         finally:
-            del os.environ["HX_DAG_BWD_SINGLE"]
+            del os.environ["HX_DAG_BWD_SINGLE"], os.environ["HX_DAG_FWD_SINGLE"]
