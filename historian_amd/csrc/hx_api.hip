@@ -1071,8 +1071,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
           if (b->dag_linear) launch_dag_linear_clear(jobs, cr.n, st);
           else launch_fill_neg_inf(b->d_agg + cr.agg_begin, cr.agg_doubles, st);
         }
-        if (b->dag_linear) LAUNCH_TRY(launch_forward_dag_linear(jobs, cr.n, cr.max_rows, Tab8{D.tab}, Tab16{D.log_tab}, st));
-        else {
+        {
           // a lone pair (or two) of more than sixteen strips: dealt to several workgroups, as the Backward fill is (below)
           int multi = 1, multi_waves = 4;
           const char* min_strips = getenv("HX_DAG_MULTI_MIN_STRIPS");
@@ -1085,7 +1084,10 @@ int hx_batch_forward(hx_batch* b, void* stream) {
               return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of the progress counters failed");
             HIP_TRY(hipMemsetAsync(b->d_multi, 0, 2 * 256 * sizeof(int), st));
           }
-          LAUNCH_TRY(launch_forward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, multi, multi_waves, b->d_multi, st));
+          if (b->dag_linear)
+            LAUNCH_TRY(launch_forward_dag_linear(jobs, cr.n, cr.max_rows, Tab8{D.tab}, Tab16{D.log_tab}, multi, multi_waves, b->d_multi, st));
+          else
+            LAUNCH_TRY(launch_forward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, multi, multi_waves, b->d_multi, st));
         }
         break;
       default:
@@ -1145,9 +1147,9 @@ int hx_batch_backward(hx_batch* b, void* stream) {
         if (banded) launch_fill_neg_inf(b->d_bwd + cr.mat_begin, cr.mat_doubles, st);
         {
           // the state-record formulation needs the pair's scratch planes (general-profile classes have them: five planes
-          // per pair, of no use once the Forward fill is done); in the scaled-probability mode the planes hold per-state
-          // packs that a later Forward launch does not rebuild, so that mode keeps the CSR walk
-          const bool records = (c == KC_DAG || c == KC_DAG_BANDED) && !b->dag_linear && !getenv("HX_DAG_BWD_OLD");
+          // per pair - twelve in the scaled-probability mode - of no use once the Forward fill is done: a later Forward
+          // launch rebuilds its per-state packs (k_lin_pack) and, with a band, clears the planes again (k_lin_clear))
+          const bool records = (c == KC_DAG || c == KC_DAG_BANDED) && !getenv("HX_DAG_BWD_OLD");
           // a lone pair (or two) of more than sixteen strips: its strips dealt to two to four workgroups (hx_dag.hip
           // k_backward_dag_multi); their progress counters - the last 256 ints of each pair's scratch planes - start at zero
           int multi = 1, multi_waves = 4;

@@ -31,6 +31,7 @@ namespace hx {
 namespace {
 
 #define HXD_MAX_WAVES 8
+#define HXD_MULTI_PATIENCE (1 << 22)   // MULTI launch: polls of another workgroup's progress before a wave gives up (lp_end = NaN)
 #define HXD_EMIN (-(1 << 28))      // exponent of a zero: loses every max()
 #define HXD_LOG_ENTRIES 1536       // the logarithm table of hx_linear.hip (build_log_table)
 #define HXD_EXP_ENTRIES 512
@@ -109,20 +110,39 @@ __device__ __forceinline__ void add2(Acc2& A, const double ma, const double mb, 
   A.E = En;
 }
 
+// COH: the pair's strips are dealt to several workgroups (the MULTI launch, see hx_dag.hip k_backward_dag_multi): every
+// scratch access is `sc1` - stores write through, loads bypass the L1
+template <bool COH = false>
 __device__ __forceinline__ double ldg(const HX_GLOBAL double* base, const unsigned byte_off) {
 #if HX_ABLATE == 33      // timing only: no source loads
   return 1e-3 * (double)(byte_off & 1023u);
 #endif
-  return *(const HX_GLOBAL double*)((const HX_GLOBAL char*)base + byte_off);
+  HX_GLOBAL double* p = (HX_GLOBAL double*)((HX_GLOBAL char*)const_cast<HX_GLOBAL double*>(base) + byte_off);
+  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
 }
+template <bool COH = false>
 __device__ __forceinline__ int ldgi(const HX_GLOBAL int* base, const unsigned byte_off) {
-  return *(const HX_GLOBAL int*)((const HX_GLOBAL char*)base + byte_off);
+  HX_GLOBAL int* p = (HX_GLOBAL int*)((HX_GLOBAL char*)const_cast<HX_GLOBAL int*>(base) + byte_off);
+  if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
 }
+template <bool COH = false>
 __device__ __forceinline__ void stg(HX_GLOBAL double* base, const unsigned byte_off, const double v) {
 #if HX_ABLATE == 32      // timing only: stores only where the value is NaN (never)
   if (v != v)
 #endif
-  *(HX_GLOBAL double*)((HX_GLOBAL char*)base + byte_off) = v;
+  {
+    HX_GLOBAL double* p = (HX_GLOBAL double*)((HX_GLOBAL char*)base + byte_off);
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+  }
+}
+template <bool COH = false>
+__device__ __forceinline__ void stgi(HX_GLOBAL int* base, const unsigned byte_off, const int v) {
+  HX_GLOBAL int* p = (HX_GLOBAL int*)((HX_GLOBAL char*)base + byte_off);
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
 }
 
 // the cell a lane computed in the previous step: stored one step late (behind the next step's loads, so that those do not
@@ -199,8 +219,9 @@ __global__ void k_lin_clear(const DevJob* __restrict__ jobs) {
   for (int64_t k = first; k < ne; k += stride) ex[k] = HXD_EMIN;
 }
 
+template <bool MULTI>
 __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab,
-                                                                           const double* __restrict__ log_tab) {
+                                                                           const double* __restrict__ log_tab, const int groups, int* const counters) {
   __shared__ volatile int prog[HXD_MAX_WAVES];
   __shared__ __attribute__((aligned(16))) double ltab_s[HXD_LOG_ENTRIES * 2];
   __shared__ double etab_s[HXD_EXP_ENTRIES];
@@ -217,7 +238,10 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
   const HX_LDS double* etab2 = (const HX_LDS double*)etab_s;
   volatile HX_LDS int* progp = (volatile HX_LDS int*)prog;
 
-  const DevJob& J = jobs[blockIdx.x];
+  const int G = MULTI ? groups : 1;
+  const int job = MULTI ? (int)blockIdx.x / G : (int)blockIdx.x, grp = MULTI ? (int)blockIdx.x % G : 0;
+  const DevJob& J = jobs[job];
+  HX_GLOBAL int* gprog = MULTI ? (HX_GLOBAL int*)as_global(counters + 256 * job) : nullptr;
   const int R = J.n_rows, Cc = J.n_cols;
   const unsigned planeB = (unsigned)(J.plane * 8), ssB = (unsigned)(J.strip_stride * 8);
   HX_GLOBAL double* M = as_global(J.fwd);
@@ -240,7 +264,18 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
   const HX_GLOBAL int32_t* win = as_global(J.fwd_windows);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_strips = (R + 63) >> 6;
-  const int prev_wave = (wave + W - 1) % W;
+  const int WT = W * G, gw = grp * W + wave;      // the pair's waves, and this one among them
+  const int prev_wave = (gw + WT - 1) % WT;
+  bool dead = false;                              // MULTI: a poll ran out of patience - run out without computing
+  const auto read_progress = [&](const int of) -> int {
+    if (MULTI) return __hip_atomic_load(gprog + of, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return progp[of];
+  };
+  const auto publish = [&](const int value) {
+    if (lane != 0) return;
+    if (MULTI) __hip_atomic_store(gprog + gw, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else progp[wave] = value;
+  };
   // transition probabilities of the pair HMM: in LDS, read as broadcasts where the outgoing sums are formed (36 scalar
   // registers on top of the plane bases and the control flow's saved masks made the compiler spill ~100 scalars per step)
   __shared__ double Psh[5][5];
@@ -289,7 +324,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
     return r;
   };
 
-  for (int s = wave; s < n_strips; s += W) {
+  for (int s = gw; s < n_strips; s += WT) {
     const int i = (s << 6) + lane;
     const bool rvalid = i < R;
     const int ir = rvalid ? i : 0;
@@ -318,8 +353,8 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
       xlx[q] = (src & 63) | ((lane > 0 && xdeg > a && src == i - 1) ? 64 : 0);     // bit 6: the row directly above
       xwx[q] = xdeg > a ? xin_w[X.in_b + a] : 0.;
     }
-    const int above_base = ((s - 1) / W) * Cc;
-    const int my_base = (s / W) * Cc;
+    const int above_base = ((s - 1) / WT) * Cc;
+    const int my_base = (s / WT) * Cc;
     int seen = 0, published = 0;
 #ifdef HX_DAG_TRACE
     long long tr_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -345,10 +380,14 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
       for (int t = wlo[w]; t < whi[w]; ++t) {
         if (s > 0) {
           const int need = above_base + (t + 1 < Cc ? t + 1 : Cc);
-          if (seen < need) {
+          if (seen < need && !dead) {
+            int polls = 0;
             do {
-              seen = __builtin_amdgcn_readfirstlane(progp[prev_wave]);
-              if (seen < need) __builtin_amdgcn_s_sleep(1);
+              seen = __builtin_amdgcn_readfirstlane(read_progress(prev_wave));
+              if (seen < need) {
+                if (MULTI && ++polls > HXD_MULTI_PATIENCE) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+              }
             } while (seen < need);
             asm volatile("" ::: "memory");
           }
@@ -358,7 +397,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
         const int j = t - lane;
         const ColRec Y = column(j);
         const int yf = Y.meta & 0xff, ydeg = HX_ABLATE == 36 ? ((Y.meta >> 8) > 1 ? 1 : (Y.meta >> 8)) : Y.meta >> 8;
-        bool act = rvalid && j >= 0 && j < Cc;
+        bool act = rvalid && j >= 0 && j < Cc && !dead;
         if (banded) {
           int dd = X.env - Y.env;
           dd = dd < 0 ? -dd : dd;
@@ -378,7 +417,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
         double elog = HX_NEG_INF;
         if (act && mode == 1) {
           if (etab) elog = etab[(int64_t)(X.cls < 0 ? 0 : X.cls) * Ky + (Y.cls < 0 ? 0 : Y.cls)];
-          else elog = ldg(eplane, own_slot_m);
+          else elog = ldg<MULTI>(eplane, own_slot_m);
           if (X.cls < 0 || Y.cls < 0) elog = HX_NEG_INF;
         }
 
@@ -398,14 +437,14 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
         double ywx[HXD_EXTRA];
 #ifdef HX_DAG_TRACE
         {   // latency probe: one source load by itself (the first transition of the row), then an old cell of the same row
-          volatile double probe = ldg(LIN, vXa + sx0);
+          volatile double probe = ldg<MULTI>(LIN, vXa + sx0);
           (void)probe;
           HXD_TR(7);
           const int told = t - 40 < wlo[w] ? wlo[w] : t - 40;
-          volatile double probe2 = ldg(LIN, V_G2 * planeB + ownB + col_part(told));     // written 40 steps ago by this lane
+          volatile double probe2 = ldg<MULTI>(LIN, V_G2 * planeB + ownB + col_part(told));     // written 40 steps ago by this lane
           (void)probe2;
           HXD_TR(6);
-          volatile double probe3 = ldg(LIN, V_G2 * planeB + ownB + col_part(told));     // the same line again
+          volatile double probe3 = ldg<MULTI>(LIN, V_G2 * planeB + ownB + col_part(told));     // the same line again
           (void)probe3;
           HXD_TR(4);
         }
@@ -414,8 +453,8 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
           // (no initial values: every element is read under the predicate it was loaded under)
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            if (xgo && xdeg > k) { xa[k] = ldg(LIN, vXa + sxs[k]); xb[k] = ldg(LIN, vXb + sxs[k]); xe[k] = ldgi(EX, sxs[k] >> 1); }
-            if (ygo && ydeg > k) { ya[k] = ldg(LIN, vYa + sys_[k]); yb[k] = ldg(LIN, vYb + sys_[k]); ye[k] = ldgi(EX, sys_[k] >> 1); }
+            if (xgo && xdeg > k) { xa[k] = ldg<MULTI>(LIN, vXa + sxs[k]); xb[k] = ldg<MULTI>(LIN, vXb + sxs[k]); xe[k] = ldgi<MULTI>(EX, sxs[k] >> 1); }
+            if (ygo && ydeg > k) { ya[k] = ldg<MULTI>(LIN, vYa + sys_[k]); yb[k] = ldg<MULTI>(LIN, vYb + sys_[k]); ye[k] = ldgi<MULTI>(EX, sys_[k] >> 1); }
           }
           if (mode == 1) {
 #pragma unroll
@@ -424,17 +463,17 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
               for (int b = 0; b < 3; ++b)
                 if (xdeg > a && ydeg > b) {
                   const unsigned sl = xr[a] + col_part(ys[b] + xl[a]);
-                  mv[a * 3 + b] = ldg(LIN, V_G4 * planeB + sl);
-                  me[a * 3 + b] = ldgi(EX, sl >> 1);
+                  mv[a * 3 + b] = ldg<MULTI>(LIN, V_G4 * planeB + sl);
+                  me[a * 3 + b] = ldgi<MULTI>(EX, sl >> 1);
                 }
           } else if (mode == 2) {
 #pragma unroll
             for (int b = 0; b < 3; ++b)
-              if (ydeg > b) { mv[b] = ldg(LIN, sys_[b]); me[b] = ygo ? ye[b] : ldgi(EX, sys_[b] >> 1); }
+              if (ydeg > b) { mv[b] = ldg<MULTI>(LIN, sys_[b]); me[b] = ygo ? ye[b] : ldgi<MULTI>(EX, sys_[b] >> 1); }
           } else if (mode == 3) {
 #pragma unroll
             for (int a = 0; a < 3; ++a)
-              if (xdeg > a) { mv[a] = ldg(LIN, sxs[a]); me[a] = xgo ? xe[a] : ldgi(EX, sxs[a] >> 1); }
+              if (xdeg > a) { mv[a] = ldg<MULTI>(LIN, sxs[a]); me[a] = xgo ? xe[a] : ldgi<MULTI>(EX, sxs[a] >> 1); }
           }
           // the column's in-transitions 3 .. 7 (CSR), fetched with the batch above
 #pragma unroll
@@ -446,8 +485,8 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
         // ---- the previous step's cell goes to memory now, behind this step's loads (every lane: an idle lane's cell is
         // all zeros, which is what padding and cells outside the envelope hold) ----
 #pragma unroll
-        for (int v = 0; v < V_PLANES; ++v) stg(LIN, v * planeB + pv.slot, pv.v[v]);
-        *(HX_GLOBAL int*)((HX_GLOBAL char*)EX + (pv.slot >> 1)) = pv.E;
+        for (int v = 0; v < V_PLANES; ++v) stg<MULTI>(LIN, v * planeB + pv.slot, pv.v[v]);
+        stgi<MULTI>(EX, pv.slot >> 1, pv.E);
         if (act) {
           // ---- values still on their way to memory: the previous step's cells of this lane and of the lane above ----
           {
@@ -498,15 +537,15 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
               for (int k = 0; k < 3; ++k) { mx2[q * 3 + k] = 0.; mxe[q * 3 + k] = HXD_EMIN; }
               const bool hx = xdeg > HX_DAG_INLINE + q;
               const unsigned slx = xrx[q] + col_part(jc + (xlx[q] & 63));
-              if (hx && (xgo || mode == 3)) xe2[q] = ldgi(EX, slx >> 1);
-              if (hx && xgo) { xa2[q] = ldg(LIN, vXa + slx); xb2[q] = ldg(LIN, vXb + slx); }
-              if (hx && mode == 3) mx2[q * 3] = ldg(LIN, slx);
+              if (hx && (xgo || mode == 3)) xe2[q] = ldgi<MULTI>(EX, slx >> 1);
+              if (hx && xgo) { xa2[q] = ldg<MULTI>(LIN, vXa + slx); xb2[q] = ldg<MULTI>(LIN, vXb + slx); }
+              if (hx && mode == 3) mx2[q * 3] = ldg<MULTI>(LIN, slx);
               if (mode == 1) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                   if (hx && ydeg > k) {                         // pair (row transition 3+q, column transition k)
                     const unsigned sl = xrx[q] + col_part(ys[k] + (xlx[q] & 63));
-                    mx2[q * 3 + k] = ldg(LIN, V_G4 * planeB + sl); mxe[q * 3 + k] = ldgi(EX, sl >> 1);
+                    mx2[q * 3 + k] = ldg<MULTI>(LIN, V_G4 * planeB + sl); mxe[q * 3 + k] = ldgi<MULTI>(EX, sl >> 1);
                   }
               }
             }
@@ -537,15 +576,15 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
               for (int k = 0; k < 3; ++k) { my2[q * 3 + k] = 0.; mye[q * 3 + k] = HXD_EMIN; }
               const bool hy = ydeg > HX_DAG_INLINE + q;
               const unsigned sly = ownB + col_part(ysx[q] + lane);
-              if (hy && (ygo || mode == 2)) ye2[q] = ldgi(EX, sly >> 1);
-              if (hy && ygo) { ya2[q] = ldg(LIN, vYa + sly); yb2[q] = ldg(LIN, vYb + sly); }
-              if (hy && mode == 2) my2[q * 3] = ldg(LIN, sly);
+              if (hy && (ygo || mode == 2)) ye2[q] = ldgi<MULTI>(EX, sly >> 1);
+              if (hy && ygo) { ya2[q] = ldg<MULTI>(LIN, vYa + sly); yb2[q] = ldg<MULTI>(LIN, vYb + sly); }
+              if (hy && mode == 2) my2[q * 3] = ldg<MULTI>(LIN, sly);
               if (mode == 1) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                   if (hy && xdeg > k) {                         // pair (row transition k, column transition 3+q)
                     const unsigned sl = xr[k] + col_part(ysx[q] + xl[k]);
-                    my2[q * 3 + k] = ldg(LIN, V_G4 * planeB + sl); mye[q * 3 + k] = ldgi(EX, sl >> 1);
+                    my2[q * 3 + k] = ldg<MULTI>(LIN, V_G4 * planeB + sl); mye[q * 3 + k] = ldgi<MULTI>(EX, sl >> 1);
                   }
               }
             }
@@ -574,7 +613,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
                 const unsigned rb = (unsigned)(srcx >> 6) * ssB + ((unsigned)(srcx & 63) << 3);
                 for (int b = HX_DAG_INLINE; b < ydeg; ++b) {
                   const unsigned sl = rb + col_part(yin_src[Y.in_b + b] + (srcx & 63));
-                  add1(am, ldg(LIN, V_G4 * planeB + sl), ldgi(EX, sl >> 1), wxa * yin_w[Y.in_b + b]);
+                  add1(am, ldg<MULTI>(LIN, V_G4 * planeB + sl), ldgi<MULTI>(EX, sl >> 1), wxa * yin_w[Y.in_b + b]);
                 }
               }
             for (int a = HX_DAG_INLINE + HXD_EXTRA; a < xdeg; ++a) {
@@ -585,16 +624,16 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
               const bool adj = lane > 0 && src == i - 1;
               if (xgo) {
                 if (adj) add2(ax, xnull ? up_imd : up_g0, xnull ? up_iiw : up_g1, up_E, wa);
-                else add2(ax, ldg(LIN, vXa + sl), ldg(LIN, vXb + sl), ldgi(EX, sl >> 1), wa);
+                else add2(ax, ldg<MULTI>(LIN, vXa + sl), ldg<MULTI>(LIN, vXb + sl), ldgi<MULTI>(EX, sl >> 1), wa);
               }
               if (mode == 3) {
                 if (adj) add1(am, up_imm, up_E, wa);
-                else add1(am, ldg(LIN, sl), ldgi(EX, sl >> 1), wa);
+                else add1(am, ldg<MULTI>(LIN, sl), ldgi<MULTI>(EX, sl >> 1), wa);
               }
               if (mode == 1)
                 for (int b = 0; b < (ydeg < HX_DAG_INLINE ? ydeg : HX_DAG_INLINE); ++b) {
                   const unsigned sp = rb + col_part((b == 0 ? Y.s0 : (b == 1 ? Y.s1 : Y.s2)) + (src & 63));
-                  add1(am, ldg(LIN, V_G4 * planeB + sp), ldgi(EX, sp >> 1), wa * (b == 0 ? Y.w0 : (b == 1 ? Y.w1 : Y.w2)));
+                  add1(am, ldg<MULTI>(LIN, V_G4 * planeB + sp), ldgi<MULTI>(EX, sp >> 1), wa * (b == 0 ? Y.w0 : (b == 1 ? Y.w1 : Y.w2)));
                 }
             }
             for (int b = HX_DAG_INLINE + HXD_EXTRA; b < ydeg; ++b) {
@@ -604,16 +643,16 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
               const bool adj = src == j - 1;
               if (ygo) {
                 if (adj) add2(ay, ynull ? pv.v[V_IDM] : pv.v[V_G2], ynull ? pv.v[V_IMI] : pv.v[V_G3], pv.E, wb);
-                else add2(ay, ldg(LIN, vYa + sl), ldg(LIN, vYb + sl), ldgi(EX, sl >> 1), wb);
+                else add2(ay, ldg<MULTI>(LIN, vYa + sl), ldg<MULTI>(LIN, vYb + sl), ldgi<MULTI>(EX, sl >> 1), wb);
               }
               if (mode == 2) {
                 if (adj) add1(am, pv.v[V_IMM], pv.E, wb);
-                else add1(am, ldg(LIN, sl), ldgi(EX, sl >> 1), wb);
+                else add1(am, ldg<MULTI>(LIN, sl), ldgi<MULTI>(EX, sl >> 1), wb);
               }
               if (mode == 1)
                 for (int a = 0; a < (xdeg < HX_DAG_INLINE ? xdeg : HX_DAG_INLINE); ++a) {
                   const unsigned sp = (a == 0 ? xrB0 : (a == 1 ? xrB1 : xrB2)) + col_part(src + (a == 0 ? xl0 : (a == 1 ? xl1 : xl2)));
-                  add1(am, ldg(LIN, V_G4 * planeB + sp), ldgi(EX, sp >> 1), (a == 0 ? X.w0 : (a == 1 ? X.w1 : X.w2)) * wb);
+                  add1(am, ldg<MULTI>(LIN, V_G4 * planeB + sp), ldgi<MULTI>(EX, sp >> 1), (a == 0 ? X.w0 : (a == 1 ? X.w1 : X.w2)) * wb);
                 }
             }
           }
@@ -639,11 +678,11 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
         HXD_TR(2);     // source loads and accumulation
         // ---- the reference's format (five logarithms, stored at once) and the kernel's: a common exponent (that of the
         // largest state), the five outgoing sums - kept in registers until the next step has issued its loads ----
-        stg(M, own_slot_m, log_scaled(m_imm, e_imm, ltab));                  // (nothing in this kernel reads these back)
-        stg(M, planeB + own_slot_m, log_scaled(m_imd, e_imd, ltab));
-        stg(M, 2 * planeB + own_slot_m, log_scaled(m_idm, e_idm, ltab));
-        stg(M, 3 * planeB + own_slot_m, log_scaled(m_imi, e_imi, ltab));
-        stg(M, 4 * planeB + own_slot_m, log_scaled(m_iiw, e_iiw, ltab));
+        stg<MULTI>(M, own_slot_m, log_scaled(m_imm, e_imm, ltab));                  // (nothing in this kernel reads these back)
+        stg<MULTI>(M, planeB + own_slot_m, log_scaled(m_imd, e_imd, ltab));
+        stg<MULTI>(M, 2 * planeB + own_slot_m, log_scaled(m_idm, e_idm, ltab));
+        stg<MULTI>(M, 3 * planeB + own_slot_m, log_scaled(m_imi, e_imi, ltab));
+        stg<MULTI>(M, 4 * planeB + own_slot_m, log_scaled(m_iiw, e_iiw, ltab));
         {
           const int b0 = m_imm > 0. ? e_imm + __builtin_amdgcn_frexp_exp(m_imm) : HXD_EMIN;
           const int b1 = m_imd > 0. ? e_imd + __builtin_amdgcn_frexp_exp(m_imd) : HXD_EMIN;
@@ -677,10 +716,10 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
           int done = t - 63;
-          done = done > Cc ? Cc : done;
+          done = (dead || done > Cc) ? Cc : done;
           if (done > published) {
             published = done;
-            if (lane == 0) progp[wave] = my_base + done;
+            publish(my_base + done);
           }
         }
         HXD_TR(4);     // publish
@@ -690,15 +729,15 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
       }
       // flush the last cell of the window
 #pragma unroll
-      for (int v = 0; v < V_PLANES; ++v) stg(LIN, v * planeB + pv.slot, pv.v[v]);
-      *(HX_GLOBAL int*)((HX_GLOBAL char*)EX + (pv.slot >> 1)) = pv.E;
+      for (int v = 0; v < V_PLANES; ++v) stg<MULTI>(LIN, v * planeB + pv.slot, pv.v[v]);
+      stgi<MULTI>(EX, pv.slot >> 1, pv.E);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // columns between / after the windows hold no in-envelope cell of this strip
       const int upto = (w == 0 && whi[1] > wlo[1]) ? wlo[1] - 63 : Cc;
-      const int done = upto > Cc ? Cc : upto;
+      const int done = (dead || upto > Cc) ? Cc : upto;
       if (done > published) {
         published = done;
-        if (lane == 0) progp[wave] = my_base + done;
+        publish(my_base + done);
       }
     }
 #ifdef HX_DAG_TRACE
@@ -710,9 +749,17 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
     // (a strip without any window still has to release the strip below)
     if (published < Cc) {
       published = Cc;
-      if (lane == 0) progp[wave] = my_base + Cc;
+      publish(my_base + Cc);
+    }
+    if (MULTI && s == n_strips - 1) {
+      // the last strip finishes last (every strip follows the one above): all of the pair's cells are in memory.  What END
+      // reads may lie in other workgroups' strips: drop this CU's L1 first (agent-scope acquire), as k_forward_dag_pipe does
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) *J.lp_end = dead ? __builtin_nan("") : forward_lp_end(J, ExactLse{exact_tab});
     }
   }
+  if (MULTI) return;
   __syncthreads();
   if (threadIdx.x == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
 }
@@ -727,12 +774,21 @@ int64_t dag_linear_scratch_doubles(int64_t plane, int nx, int ny, int tx, int ty
 // byte offsets inside a job's planes are 32-bit
 bool dag_linear_fits(int64_t plane) { return (V_PLANES + 1) * plane * 8 < ((int64_t)1 << 32); }
 
-int launch_forward_dag_linear(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 log_tab, hipStream_t st) {
+// multi > 1: one or two pairs of many strips, each dealt to `multi` workgroups of `multi_waves` waves (MULTI instantiation);
+// `counters`: 256 zeroed ints per pair
+int launch_forward_dag_linear(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 log_tab, int multi, int multi_waves,
+                              int* counters, hipStream_t st) {
   int w = (max_rows + 63) / 64;
   w = w < 1 ? 1 : (w > HXD_MAX_WAVES ? HXD_MAX_WAVES : w);
   hipLaunchKernelGGL(k_lin_pack, dim3(n_jobs), dim3(256), 0, st, d_jobs);
-  HX_CHECK_LDS(k_forward_dag_linear, 0, "k_forward_dag_linear");
-  hipLaunchKernelGGL(k_forward_dag_linear, dim3(n_jobs), dim3(w * 64), 0, st, d_jobs, tab8.p, log_tab.p);
+  if (multi > 1) {
+    if (multi_waves > HXD_MAX_WAVES) multi_waves = HXD_MAX_WAVES;
+    HX_CHECK_LDS(k_forward_dag_linear<true>, 0, "k_forward_dag_linear<multi>");
+    hipLaunchKernelGGL(k_forward_dag_linear<true>, dim3(n_jobs * multi), dim3(multi_waves * 64), 0, st, d_jobs, tab8.p, log_tab.p, multi, counters);
+    return 0;
+  }
+  HX_CHECK_LDS(k_forward_dag_linear<false>, 0, "k_forward_dag_linear");
+  hipLaunchKernelGGL(k_forward_dag_linear<false>, dim3(n_jobs), dim3(w * 64), 0, st, d_jobs, tab8.p, log_tab.p, 1, nullptr);
   return 0;
 }
 

@@ -9,7 +9,7 @@ MODEL = os.path.join(ROOT, "tests", "golden", "models", "wag.json")
 tree, seqs = R.balanced_family(32, 1000, "arndcqeghilkmfpstwyv", seed=21, branch=.05)
 exe = os.path.join(ROOT, "historian_amd", "bin", "hxrecon")
 with tempfile.TemporaryDirectory() as d:
-    for mode in ("fast", "exact"):
+    for mode in (sys.argv[1:] or ("fast", "exact")):       # also: linear
         job = os.path.join(d, "job.txt")
         R.write_job(job, MODEL, tree, seqs, {}, os.path.join(d, "s.fa"), os.path.join(d, "g.fa"), posterior=.01, batch=1)
         env = dict(os.environ, HX_TIMING="1", HX_FILL_MODE=mode)
