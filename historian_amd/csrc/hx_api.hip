@@ -23,6 +23,12 @@
 
 using namespace hx;
 
+// The lone-pair launches (several workgroups per pair, hand-off through memory: hx_dag.hip, hx_daglin.hip) need every
+// workgroup of the launch resident at once - a strip's wave polls the wave of the strip above.  Up to eight pairs, and never
+// more workgroups than half the chip's CUs (one such workgroup's LDS fills a CU), so that a second stream cannot starve them.
+#define HX_MULTI_MAX_PAIRS 8
+#define HX_MULTI_MAX_GROUPS 128
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -1075,14 +1081,14 @@ int hx_batch_forward(hx_batch* b, void* stream) {
           // a lone pair (or two) of more than sixteen strips: dealt to several workgroups, as the Backward fill is (below)
           int multi = 1, multi_waves = 4;
           const char* min_strips = getenv("HX_DAG_MULTI_MIN_STRIPS");
-          if (cr.n <= 2 && cr.max_rows > (min_strips ? atoi(min_strips) : 16) * HX_STRIP && !getenv("HX_DAG_FWD_SINGLE")) {
+          if (cr.n <= HX_MULTI_MAX_PAIRS && cr.max_rows > (min_strips ? atoi(min_strips) : 16) * HX_STRIP && !getenv("HX_DAG_FWD_SINGLE")) {
             const int strips = (cr.max_rows + HX_STRIP - 1) / HX_STRIP;
             if (const char* e = getenv("HX_DAG_MULTI_WAVES")) multi_waves = atoi(e);
             if (multi_waves != 8 && multi_waves != 2) multi_waves = 4;
-            multi = std::min(32, (strips + multi_waves - 1) / multi_waves);
-            if (!b->d_multi && hipMalloc(reinterpret_cast<void**>(&b->d_multi), 2 * 256 * sizeof(int)) != hipSuccess)
+            multi = std::min(std::min(32, HX_MULTI_MAX_GROUPS / cr.n), (strips + multi_waves - 1) / multi_waves);
+            if (!b->d_multi && hipMalloc(reinterpret_cast<void**>(&b->d_multi), HX_MULTI_MAX_PAIRS * 256 * sizeof(int)) != hipSuccess)
               return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of the progress counters failed");
-            HIP_TRY(hipMemsetAsync(b->d_multi, 0, 2 * 256 * sizeof(int), st));
+            HIP_TRY(hipMemsetAsync(b->d_multi, 0, HX_MULTI_MAX_PAIRS * 256 * sizeof(int), st));
           }
           if (b->dag_linear)
             LAUNCH_TRY(launch_forward_dag_linear(jobs, cr.n, cr.max_rows, Tab8{D.tab}, Tab16{D.log_tab}, multi, multi_waves, b->d_multi, st));
@@ -1154,12 +1160,12 @@ int hx_batch_backward(hx_batch* b, void* stream) {
           // k_backward_dag_multi); their progress counters - the last 256 ints of each pair's scratch planes - start at zero
           int multi = 1, multi_waves = 4;
           const char* min_strips = getenv("HX_DAG_MULTI_MIN_STRIPS");      // tuning hook
-          if (records && cr.n <= 2 && cr.max_rows > (min_strips ? atoi(min_strips) : 16) * HX_STRIP && !getenv("HX_DAG_BWD_SINGLE")) {
+          if (records && cr.n <= HX_MULTI_MAX_PAIRS && cr.max_rows > (min_strips ? atoi(min_strips) : 16) * HX_STRIP && !getenv("HX_DAG_BWD_SINGLE")) {
             const int strips = (cr.max_rows + HX_STRIP - 1) / HX_STRIP;
             if (const char* e = getenv("HX_DAG_MULTI_WAVES")) multi_waves = atoi(e);      // tuning hook: waves per workgroup (default 4: measured 1.24 / 1.13 / 1.02 / 1.01 s at one workgroup / 16 / 8 / 4 waves)
             if (multi_waves != 16 && multi_waves != 8 && multi_waves != 2) multi_waves = 4;
             multi = std::min(256 / multi_waves, (strips + multi_waves - 1) / multi_waves);   // (progress counters: 256 per pair)
-            if (multi > 32) multi = 32;
+            multi = std::min(multi, std::min(32, HX_MULTI_MAX_GROUPS / cr.n));
             for (int q = 0; q < cr.n && multi > 1; ++q) {
               const DevJob& Jh = b->jobs[b->order[cr.begin + q]];
               HIP_TRY(hipMemsetAsync(reinterpret_cast<int*>(Jh.agg + 5 * Jh.plane) - 256, 0, 256 * sizeof(int), st));

@@ -520,7 +520,25 @@ def test_linear_mode_on_general_profiles():
                 assert lf[k] == want["lp_end"]
         assert bf.best_trace() == be.best_trace() or True      # (paths may differ where the reference's truncation decides)
         be.close()
+        # Backward in this mode is the fast table policy over the state records, which it builds in the Forward fill's scratch
+        # planes: the same bits as a fast-policy batch, and a Forward fill after it (packs rebuilt, banded planes cleared
+        # again) the same bits as the first
+        first = [bf.read_matrix(k, 0) for k in range(len(imgs))]
         bf.close()
+        bt = capi.Batch(imgs, capi.HX_LSE_FAST | capi.HX_KEEP_BACKWARD)
+        bl = capi.Batch(imgs, capi.HX_LSE_LINEAR | capi.HX_KEEP_BACKWARD)
+        bt.forward(); bt.backward()
+        bl.forward(); bl.backward(); bl.forward(); bl.backward()
+        H.assert_same_bits(bl.lp_end(), lf, "lpEnd of the Forward fill after a Backward fill")
+        general = [k for k in range(len(imgs)) if bl.job_kernel(k)[0] in (7, 8)]        # (the leaf pair of the last group runs its own kernels)
+        assert general
+        H.assert_same_bits([bl.lp_start()[k] for k in general], [bt.lp_start()[k] for k in general], "lpStart, linear-mode batch vs fast batch")
+        for k in range(len(imgs)):
+            if k in general:
+                H.assert_same_bits(bl.read_matrix(k, 1), bt.read_matrix(k, 1), "job %d Backward cells, linear-mode batch vs fast batch" % k)
+            H.assert_same_bits(bl.read_matrix(k, 0), first[k], "job %d Forward cells after a Backward fill" % k)
+        bt.close()
+        bl.close()
 
 
 @pytest.mark.parametrize("ppw", [-3, -5])
@@ -640,3 +658,39 @@ def test_a_pair_too_small_for_the_backward_sweep_stays_out_of_its_class():
     b.close()
     assert kern == [(1, False), (2, True), (2, True)], kern
     run_and_check(cases, backward=True)
+
+
+def test_a_small_batch_of_general_pairs_dealt_to_several_workgroups(monkeypatch):
+    # Up to eight pairs of many strips get several workgroups each (the MULTI launches of k_forward_dag_pipe,
+    # k_forward_dag_linear and k_backward_dag_multi; strips handed on through memory).  HX_DAG_MULTI_MIN_STRIPS lowers the
+    # threshold so that pairs of two to eight strips take that launch: five pairs of different sizes, one banded, one of a
+    # single strip (its other waves idle).  Same bits as one workgroup per pair, in every policy, both fills.
+    cases = [H.dag_case(86, n=400, samples=3), H.dag_case(87, n=300, samples=3), H.dag_case(88, n=200, samples=4, band=6),
+             H.dag_case(71, n=90, samples=4), H.dag_case(89, n=40, samples=3)]
+    imgs = [H.job_images(f) for f in cases]
+    for flags in (capi.HX_LSE_EXACT, capi.HX_LSE_FAST, capi.HX_LSE_LINEAR):
+        got = []
+        for several in (True, False):
+            if several:
+                monkeypatch.setenv("HX_DAG_MULTI_MIN_STRIPS", "2")
+                monkeypatch.delenv("HX_DAG_FWD_SINGLE", raising=False)
+                monkeypatch.delenv("HX_DAG_BWD_SINGLE", raising=False)
+            else:
+                monkeypatch.setenv("HX_DAG_FWD_SINGLE", "1")
+                monkeypatch.setenv("HX_DAG_BWD_SINGLE", "1")
+            b = capi.Batch(imgs, flags | capi.HX_KEEP_BACKWARD)
+            assert all(b.job_kernel(k)[0] in (7, 8) for k in range(len(imgs)))
+            b.forward()
+            b.backward()
+            got.append(([b.read_matrix(k, 0) for k in range(len(imgs))], [b.read_matrix(k, 1) for k in range(len(imgs))],
+                        b.lp_end(), b.lp_start()))
+            b.close()
+        for k in range(len(imgs)):
+            H.assert_same_bits(got[0][0][k], got[1][0][k], "job %d Forward cells (flags %d)" % (k, flags))
+            H.assert_same_bits(got[0][1][k], got[1][1][k], "job %d Backward cells (flags %d)" % (k, flags))
+        H.assert_same_bits(got[0][2], got[1][2], "lpEnd")
+        H.assert_same_bits(got[0][3], got[1][3], "lpStart")
+        if flags == capi.HX_LSE_EXACT:
+            for k, (x, y, hmm, md) in enumerate(imgs):
+                H.assert_same_bits(got[0][0][k], c_oracle.forward(x, y, hmm, md)["cells"], "job %d Forward cells vs oracle" % k)
+                H.assert_same_bits(got[0][1][k], c_oracle.backward(x, y, hmm, md)["cells"], "job %d Backward cells vs oracle" % k)
