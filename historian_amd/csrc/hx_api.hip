@@ -28,6 +28,9 @@ using namespace hx;
 // more workgroups than half the chip's CUs (one such workgroup's LDS fills a CU), so that a second stream cannot starve them.
 #define HX_MULTI_MAX_PAIRS 8
 #define HX_MULTI_MAX_GROUPS 128
+// progress counters (256 ints per pair): the leaf-pair launch of hx_chain.hip takes up to 128 pairs; Forward fills use the
+// first half of the buffer, Backward fills the second (a caller may run the two fills on two streams)
+#define HX_MULTI_COUNTER_PAIRS 128
 
 namespace {
 
@@ -1066,8 +1069,16 @@ int hx_batch_forward(hx_batch* b, void* stream) {
         // table log-sum-exps (hx_linear.hip)
         if (linear && leaf == 2)
           LAUNCH_TRY(launch_forward_leaf_linear(jobs, cr.n, cr.max_rows, banded, Tab8{D.tab}, Tab16{D.log_tab}, cr.yl_cols, cr.yl_emis, cr.max_cls + 1, st));
-        else
-          LAUNCH_TRY(launch_forward_chain(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, st));
+        else {
+          // a small batch of unbanded leaf pairs (one rank's share of a strong-scaling run): several workgroups per pair
+          int multi = (leaf == 2 && !banded && cr.n <= HX_MULTI_COUNTER_PAIRS) ? chain_multi_groups(cr.n, cr.max_rows) : 1;
+          if (multi > 1) {
+            if (!b->d_multi && hipMalloc(reinterpret_cast<void**>(&b->d_multi), 2 * HX_MULTI_COUNTER_PAIRS * 256 * sizeof(int)) != hipSuccess)
+              return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of the progress counters failed");
+            HIP_TRY(hipMemsetAsync(b->d_multi, 0, (size_t)cr.n * 256 * sizeof(int), st));
+          }
+          LAUNCH_TRY(launch_forward_chain(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, multi, b->d_multi, st));
+        }
         break;
       }
       case KC_DAG: case KC_DAG_BANDED:
@@ -1086,7 +1097,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
             if (const char* e = getenv("HX_DAG_MULTI_WAVES")) multi_waves = atoi(e);
             if (multi_waves != 8 && multi_waves != 2) multi_waves = 4;
             multi = std::min(std::min(32, HX_MULTI_MAX_GROUPS / cr.n), (strips + multi_waves - 1) / multi_waves);
-            if (!b->d_multi && hipMalloc(reinterpret_cast<void**>(&b->d_multi), HX_MULTI_MAX_PAIRS * 256 * sizeof(int)) != hipSuccess)
+            if (!b->d_multi && hipMalloc(reinterpret_cast<void**>(&b->d_multi), 2 * HX_MULTI_COUNTER_PAIRS * 256 * sizeof(int)) != hipSuccess)
               return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of the progress counters failed");
             HIP_TRY(hipMemsetAsync(b->d_multi, 0, HX_MULTI_MAX_PAIRS * 256 * sizeof(int), st));
           }
@@ -1145,8 +1156,17 @@ int hx_batch_backward(hx_batch* b, void* stream) {
                                           linear ? Tab16{D.log_tab} : lse_tab, (b->flags & HX_SPARSE_ENVELOPE) != 0, st));
         else if (linear && leaf == 2)
           LAUNCH_TRY(launch_backward_leaf_linear(jobs, cr.n, cr.max_rows, banded, Tab8{D.tab}, Tab16{D.log_tab}, cr.yl_cols, cr.yl_emis, cr.max_cls + 1, st));
-        else
-          LAUNCH_TRY(launch_backward_chain(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, st));
+        else {
+          int multi = (leaf == 2 && !banded && cr.n <= HX_MULTI_COUNTER_PAIRS) ? chain_multi_groups(cr.n, cr.max_rows) : 1;
+          int* counters = nullptr;
+          if (multi > 1) {
+            if (!b->d_multi && hipMalloc(reinterpret_cast<void**>(&b->d_multi), 2 * HX_MULTI_COUNTER_PAIRS * 256 * sizeof(int)) != hipSuccess)
+              return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of the progress counters failed");
+            counters = b->d_multi + HX_MULTI_COUNTER_PAIRS * 256;
+            HIP_TRY(hipMemsetAsync(counters, 0, (size_t)cr.n * 256 * sizeof(int), st));
+          }
+          LAUNCH_TRY(launch_backward_chain(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, multi, counters, st));
+        }
         break;
       }
       case KC_CHAIN: case KC_CHAIN_BANDED: case KC_DAG: case KC_DAG_BANDED:

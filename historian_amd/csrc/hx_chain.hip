@@ -22,6 +22,7 @@
 //
 // Compiled with -ffp-contract=off (see hx_lse.h); FastLse uses explicit FMAs.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 #include "hx_device.h"
 #include "hx_lse.h"
@@ -138,6 +139,7 @@ __device__ __forceinline__ C5 chain_cell(const DevJob& J, const LSE& L, const XR
 // block-loads 64 columns of it at a time (L1-bypassing loads) once the producer's
 // progress counter (LDS, monotonic) says those columns are complete and drained.
 #define HX_PUBLISH_LAG 16
+#define HX_CHAIN_MULTI_WAVES 4    // waves per workgroup of the several-workgroups-per-pair launch (MULTI)
 #define HX_EXACT_LDS 15000      // table entries (d < 1.5) the exact chain kernel keeps in LDS: 117 KB (the y side may need 33 KB more)
 #define HX_YL_MAX_COLS 6144
 #define HX_YL_MAX_CLS 64
@@ -147,10 +149,20 @@ __device__ __forceinline__ C5 chain_cell(const DevJob& J, const LSE& L, const XR
 // banded batches: the strips of a banded pair run almost one after the other (a strip's window opens
 // when the strip above has all but finished its own), so a pair keeps one wave busy, and the GPU is
 // filled by putting many pairs, not many strips, in flight.
-template <int DIR, int RPT, int W, class LSE, bool FAST, bool LEAF, bool YL, bool BANDED, int MINW = 1, int PPW = 1>
+//
+// MULTI: few pairs of many strips (one rank's share of a strong-scaling run): a pair's strips are dealt to `groups`
+// workgroups of W waves, so that its waves spread over several CUs instead of sharing one CU's four SIMDs.  What a strip
+// takes from the strip above already travels through the matrix; across workgroups (and XCDs) the stores are write-through
+// (`sc1`), the progress counters sit in memory (`counters`, 256 zeroed ints per pair: one per wave, [255] = a poll gave up)
+// and are written / polled with `sc1` accesses behind the storing wave's own s_waitcnt - the hand-off of hx_dag.hip's
+// lone-pair launches.  A poll gives up after HX_CHAIN_PATIENCE rounds and the pair's lpEnd / lpStart becomes NaN.
+#define HX_CHAIN_PATIENCE (1 << 22)
+template <int DIR, int RPT, int W, class LSE, bool FAST, bool LEAF, bool YL, bool BANDED, int MINW = 1, int PPW = 1, bool MULTI = false>
 __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob* __restrict__ jobs,
                                                                       const double* __restrict__ exact_tab,
-                                                                      const double* __restrict__ fast_tab, const int n_jobs, const int yl_emis) {
+                                                                      const double* __restrict__ fast_tab, const int n_jobs, const int yl_emis,
+                                                                      const int groups = 1, int* const counters = nullptr) {
+  static_assert(!MULTI || (PPW == 1 && !BANDED && RPT == 1), "several workgroups per pair: unbanded pairs, one pair per workgroup");
   constexpr int THREADS = W * PPW * 64;
   constexpr int SR = 64 * RPT;                      // rows per strip
   static_assert(PPW == 1 || !YL, "the LDS-resident y side belongs to one pair");
@@ -173,8 +185,10 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
 
   // (wave-uniform by construction; said explicitly so that the job record is addressed with scalar loads)
   const int pair_in_wg = PPW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) / W;
-  const int job_index = (int)blockIdx.x * PPW + pair_in_wg;
-  const bool live = PPW == 1 || job_index < n_jobs;   // (PPW == 1: the grid is exactly n_jobs)
+  const int G = MULTI ? groups : 1;
+  const int job_index = MULTI ? (int)blockIdx.x / G : (int)blockIdx.x * PPW + pair_in_wg;
+  const int grp = MULTI ? (int)blockIdx.x % G : 0;
+  const bool live = PPW == 1 || job_index < n_jobs;   // (PPW == 1: the grid is exactly n_jobs [x groups])
   const DevJob& J = jobs[live ? job_index : 0];
   // YL: the whole y side lives in LDS (leaf-like y profile whose transitions all have
   // lpTrans 0): per column one word {emission class, not-ready bit}, per class
@@ -223,9 +237,34 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
     }
   volatile HX_LDS int* progp = (volatile HX_LDS int*)prog + pair_in_wg * W;   // keep the LDS address space through the lambdas
   const int n_strips = live ? (R + SR - 1) / SR : 0;
-  const int prev_wave = (wave + W - 1) % W;
+  const int WT = W * G, gw = grp * W + wave;        // the pair's waves, and this one among them
+  const int prev_wave = (gw + WT - 1) % WT;
+  HX_GLOBAL int* gprog = MULTI ? (HX_GLOBAL int*)as_global(counters + 256 * job_index) : nullptr;
+  bool dead = false;                                // MULTI: a poll ran out of patience
+  const auto wait_above = [&](const int need) {
+    if (!MULTI) {
+      while (progp[prev_wave] < need) __builtin_amdgcn_s_sleep(1);
+      return;
+    }
+    if (dead) return;
+    int polls = 0;
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(gprog + prev_wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+      if (++polls > HX_CHAIN_PATIENCE) {
+        dead = true;
+        if (lane == 0) __hip_atomic_store(gprog + 255, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+  };
+  const auto publish = [&](const int value) {      // (behind the caller's s_waitcnt: the columns up to `value` are out)
+    if (lane != 0) return;
+    if (MULTI) __hip_atomic_store(gprog + gw, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else progp[wave] = value;
+  };
 
-  for (int s = wave; s < n_strips; s += W) {
+  for (int s = gw; s < n_strips; s += WT) {
     const int row0 = s * SR;
     const int i0 = row0 + lane * RPT;              // first row of this lane
     XRow X[RPT];
@@ -265,8 +304,8 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
     C5 ua = c5_neg_inf(), ub = c5_neg_inf();
     C5 bnd = c5_neg_inf();                         // 64 columns of the strip above's last row
     const bool has_above = s > 0;
-    const int above_base = ((s - 1) / W) * Cc;     // columns the producer wave published in earlier strips
-    const int my_base = (s / W) * Cc;
+    const int above_base = ((s - 1) / WT) * Cc;    // columns the producer wave published in earlier strips
+    const int my_base = (s / WT) * Cc;
     // strip-skewed store base (hx_device.h cell_slot): a lane's rows are adjacent pairs
     const int strip64 = i0 >> 6;
     const int64_t store_base2 = (int64_t)strip64 * ss + ((i0 & 63) << 1);
@@ -314,7 +353,7 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
           const int tb = t & ~63;
           const int hi = (tb + 64 < Cc) ? tb + 64 : Cc;
           const int need = above_base + hi;
-          while (progp[prev_wave] < need) __builtin_amdgcn_s_sleep(1);
+          wait_above(need);
           const int jj = tb + lane;
           bnd = c5_neg_inf();
           const int64_t sl = jj < Cc ? (sbase ? stored_slot(J, row0 - 1, jj) : cell_slot(ss, row0 - 1, jj)) : -1;
@@ -453,7 +492,7 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
       // above and may well be inside the envelope: fetch it (in the steady state it is the boundary
       // value of the previous step)
       const int need = above_base + wstart;
-      while (progp[prev_wave] < need) __builtin_amdgcn_s_sleep(1);
+      wait_above(need);
       const int64_t sl = sbase ? stored_slot(J, row0 - 1, wstart - 1) : cell_slot(ss, row0 - 1, wstart - 1);
       if (lane == 0 && sl >= 0) {
         ub.imm = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -504,6 +543,16 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
         const int64_t plane2 = plane >> 1;
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
+          if (MULTI) {
+            // the strip below may run on another XCD: write-through stores (never `nt`, which stays in this XCD's L2)
+            const d2v v0{oa[k].imm, ob[k].imm}, v1{oa[k].imd, ob[k].imd}, v2{oa[k].idm, ob[k].idm}, v3{oa[k].imi, ob[k].imi}, v4{oa[k].iiw, ob[k].iiw};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&M2[k]), "v"(v0) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&M2[plane2 + k]), "v"(v1) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&M2[2 * plane2 + k]), "v"(v2) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&M2[3 * plane2 + k]), "v"(v3) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&M2[4 * plane2 + k]), "v"(v4) : "memory");
+            continue;
+          }
           // write-once data: non-temporal stores (the 1/64 of it that the strip below reads back comes from L2 or memory)
           __builtin_nontemporal_store(d2v{oa[k].imm, ob[k].imm}, &M2[k]);
           __builtin_nontemporal_store(d2v{oa[k].imd, ob[k].imd}, &M2[plane2 + k]);
@@ -526,13 +575,13 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
       if (fin >= Cc) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (WIN) published = Cc;
-        if (lane == 0) progp[wave] = my_base + Cc;
+        publish(my_base + Cc);
       } else {
         const int done = fin - HX_PUBLISH_LAG;
         if (done > (WIN ? published : 0) && ((done >> 6) != ((done - 2) >> 6))) {
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PUBLISH_WAIT) : "memory");
           if (WIN) published = done;
-          if (lane == 0) progp[wave] = my_base + done;
+          publish(my_base + done);
         }
       }
     }
@@ -544,15 +593,27 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
       if (done > published) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         published = done;
-        if (lane == 0) progp[wave] = my_base + done;
+        publish(my_base + done);
       }
     }
     }
     if (WIN && published < Cc) {   // (a strip without any window still releases the strip below)
       published = Cc;
-      if (lane == 0) progp[wave] = my_base + Cc;
+      publish(my_base + Cc);
+    }
+    if (MULTI && s == n_strips - 1) {
+      // the last strip finishes last (every strip follows the one above) and its own stores are out (vmcnt(0) in front of
+      // its last publish); what END reads may lie in other workgroups' strips: drop this CU's L1 first
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const bool gave_up = __hip_atomic_load(gprog + 255, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      if (lane == 0) {
+        if (DIR == 0) *J.lp_end = gave_up ? __builtin_nan("") : forward_lp_end(J, LX);
+        else *J.lp_start = gave_up ? __builtin_nan("") : J.bwd[cell_slot(ss, R - 1, Cc - 1)];
+      }
     }
   }
+  if (MULTI) return;
   __syncthreads();
   if (live && wave == 0 && lane == 0) {
     if (DIR == 0) *J.lp_end = forward_lp_end(J, LX);
@@ -607,9 +668,30 @@ static void launch_banded_leaf(const DevJob* d_jobs, int n_jobs, const double* t
   else launch_banded_leaf_ppw<DIR, 8>(d_jobs, n_jobs, tab, fast_tab, fast, st);
 }
 
+// few unbanded leaf pairs of many strips: `multi` workgroups of four waves per pair (k_fill_chain, MULTI)
+template <int DIR>
+static int launch_chain_multi(const DevJob* d_jobs, int n_jobs, const double* tab, const double* fast_tab, bool fast,
+                              int yl_cols, int yl_emis, int multi, int* counters, hipStream_t st) {
+  constexpr int W = HX_CHAIN_MULTI_WAVES;
+  const dim3 g(n_jobs * multi), b(W * 64);
+  const size_t dyn = sizeof(double) * (size_t)yl_emis + sizeof(unsigned) * (size_t)yl_cols;
+  if (yl_cols > HX_YL_MAX_COLS || yl_emis > HX_YL_MAX_EMIS + 2)
+    return launch_fail("LDS-resident y side of %d columns / %d class pairs exceeds the chain kernel's tables", yl_cols, yl_emis);
+  if (fast) {
+    HX_CHECK_LDS((k_fill_chain<DIR, 1, W, FastLse, true, true, true, false, 1, 1, true>), dyn, "k_fill_chain<multi>");
+    hipLaunchKernelGGL((k_fill_chain<DIR, 1, W, FastLse, true, true, true, false, 1, 1, true>), g, b, dyn, st, d_jobs, tab, fast_tab, n_jobs, yl_emis, multi, counters);
+  } else {
+    HX_CHECK_LDS((k_fill_chain<DIR, 1, W, ExactLse3, false, true, true, false, 1, 1, true>), dyn, "k_fill_chain<multi>");
+    hipLaunchKernelGGL((k_fill_chain<DIR, 1, W, ExactLse3, false, true, true, false, 1, 1, true>), g, b, dyn, st, d_jobs, tab, fast_tab, n_jobs, yl_emis, multi, counters);
+  }
+  return 0;
+}
+
 template <int DIR>
 static int launch_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const double* tab, const double* fast_tab,
-                         bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
+                         bool fast, int leaf, bool banded, int yl_cols, int yl_emis, int multi, int* counters, hipStream_t st) {
+  if (multi > 1 && leaf == 2 && !banded)
+    return launch_chain_multi<DIR>(d_jobs, n_jobs, tab, fast_tab, fast, yl_cols, yl_emis, multi, counters, st);
   const char* v = getenv("HX_CHAIN_VARIANT");   // tuning hook: override for long profiles
   const int vi = v ? atoi(v) : 0;
   if (banded && leaf >= 1 && vi == 0 && n_jobs >= 64) {
@@ -629,21 +711,39 @@ static int launch_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const do
   return launch_variant<DIR, 1, 16>(d_jobs, n_jobs, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);   // measured fastest on 2x2000
 }
 
+// Workgroups per pair for a batch of n_jobs unbanded leaf pairs (y side in LDS) of up to max_rows rows: 1 = the ordinary launch.
+// Several only when the ordinary launch (one workgroup of sixteen waves per pair) would leave most CUs idle - at most 128
+// pairs - and never more than 256 workgroups, one per CU (two fit: every workgroup of the launch has to be resident).
+// HX_CHAIN_MULTI: 0 = never, n > 1 = that many workgroups per pair (tuning / test hook).
+int chain_multi_groups(int n_jobs, int max_rows) {
+  const int strips = (max_rows + 63) / 64;
+  const int cap = (strips + HX_CHAIN_MULTI_WAVES - 1) / HX_CHAIN_MULTI_WAVES;
+  if (const char* e = getenv("HX_CHAIN_MULTI")) {
+    const int forced = atoi(e);
+    if (forced <= 1) return 1;
+    return std::max(1, std::min(std::min(forced, cap), 256 / HX_CHAIN_MULTI_WAVES));
+  }
+  if (n_jobs > 128 || strips <= 16) return 1;
+  const int groups = std::min(cap, 256 / n_jobs);
+  return groups >= 2 ? groups : 1;
+}
+
 // leaf: 0 = general chain profiles, 1 = leaf-like, 2 = leaf-like with the y side in LDS
+// multi > 1 (unbanded pairs with the y side in LDS only, see chain_multi_groups): workgroups per pair; counters: 256 zeroed ints per pair
 int launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 tab16,
-                         bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
+                         bool fast, int leaf, bool banded, int yl_cols, int yl_emis, int multi, int* counters, hipStream_t st) {
   const double* tab = tab8.p;
   const double* fast_tab = tab16.p;
-  return launch_chain<0>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
+  return launch_chain<0>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, multi, counters, st);
 }
 
 // leaf-like profiles only (leaf >= 1)
 int launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 tab16,
-                          bool fast, int leaf, bool banded, int yl_cols, int yl_emis, hipStream_t st) {
+                          bool fast, int leaf, bool banded, int yl_cols, int yl_emis, int multi, int* counters, hipStream_t st) {
   const double* tab = tab8.p;
   const double* fast_tab = tab16.p;
   if (leaf < 1) return launch_fail("the Backward strip pipeline exists for leaf-like profiles only");
-  return launch_chain<1>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, st);
+  return launch_chain<1>(d_jobs, n_jobs, max_rows, tab, fast_tab, fast, leaf, banded, yl_cols, yl_emis, multi, counters, st);
 }
 
 }  // namespace hx

@@ -694,3 +694,37 @@ def test_a_small_batch_of_general_pairs_dealt_to_several_workgroups(monkeypatch)
             for k, (x, y, hmm, md) in enumerate(imgs):
                 H.assert_same_bits(got[0][0][k], c_oracle.forward(x, y, hmm, md)["cells"], "job %d Forward cells vs oracle" % k)
                 H.assert_same_bits(got[0][1][k], c_oracle.backward(x, y, hmm, md)["cells"], "job %d Backward cells vs oracle" % k)
+
+
+@pytest.mark.parametrize("groups", ["2", "3", "64"])
+def test_a_small_batch_of_leaf_pairs_dealt_to_several_workgroups(groups, monkeypatch):
+    # Few unbanded leaf pairs of many strips (one rank's share of a strong-scaling run) get several workgroups of four waves
+    # per pair (k_fill_chain, MULTI: write-through stores, progress counters in memory).  HX_CHAIN_MULTI forces the number of
+    # workgroups (capped at strips / 4) on pairs of 2 to 11 strips, one of them shorter than a workgroup's four strips.
+    # Exact mode: bit for bit the oracle, both fills; fast: the same bits as the ordinary launch.
+    aa = "arndcqeghilkmfpstwyv"
+    cases = [H.leaf_case(701, 700, 650, alphabet=aa, jc=False), H.leaf_case(702, 330, 400), H.leaf_case(703, 130, 90),
+             H.leaf_case(704, 520, 300, alphabet=aa, jc=False, components=2), H.leaf_case(705, 641, 64)]
+    imgs = [H.job_images(f) for f in cases]
+    for flags in (capi.HX_LSE_EXACT, capi.HX_LSE_FAST):
+        got = []
+        for forced in (groups, "0"):
+            monkeypatch.setenv("HX_CHAIN_MULTI", forced)
+            b = capi.Batch(imgs, flags | capi.HX_KEEP_BACKWARD)
+            assert all(b.job_kernel(k)[0] == 0 for k in range(len(imgs)))
+            b.forward()
+            b.backward()
+            got.append(([b.read_matrix(k, 0) for k in range(len(imgs))], [b.read_matrix(k, 1) for k in range(len(imgs))],
+                        b.lp_end(), b.lp_start()))
+            b.close()
+        for k in range(len(imgs)):
+            H.assert_same_bits(got[0][0][k], got[1][0][k], "job %d Forward cells (flags %d)" % (k, flags))
+            H.assert_same_bits(got[0][1][k], got[1][1][k], "job %d Backward cells (flags %d)" % (k, flags))
+        H.assert_same_bits(got[0][2], got[1][2], "lpEnd")
+        H.assert_same_bits(got[0][3], got[1][3], "lpStart")
+        if flags == capi.HX_LSE_EXACT:
+            for k, (x, y, hmm, md) in enumerate(imgs):
+                wf, wb = c_oracle.forward(x, y, hmm, md), c_oracle.backward(x, y, hmm, md)
+                H.assert_same_bits(got[0][0][k], wf["cells"], "job %d Forward cells vs oracle" % k)
+                H.assert_same_bits(got[0][1][k], wb["cells"], "job %d Backward cells vs oracle" % k)
+                H.assert_same_bits([got[0][2][k], got[0][3][k]], [wf["lp_end"], wb["lp_start"]], "job %d lpEnd, lpStart" % k)
