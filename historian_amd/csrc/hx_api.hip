@@ -1067,18 +1067,18 @@ int hx_batch_forward(hx_batch* b, void* stream) {
         const int leaf = (c == KC_LEAF_LDS || c == KC_LEAF_LDS_BANDED) ? 2 : ((c == KC_LEAF || c == KC_LEAF_BANDED) ? 1 : 0);
         // HX_LSE_LINEAR on leaf pairs whose y side fits LDS: the recursion runs on scaled probabilities instead of
         // table log-sum-exps (hx_linear.hip)
-        if (linear && leaf == 2)
-          LAUNCH_TRY(launch_forward_leaf_linear(jobs, cr.n, cr.max_rows, banded, Tab8{D.tab}, Tab16{D.log_tab}, cr.yl_cols, cr.yl_emis, cr.max_cls + 1, st));
-        else {
-          // a small batch of unbanded leaf pairs (one rank's share of a strong-scaling run): several workgroups per pair
-          int multi = (leaf == 2 && !banded && cr.n <= HX_MULTI_COUNTER_PAIRS) ? chain_multi_groups(cr.n, cr.max_rows) : 1;
-          if (multi > 1) {
-            if (!b->d_multi && hipMalloc(reinterpret_cast<void**>(&b->d_multi), 2 * HX_MULTI_COUNTER_PAIRS * 256 * sizeof(int)) != hipSuccess)
-              return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of the progress counters failed");
-            HIP_TRY(hipMemsetAsync(b->d_multi, 0, (size_t)cr.n * 256 * sizeof(int), st));
-          }
-          LAUNCH_TRY(launch_forward_chain(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, multi, b->d_multi, st));
+        // a small batch of unbanded leaf pairs (one rank's share of a strong-scaling run): several workgroups per pair
+        int multi = (leaf == 2 && !banded && cr.n <= HX_MULTI_COUNTER_PAIRS) ? chain_multi_groups(cr.n, cr.max_rows, linear ? 64 : 128) : 1;
+        if (multi > 1) {
+          if (!b->d_multi && hipMalloc(reinterpret_cast<void**>(&b->d_multi), 2 * HX_MULTI_COUNTER_PAIRS * 256 * sizeof(int)) != hipSuccess)
+            return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of the progress counters failed");
+          HIP_TRY(hipMemsetAsync(b->d_multi, 0, (size_t)cr.n * 256 * sizeof(int), st));
         }
+        if (linear && leaf == 2)
+          LAUNCH_TRY(launch_forward_leaf_linear(jobs, cr.n, cr.max_rows, banded, Tab8{D.tab}, Tab16{D.log_tab}, cr.yl_cols, cr.yl_emis, cr.max_cls + 1,
+                                                multi, b->d_multi, st));
+        else
+          LAUNCH_TRY(launch_forward_chain(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, multi, b->d_multi, st));
         break;
       }
       case KC_DAG: case KC_DAG_BANDED:
@@ -1154,10 +1154,8 @@ int hx_batch_backward(hx_batch* b, void* stream) {
           // the rotating-row sweep in mirrored coordinates (hx_band.hip)
           LAUNCH_TRY(launch_backward_band(jobs, cr.n, linear ? 0 : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab},
                                           linear ? Tab16{D.log_tab} : lse_tab, (b->flags & HX_SPARSE_ENVELOPE) != 0, st));
-        else if (linear && leaf == 2)
-          LAUNCH_TRY(launch_backward_leaf_linear(jobs, cr.n, cr.max_rows, banded, Tab8{D.tab}, Tab16{D.log_tab}, cr.yl_cols, cr.yl_emis, cr.max_cls + 1, st));
         else {
-          int multi = (leaf == 2 && !banded && cr.n <= HX_MULTI_COUNTER_PAIRS) ? chain_multi_groups(cr.n, cr.max_rows) : 1;
+          int multi = (leaf == 2 && !banded && cr.n <= HX_MULTI_COUNTER_PAIRS) ? chain_multi_groups(cr.n, cr.max_rows, linear ? 64 : 128) : 1;
           int* counters = nullptr;
           if (multi > 1) {
             if (!b->d_multi && hipMalloc(reinterpret_cast<void**>(&b->d_multi), 2 * HX_MULTI_COUNTER_PAIRS * 256 * sizeof(int)) != hipSuccess)
@@ -1165,7 +1163,11 @@ int hx_batch_backward(hx_batch* b, void* stream) {
             counters = b->d_multi + HX_MULTI_COUNTER_PAIRS * 256;
             HIP_TRY(hipMemsetAsync(counters, 0, (size_t)cr.n * 256 * sizeof(int), st));
           }
-          LAUNCH_TRY(launch_backward_chain(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, multi, counters, st));
+          if (linear && leaf == 2)
+            LAUNCH_TRY(launch_backward_leaf_linear(jobs, cr.n, cr.max_rows, banded, Tab8{D.tab}, Tab16{D.log_tab}, cr.yl_cols, cr.yl_emis, cr.max_cls + 1,
+                                                   multi, counters, st));
+          else
+            LAUNCH_TRY(launch_backward_chain(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, multi, counters, st));
         }
         break;
       }

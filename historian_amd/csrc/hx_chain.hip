@@ -715,7 +715,9 @@ static int launch_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const do
 // Several only when the ordinary launch (one workgroup of sixteen waves per pair) would leave most CUs idle - at most 128
 // pairs - and never more than 256 workgroups, one per CU (two fit: every workgroup of the launch has to be resident).
 // HX_CHAIN_MULTI: 0 = never, n > 1 = that many workgroups per pair (tuning / test hook).
-int chain_multi_groups(int n_jobs, int max_rows) {
+// max_pairs: 128 for the table policies' kernel, 64 for the scaled-probability one (k_fill_leaf_linear: 128 pairs measured
+// 5.1 ms in the ordinary launch, 5.5 ms dealt out).
+int chain_multi_groups(int n_jobs, int max_rows, int max_pairs) {
   const int strips = (max_rows + 63) / 64;
   const int cap = (strips + HX_CHAIN_MULTI_WAVES - 1) / HX_CHAIN_MULTI_WAVES;
   if (const char* e = getenv("HX_CHAIN_MULTI")) {
@@ -723,7 +725,7 @@ int chain_multi_groups(int n_jobs, int max_rows) {
     if (forced <= 1) return 1;
     return std::max(1, std::min(std::min(forced, cap), 256 / HX_CHAIN_MULTI_WAVES));
   }
-  if (n_jobs > 128 || strips <= 16) return 1;
+  if (n_jobs > max_pairs || strips <= 16) return 1;
   const int groups = std::min(cap, 256 / n_jobs);
   return groups >= 2 ? groups : 1;
 }

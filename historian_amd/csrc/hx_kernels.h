@@ -39,7 +39,7 @@ int launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 ta
                           bool fast, int leaf, bool banded, int yl_cols, int yl_emis, int multi, int* counters, hipStream_t st);
 int launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 fast_tab,
                            bool fast, int leaf, bool banded, int yl_cols, int yl_emis, int multi, int* counters, hipStream_t st);
-int chain_multi_groups(int n_jobs, int max_rows);   // workgroups per pair of a small batch of unbanded leaf pairs (1: the ordinary launch)
+int chain_multi_groups(int n_jobs, int max_rows, int max_pairs);   // workgroups per pair of a small batch of unbanded leaf pairs (1: the ordinary launch)
 void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, Tab8 tab, hipStream_t st);
 void launch_fill_neg_inf(double* p, int64_t n, hipStream_t st);
 // scaled-probability Forward fill of general profiles (hx_daglin.hip); scratch per job in DevJob::agg
@@ -62,10 +62,10 @@ void launch_gather_cells(const DevJob* d_jobs, int job, const double* M, int mir
 int log_table_doubles();
 void build_log_table(double* out /* [log_table_doubles()] */);
 int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, Tab8 tab, Tab16 log_tab,
-                                int yl_cols, int yl_emis, int yl_cls, hipStream_t st);
+                                int yl_cols, int yl_emis, int yl_cls, int multi, int* counters, hipStream_t st);
 
 int launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, Tab8 tab, Tab16 log_tab,
-                                 int yl_cols, int yl_emis, int yl_cls, hipStream_t st);
+                                 int yl_cols, int yl_emis, int yl_cls, int multi, int* counters, hipStream_t st);
 
 // banded leaf-like pairs, rotating-row sweep (hx_band.hip); pol: 0 = scaled probabilities, 1 = fast, 2 = exact
 bool band_kernel_fits(int pol, int rows, int cols, int cls);

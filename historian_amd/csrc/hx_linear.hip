@@ -109,10 +109,17 @@ struct LdsPlan { int elds, ycol, yclass, flags, zero;   // inside block A
 // DIR = 1: the Backward fill (reference src/forward.cpp:975-1088 for leaf-like profiles) - the same pipeline in mirrored
 // coordinates (sweep row i' = R-1-i, sweep column j' = Cc-1-j, as k_fill_chain<1> and the stored layout), with the Backward
 // recursion: B(i,j,s) = sum over the destination cells (i+1,j+1), (i+1,j), (i,j+1) of P[s][dest state] x emission x B(dest).
-template <int W, bool BANDED, int PPW, int DIR>
+// MULTI: few pairs of many strips (one rank's share of a strong-scaling run): a pair's passes of W strips are dealt to
+// `groups` workgroups, so that its waves spread over several CUs.  Inside a workgroup nothing changes (LDS rings); the
+// wrap-around link - already a trip through the matrix - now crosses workgroups: write-through stores (`sc1`), its progress
+// counter in memory (`counters`: 256 zeroed ints per pair, one per workgroup, [255] = a poll gave up), `sc1` polls that give
+// up after HXL_PATIENCE rounds (the pair's lpEnd / lpStart becomes NaN).  As k_fill_chain's MULTI (hx_chain.hip).
+#define HXL_PATIENCE (1 << 22)
+template <int W, bool BANDED, int PPW, int DIR, bool MULTI = false>
 __global__ void __launch_bounds__(W * PPW * 64, 4)   // four waves per SIMD: 128 vector registers
 k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const double* __restrict__ log_tab,
-                      const LdsPlan plan, const int n_jobs) {
+                      const LdsPlan plan, const int n_jobs, const int groups = 1, int* const counters = nullptr) {
+  static_assert(!MULTI || (!BANDED && PPW == 1 && W > 1), "several workgroups per pair: unbanded pairs, one pair per workgroup");
   static_assert(!BANDED || W == 1, "banded batches run one wavefront per pair");
   static_assert(PPW == 1 || BANDED, "several pairs per workgroup: banded batches only");
   constexpr int THREADS = W * PPW * 64, PT = W * 64;       // threads of the workgroup / of a pair
@@ -122,7 +129,9 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
   double* ltab = reinterpret_cast<double*>(lds);
   const int pair = PPW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int tid = (int)threadIdx.x - pair * PT;              // thread within its pair
-  const int job = (int)blockIdx.x * PPW + pair;
+  const int G = MULTI ? groups : 1;
+  const int job = MULTI ? (int)blockIdx.x / G : (int)blockIdx.x * PPW + pair;
+  const int grp = MULTI ? (int)blockIdx.x % G : 0;
   const bool live = PPW == 1 || job < n_jobs;
   const DevJob& J = jobs[live ? job : 0];
   unsigned char* blk_a = lds + (pair == 0 ? plan.a0 : plan.a1 + (pair - 1) * plan.stride);
@@ -198,6 +207,33 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
   HX_LDS d2v* ring_mine = (HX_LDS d2v*)blk_b + (size_t)wave * (HXL_RING * 3);
   const int n_strips = live ? (R + 63) / 64 : 0;
   const int prev_wave = (wave + W - 1) % W, next_wave = (wave + 1) % W;
+  const int WT = W * G, gw = grp * W + wave;        // the pair's waves, and this one among them
+  HX_GLOBAL int* gdrain = MULTI ? (HX_GLOBAL int*)as_global(counters + 256 * job) : nullptr;
+  const int prev_grp = (grp + G - 1) % G;
+  bool dead = false;                                // MULTI: a poll ran out of patience
+  const auto wait_drained = [&](const int need) {   // the wrap-around link: columns of the strip above that are in memory
+    if (!MULTI) {
+      while (drainp[0] < need) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      return;
+    }
+    if (dead) return;
+    int polls = 0;
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(gdrain + prev_grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+      if (++polls > HXL_PATIENCE) {
+        dead = true;
+        if (lane == 0) __hip_atomic_store(gdrain + 255, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+  };
+  const auto publish_drained = [&](const int value) {   // (behind the caller's s_waitcnt)
+    if (lane != 0) return;
+    if (MULTI) __hip_atomic_store(gdrain + grp, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else drainp[0] = value;
+  };
   // Strips are dealt round-robin, so with more strips than waves the last wave feeds the first one's NEXT strip, which
   // starts a whole sweep later: that link cannot be a bounded ring (the waves would wait for each other in a circle).
   // It goes through the matrix instead - wave W-1 publishes how many columns of its last row have reached memory, wave 0
@@ -205,7 +241,7 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
   HX_LDS d2v* staging = (HX_LDS d2v*)blk_b + (size_t)RING_ENTRIES * 3;   // [HXL_STAGE] entries
   const HX_LDS d2v* ring_prev = (const HX_LDS d2v*)blk_b + (size_t)prev_wave * (HXL_RING * 3);
 
-  for (int s = wave; s < n_strips; s += W) {
+  for (int s = gw; s < n_strips; s += WT) {
     const int row0 = s * 64;
     const int i0 = row0 + lane;
     const bool row_valid = i0 < R;
@@ -241,8 +277,8 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
     const bool wrap_out = has_below && wave == W - 1;        // this strip's last row is read back from memory
     const bool ring_out = has_below && !wrap_out;
     // column sequence numbers: column j of strip s is number (s / W) * Cc + j of its wave's ring
-    const int above_base = ((s - 1) / W) * Cc;
-    const int my_base = (s / W) * Cc;
+    const int above_base = ((s - 1) / WT) * Cc;
+    const int my_base = (s / WT) * Cc;
     int64_t store_base2 = (int64_t)s * ss + (lane << 1);
     int store_t0 = 0;                              // (band-compressed storage: a window's cells are stored from its own offset)
     const int nsteps = (Cc + 64) & ~1;             // Cc + 63 anti-diagonals, rounded up to whole step pairs
@@ -269,8 +305,7 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
     auto stage_block = [&](const int c0) {
       const int hi = (c0 + 64 < Cc) ? c0 + 64 : Cc;
       const int need = above_base + hi;
-      while (drainp[0] < need) __builtin_amdgcn_s_sleep(1);
-      asm volatile("" ::: "memory");
+      wait_drained(need);
       const int jj = c0 + lane;
       const int64_t sl = jj < Cc ? ((BANDED && DIR == 0) ? stored_slot(J, row0 - 1, jj) : cell_slot_blk(ss, blk, row0 - 1, jj)) : -1;
       if (jj < Cc && sl < 0) {                     // band-compressed storage: not stored = outside the envelope
@@ -515,11 +550,21 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
         // write-once data that this kernel never reads again (the wrap-around link reads 1/64 of it, from L2 or
         // memory): non-temporal stores - 17.4 -> 15.8 ms on the headline workload with separate state planes; with the
         // interleaved layout (5 KiB contiguous per iteration) they measure the same as plain stores
+        if (MULTI) {
+          // the strip below may run on another XCD: write-through stores (never `nt`, which stays in this XCD's L2)
+          const d2v v0{l0, h0}, v1{l1, h1}, v2{l2, h2}, v3{l3, h3}, v4{l4, h4};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&M2[0]), "v"(v0) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&M2[plane2]), "v"(v1) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&M2[2 * plane2]), "v"(v2) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&M2[3 * plane2]), "v"(v3) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&M2[4 * plane2]), "v"(v4) : "memory");
+        } else {
         __builtin_nontemporal_store(d2v{l0, h0}, &M2[0]);
         __builtin_nontemporal_store(d2v{l1, h1}, &M2[plane2]);
         __builtin_nontemporal_store(d2v{l2, h2}, &M2[2 * plane2]);
         __builtin_nontemporal_store(d2v{l3, h3}, &M2[3 * plane2]);
         __builtin_nontemporal_store(d2v{l4, h4}, &M2[4 * plane2]);
+        }
 #endif
       }
       if (wrap_out && !BANDED) {
@@ -529,7 +574,7 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
         const int fin = (t + 2 < nsteps ? t + 2 : nsteps) - 63;
         if (fin >= Cc) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) drainp[0] = my_base + Cc;
+          publish_drained(my_base + Cc);
         } else {
           const int done = fin - HXL_PUBLISH_LAG;
           if (done > 0 && ((done >> 6) != ((done - 2) >> 6))) {
@@ -537,7 +582,7 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
             constexpr int PUBLISH_WAIT = 5 * (HXL_PUBLISH_LAG / 2);
             static_assert(PUBLISH_WAIT <= 63 && HXL_PUBLISH_LAG % 2 == 0, "s_waitcnt vmcnt holds 6 bits");
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PUBLISH_WAIT) : "memory");
-            if (lane == 0) drainp[0] = my_base + done;
+            publish_drained(my_base + done);
           }
         }
       }
@@ -547,10 +592,22 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
     if (BANDED && wrap_out) {
       // (the windows need not reach the strip's last step: everything this strip will ever write is out)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) drainp[0] = my_base + Cc;
+      publish_drained(my_base + Cc);
     }
     if (has_above && !wrap_in && lane == 0) consp[wave] = above_base + Cc;
+    if (MULTI && s == n_strips - 1) {
+      // the last strip finishes last; what lpEnd / lpStart read lies in this strip - its stores are write-through
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const bool gave_up = __hip_atomic_load(gdrain + 255, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      if (lane == 0) {
+        if (DIR == 0) *J.lp_end = gave_up ? __builtin_nan("") : forward_lp_end(J, ExactLse{exact_tab});
+        else *J.lp_start = gave_up ? __builtin_nan("") : J.bwd[cell_slot_blk(ss, blk, R - 1, Cc - 1)];
+      }
+    }
   }
+  if (MULTI) return;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (live && wave == 0 && lane == 0) {
@@ -597,10 +654,17 @@ static LdsPlan plan_lds(int W, int PPW, bool banded, int yl_cols, int yl_emis, i
 }
 
 int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, Tab8 tab8, Tab16 tab16,
-                               int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
+                               int yl_cols, int yl_emis, int yl_cls, int multi, int* counters, hipStream_t st) {
   const double* tab = tab8.p;
   const double* log_tab = tab16.p;
   if (yl_cls > HX_YL_MAX_CLS_LINEAR + 1) return launch_fail("%d emission classes exceed the scaled-probability kernel's column words", yl_cls);
+  if (multi > 1 && !banded) {     // a small batch: `multi` workgroups of four waves per pair (MULTI; see chain_multi_groups)
+    const LdsPlan p = plan_lds(4, 1, false, yl_cols, yl_emis, yl_cls);
+    if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_leaf_linear<multi> needs %d bytes of LDS (limit %d)", p.total, HX_LDS_LIMIT);
+    hipLaunchKernelGGL((k_fill_leaf_linear<4, false, 1, 0, true>), dim3(n_jobs * multi), dim3(4 * 64), p.total, st, d_jobs, tab, log_tab, p, n_jobs,
+                       multi, counters);
+    return 0;
+  }
 #define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis, yl_cls); \
     if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_leaf_linear<%d> needs %d bytes of LDS (limit %d)", W_, p.total, HX_LDS_LIMIT); \
     hipLaunchKernelGGL((k_fill_leaf_linear<W_, B_, PPW_, 0>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
@@ -637,10 +701,17 @@ int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, b
 
 // Backward fill of leaf batches on scaled probabilities (the same kernel, DIR = 1)
 int launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, Tab8 tab8, Tab16 tab16,
-                                int yl_cols, int yl_emis, int yl_cls, hipStream_t st) {
+                                int yl_cols, int yl_emis, int yl_cls, int multi, int* counters, hipStream_t st) {
   const double* tab = tab8.p;
   const double* log_tab = tab16.p;
   if (yl_cls > HX_YL_MAX_CLS_LINEAR + 1) return launch_fail("%d emission classes exceed the scaled-probability kernel's column words", yl_cls);
+  if (multi > 1 && !banded) {     // a small batch: `multi` workgroups of four waves per pair (MULTI; see chain_multi_groups)
+    const LdsPlan p = plan_lds(4, 1, false, yl_cols, yl_emis, yl_cls);
+    if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_leaf_linear<multi> needs %d bytes of LDS (limit %d)", p.total, HX_LDS_LIMIT);
+    hipLaunchKernelGGL((k_fill_leaf_linear<4, false, 1, 1, true>), dim3(n_jobs * multi), dim3(4 * 64), p.total, st, d_jobs, tab, log_tab, p, n_jobs,
+                       multi, counters);
+    return 0;
+  }
 #define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis, yl_cls); \
     if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_leaf_linear<%d, bwd> needs %d bytes of LDS (limit %d)", W_, p.total, HX_LDS_LIMIT); \
     hipLaunchKernelGGL((k_fill_leaf_linear<W_, B_, PPW_, 1>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \

@@ -728,3 +728,21 @@ def test_a_small_batch_of_leaf_pairs_dealt_to_several_workgroups(groups, monkeyp
                 H.assert_same_bits(got[0][0][k], wf["cells"], "job %d Forward cells vs oracle" % k)
                 H.assert_same_bits(got[0][1][k], wb["cells"], "job %d Backward cells vs oracle" % k)
                 H.assert_same_bits([got[0][2][k], got[0][3][k]], [wf["lp_end"], wb["lp_start"]], "job %d lpEnd, lpStart" % k)
+    # scaled probabilities (k_fill_leaf_linear, MULTI: whole passes of four strips dealt to the workgroups; the rows handed on
+    # between workgroups travel as logarithms, as on the wrap-around link of the ordinary launch): the libm-arithmetic oracle
+    monkeypatch.setenv("HX_CHAIN_MULTI", groups)
+    b = capi.Batch(imgs, capi.HX_LSE_LINEAR | capi.HX_KEEP_BACKWARD)
+    b.forward()
+    b.backward()
+    lf, sf = b.lp_end(), b.lp_start()
+    for k, (x, y, hmm, md) in enumerate(imgs):
+        for which, want in ((0, c_oracle.forward(x, y, hmm, md, true_math=True)), (1, c_oracle.backward(x, y, hmm, md, true_math=True))):
+            m = b.read_matrix(k, which)
+            assert not np.isnan(m).any(), "job %d" % k
+            assert np.array_equal(np.isneginf(want["cells"]), np.isneginf(m)), "job %d matrix %d: -inf pattern" % (k, which)
+            fin = np.isfinite(m)
+            assert np.max(np.abs(want["cells"][fin] - m[fin]), initial=0.) < 1e-9, "job %d matrix %d" % (k, which)
+            got_lp = lf[k] if which == 0 else sf[k]
+            want_lp = want["lp_end"] if which == 0 else want["lp_start"]
+            assert abs(want_lp - got_lp) <= 1e-12 * abs(got_lp), "job %d matrix %d" % (k, which)
+    b.close()
