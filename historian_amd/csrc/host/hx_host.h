@@ -213,7 +213,7 @@ struct RateModel : AlphabetOwner {
   void readFile(const char* jsonFile);       // JSON, reference src/model.cpp:172-232
   void read(const string& jsonText);
   static Vec getEqmProbVector(const Mat& rates);       // src/model.cpp:282-320
-  vguard<Mat> getSubProbMatrix(double time) const;     // src/model.cpp:322-334 (own scaling-and-squaring exp(Rt))
+  vguard<Mat> getSubProbMatrix(double time) const;     // src/model.cpp:322-334 (gsl_linalg_exponential_ss restated)
 };
 
 struct ProbModel : AlphabetOwner {

@@ -396,9 +396,11 @@ Vec RateModel::getEqmProbVector(const Mat& sr) {
   return eqm;
 }
 
-// exp(R t) by scaling and squaring of a Taylor series (the reference calls
-// gsl_linalg_exponential_ss, src/model.cpp:322-334; GSL is not vendored, so the substitution
-// matrix is an explicit input of every DP parity definition -- SURVEY.md 8c).
+// exp(R t) as the reference obtains it: gsl_linalg_exponential_ss(R t, GSL_PREC_DOUBLE), src/model.cpp:322-334.
+// GSL is not vendored and not in this image, so its published algorithm is restated (Moler & Van Loan's method 3 as
+// GSL's linalg/exponential.c tabulates it): divide by 2^j, a k-term Taylor series in Horner form, j squarings, (k, j)
+// by the largest |element|; every multiply and add rounded separately, products accumulated in increasing inner
+// index.  oracle/historian_oracle.py::sub_prob_matrix_ss performs the same operations in the same order.
 static Mat matmul(const Mat& a, const Mat& b) {
   const size_t n = a.size();
   Mat c(n, Vec(n, 0.));
@@ -411,33 +413,42 @@ static Mat matmul(const Mat& a, const Mat& b) {
   return c;
 }
 
+static void seriesShape(double supNorm, int& terms, int& squarings) {
+  static const int table[6][2] = {{5, 1}, {5, 4}, {7, 5}, {9, 7}, {10, 10}, {8, 14}};
+  static const double below[6] = {0.01, 0.1, 1., 10., 100., 1000.};
+  for (int r = 0; r < 6; ++r)
+    if (supNorm < below[r]) { terms = table[r][0]; squarings = table[r][1]; return; }
+  terms = table[5][0];
+  squarings = table[5][1] + (int)ceil(log(1.01 * supNorm / 1000.) / log(2.));
+}
+
 vguard<Mat> RateModel::getSubProbMatrix(double t) const {
   vguard<Mat> v;
   for (int c = 0; c < components(); ++c) {
     const size_t n = subRate[c].size();
-    Mat rt = subRate[c];
+    Mat b = subRate[c];
     double norm = 0;
-    for (size_t i = 0; i < n; ++i) {
-      double row = 0;
-      for (size_t j = 0; j < n; ++j) { rt[i][j] *= t; row += fabs(rt[i][j]); }
-      norm = std::max(norm, row);
+    for (auto& row : b)
+      for (auto& x : row) { x *= t; norm = std::max(norm, fabs(x)); }
+    int terms, squarings;
+    seriesShape(norm, terms, squarings);
+    const double shrink = 1. / exp(log(2.) * squarings);
+    for (auto& row : b)
+      for (auto& x : row) x *= shrink;
+    Mat eb = b;
+    const double first = 1. / terms;
+    for (auto& row : eb)
+      for (auto& x : row) x *= first;
+    for (size_t i = 0; i < n; ++i) eb[i][i] += 1.;
+    for (int count = terms - 1; count >= 1; --count) {
+      eb = matmul(b, eb);
+      const double inv = 1. / count;
+      for (auto& row : eb)
+        for (auto& x : row) x *= inv;
+      for (size_t i = 0; i < n; ++i) eb[i][i] += 1.;
     }
-    int squarings = 0;
-    while (norm > 0.25) { norm /= 2; ++squarings; }
-    const double scale = ldexp(1.0, -squarings);
-    for (auto& row : rt)
-      for (auto& x : row) x *= scale;
-    Mat result(n, Vec(n, 0.)), term(n, Vec(n, 0.));
-    for (size_t i = 0; i < n; ++i) result[i][i] = term[i][i] = 1;
-    for (int k = 1; k <= 24; ++k) {
-      term = matmul(term, rt);
-      for (auto& row : term)
-        for (auto& x : row) x /= k;
-      for (size_t i = 0; i < n; ++i)
-        for (size_t j = 0; j < n; ++j) result[i][j] += term[i][j];
-    }
-    for (int s = 0; s < squarings; ++s) result = matmul(result, result);
-    v.push_back(result);
+    for (int s = 0; s < squarings; ++s) eb = matmul(eb, eb);
+    v.push_back(eb);
   }
   return v;
 }

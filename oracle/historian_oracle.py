@@ -1620,50 +1620,75 @@ class _StdMaxHeap:
 # (reference src/recon.cpp:864-915, 917-1052), default options (sampled profiles,
 # IncludeBestTrace | CollapseChains, band-doubling retry), root reconstruction only.
 # ----------------------------------------------------------------------------
+# (terms of the series, squarings) by the size of the matrix: double-precision row of the table in
+# GSL's linalg/exponential.c (Moler & Van Loan, "Nineteen dubious ways to compute the exponential of a
+# matrix", method 3), for sup-norms below 0.01, 0.1, 1, 10, 100, 1000
+_MVL_DOUBLE = ((5, 1), (5, 4), (7, 5), (9, 7), (10, 10), (8, 14))
+
+
 def sub_prob_matrix_ss(sr, t):
-    """exp(R t) by scaling-and-squaring of a 24-term Taylor series.  This is NOT the
-    reference's arithmetic (GSL gsl_linalg_exponential_ss, un-vendored): it is the same
-    plain-IEEE sequence of operations as RateModel::getSubProbMatrix of the C++ host
-    mirror, restated here so that both sides of a whole-tree parity test feed the DP the
-    bit-identical substitution matrix (the matrix is an input of the parity definition)."""
+    """exp(R t) as the reference obtains it: gsl_linalg_exponential_ss(R t, GSL_PREC_DOUBLE)
+    (src/model.cpp:322-334).  GSL is a third-party dependency absent from /root/reference and from
+    this image (README.md:28 asks for "2.2.1 or later"; no lock file pins it), so its published
+    algorithm is restated: the matrix is divided by 2^j, a k-term Taylor series is evaluated in
+    Horner form (eB = 1 + B/k, then eB = 1 + B eB / c for c = k-1 .. 1), and the result is squared
+    j times, with (k, j) from the table above by the largest |element|; products accumulate in
+    increasing inner index (the row-major loop of GSL's own BLAS), every multiply and add rounded
+    separately.  RateModel::getSubProbMatrix of the C++ host mirror performs the same IEEE
+    operations in the same order, so both sides of a whole-tree parity test feed the DP
+    bit-identical matrices.  Anchor: with these matrices the sampling-mode reconstructions of the
+    reference's `testhist` target (Makefile:307-308) come out byte for byte; a 24-term series with
+    other scaling, accurate to the same 1e-14, flips an exact tie at the root of that family by one
+    ulp (tests/test_oracle_testhist.py)."""
     n = len(sr)
     rt = [[float(sr[i][j]) * t for j in range(n)] for i in range(n)]
     norm = 0.
-    for i in range(n):
-        row = 0.
-        for j in range(n):
-            row += abs(rt[i][j])
-        norm = max(norm, row)
-    squarings = 0
-    while norm > 0.25:
-        norm /= 2
-        squarings += 1
-    scale = math.ldexp(1.0, -squarings)
-    rt = [[v * scale for v in row] for row in rt]
+    for row in rt:
+        for v in row:
+            norm = max(norm, abs(v))
+    if norm < 0.01:
+        terms, squarings = _MVL_DOUBLE[0]
+    elif norm < 0.1:
+        terms, squarings = _MVL_DOUBLE[1]
+    elif norm < 1.:
+        terms, squarings = _MVL_DOUBLE[2]
+    elif norm < 10.:
+        terms, squarings = _MVL_DOUBLE[3]
+    elif norm < 100.:
+        terms, squarings = _MVL_DOUBLE[4]
+    elif norm < 1000.:
+        terms, squarings = _MVL_DOUBLE[5]
+    else:
+        terms, squarings = _MVL_DOUBLE[5]
+        squarings += int(math.ceil(math.log(1.01 * norm / 1000.) / math.log(2.)))
+    shrink = 1. / math.exp(math.log(2.) * squarings)
+    b = [[v * shrink for v in row] for row in rt]
 
-    def matmul(a, b):
+    def matmul(p, q):
         c = [[0.] * n for _ in range(n)]
         for i in range(n):
             ci = c[i]
             for k in range(n):
-                aik = a[i][k]
-                if aik != 0:
-                    bk = b[k]
+                pik = p[i][k]
+                if pik != 0:
+                    qk = q[k]
                     for j in range(n):
-                        ci[j] += aik * bk[j]
+                        ci[j] += pik * qk[j]
         return c
 
-    result = [[1. if i == j else 0. for j in range(n)] for i in range(n)]
-    term = [[1. if i == j else 0. for j in range(n)] for i in range(n)]
-    for k in range(1, 25):
-        term = matmul(term, rt)
-        term = [[v / k for v in row] for row in term]
+    first = 1. / terms
+    eb = [[v * first for v in row] for row in b]
+    for i in range(n):
+        eb[i][i] += 1.
+    for count in range(terms - 1, 0, -1):
+        eb = matmul(b, eb)
+        inv = 1. / count
+        eb = [[v * inv for v in row] for row in eb]
         for i in range(n):
-            for j in range(n):
-                result[i][j] += term[i][j]
+            eb[i][i] += 1.
     for _ in range(squarings):
-        result = matmul(result, result)
-    return result
+        eb = matmul(eb, eb)
+    return eb
 
 
 class ReconTree:

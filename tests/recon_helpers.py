@@ -139,6 +139,16 @@ def oracle_reconstruct(model_path, tree, seqs, guide, **kw):
     return res, rows
 
 
+def fasta_rows(tree, rows):
+    """the reference's `-output fasta` of a reconstruction: one record per tree node in node order; an unnamed
+    internal node is called by its subtree (Tree::seqName, reference src/tree.cpp:464-477: default ostream format)"""
+    def seq_name(n):
+        if tree.is_leaf(n) or not tree.name[n].startswith("node"):
+            return tree.name[n]
+        return "(" + ",".join("%s:%g" % (seq_name(c), tree.branch_length[c]) for c in tree.child[n]) + ")"
+    return "".join(">%s\n%s\n" % (seq_name(n), rows[n]) for n in sorted(rows))
+
+
 def parse_hxrecon(text):
     out = {"rows": {}, "bands": {}}
     for line in text.splitlines():

@@ -183,3 +183,30 @@ def test_posterior_profiles_in_linear_fill_mode(tmp_path):
     assert abs(got["lpFinalFwd"] - res["lp_final_fwd"]) <= 1e-4 * abs(res["lp_final_fwd"])
     assert {k: v.replace("-", "") for k, v in got["rows"].items() if k in rows} == {k: v.replace("-", "") for k, v in rows.items()}
     assert len({len(v) for v in got["rows"].values()}) == 1
+
+
+# ---- the reference's own whole-pipeline outputs (`testhist`, reference Makefile:304-308) through the GPU ----
+from tests import test_oracle_testhist as TH
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("name", sorted(TH.CASES))
+def test_hxrecon_reproduces_the_references_testhist_output(tmp_path, name, mode):
+    # posterior-profile mode (cases 1, 2: Forward + Backward + threshold scan at every node) and sampling mode with
+    # 100 traces per node on the shared generator (cases 3, 4: 43 sequences, 42 pair DPs): the C++ mirror with every
+    # fill on the device prints the reference's file byte for byte
+    case = TH.CASES[name]
+    tree, seqs, guide = TH.load_case(case)
+    kw = case["kw"]
+    opts = dict(band=kw["max_distance_from_guide"], maxstates=0, seed=5489)
+    if "min_post_prob" in kw:
+        opts["posterior"] = kw["min_post_prob"]
+    else:
+        opts["samples"] = kw["profile_samples"]
+    job = str(tmp_path / "job.txt")
+    R.write_job(job, G + case["model"], tree, seqs, guide, str(tmp_path / "seqs.fa"), str(tmp_path / "guide.fa"), **opts)
+    env = dict(os.environ, HX_FILL_MODE=mode)
+    out = subprocess.run([HXRECON, job], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()
+    got = R.parse_hxrecon(out.stdout.decode())
+    assert R.fasta_rows(tree, got["rows"]) == open(G + name.split()[0]).read()
