@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--band", type=int, default=-1,
                     help="guide-alignment band (maxDistanceFromGuide); the guide is the pair's true alignment. "
                          "-1 = full envelope (the headline configuration)")
-    ap.add_argument("--mode", choices=["exact", "fast", "linear"], default="fast",
+    ap.add_argument("--mode", choices=["exact", "fast", "linear", "trunc"], default="fast",
                     help="arithmetic of the headline fill.  fast (default) = LDS-table log-sum-exp with the reference's truncation: "
                          "best paths identical to the reference's on all 2000 pairs of tools/sweep_trace_identity.py.  exact = the "
                          "reference's table bit for bit.  linear = scaled probabilities (HX_LSE_LINEAR): fastest, but without the "
@@ -139,7 +139,7 @@ def main():
     def run_mode(mode):
         """K timed passes of the hot path in one fill mode; returns (seconds, kernel ms list, lp_end, cells)."""
         # banded batches are stored band-compressed (per strip only the swept step windows): thousands of pairs fit
-        batch = capi.Batch(triples, {"exact": capi.HX_LSE_EXACT, "fast": capi.HX_LSE_FAST, "linear": capi.HX_LSE_LINEAR}[mode] |
+        batch = capi.Batch(triples, {"exact": capi.HX_LSE_EXACT, "fast": capi.HX_LSE_FAST, "linear": capi.HX_LSE_LINEAR, "trunc": capi.HX_LSE_TRUNC}[mode] |
                            (capi.HX_BAND_COMPRESSED if args.band >= 0 else 0))
         n_cells = batch.total_cells()
         for _ in range(args.warmup):
@@ -165,16 +165,20 @@ def main():
         assert np.all(np.isfinite(lp)) or os.environ.get("HX_BENCH_NOCHECK"), "non-finite Forward log-likelihood"
         return dt, k_ms, lp, n_cells
 
-    order = [args.mode] + ([m for m in ("fast", "exact", "linear") if m != args.mode] if not args.single_mode else [])
+    order = [args.mode] + ([m for m in ("trunc", "fast", "exact", "linear") if m != args.mode] if not args.single_mode else [])
     runs = {m: run_mode(m) for m in order}
     dt, kernel_ms, lp_end, cells = runs[args.mode]
 
     KERNELS = {("exact", False): "hx::k_fill_chain<0,...,ExactLse3>", ("fast", False): "hx::k_fill_chain<0,...,FastLse>",
                ("linear", False): "hx::k_fill_leaf_linear<W>", ("exact", True): "hx::k_fill_band<exact>",
-               ("fast", True): "hx::k_fill_band<fast>", ("linear", True): "hx::k_fill_band<scaled>"}
+               ("fast", True): "hx::k_fill_band<fast>", ("linear", True): "hx::k_fill_band<scaled>",
+               ("trunc", False): "hx::k_fill_leaf_linear<W,...,TRUNC>", ("trunc", True): "hx::k_fill_band<truncating scaled>"}
     ARITH = {"exact": "the reference's table log-sum-exp, cells bit-identical to the reference recursion",
              "fast": "LDS-table log-sum-exp with the reference's truncation (lpEnd within 1e-9 rel. of the reference's, best paths "
                      "identical to the reference's: 2000 of 2000 pairs, profiles/r02/trace_identity_sweep.json)",
+             "trunc": "scaled-probability recursion with the reference's truncation (every pairwise sum of the reference's left-nested "
+                      "log_sum_exp drops a term that is at most e^-10 of the other, as the reference's table does; no table, "
+                      "log-probabilities at the store)",
              "linear": "scaled-probability recursion (fp64 sums of probabilities with a per-cell exponent, log-probabilities at the "
                        "store; no truncation of small terms: lpEnd within 1e-5 rel., 4 of 2000 best paths differ from the reference's)"}
     if rank == 0:
@@ -219,7 +223,7 @@ def main():
         for m in order[1:]:
             dt_m, k_list, lp_m, _ = runs[m]
             k_m = float(np.mean(k_list))
-            out[{"exact": "exact_mode", "fast": "fast_mode", "linear": "scaled_probability_mode"}[m]] = {
+            out[{"exact": "exact_mode", "fast": "fast_mode", "linear": "scaled_probability_mode", "trunc": "truncating_scaled_probability_mode"}[m]] = {
                 "arithmetic": ARITH[m], "kernel": KERNELS[(m, args.band >= 0)],
                 "value": gcells * args.steps / dt_m, "unit": "cells/s", "ms_per_step": dt_m / args.steps * 1e3, "kernel_ms": k_m,
                 "roofline_frac": cells * BYTES_PER_CELL / (k_m * 1e-3) / 1e9 / HBM_PEAK_GBS}

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("HX_LIB_PATH") or os.path.join(_HERE, "lib", "libhisto
 HX_LSE_TABLE_ENTRIES = 100002
 HX_LSE_EXACT, HX_LSE_FAST, HX_KEEP_BACKWARD, HX_FORCE_GENERIC, HX_SPARSE_ENVELOPE = 0, 1, 2, 4, 8
 HX_BAND_COMPRESSED = 32   # banded jobs keep only the swept step windows (include/historian_hip.h)
+HX_LSE_TRUNC = 81       # HX_LSE_LINEAR with the reference's truncation of terms at most e^-10 of their sum (include/historian_hip.h)
 HX_LSE_LINEAR = 17      # HX_LSE_FAST + scaled-probability Forward fill where it applies (include/historian_hip.h)
 IMM, IMD, IDM, IMI, IIW, EEE = 0, 1, 2, 3, 4, 5
 

@@ -24,7 +24,7 @@ static bool g_deviceReady[32] = {false};
 static bool g_modeRead = false;
 static thread_local int t_device = -1;
 
-void DPMatrix::setFillMode(unsigned hxFlags) { g_fillMode = hxFlags & HX_LSE_LINEAR; }
+void DPMatrix::setFillMode(unsigned hxFlags) { g_fillMode = hxFlags & HX_LSE_TRUNC; }
 static int g_deviceTraceback = -1;
 void DPMatrix::setDeviceTraceback(bool on) { g_deviceTraceback = on ? 1 : 0; }
 bool DPMatrix::deviceTraceback() {
@@ -52,6 +52,7 @@ static void ensureDevice(int ordinal) {
     const char* mode = getenv("HX_FILL_MODE");   // "fast" selects the fast log-sum-exp policy for this process
     if (mode && string(mode) == "fast") g_fillMode = HX_LSE_FAST;
     if (mode && string(mode) == "linear") g_fillMode = HX_LSE_LINEAR;
+    if (mode && string(mode) == "trunc") g_fillMode = HX_LSE_TRUNC;
     g_modeRead = true;
   }
   if (g_deviceReady[ordinal]) return;

@@ -827,7 +827,7 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
     }
     if (kc == KC_LEAF_LDS_BANDED && jo.x.lp_zero && !band_old) {
       // the banded rotating-row sweep (hx_band.hip), when the pair satisfies its assumptions and its sides fit LDS
-      const int pol = linear ? 0 : ((flags & HX_LSE_FAST) ? 1 : 2);
+      const int pol = linear ? ((flags & HX_LSE_TRUNC) == HX_LSE_TRUNC ? 3 : 0) : ((flags & HX_LSE_FAST) ? 1 : 2);
       std::vector<int32_t> rows;
       int n_steps = 0;
       const std::vector<uint8_t> xf(ar.host.data() + jo.x.flags, ar.host.data() + jo.x.flags + jo.x.n);
@@ -891,7 +891,8 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
   // The general-profile classes need scratch planes next to the matrices: the five outgoing sums of every cell
   // (hx_dag.hip), or - HX_LSE_LINEAR, when every such job's planes fit 32-bit byte offsets - the cells in the
   // scaled-probability fill's own format (hx_daglin.hip).
-  b->dag_linear = (flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && !(flags & HX_FORCE_GENERIC);
+  // (the truncating policy has no general-profile kernel yet: those classes run as HX_LSE_FAST, which truncates as the reference does)
+  b->dag_linear = (flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && (flags & HX_LSE_TRUNC) != HX_LSE_TRUNC && !(flags & HX_FORCE_GENERIC);
   for (int k = 0; k < n_jobs && b->dag_linear; ++k)
     if ((kclass[k] == KC_DAG || kclass[k] == KC_DAG_BANDED) && !dag_linear_fits(b->jobs[k].plane)) b->dag_linear = false;
   int64_t mat_total = 0, agg_total = 0;
@@ -1042,6 +1043,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   const DeviceTables& D = g_dev[b->device];
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool fast = (b->flags & HX_LSE_FAST) != 0, linear = (b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR;
+  const bool trunc = (b->flags & HX_LSE_TRUNC) == HX_LSE_TRUNC;
   const Tab16 lse_tab{fast ? D.fast_tab : D.pair_tab};    // FastPiece table, or the exact mode's {f0, df} pairs
   LAUNCH_TRY(launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_cls, b->max_ca, b->max_cls_pairs, Tab8{D.tab}, st));
   HIP_TRY(hipEventRecord(b->ev[0][0], st));
@@ -1056,7 +1058,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
     switch (c) {
       case KC_LEAF_ROT_BANDED:
         if (!(b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED))) launch_fill_neg_inf(b->d_fwd + cr.mat_begin, cr.mat_doubles, st);
-        LAUNCH_TRY(launch_forward_band(jobs, cr.n, linear ? 0 : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab},
+        LAUNCH_TRY(launch_forward_band(jobs, cr.n, linear ? (trunc ? 3 : 0) : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab},
                                        linear ? Tab16{D.log_tab} : lse_tab, (b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED)) != 0, st));
         break;
       case KC_LEAF_LDS: case KC_LEAF_LDS_BANDED: case KC_LEAF: case KC_LEAF_BANDED: case KC_CHAIN: case KC_CHAIN_BANDED: {
@@ -1076,7 +1078,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
         }
         if (linear && leaf == 2)
           LAUNCH_TRY(launch_forward_leaf_linear(jobs, cr.n, cr.max_rows, banded, Tab8{D.tab}, Tab16{D.log_tab}, cr.yl_cols, cr.yl_emis, cr.max_cls + 1,
-                                                multi, b->d_multi, st));
+                                                multi, b->d_multi, trunc, st));
         else
           LAUNCH_TRY(launch_forward_chain(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, multi, b->d_multi, st));
         break;
@@ -1128,6 +1130,7 @@ int hx_batch_backward(hx_batch* b, void* stream) {
   const DeviceTables& D = g_dev[b->device];
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool fast = (b->flags & HX_LSE_FAST) != 0, linear = (b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR;
+  const bool trunc = (b->flags & HX_LSE_TRUNC) == HX_LSE_TRUNC;
   const Tab16 lse_tab{fast ? D.fast_tab : D.pair_tab};
   if (!b->d_bwd) {
     // not pre-allocated with HX_KEEP_BACKWARD: allocate the Backward matrices now and re-publish the job tables
@@ -1152,7 +1155,7 @@ int hx_batch_backward(hx_batch* b, void* stream) {
         const int leaf = (c == KC_LEAF_LDS || c == KC_LEAF_LDS_BANDED || c == KC_LEAF_ROT_BANDED) ? 2 : 1;
         if (c == KC_LEAF_ROT_BANDED && cr.bwd_band)
           // the rotating-row sweep in mirrored coordinates (hx_band.hip)
-          LAUNCH_TRY(launch_backward_band(jobs, cr.n, linear ? 0 : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab},
+          LAUNCH_TRY(launch_backward_band(jobs, cr.n, linear ? (trunc ? 3 : 0) : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab},
                                           linear ? Tab16{D.log_tab} : lse_tab, (b->flags & HX_SPARSE_ENVELOPE) != 0, st));
         else {
           int multi = (leaf == 2 && !banded && cr.n <= HX_MULTI_COUNTER_PAIRS) ? chain_multi_groups(cr.n, cr.max_rows, linear ? 64 : 128) : 1;
@@ -1165,7 +1168,7 @@ int hx_batch_backward(hx_batch* b, void* stream) {
           }
           if (linear && leaf == 2)
             LAUNCH_TRY(launch_backward_leaf_linear(jobs, cr.n, cr.max_rows, banded, Tab8{D.tab}, Tab16{D.log_tab}, cr.yl_cols, cr.yl_emis, cr.max_cls + 1,
-                                                   multi, counters, st));
+                                                   multi, counters, trunc, st));
           else
             LAUNCH_TRY(launch_backward_chain(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, leaf, banded, cr.yl_cols, cr.yl_emis, multi, counters, st));
         }

@@ -66,6 +66,15 @@ __device__ __forceinline__ double ror1(double v) {
 
 struct L5 { double imm, imd, idm, imi, iiw; int e; };
 __device__ __forceinline__ L5 l5_zero() { return L5{0., 0., 0., 0., 0., HXB_EMIN}; }
+// (hx_linear.hip) the reference's pairwise log_sum_exp on probabilities: the smaller term is dropped when it is at most e^-10 of the larger
+__device__ __forceinline__ double trunc_sum(double a, double b) {
+  const double hi = vmax(a, b), lo = vmin(a, b);
+  return hi + (lo > hi * 4.5399929762484854e-05 ? lo : 0.0);
+}
+template <bool TRUNC> __device__ __forceinline__ double lin_acc(double m, double p, double acc) {
+  if (TRUNC) return trunc_sum(acc, m * p);
+  return __builtin_fma(m, p, acc);
+}
 __device__ __forceinline__ L5 ror1(const L5& c) { return L5{ror1(c.imm), ror1(c.imd), ror1(c.idm), ror1(c.imi), ror1(c.iiw), ror1(c.e)}; }
 __device__ __forceinline__ C5 ror1(const C5& c) { return C5{ror1(c.imm), ror1(c.imd), ror1(c.idm), ror1(c.imi), ror1(c.iiw)}; }
 
@@ -86,7 +95,8 @@ __device__ __forceinline__ double read_lane(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-enum { POL_LINEAR = 0, POL_FAST = 1, POL_EXACT = 2 };
+enum { POL_LINEAR = 0, POL_FAST = 1, POL_EXACT = 2, POL_TRUNC = 3 };   // POL_TRUNC: scaled probabilities with the reference's truncation (hx_linear.hip trunc_sum)
+#define HXB_IS_LIN(POL_) ((POL_) == POL_LINEAR || (POL_) == POL_TRUNC)
 
 // LDS plan (bytes), computed on the host (plan_band): the arithmetic's table first, then one block per pair
 struct BandPlan { int table, xrec, sbase, ycol, yclass, xclass, elds, ring, flags, stride, total; };
@@ -113,7 +123,8 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
             const BandPlan plan, const int n_jobs, const int write_edges) {
   constexpr int THREADS = 2 * PPW * 64;
   constexpr int RING = LEAN ? HXB_RING_LEAN : HXB_RING;
-  constexpr bool OFFLOAD = POL == POL_LINEAR;        // the second wave converts and stores the sweep's cells
+  constexpr bool LIN = HXB_IS_LIN(POL), TRUNC = POL == POL_TRUNC;
+  constexpr bool OFFLOAD = LIN;        // the second wave converts and stores the sweep's cells
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
@@ -139,7 +150,7 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   auto xrec_at = [&](const int i) -> i2v { return LEAN ? xrecG[i] : xrecL[i]; };
 
   // ---- stage the shared table and the pair's two sides ----
-  if (POL == POL_LINEAR) {
+  if (LIN) {
     // (entries 1..1023 of the logarithm table are never addressed)
     for (int k = threadIdx.x; k < 2; k += THREADS) ptab[k] = pol_tab[k];
     for (int k = 2048 + threadIdx.x; k < 2 * HXB_LOG_ENTRIES; k += THREADS) ptab[k] = pol_tab[k];
@@ -166,15 +177,15 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
       const bool real = c < J.y.n_cls;
       const int rep = real ? J.y.cls_rep[c] : 0;
       const double rs = real ? J.y.pack[4 * (size_t)rep + 1] : HX_NEG_INF, in = real ? J.y.pack[4 * (size_t)rep + 2] : HX_NEG_INF;
-      yclassL[c] = POL == POL_LINEAR ? d2v{exp(rs), exp(in)} : d2v{rs, in};
+      yclassL[c] = LIN ? d2v{exp(rs), exp(in)} : d2v{rs, in};
     }
     for (int c = pt; c < Kx1; c += 128) {
       const bool real = c < J.x.n_cls;
       const int rep = real ? J.x.cls_rep[c] : 0;
       const double rs = real ? J.x.pack[4 * (size_t)rep + 1] : HX_NEG_INF, in = real ? J.x.pack[4 * (size_t)rep + 2] : HX_NEG_INF;
-      xclassL[c] = POL == POL_LINEAR ? d2v{exp(rs), exp(in)} : d2v{rs, in};
+      xclassL[c] = LIN ? d2v{exp(rs), exp(in)} : d2v{rs, in};
     }
-    for (int e = pt; e < Kx1 * Ky1; e += 128) eldsL[e] = POL == POL_LINEAR ? exp(J.emis_pad[e]) : J.emis_pad[e];
+    for (int e = pt; e < Kx1 * Ky1; e += 128) eldsL[e] = LIN ? exp(J.emis_pad[e]) : J.emis_pad[e];
     if (pt < 2) progL[pt] = 0;
   }
   __syncthreads();
@@ -267,8 +278,8 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
       for (int j0 = 0; j0 < Cc; j0 += 64) {
         const int jl = j0 + lane < Cc ? j0 + lane : Cc - 1;
         const unsigned w = ycolL[jl];
-        const double lrs = POL == POL_LINEAR ? J.y.pack[4 * (size_t)jl + 1] : yclassL[w & 0xFFu].x;
-        const double lin = POL == POL_LINEAR ? J.y.pack[4 * (size_t)jl + 2] : yclassL[w & 0xFFu].y;
+        const double lrs = LIN ? J.y.pack[4 * (size_t)jl + 1] : yclassL[w & 0xFFu].x;
+        const double lin = LIN ? J.y.pack[4 * (size_t)jl + 2] : yclassL[w & 0xFFu].y;
         double kidm = HX_NEG_INF, kimi = HX_NEG_INF;
 #pragma unroll 2
         for (int m = 0; m < 64; ++m) {
@@ -302,13 +313,24 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
       const unsigned c = w & 0xFFu;
       const unsigned eo = (unsigned)(rec1.y & 0xFF) * (unsigned)Ky1;
       C5 nw = c5_neg_inf();
-      if (POL == POL_LINEAR) {
+      if (LIN) {
         double sum = 0.;
         const double dv[5] = {diag.imm, diag.imd, diag.idm, diag.imi, diag.iiw};
         double mx = HX_NEG_INF;
         for (int q = 0; q < 5; ++q) mx = vmax(mx, dv[q] + J.T[q][0]);
+        if (TRUNC) {
+          // the reference's left-nested sum with its truncation, in libm arithmetic
+          double acc = HX_NEG_INF;
+          for (int q = 0; q < 5; ++q) {
+            const double t = dv[q] + J.T[q][0];
+            const double hi = vmax(acc, t), lo = vmin(acc, t);
+            acc = (hi > HX_NEG_INF && hi - lo < 10.0) ? hi + log1p(exp(lo - hi)) : hi;
+          }
+          nw.imm = acc > HX_NEG_INF ? acc + J.emis_pad[eo + c] : HX_NEG_INF;
+        } else {
         for (int q = 0; q < 5; ++q) sum += (dv[q] + J.T[q][0] > HX_NEG_INF) ? exp(dv[q] + J.T[q][0] - mx) : 0.;
         nw.imm = mx > HX_NEG_INF ? mx + log(sum) + J.emis_pad[eo + c] : HX_NEG_INF;
+        }
       } else {
         XLeaf X;
         const d2v xc = xclassL[rec1.y & 0xFF];
@@ -378,8 +400,8 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
       const bool used = d == 0 || (d == 1 && a != 4) || (d == 2 && a != 3) || (d == 3 && (a == 0 || a == 3)) ||
                         (d == 4 && (a == 0 || a == 3 || a == 4));
       double v = J.T[a][d];
-      if (!used) { P[a][d] = POL == POL_LINEAR ? 0. : v; continue; }
-      if (POL == POL_LINEAR) {
+      if (!used) { P[a][d] = LIN ? 0. : v; continue; }
+      if (LIN) {
         const double pv = exp(v);
         v = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(pv)), __builtin_amdgcn_readfirstlane(__double2loint(pv)));
       }
@@ -393,7 +415,7 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   if (DIR == 1) {
     const double lpe = J.x.pack[4 * (size_t)R] + J.y.pack[4 * (size_t)Cc];
     end_cell = C5{lpe + J.T[0][5], lpe + J.T[1][5], lpe + J.T[2][5], lpe + J.T[3][5], lpe + J.T[4][5]};
-    if (POL == POL_LINEAR) end_cell = C5{exp(end_cell.imm), exp(end_cell.imd), exp(end_cell.idm), exp(end_cell.imi), exp(end_cell.iiw)};
+    if (LIN) end_cell = C5{exp(end_cell.imm), exp(end_cell.imd), exp(end_cell.idm), exp(end_cell.imi), exp(end_cell.iiw)};
   }
 
   // cell registers, ping-ponged: at an even step the lane's previous cell is in cb (the one before in ca, which the new
@@ -461,11 +483,11 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
       const double D = __builtin_ldexp(tD, dd);
       const double d1x = __builtin_ldexp(t1x, du), d2x = __builtin_ldexp(t2x, du);
       const double d1y = __builtin_ldexp(t1y, dl), d2y = __builtin_ldexp(t2y, dl);
-      out.imm = __builtin_fma(P[0][3], d2y, __builtin_fma(P[0][2], d1y, __builtin_fma(P[0][4], d2x, __builtin_fma(P[0][1], d1x, P[0][0] * D))));
-      out.imd = __builtin_fma(P[1][2], d1y, __builtin_fma(P[1][1], d1x, P[1][0] * D));
-      out.idm = __builtin_fma(P[2][2], d1y, __builtin_fma(P[2][1], d1x, P[2][0] * D));
-      out.imi = __builtin_fma(P[3][3], d2y, __builtin_fma(P[3][4], d2x, __builtin_fma(P[3][1], d1x, P[3][0] * D)));
-      out.iiw = __builtin_fma(P[4][2], d1y, __builtin_fma(P[4][4], d2x, P[4][0] * D));
+      out.imm = lin_acc<TRUNC>(P[0][3], d2y, lin_acc<TRUNC>(P[0][2], d1y, lin_acc<TRUNC>(P[0][4], d2x, lin_acc<TRUNC>(P[0][1], d1x, P[0][0] * D))));
+      out.imd = lin_acc<TRUNC>(P[1][2], d1y, lin_acc<TRUNC>(P[1][1], d1x, P[1][0] * D));
+      out.idm = lin_acc<TRUNC>(P[2][2], d1y, lin_acc<TRUNC>(P[2][1], d1x, P[2][0] * D));
+      out.imi = lin_acc<TRUNC>(P[3][3], d2y, lin_acc<TRUNC>(P[3][4], d2x, lin_acc<TRUNC>(P[3][1], d1x, P[3][0] * D)));
+      out.iiw = lin_acc<TRUNC>(P[4][2], d1y, lin_acc<TRUNC>(P[4][4], d2x, P[4][0] * D));
       out.e = E;
     } else {
     // the five sums of src/forward.cpp:103-115,139-150,171-180 on probabilities
@@ -474,19 +496,19 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     double s_idm = left.imm * P[0][2];
     double s_imi = left.imm * P[0][3];
     double s_imm = u2.imm * P[0][0];
-    s_imd = __builtin_fma(u1.imd, P[1][1], s_imd);
-    s_iiw = __builtin_fma(u1.imi, P[3][4], s_iiw);
-    s_idm = __builtin_fma(left.imd, P[1][2], s_idm);
-    s_imi = __builtin_fma(left.imi, P[3][3], s_imi);
-    s_imm = __builtin_fma(u2.imd, P[1][0], s_imm);
-    s_imd = __builtin_fma(u1.idm, P[2][1], s_imd);
-    s_iiw = __builtin_fma(u1.iiw, P[4][4], s_iiw);
-    s_idm = __builtin_fma(left.idm, P[2][2], s_idm);
-    s_imm = __builtin_fma(u2.idm, P[2][0], s_imm);
-    s_imd = __builtin_fma(u1.imi, P[3][1], s_imd);
-    s_idm = __builtin_fma(left.iiw, P[4][2], s_idm);
-    s_imm = __builtin_fma(u2.imi, P[3][0], s_imm);
-    s_imm = __builtin_fma(u2.iiw, P[4][0], s_imm);
+    s_imd = lin_acc<TRUNC>(u1.imd, P[1][1], s_imd);
+    s_iiw = lin_acc<TRUNC>(u1.imi, P[3][4], s_iiw);
+    s_idm = lin_acc<TRUNC>(left.imd, P[1][2], s_idm);
+    s_imi = lin_acc<TRUNC>(left.imi, P[3][3], s_imi);
+    s_imm = lin_acc<TRUNC>(u2.imd, P[1][0], s_imm);
+    s_imd = lin_acc<TRUNC>(u1.idm, P[2][1], s_imd);
+    s_iiw = lin_acc<TRUNC>(u1.iiw, P[4][4], s_iiw);
+    s_idm = lin_acc<TRUNC>(left.idm, P[2][2], s_idm);
+    s_imm = lin_acc<TRUNC>(u2.idm, P[2][0], s_imm);
+    s_imd = lin_acc<TRUNC>(u1.imi, P[3][1], s_imd);
+    s_idm = lin_acc<TRUNC>(left.iiw, P[4][2], s_idm);
+    s_imm = lin_acc<TRUNC>(u2.imi, P[3][0], s_imm);
+    s_imm = lin_acc<TRUNC>(u2.iiw, P[4][0], s_imm);
     // common exponent of the new cell, the three source groups brought to it; a state that may not be entered
     // (y or x state not ready: src/forward.cpp:97,133) and a cell outside the envelope are shifted out of range: zero
     int E = left.e > u1.e ? left.e : u1.e;
@@ -600,7 +622,7 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
 
 BandPlan plan_band(int pol, int ppw, int max_rows, int max_cols, int max_cls, bool lean = false) {
   BandPlan p;
-  p.table = pol == POL_LINEAR ? 16 * HXB_LOG_ENTRIES : (pol == POL_FAST ? 16 * (HX_FAST_INTERVALS + 1) : 16);
+  p.table = HXB_IS_LIN(pol) ? 16 * HXB_LOG_ENTRIES : (pol == POL_FAST ? 16 * (HX_FAST_INTERVALS + 1) : 16);
   int a = 0;
   p.xrec = a; a += lean ? 0 : (8 * (max_rows + 64) + 15) & ~15;
   p.sbase = a; a += (4 * ((max_rows + 63) / 64 + 1) + 15) & ~15;
@@ -608,7 +630,7 @@ BandPlan plan_band(int pol, int ppw, int max_rows, int max_cols, int max_cls, bo
   p.yclass = a; a += 16 * (max_cls + 1);
   p.xclass = a; a += 16 * (max_cls + 1);
   p.elds = a; a += (8 * (max_cls + 1) * (max_cls + 1) + 15) & ~15;
-  p.ring = a; a += pol == POL_LINEAR ? (lean ? HXB_RING_LEAN : HXB_RING) * 3 * 64 * 16 : 0;
+  p.ring = a; a += HXB_IS_LIN(pol) ? (lean ? HXB_RING_LEAN : HXB_RING) * 3 * 64 * 16 : 0;
   p.flags = a; a += 16;
   p.stride = a;
   p.total = p.table + ppw * a;
@@ -671,6 +693,7 @@ int launch_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max
     if (ppw >= 2) return launch_pol<POL_, 2, false, DIR>(d_jobs, n_jobs, plan_band(POL_, 2, max_rows, max_cols, max_cls), tab, pol_tab, we, st); \
     return launch_pol<POL_, 1, false, DIR>(d_jobs, n_jobs, plan_band(POL_, 1, max_rows, max_cols, max_cls), tab, pol_tab, we, st); } while (0)
   if (pol == POL_LINEAR) HXB_GO(POL_LINEAR);
+  if (pol == POL_TRUNC) HXB_GO(POL_TRUNC);
   if (pol == POL_FAST) HXB_GO(POL_FAST);
   HXB_GO(POL_EXACT);
 #undef HXB_LEAN

@@ -1,0 +1,520 @@
+// Banded fills of leaf-like pairs on scaled probabilities, TWO PAIRS PER WAVEFRONT.
+//
+// Reference: ForwardMatrix::ForwardMatrix (src/forward.cpp:68-223) / BackwardMatrix::BackwardMatrix (:975-1088) inside a
+// GuideAlignmentEnvelope (src/forward.h:92-98, src/alignpath.h:56-61) - the reference's default mode (band 20).
+//
+// The rotating-row sweep of hx_band.hip gives a pair one 64-lane wavefront, lane = row mod 64; an anti-diagonal of a
+// band-20 envelope holds ~21 cells, so two thirds of every vector instruction of that sweep are idle lanes.  Here a
+// wavefront sweeps TWO pairs: lanes 0-31 are a ring of 32 rows (lane = row mod 32) of one pair, lanes 32-63 of another.
+// Nothing else changes in the recursion: left is the lane's own previous cell, up and diagonal are the previous lane's
+// cells of one and two steps ago, handed over inside each 32-lane ring (ds_bpermute: the LDS crossbar, no LDS memory - a
+// DPP rotation is a ring of 64).  A pair is admitted when rows i and i + 31 are never alive together (hx_api.hip:
+// band2_admits); the row records, store bases and step counts are those of hx_band.hip (build_band_rows).
+//
+// One wavefront does everything for its two pairs - the recursion, the five logarithms per cell, the stores - so there is
+// no ring between a sweeping and a converting wave and no flow control; a workgroup is NW such wavefronts plus one that
+// writes the one-dimensional envelope edges of the workgroup's pairs (row 0 beyond the band, the column feeding END).
+// Per-pair constants that are wave-uniform in hx_band.hip (the 18 transition probabilities, plane bases, LDS block) are
+// per-lane here, since the two halves belong to different pairs.
+//
+// Arithmetic: scaled probabilities (HX_LSE_LINEAR) or scaled probabilities with the reference's truncation (HX_LSE_TRUNC:
+// trunc_sum drops the smaller term of every pairwise sum when it is at most e^-10 of the larger, as the reference's table
+// does for differences >= 10, src/logsumexp.h:45; left-nested as src/logsumexp.h:86-100).
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include "hx_device.h"
+#include "hx_lse.h"
+#include "hx_common.h"
+#include "hx_policy.h"
+#include "hx_kernels.h"
+
+namespace hx {
+
+namespace {
+
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+
+#define HXB2_EMIN (-(1 << 28))
+#define HXB2_LOG_ENTRIES 1536      // the logarithm table of hx_linear.hip (build_log_table): entry 0 and entries 1024..1535 are used
+#define HXB2_HOLE_BEGIN 16         // bytes [16, 16384) of the table are never addressed: pair blocks live there
+#define HXB2_HOLE_END 16384
+#define HXB2_W 32                  // rows per ring
+
+struct L5 { double imm, imd, idm, imi, iiw; int e; };
+__device__ __forceinline__ L5 l5_zero() { return L5{0., 0., 0., 0., 0., HXB2_EMIN}; }
+
+// value of the previous lane of the lane's 32-lane ring (lane 0 receives lane 31's, lane 32 lane 63's)
+__device__ __forceinline__ int rot(const int addr, const int v) { return __builtin_amdgcn_ds_bpermute(addr, v); }
+__device__ __forceinline__ double rot(const int addr, const double v) {
+  return __hiloint2double(rot(addr, __double2hiint(v)), rot(addr, __double2loint(v)));
+}
+__device__ __forceinline__ L5 rot(const int addr, const L5& c) {
+  return L5{rot(addr, c.imm), rot(addr, c.imd), rot(addr, c.idm), rot(addr, c.imi), rot(addr, c.iiw), rot(addr, c.e)};
+}
+
+// (hx_linear.hip) one pairwise sum of the reference's log_sum_exp on probabilities
+__device__ __forceinline__ double trunc_sum(double a, double b) {
+  const double hi = vmax(a, b), lo = vmin(a, b);
+  return hi + (lo > hi * 4.5399929762484854e-05 ? lo : 0.0);
+}
+template <bool TRUNC> __device__ __forceinline__ double lin_acc(double m, double p, double acc) {
+  if (TRUNC) return trunc_sum(acc, m * p);
+  return __builtin_fma(m, p, acc);
+}
+
+// log(m * 2^e), m >= 0 (hx_linear.hip log_scaled: frexp, one 16-byte table entry, a cubic)
+__device__ __forceinline__ double log_scaled(double m, int e, const HX_LDS double* ltab) {
+  const double f = __builtin_amdgcn_frexp_mant(m);
+  const int k = __builtin_amdgcn_frexp_exp(m);
+  const unsigned byte_off = ((unsigned)__double2hiint(f) >> 7) & 0x7FF0u;
+  const d2v ce = *(const HX_LDS d2v*)((const HX_LDS char*)ltab + byte_off);
+  const double r = __builtin_fma(f, ce.x, -1.0);
+  double p = __builtin_fma(r, 1.0 / 3.0, -0.5);
+  p = __builtin_fma(p, r, 1.0);
+  const double lf = __builtin_fma(p, r, ce.y);
+  return __builtin_fma((double)(e + k), 0.693147180559945309417, lf);
+}
+
+__device__ __forceinline__ double read_lane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// LDS plan (bytes, computed on the host): the logarithm table first (pair blocks 0.. sit in its hole while they fit), one
+// block per pair: store bases of the strips, one byte per column {emission class : 7, not ready : 1}, the class constants
+// of both sides, the class-pair emission table
+struct Band2Plan { int sbase, ycol, yclass, xclass, elds, stride, in_hole, total; };
+
+__device__ __forceinline__ int block_offset(const Band2Plan& p, const int pair) {
+  return pair < p.in_hole ? HXB2_HOLE_BEGIN + pair * p.stride : 16 * HXB2_LOG_ENTRIES + (pair - p.in_hole) * p.stride;
+}
+
+// NW sweeping wavefronts (two pairs each) + one edge wavefront per workgroup.  DIR = 1: the Backward fill as the same sweep
+// in mirrored coordinates (see hx_band.hip).
+template <bool TRUNC, int NW, int DIR>
+__global__ void __launch_bounds__((NW + 1) * 64)
+k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const double* __restrict__ log_tab,
+             const Band2Plan plan, const int n_jobs, const int write_edges) {
+  constexpr int THREADS = (NW + 1) * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int half = lane >> 5, r32 = lane & 31;
+  const bool edge_wave = wave == NW;
+  double* ptab = reinterpret_cast<double*>(lds);
+  // (entries 1..1023 of the logarithm table are never addressed)
+  for (int k = threadIdx.x; k < 2; k += THREADS) ptab[k] = log_tab[k];
+  for (int k = 2048 + threadIdx.x; k < 2 * HXB2_LOG_ENTRIES; k += THREADS) ptab[k] = log_tab[k];
+  const HX_LDS double* lt = (const HX_LDS double*)ptab;
+  const int first_job = (int)blockIdx.x * 2 * NW;
+
+  // ---- the sweeping wavefronts stage their two pairs' blocks (32 lanes per pair) ----
+  const int my_pair = edge_wave ? 0 : 2 * wave + half;
+  const int my_job = first_job + my_pair;
+  const bool live = !edge_wave && my_job < n_jobs;
+  const DevJob* __restrict__ Jp = jobs + (my_job < n_jobs ? my_job : 0);
+  unsigned char* blkp = lds + block_offset(plan, my_pair);
+  HX_LDS int* sbaseL = (HX_LDS int*)(blkp + plan.sbase);
+  HX_LDS unsigned char* ycolL = (HX_LDS unsigned char*)(blkp + plan.ycol);
+  HX_LDS d2v* yclassL = (HX_LDS d2v*)(blkp + plan.yclass);
+  HX_LDS d2v* xclassL = (HX_LDS d2v*)(blkp + plan.xclass);
+  HX_LDS double* eldsL = (HX_LDS double*)(blkp + plan.elds);
+  const int R = Jp->n_rows, Cc = Jp->n_cols;
+  const int n_strips = (R + 63) >> 6;
+  const int Ky1 = Jp->y.n_cls + 1, Kx1 = Jp->x.n_cls + 1;
+  const i2v* rowsG = reinterpret_cast<const i2v*>(DIR ? Jp->band_rows_bwd : Jp->band_rows);
+  if (live) {
+    const int* sb = reinterpret_cast<const int*>(rowsG + (R + 64));
+    for (int q = r32; q < n_strips; q += 32) sbaseL[q] = sb[q];
+    for (int j = r32; j < Cc; j += 32) {
+      // Backward: sweep column j is y state Cc-1-j; the class is that of the state an absorbing move leads to, the ready
+      // bit that of the state itself
+      const int jc = DIR ? Cc - 1 - j : j;
+      ycolL[j] = (unsigned char)((unsigned)Jp->y.ecls[DIR ? jc + 1 : jc] | (Jp->y.pack[4 * (size_t)jc + 3] < 0.0 ? 0x80u : 0u));
+    }
+    for (int c = r32; c < Ky1; c += 32) {
+      const bool real = c < Jp->y.n_cls;
+      const int rep = real ? Jp->y.cls_rep[c] : 0;
+      yclassL[c] = real ? d2v{exp(Jp->y.pack[4 * (size_t)rep + 1]), exp(Jp->y.pack[4 * (size_t)rep + 2])} : d2v{0., 0.};
+    }
+    for (int c = r32; c < Kx1; c += 32) {
+      const bool real = c < Jp->x.n_cls;
+      const int rep = real ? Jp->x.cls_rep[c] : 0;
+      xclassL[c] = real ? d2v{exp(Jp->x.pack[4 * (size_t)rep + 1]), exp(Jp->x.pack[4 * (size_t)rep + 2])} : d2v{0., 0.};
+    }
+    for (int e = r32; e < Kx1 * Ky1; e += 32) eldsL[e] = exp(Jp->emis_pad[e]);
+  }
+  __syncthreads();
+
+  if (edge_wave) {
+    // =====================================================================================================
+    // the envelope's one-dimensional edges of every pair of the workgroup (see hx_band.hip).  Nothing here is read by
+    // the sweeps.
+    // =====================================================================================================
+    for (int p = 0; p < 2 * NW; ++p) {
+      const int job = first_job + p;
+      if (job >= n_jobs) break;
+      const DevJob& J = jobs[job];
+      const unsigned char* bp = lds + block_offset(plan, p);
+      const HX_LDS unsigned char* ycolE = (const HX_LDS unsigned char*)(bp + plan.ycol);
+      const int Re = J.n_rows, Ce = J.n_cols;
+      const int nse = (Re + 63) >> 6;
+      const int64_t plane = J.plane;
+      const int blk = J.blk;
+      HX_GLOBAL double* __restrict__ M = as_global(DIR ? J.bwd : J.fwd);
+      const HX_GLOBAL i2v* xrecG = (const HX_GLOBAL i2v*)as_global(reinterpret_cast<const i2v*>(DIR ? J.band_rows_bwd : J.band_rows));
+      if (DIR == 1) {
+        const int64_t ssd = J.strip_stride;
+        const int lo_last = reinterpret_cast<const int*>(reinterpret_cast<const i2v*>(J.band_rows_bwd) + (Re + 64))[nse];   // first column the sweep owns on the last row
+        auto put_inf = [&](const int ip, const int jp) {
+          const int64_t sl = cell_slot_blk(ssd, blk, ip, jp);
+          M[sl] = HX_NEG_INF; M[plane + sl] = HX_NEG_INF; M[2 * plane + sl] = HX_NEG_INF; M[3 * plane + sl] = HX_NEG_INF;
+          M[4 * plane + sl] = HX_NEG_INF;
+        };
+        if (write_edges) {
+          for (int ip = 1 + lane; ip < Re; ip += 64) {
+            const i2v rec = xrecG[ip];
+            if ((rec.x & 0xFFFF) + ((rec.y >> 9) & 1) - ip > 0) put_inf(ip, 0);      // (the sweep owns the row from a later column on)
+          }
+          for (int jp = 1 + lane; jp < lo_last; jp += 64) put_inf(Re - 1, jp);
+        }
+        {
+          // a first row whose band does not reach column 0: the END-feeding cell itself (src/forward.cpp:981-995)
+          const i2v rec = xrecG[0];
+          if (lane == 0 && (rec.x & 0xFFFF) + ((rec.y >> 9) & 1) > 0) {
+            const double lpe = J.x.pack[4 * (size_t)Re] + J.y.pack[4 * (size_t)Ce];
+            const int64_t sl = cell_slot_blk(ssd, blk, 0, 0);
+            for (int st = 0; st < 5; ++st) M[st * plane + sl] = lpe + J.T[st][5];
+          }
+        }
+      } else {
+        // row 0 beyond what the sweep owns: the chain in log space
+        const int own0 = (xrecG[0].x >> 16) & 0xFFFF;                    // row 0 is owned from step 0 to this step = column
+        const i2v rec1 = xrecG[1];
+        const bool row1_edge = ((rec1.x & 0xFFFF) + ((rec1.x >> 16) & 0xFFFF) - 1) < Ce - 1;   // row 1 does not own column Ny-2
+        const double T02 = J.T[0][2], T03 = J.T[0][3], T22 = J.T[2][2], T33 = J.T[3][3];
+        const double pen0 = J.x.pack[3];                                 // x START ready (or x empty): 0, else -inf
+        double d_idm = HX_NEG_INF, d_imi = HX_NEG_INF;                   // cell (0, Ny-3): the diagonal source of (1, Ny-2)
+        if (own0 < Ce - 1 || row1_edge) {
+          double idm = HX_NEG_INF, imi = HX_NEG_INF;                     // (the chain's value in every lane)
+          for (int j0 = 0; j0 < Ce; j0 += 64) {
+            const int jl = j0 + lane < Ce ? j0 + lane : Ce - 1;
+            const double lrs = J.y.pack[4 * (size_t)jl + 1];
+            const double lin = J.y.pack[4 * (size_t)jl + 2];
+            double kidm = HX_NEG_INF, kimi = HX_NEG_INF;
+#pragma unroll 2
+            for (int m = 0; m < 64; ++m) {
+              const int j = j0 + m;                                       // (wave-uniform)
+              const double rr = read_lane(lrs, m), nn = read_lane(lin, m);
+              if (j >= 1) {
+                idm = (((j == 1 ? T02 : idm + T22) + 0.0) + rr) + pen0;
+                imi = (((j == 1 ? T03 : imi + T33) + 0.0) + nn) + pen0;
+              }
+              if (j == Ce - 2) { d_idm = idm; d_imi = imi; }
+              if (lane == m) { kidm = idm; kimi = imi; }
+            }
+            const int j = j0 + lane;
+            if (j > own0 && j < Ce) {
+              const int64_t sl = stored_slot(J, 0, j);
+              if (sl >= 0) {
+                M[sl] = HX_NEG_INF; M[plane + sl] = HX_NEG_INF; M[2 * plane + sl] = kidm; M[3 * plane + sl] = kimi; M[4 * plane + sl] = HX_NEG_INF;
+              }
+            }
+          }
+        }
+        // cell (1, Ny-2) when row 1's band does not reach it (see hx_band.hip): the nested sum over the diagonal cell
+        // (0, Ny-3), in libm arithmetic (with the reference's truncation under HX_LSE_TRUNC), written as a log-probability
+        if (row1_edge) {
+          double dv[5] = {HX_NEG_INF, HX_NEG_INF, HX_NEG_INF, HX_NEG_INF, HX_NEG_INF};
+          if (Ce - 2 == 0) dv[0] = 0.0; else { dv[2] = d_idm; dv[3] = d_imi; }
+          const unsigned c = ycolE[Ce - 1] & 0x7Fu;
+          const unsigned eo = (unsigned)(rec1.y & 0xFF) * (unsigned)(J.y.n_cls + 1);
+          double acc = HX_NEG_INF;
+          for (int q = 0; q < 5; ++q) {
+            const double t = dv[q] + J.T[q][0];
+            const double hi = vmax(acc, t), lo = vmin(acc, t);
+            const bool add = hi > HX_NEG_INF && lo > HX_NEG_INF && (!TRUNC || hi - lo < 10.0);
+            acc = add ? hi + log1p(exp(lo - hi)) : hi;
+          }
+          const double imm = acc > HX_NEG_INF ? acc + J.emis_pad[eo + c] : HX_NEG_INF;
+          const int64_t sl = stored_slot(J, 1, Ce - 1);
+          if (lane == 0 && sl >= 0) {
+            M[sl] = imm; M[plane + sl] = HX_NEG_INF; M[2 * plane + sl] = HX_NEG_INF; M[3 * plane + sl] = HX_NEG_INF; M[4 * plane + sl] = HX_NEG_INF;
+          }
+        }
+        // the rest of column Ny-2 away from the band: -inf (only where the matrix was not pre-filled)
+        if (write_edges)
+          for (int i = 2 + lane; i < Re; i += 64) {
+            const i2v rec = xrecG[i];
+            const int last_col = (rec.x & 0xFFFF) + ((rec.x >> 16) & 0xFFFF) - i;   // column of the row's last owned step
+            if (last_col < Ce - 1) {
+              const int64_t sl = stored_slot(J, i, Ce - 1);
+              if (sl >= 0) {
+                M[sl] = HX_NEG_INF; M[plane + sl] = HX_NEG_INF; M[2 * plane + sl] = HX_NEG_INF; M[3 * plane + sl] = HX_NEG_INF; M[4 * plane + sl] = HX_NEG_INF;
+              }
+            }
+          }
+      }
+    }
+  } else {
+    // =======================================================================================================
+    // the sweep: lane = row mod 32 inside the lane's half
+    // =======================================================================================================
+    const int rot_addr = 4 * (((lane - 1) & 31) | (lane & 32));
+    const int64_t plane2 = Jp->plane >> 1;
+    const int blk = Jp->blk;
+    HX_GLOBAL double* __restrict__ M = as_global(DIR ? Jp->bwd : Jp->fwd);
+    const HX_GLOBAL i2v* xrecG = (const HX_GLOBAL i2v*)as_global(rowsG);
+    auto xrec_at = [&](const int i) -> i2v { return xrecG[i]; };
+    // anti-diagonal steps: the longer of the wavefront's two pairs, in whole blocks of eight (extra steps own nothing)
+    const int my_steps = live ? ((DIR ? Jp->band_steps_bwd : Jp->band_steps) + 7) & ~7 : 0;
+    const int s0 = __builtin_amdgcn_readlane(my_steps, 0), s1 = __builtin_amdgcn_readlane(my_steps, 32);
+    const int n_steps = s0 > s1 ? s0 : s1;
+
+    int i = r32, os, oe, as, ae, store;
+    unsigned eoff;
+    double xc_rs, xc_in;         // exp(rootsubx), exp(insx)
+    int x_wait;                  // x state not ready: 2^29 (an exponent shift)
+    i2v nrec;
+    d2v nxc = d2v{0., 0.};
+    int nstore = 0;
+    auto decode = [&](const i2v r, const d2v xc, const int sb) {
+      os = r.x & 0xFFFF; oe = os + ((r.x >> 16) & 0xFFFF);
+      as = os + ((r.y >> 9) & 1); ae = oe - ((r.y >> 10) & 1);
+      if ((r.x & 0xFFFF) == 0xFFFF || !live) { os = 0x7FFFFFF0; oe = 0x7FFFFFF1; as = os; ae = oe; }     // sentinel: never owned
+      store = sb;
+      eoff = (unsigned)(r.y & 0xFF) * (unsigned)Ky1;
+      x_wait = (r.y & 0x100) ? (1 << 29) : 0;
+      xc_rs = xc.x; xc_in = xc.y;
+    };
+    auto store_base = [&](const int row) -> int { return sbaseL[row < R ? row >> 6 : 0] + 2 * (row & 63); };
+    {
+      const i2v r0 = xrec_at(r32 < R ? r32 : R);
+      decode(r0, xclassL[r0.y & 0xFF], store_base(r32));
+      nrec = xrec_at(r32 + HXB2_W < R ? r32 + HXB2_W : R);
+    }
+    // the 18 transition probabilities the recursion reads (dest 5 = EEE is only read by lpEnd): per lane - the halves
+    // belong to different pairs
+    double P[5][5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+      for (int d = 0; d < 5; ++d) {
+        const bool used = d == 0 || (d == 1 && a != 4) || (d == 2 && a != 3) || (d == 3 && (a == 0 || a == 3)) ||
+                          (d == 4 && (a == 0 || a == 3 || a == 4));
+        P[a][d] = used ? exp(Jp->T[a][d]) : 0.;
+      }
+    // Backward: the cell feeding END
+    double end_cell[5] = {0., 0., 0., 0., 0.};
+    if (DIR == 1) {
+      const double lpe = Jp->x.pack[4 * (size_t)R] + Jp->y.pack[4 * (size_t)Cc];
+      for (int s = 0; s < 5; ++s) end_cell[s] = exp(lpe + Jp->T[s][5]);
+    }
+
+    // cell registers, ping-ponged: at an even step the lane's previous cell is in lb (the one before in la, which the new
+    // cell overwrites), the previous lane's cells of one / two steps ago in lua / lub
+    L5 la = l5_zero(), lb = l5_zero(), lua = l5_zero(), lub = l5_zero();
+
+    // The y side of a step, fetched ahead (see hx_band.hip): the column's byte two steps ahead, the column's class constants
+    // and the emission term one step ahead.  A lane that is about to change rows looks up the NEXT row's column.
+    auto word_at = [&](const int col) -> unsigned {
+      const int c = col < 0 ? 0 : (col >= Cc ? Cc - 1 : col);
+      return ycolL[c];
+    };
+    unsigned neoff = 0;
+    unsigned w_cur = word_at(0 - i), w_nxt = word_at(1 - i);        // bytes of steps k, k + 1
+    d2v rc_cur = yclassL[w_cur & 0x7Fu];                            // class constants of step k
+    double em_cur = eldsL[eoff + (w_cur & 0x7Fu)];
+
+    auto roll_even = [&](const int k) {
+      if (k > oe) {
+        i += HXB2_W;
+        decode(nrec, nxc, nstore);
+        nrec = xrec_at(i + HXB2_W < R ? i + HXB2_W : R);
+      }
+    };
+    auto roll_odd = [&](const int k) {
+      if (k == oe) {
+        nxc = xclassL[nrec.y & 0xFF];
+        nstore = store_base(i + HXB2_W);
+        neoff = (unsigned)(nrec.y & 0xFF) * (unsigned)Ky1;
+      }
+    };
+    struct YSide { unsigned w; d2v rc; double em; };
+    auto y_side = [&](const int k) -> YSide {
+      const YSide now{w_cur, rc_cur, em_cur};
+      const unsigned c1 = w_nxt & 0x7Fu;
+      rc_cur = yclassL[c1];
+      em_cur = eldsL[((k + 1 > oe) ? neoff : eoff) + c1];
+      w_cur = w_nxt;
+      w_nxt = word_at(k + 2 - ((oe <= k + 1) ? i + HXB2_W : i));
+      return now;
+    };
+
+    auto step = [&](const int k, const bool renorm, const L5& left, L5& out, L5& u1, L5& u2, const YSide ys) {
+      const d2v rc = ys.rc;
+      const int y_wait = (int)((ys.w & 0x80u) << 22);          // y state not ready: 2^29, else 0
+      const double em = ys.em;
+      int E = left.e > u1.e ? left.e : u1.e;
+      E = E > u2.e ? E : u2.e;
+      const int outside = (k >= as && k <= ae) ? 0 : (1 << 29);
+      const int du = ((u1.e - E) - y_wait) - outside, dl = ((left.e - E) - x_wait) - outside, dd = (u2.e - E) - outside;
+      if (DIR == 1) {
+        // Backward (src/forward.cpp:1018-1065 for leaf-like profiles): the five destination terms brought to the cell's
+        // exponent (a move that may not be made, a cell outside the envelope: shifted out of range), then the sums in the
+        // reference's accumulation order
+        const double tD = u2.imm * em;
+        const double t1x = u1.imd * xc_rs, t2x = u1.iiw * xc_in;
+        const double t1y = left.idm * rc.x, t2y = left.imi * rc.y;
+        const double D = __builtin_ldexp(tD, dd);
+        const double d1x = __builtin_ldexp(t1x, du), d2x = __builtin_ldexp(t2x, du);
+        const double d1y = __builtin_ldexp(t1y, dl), d2y = __builtin_ldexp(t2y, dl);
+        out.imm = lin_acc<TRUNC>(P[0][3], d2y, lin_acc<TRUNC>(P[0][2], d1y, lin_acc<TRUNC>(P[0][4], d2x, lin_acc<TRUNC>(P[0][1], d1x, P[0][0] * D))));
+        out.imd = lin_acc<TRUNC>(P[1][2], d1y, lin_acc<TRUNC>(P[1][1], d1x, P[1][0] * D));
+        out.idm = lin_acc<TRUNC>(P[2][2], d1y, lin_acc<TRUNC>(P[2][1], d1x, P[2][0] * D));
+        out.imi = lin_acc<TRUNC>(P[3][3], d2y, lin_acc<TRUNC>(P[3][4], d2x, lin_acc<TRUNC>(P[3][1], d1x, P[3][0] * D)));
+        out.iiw = lin_acc<TRUNC>(P[4][2], d1y, lin_acc<TRUNC>(P[4][4], d2x, P[4][0] * D));
+      } else {
+        // the five sums of src/forward.cpp:103-115,139-150,171-180 on probabilities, left-nested as the reference's
+        double s_imd = u1.imm * P[0][1];
+        double s_iiw = u1.imm * P[0][4];
+        double s_idm = left.imm * P[0][2];
+        double s_imi = left.imm * P[0][3];
+        double s_imm = u2.imm * P[0][0];
+        s_imd = lin_acc<TRUNC>(u1.imd, P[1][1], s_imd);
+        s_iiw = lin_acc<TRUNC>(u1.imi, P[3][4], s_iiw);
+        s_idm = lin_acc<TRUNC>(left.imd, P[1][2], s_idm);
+        s_imi = lin_acc<TRUNC>(left.imi, P[3][3], s_imi);
+        s_imm = lin_acc<TRUNC>(u2.imd, P[1][0], s_imm);
+        s_imd = lin_acc<TRUNC>(u1.idm, P[2][1], s_imd);
+        s_iiw = lin_acc<TRUNC>(u1.iiw, P[4][4], s_iiw);
+        s_idm = lin_acc<TRUNC>(left.idm, P[2][2], s_idm);
+        s_imm = lin_acc<TRUNC>(u2.idm, P[2][0], s_imm);
+        s_imd = lin_acc<TRUNC>(u1.imi, P[3][1], s_imd);
+        s_idm = lin_acc<TRUNC>(left.iiw, P[4][2], s_idm);
+        s_imm = lin_acc<TRUNC>(u2.imi, P[3][0], s_imm);
+        s_imm = lin_acc<TRUNC>(u2.iiw, P[4][0], s_imm);
+        // the three source groups brought to the cell's exponent; a state that may not be entered (y or x state not ready:
+        // src/forward.cpp:97,133) and a cell outside the envelope are shifted out of range: zero
+        out.imd = __builtin_ldexp(s_imd * xc_rs, du);
+        out.iiw = __builtin_ldexp(s_iiw * xc_in, du);
+        out.idm = __builtin_ldexp(s_idm * rc.x, dl);
+        out.imi = __builtin_ldexp(s_imi * rc.y, dl);
+        out.imm = __builtin_ldexp(s_imm * em, dd);
+      }
+      out.e = E;
+      if (renorm) {                                  // (compile-time: the first two steps of every block of eight)
+        if (k == 0 && r32 == 0 && live) {
+          if (DIR == 0) { out.imm = 1.0; out.e = 0; }   // cell (0,0): lpStart() = 0 (src/forward.cpp:73)
+          else {
+            // the cell feeding END is initialised by assignment (src/forward.cpp:981-995)
+            out.imm = end_cell[0]; out.imd = end_cell[1]; out.idm = end_cell[2]; out.imi = end_cell[3]; out.iiw = end_cell[4];
+            out.e = 0;
+          }
+        }
+        const double mx = vmax(vmax(vmax(out.imm, out.imd), vmax(out.idm, out.imi)), out.iiw);
+        const int kk = __builtin_amdgcn_frexp_exp(mx);
+        out.imm = __builtin_ldexp(out.imm, -kk);
+        out.imd = __builtin_ldexp(out.imd, -kk);
+        out.idm = __builtin_ldexp(out.idm, -kk);
+        out.imi = __builtin_ldexp(out.imi, -kk);
+        out.iiw = __builtin_ldexp(out.iiw, -kk);
+        out.e = mx > 0. ? out.e + kk : HXB2_EMIN;
+      }
+      u2 = rot(rot_addr, out);                       // the previous lane's new cell: next step's upper neighbour
+    };
+
+    // a pair of steps: in the strip-skewed layout the two cells are adjacent, 16 bytes per lane and state plane
+    auto step_pair = [&](const int k, const bool renorm) {
+      roll_even(k);
+      const bool own = k >= os && k <= oe;           // (owned spans are whole step pairs)
+      const int sl = store + (k >> 1) * blk;
+      step(k, renorm, lb, la, lua, lub, y_side(k));
+      const double l0 = log_scaled(la.imm, la.e, lt), l1 = log_scaled(la.imd, la.e, lt), l2 = log_scaled(la.idm, la.e, lt),
+                   l3 = log_scaled(la.imi, la.e, lt), l4 = log_scaled(la.iiw, la.e, lt);
+      roll_odd(k + 1);
+      step(k + 1, renorm, la, lb, lub, lua, y_side(k + 1));
+      const double h0 = log_scaled(lb.imm, lb.e, lt), h1 = log_scaled(lb.imd, lb.e, lt), h2 = log_scaled(lb.idm, lb.e, lt),
+                   h3 = log_scaled(lb.imi, lb.e, lt), h4 = log_scaled(lb.iiw, lb.e, lt);
+      if (own) {
+        HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
+        // write-once data: non-temporal stores
+        __builtin_nontemporal_store(d2v{l0, h0}, &M2[0]);
+        __builtin_nontemporal_store(d2v{l1, h1}, &M2[plane2]);
+        __builtin_nontemporal_store(d2v{l2, h2}, &M2[2 * plane2]);
+        __builtin_nontemporal_store(d2v{l3, h3}, &M2[3 * plane2]);
+        __builtin_nontemporal_store(d2v{l4, h4}, &M2[4 * plane2]);
+      }
+    };
+    for (int k = 0; k < n_steps; k += 8) {
+      step_pair(k, true);                            // (mantissas renormalised every eighth step)
+      step_pair(k + 2, false);
+      step_pair(k + 4, false);
+      step_pair(k + 6, false);
+    }
+  }
+  // lpEnd reads cell (Nx-2, Ny-2): the sweep's last cell, or - a one-row band - an edge cell
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (live && r32 == 0) {
+    if (DIR == 0) *Jp->lp_end = forward_lp_end(*Jp, ExactLse{exact_tab});
+    else *Jp->lp_start = Jp->bwd[cell_slot_blk(Jp->strip_stride, Jp->blk, R - 1, Cc - 1)];   // B(START, START).IMM: the sweep's last cell
+  }
+}
+
+Band2Plan plan_band2(int nw, int max_rows, int max_cols, int max_cls) {
+  Band2Plan p;
+  int a = 0;
+  p.sbase = a; a += (4 * ((max_rows + 63) / 64 + 1) + 15) & ~15;
+  p.ycol = a; a += (max_cols + 15) & ~15;
+  p.yclass = a; a += 16 * (max_cls + 1);
+  p.xclass = a; a += 16 * (max_cls + 1);
+  p.elds = a; a += (8 * (max_cls + 1) * (max_cls + 1) + 15) & ~15;
+  p.stride = a;
+  p.in_hole = (HXB2_HOLE_END - HXB2_HOLE_BEGIN) / a;
+  if (p.in_hole > 2 * nw) p.in_hole = 2 * nw;
+  p.total = 16 * HXB2_LOG_ENTRIES + (2 * nw - p.in_hole) * a;
+  return p;
+}
+
+template <bool TRUNC, int NW, int DIR>
+int launch_b2(const DevJob* d_jobs, int n_jobs, const Band2Plan& p, const double* tab, const double* log_tab, int write_edges, hipStream_t st) {
+  if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_band2<%d> needs %d bytes of LDS (limit %d)", NW, p.total, HX_LDS_LIMIT);
+  hipLaunchKernelGGL((k_fill_band2<TRUNC, NW, DIR>), dim3((n_jobs + 2 * NW - 1) / (2 * NW)), dim3((NW + 1) * 64), p.total, st, d_jobs, tab,
+                     log_tab, p, n_jobs, write_edges);
+  return 0;
+}
+
+template <int DIR>
+int launch_band2_dir(const DevJob* d_jobs, int n_jobs, bool trunc, int max_rows, int max_cols, int max_cls, Tab8 tab8, Tab16 log_tab,
+                     bool write_edges, hipStream_t st) {
+  if (max_cls + 1 > 127) return launch_fail("%d emission classes exceed the two-pairs-per-wavefront sweep's column bytes", max_cls);
+  const char* v = getenv("HX_BAND2_NW");           // tuning / test hook: sweeping wavefronts per workgroup (1, 2 or 4)
+  int nw = v ? atoi(v) : 0;
+  if (nw != 1 && nw != 2 && nw != 4) nw = n_jobs > 1024 ? 2 : 1;
+  const int we = write_edges ? 1 : 0;
+#define HXB2_GO(NW_) do { const Band2Plan p = plan_band2(NW_, max_rows, max_cols, max_cls); \
+    return trunc ? launch_b2<true, NW_, DIR>(d_jobs, n_jobs, p, tab8.p, log_tab.p, we, st) \
+                 : launch_b2<false, NW_, DIR>(d_jobs, n_jobs, p, tab8.p, log_tab.p, we, st); } while (0)
+  if (nw == 4) HXB2_GO(4);
+  if (nw == 2) HXB2_GO(2);
+  HXB2_GO(1);
+#undef HXB2_GO
+}
+
+}  // namespace
+
+bool band2_kernel_fits(int rows, int cols, int cls) {
+  return cls + 1 <= 127 && plan_band2(1, rows, cols, cls).total <= HX_LDS_LIMIT;
+}
+
+int launch_forward_band2(const DevJob* d_jobs, int n_jobs, bool trunc, int max_rows, int max_cols, int max_cls, Tab8 tab8, Tab16 log_tab,
+                         bool write_edges, hipStream_t st) {
+  return launch_band2_dir<0>(d_jobs, n_jobs, trunc, max_rows, max_cols, max_cls, tab8, log_tab, write_edges, st);
+}
+int launch_backward_band2(const DevJob* d_jobs, int n_jobs, bool trunc, int max_rows, int max_cols, int max_cls, Tab8 tab8, Tab16 log_tab,
+                          bool write_edges, hipStream_t st) {
+  return launch_band2_dir<1>(d_jobs, n_jobs, trunc, max_rows, max_cols, max_cls, tab8, log_tab, write_edges, st);
+}
+
+}  // namespace hx

@@ -62,12 +62,12 @@ void launch_gather_cells(const DevJob* d_jobs, int job, const double* M, int mir
 int log_table_doubles();
 void build_log_table(double* out /* [log_table_doubles()] */);
 int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, Tab8 tab, Tab16 log_tab,
-                                int yl_cols, int yl_emis, int yl_cls, int multi, int* counters, hipStream_t st);
+                                int yl_cols, int yl_emis, int yl_cls, int multi, int* counters, bool trunc, hipStream_t st);
 
 int launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, Tab8 tab, Tab16 log_tab,
-                                 int yl_cols, int yl_emis, int yl_cls, int multi, int* counters, hipStream_t st);
+                                 int yl_cols, int yl_emis, int yl_cls, int multi, int* counters, bool trunc, hipStream_t st);
 
-// banded leaf-like pairs, rotating-row sweep (hx_band.hip); pol: 0 = scaled probabilities, 1 = fast, 2 = exact
+// banded leaf-like pairs, rotating-row sweep (hx_band.hip); pol: 0 = scaled probabilities, 1 = fast, 2 = exact, 3 = scaled probabilities with the reference's truncation
 bool band_kernel_fits(int pol, int rows, int cols, int cls);
 int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, Tab8 tab,
                         Tab16 pol_tab, bool write_edges, hipStream_t st);

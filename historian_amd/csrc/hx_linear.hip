@@ -36,6 +36,21 @@ namespace {
 
 struct L5 { double imm, imd, idm, imi, iiw; int e; };
 
+// One pairwise sum of the reference's log_sum_exp, on probabilities: the reference returns max + T(|a - b|) with T = 0 once the
+// difference reaches 10 (src/logsumexp.h:45), i.e. it DROPS the smaller term when it is at most e^-10 of the larger.  Keeping
+// that - and the reference's left-nested order of the sums (src/logsumexp.h:86-100) - is what separates the truncating policy
+// (HX_LSE_TRUNC) from plain multiply-adds: the dropped terms are the 4.5e-5-per-operation bias that moves near-tied best paths.
+#define HXL_EXP_M10 4.5399929762484854e-05      // e^-10
+__device__ __forceinline__ double trunc_sum(double a, double b) {
+  const double hi = vmax(a, b), lo = vmin(a, b);
+  return hi + (lo > hi * HXL_EXP_M10 ? lo : 0.0);
+}
+// acc (+) m * p
+template <bool TRUNC> __device__ __forceinline__ double lin_acc(double m, double p, double acc) {
+  if (TRUNC) return trunc_sum(acc, m * p);
+  return __builtin_fma(m, p, acc);
+}
+
 __device__ __forceinline__ L5 l5_zero() { return L5{0., 0., 0., 0., 0., HXL_EMIN}; }
 
 __device__ __forceinline__ int dpp_shr1_keep0(int old, int v) {
@@ -115,7 +130,7 @@ struct LdsPlan { int elds, ycol, yclass, flags, zero;   // inside block A
 // counter in memory (`counters`: 256 zeroed ints per pair, one per workgroup, [255] = a poll gave up), `sc1` polls that give
 // up after HXL_PATIENCE rounds (the pair's lpEnd / lpStart becomes NaN).  As k_fill_chain's MULTI (hx_chain.hip).
 #define HXL_PATIENCE (1 << 22)
-template <int W, bool BANDED, int PPW, int DIR, bool MULTI = false>
+template <int W, bool BANDED, int PPW, int DIR, bool MULTI = false, bool TRUNC = false>
 __global__ void __launch_bounds__(W * PPW * 64, 4)   // four waves per SIMD: 128 vector registers
 k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const double* __restrict__ log_tab,
                       const LdsPlan plan, const int n_jobs, const int groups = 1, int* const counters = nullptr) {
@@ -394,19 +409,19 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
         double s_idm = left.imm * P[0][2];
         double s_imi = left.imm * P[0][3];
         double s_imm = u2.imm * P[0][0];
-        s_imd = __builtin_fma(u1.imd, P[1][1], s_imd);
-        s_iiw = __builtin_fma(u1.imi, P[3][4], s_iiw);
-        s_idm = __builtin_fma(left.imd, P[1][2], s_idm);
-        s_imi = __builtin_fma(left.imi, P[3][3], s_imi);
-        s_imm = __builtin_fma(u2.imd, P[1][0], s_imm);
-        s_imd = __builtin_fma(u1.idm, P[2][1], s_imd);
-        s_iiw = __builtin_fma(u1.iiw, P[4][4], s_iiw);
-        s_idm = __builtin_fma(left.idm, P[2][2], s_idm);
-        s_imm = __builtin_fma(u2.idm, P[2][0], s_imm);
-        s_imd = __builtin_fma(u1.imi, P[3][1], s_imd);
-        s_idm = __builtin_fma(left.iiw, P[4][2], s_idm);
-        s_imm = __builtin_fma(u2.imi, P[3][0], s_imm);
-        s_imm = __builtin_fma(u2.iiw, P[4][0], s_imm);
+        s_imd = lin_acc<TRUNC>(u1.imd, P[1][1], s_imd);
+        s_iiw = lin_acc<TRUNC>(u1.imi, P[3][4], s_iiw);
+        s_idm = lin_acc<TRUNC>(left.imd, P[1][2], s_idm);
+        s_imi = lin_acc<TRUNC>(left.imi, P[3][3], s_imi);
+        s_imm = lin_acc<TRUNC>(u2.imd, P[1][0], s_imm);
+        s_imd = lin_acc<TRUNC>(u1.idm, P[2][1], s_imd);
+        s_iiw = lin_acc<TRUNC>(u1.iiw, P[4][4], s_iiw);
+        s_idm = lin_acc<TRUNC>(left.idm, P[2][2], s_idm);
+        s_imm = lin_acc<TRUNC>(u2.idm, P[2][0], s_imm);
+        s_imd = lin_acc<TRUNC>(u1.imi, P[3][1], s_imd);
+        s_idm = lin_acc<TRUNC>(left.iiw, P[4][2], s_idm);
+        s_imm = lin_acc<TRUNC>(u2.imi, P[3][0], s_imm);
+        s_imm = lin_acc<TRUNC>(u2.iiw, P[4][0], s_imm);
         const int e_diag = u2.e;
         // (row0-1, t+1), lane 0's upper neighbour of the next step, into the registers the diagonal cell has just
         // vacated.  Unconditional: past the last column it returns a stale entry, which only feeds cells outside the lattice.
@@ -450,11 +465,12 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
         const double D = __builtin_ldexp(tD, dd);
         const double d1x = __builtin_ldexp(t1x, du), d2x = __builtin_ldexp(t2x, du);
         const double d1y = __builtin_ldexp(t1y, dl), d2y = __builtin_ldexp(t2y, dl);
-        out.imm = __builtin_fma(P[0][3], d2y, __builtin_fma(P[0][2], d1y, __builtin_fma(P[0][4], d2x, __builtin_fma(P[0][1], d1x, P[0][0] * D))));
-        out.imd = __builtin_fma(P[1][2], d1y, __builtin_fma(P[1][1], d1x, P[1][0] * D));
-        out.idm = __builtin_fma(P[2][2], d1y, __builtin_fma(P[2][1], d1x, P[2][0] * D));
-        out.imi = __builtin_fma(P[3][3], d2y, __builtin_fma(P[3][4], d2x, __builtin_fma(P[3][1], d1x, P[3][0] * D)));
-        out.iiw = __builtin_fma(P[4][2], d1y, __builtin_fma(P[4][4], d2x, P[4][0] * D));
+        // (the reference accumulates term by term, in this order: src/forward.cpp:1018-1065)
+        out.imm = lin_acc<TRUNC>(P[0][3], d2y, lin_acc<TRUNC>(P[0][2], d1y, lin_acc<TRUNC>(P[0][4], d2x, lin_acc<TRUNC>(P[0][1], d1x, P[0][0] * D))));
+        out.imd = lin_acc<TRUNC>(P[1][2], d1y, lin_acc<TRUNC>(P[1][1], d1x, P[1][0] * D));
+        out.idm = lin_acc<TRUNC>(P[2][2], d1y, lin_acc<TRUNC>(P[2][1], d1x, P[2][0] * D));
+        out.imi = lin_acc<TRUNC>(P[3][3], d2y, lin_acc<TRUNC>(P[3][4], d2x, lin_acc<TRUNC>(P[3][1], d1x, P[3][0] * D)));
+        out.iiw = lin_acc<TRUNC>(P[4][2], d1y, lin_acc<TRUNC>(P[4][4], d2x, P[4][0] * D));
       }
       out.e = E;
       if ((t & HXL_RENORM_MASK) == 0) {            // wave-uniform
@@ -654,20 +670,26 @@ static LdsPlan plan_lds(int W, int PPW, bool banded, int yl_cols, int yl_emis, i
 }
 
 int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, Tab8 tab8, Tab16 tab16,
-                               int yl_cols, int yl_emis, int yl_cls, int multi, int* counters, hipStream_t st) {
+                               int yl_cols, int yl_emis, int yl_cls, int multi, int* counters, bool trunc, hipStream_t st) {
   const double* tab = tab8.p;
   const double* log_tab = tab16.p;
   if (yl_cls > HX_YL_MAX_CLS_LINEAR + 1) return launch_fail("%d emission classes exceed the scaled-probability kernel's column words", yl_cls);
   if (multi > 1 && !banded) {     // a small batch: `multi` workgroups of four waves per pair (MULTI; see chain_multi_groups)
     const LdsPlan p = plan_lds(4, 1, false, yl_cols, yl_emis, yl_cls);
     if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_leaf_linear<multi> needs %d bytes of LDS (limit %d)", p.total, HX_LDS_LIMIT);
-    hipLaunchKernelGGL((k_fill_leaf_linear<4, false, 1, 0, true>), dim3(n_jobs * multi), dim3(4 * 64), p.total, st, d_jobs, tab, log_tab, p, n_jobs,
-                       multi, counters);
+    if (trunc)
+      hipLaunchKernelGGL((k_fill_leaf_linear<4, false, 1, 0, true, true>), dim3(n_jobs * multi), dim3(4 * 64), p.total, st, d_jobs, tab, log_tab, p, n_jobs,
+                         multi, counters);
+    else
+      hipLaunchKernelGGL((k_fill_leaf_linear<4, false, 1, 0, true>), dim3(n_jobs * multi), dim3(4 * 64), p.total, st, d_jobs, tab, log_tab, p, n_jobs,
+                         multi, counters);
     return 0;
   }
 #define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis, yl_cls); \
     if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_leaf_linear<%d> needs %d bytes of LDS (limit %d)", W_, p.total, HX_LDS_LIMIT); \
-    hipLaunchKernelGGL((k_fill_leaf_linear<W_, B_, PPW_, 0>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
+    if (trunc) hipLaunchKernelGGL((k_fill_leaf_linear<W_, B_, PPW_, 0, false, true>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
+                       d_jobs, tab, log_tab, p, n_jobs); \
+    else hipLaunchKernelGGL((k_fill_leaf_linear<W_, B_, PPW_, 0>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
                        d_jobs, tab, log_tab, p, n_jobs); } while (0)
   if (banded) {
     // one wavefront per pair; with more pairs than fit the CUs one by one (LDS: four workgroups of one pair), six pairs
@@ -701,20 +723,26 @@ int launch_forward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, b
 
 // Backward fill of leaf batches on scaled probabilities (the same kernel, DIR = 1)
 int launch_backward_leaf_linear(const DevJob* d_jobs, int n_jobs, int max_rows, bool banded, Tab8 tab8, Tab16 tab16,
-                                int yl_cols, int yl_emis, int yl_cls, int multi, int* counters, hipStream_t st) {
+                                int yl_cols, int yl_emis, int yl_cls, int multi, int* counters, bool trunc, hipStream_t st) {
   const double* tab = tab8.p;
   const double* log_tab = tab16.p;
   if (yl_cls > HX_YL_MAX_CLS_LINEAR + 1) return launch_fail("%d emission classes exceed the scaled-probability kernel's column words", yl_cls);
   if (multi > 1 && !banded) {     // a small batch: `multi` workgroups of four waves per pair (MULTI; see chain_multi_groups)
     const LdsPlan p = plan_lds(4, 1, false, yl_cols, yl_emis, yl_cls);
     if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_leaf_linear<multi> needs %d bytes of LDS (limit %d)", p.total, HX_LDS_LIMIT);
-    hipLaunchKernelGGL((k_fill_leaf_linear<4, false, 1, 1, true>), dim3(n_jobs * multi), dim3(4 * 64), p.total, st, d_jobs, tab, log_tab, p, n_jobs,
-                       multi, counters);
+    if (trunc)
+      hipLaunchKernelGGL((k_fill_leaf_linear<4, false, 1, 1, true, true>), dim3(n_jobs * multi), dim3(4 * 64), p.total, st, d_jobs, tab, log_tab, p, n_jobs,
+                         multi, counters);
+    else
+      hipLaunchKernelGGL((k_fill_leaf_linear<4, false, 1, 1, true>), dim3(n_jobs * multi), dim3(4 * 64), p.total, st, d_jobs, tab, log_tab, p, n_jobs,
+                         multi, counters);
     return 0;
   }
 #define HXL_LAUNCH(W_, B_, PPW_) do { const LdsPlan p = plan_lds(W_, PPW_, B_, yl_cols, yl_emis, yl_cls); \
     if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_leaf_linear<%d, bwd> needs %d bytes of LDS (limit %d)", W_, p.total, HX_LDS_LIMIT); \
-    hipLaunchKernelGGL((k_fill_leaf_linear<W_, B_, PPW_, 1>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
+    if (trunc) hipLaunchKernelGGL((k_fill_leaf_linear<W_, B_, PPW_, 1, false, true>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
+                       d_jobs, tab, log_tab, p, n_jobs); \
+    else hipLaunchKernelGGL((k_fill_leaf_linear<W_, B_, PPW_, 1>), dim3((n_jobs + PPW_ - 1) / PPW_), dim3(W_ * PPW_ * 64), p.total, st, \
                        d_jobs, tab, log_tab, p, n_jobs); } while (0)
   if (banded) {
     const char* v = getenv("HX_LINEAR_PPW");

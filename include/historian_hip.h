@@ -63,6 +63,12 @@ enum { HX_IMM = 0, HX_IMD = 1, HX_IDM = 2, HX_IMI = 3, HX_IIW = 4, HX_STATES = 5
                             reference's truncation of terms below e^-10: lpEnd agrees with the reference to
                             ~3e-6 relative (north_star tolerance 1e-4), cells to ~1e-5 per alignment column.
                             Batches that kernel does not cover run as HX_LSE_FAST.                          */
+#define HX_LSE_TRUNC 81u  /* HX_LSE_LINEAR with the reference's truncation: the same scaled-probability fills, but every pairwise
+                            sum of the reference's left-nested log_sum_exp (src/logsumexp.h:66-100) drops its smaller term when
+                            that is at most e^-10 of the larger - what the reference's table does for differences >= 10
+                            (src/logsumexp.h:45) - instead of adding it.  No table, no logarithm until the store.  Cells agree
+                            with HX_LSE_EXACT to the interpolation error of the reference's table (~3e-10 per operation), as
+                            HX_LSE_FAST does; best paths are the reference's.  General profiles run as HX_LSE_FAST.           */
 #define HX_KEEP_BACKWARD 2u /* pre-allocate the Backward matrices at hx_batch_create        */
 #define HX_FORCE_GENERIC 4u /* always use the general (DAG) kernels, even for chain profiles */
 #define HX_SPARSE_ENVELOPE 8u /* banded jobs: do not pre-fill the matrices with -inf.  Cells outside the

@@ -52,9 +52,10 @@ def _ptr(a):
 def forward(x, y, hmm, max_distance=-1, true_math=False):
     """Returns dict(cells [R][Cc][5], lp_end, subx, suby, insx, rootsubx, insy, rootsuby).
     true_math: the cell recursion sums probabilities with libm's log1p/exp instead of the reference's table
-    operator (a second yardstick for the scaled-linear HIP kernel; everything else stays the reference's)."""
+    operator (a second yardstick for the scaled-linear HIP kernel; everything else stays the reference's);
+    true_math=2: the same with the reference's truncation of differences >= 10 kept (yardstick of HX_LSE_TRUNC)."""
     lib = load()
-    lib.orc_set_true_math(1 if true_math else 0)
+    lib.orc_set_true_math(int(true_math))
     jobs = capi.make_jobs([(x, y, hmm, max_distance)])
     R, Cc, ca = x.n_states - 1, y.n_states - 1, hmm.alph_size * hmm.components
     cells = np.empty((R, Cc, 5))
@@ -71,7 +72,7 @@ def forward(x, y, hmm, max_distance=-1, true_math=False):
 
 def backward(x, y, hmm, max_distance=-1, true_math=False):
     lib = load()
-    lib.orc_set_true_math(1 if true_math else 0)
+    lib.orc_set_true_math(int(true_math))
     jobs = capi.make_jobs([(x, y, hmm, max_distance)])
     cells = np.empty((x.n_states - 1, y.n_states - 1, 5))
     lp_start = C.c_double()

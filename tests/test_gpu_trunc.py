@@ -1,0 +1,131 @@
+"""HX_LSE_TRUNC: the scaled-probability fills with the reference's truncation (hx_linear.hip / hx_band.hip trunc_sum).
+
+The reference's log_sum_exp(a, b) is max + T(|a - b|) with T = 0 for differences >= 10 (src/logsumexp.h:42-84): it drops
+the smaller term when it is at most e^-10 of the larger, and its n-ary forms are left-nested (:86-100).  The policy
+does exactly that on probabilities - no table, no logarithm until the store.  Two yardsticks:
+  * the oracle's recursion in libm arithmetic WITH the truncation (c_oracle true_math=2): same -inf pattern, finite
+    cells within 1e-9, lpEnd within 1e-12 relative - the kernel is that arithmetic up to fp64 rounding;
+  * the pinned oracle (the reference's table arithmetic): cells within 1e-6 (what is left is the interpolation error of
+    the reference's table, < 3e-10 per operation, accumulated along the alignment), lpEnd within 1e-9 relative - and the
+    best path through the device matrix is the reference's (tests/test_gpu_trace_identity.py)."""
+import numpy as np
+import pytest
+
+from historian_amd import capi
+from oracle import c_oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+AA = "arndcqeghilkmfpstwyv"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def engine():
+    capi.init(0, c_oracle.table())      # host-libm table
+    yield
+    capi.shutdown()
+
+
+def check_forward(cases, flags=0, env_only=False, monkeypatch=None):
+    imgs = [H.job_images(f) for f in cases]
+    bt = capi.Batch(imgs, capi.HX_LSE_TRUNC | flags)
+    bt.forward()
+    lt = bt.lp_end()
+    for k, (x, y, hmm, md) in enumerate(imgs):
+        want = c_oracle.forward(x, y, hmm, md, true_math=2)
+        ref = c_oracle.forward(x, y, hmm, md)
+        got = bt.read_matrix(k, 0)
+        sel = H.envelope_mask(cases[k]) if env_only else np.ones(got.shape[:2], dtype=bool)
+        assert not np.isnan(got[sel]).any()
+        assert np.array_equal(np.isneginf(want["cells"][sel]), np.isneginf(got[sel])), "job %d: -inf pattern" % k
+        fin = np.isfinite(want["cells"]) & sel[:, :, None]
+        assert np.max(np.abs(want["cells"][fin] - got[fin]), initial=0.) < 1e-9, "job %d" % k
+        assert np.array_equal(np.isneginf(ref["cells"][sel]), np.isneginf(got[sel])), "job %d: -inf pattern of the reference" % k
+        assert np.max(np.abs(ref["cells"][fin] - got[fin]), initial=0.) < 1e-6, "job %d vs the reference arithmetic" % k
+        if np.isfinite(ref["lp_end"]):
+            assert abs(want["lp_end"] - lt[k]) <= 1e-12 * abs(lt[k])
+            assert abs(ref["lp_end"] - lt[k]) <= 1e-9 * abs(lt[k])
+        else:
+            assert lt[k] == ref["lp_end"]
+    return bt, imgs
+
+
+@pytest.mark.parametrize("waves", [0, 1, 2, 8])
+def test_unbanded_leaf_pairs(waves, monkeypatch):
+    if waves:
+        monkeypatch.setenv("HX_LINEAR_WAVES", str(waves))
+    groups = [[H.leaf_case(301, 40, 45), H.leaf_case(312, 1, 1), H.leaf_case(305, 63, 64, alphabet=AA, jc=False, tl=.3, tr=.2)],
+              [H.leaf_case(306, 100, 130), H.leaf_case(307, 127, 20, alphabet=AA, components=2, jc=False)],
+              [H.leaf_case(308, 250, 200, alphabet=AA, jc=False), H.leaf_case(313, 0, 4)],
+              [H.leaf_case(310, 1100, 700, alphabet=AA, jc=False, tl=.2, tr=.3), H.leaf_case(311, 700, 1500)]]
+    for cases in groups:
+        bt, imgs = check_forward(cases)
+        # the best path through the device's matrix is the path through the exact fill's matrix
+        be = capi.Batch(imgs)
+        be.forward()
+        assert bt.best_trace() == be.best_trace()
+        be.close()
+        bt.close()
+
+
+def test_backward_on_unbanded_leaf_pairs():
+    cases = [H.leaf_case(306, 100, 130), H.leaf_case(307, 127, 20, alphabet=AA, components=2, jc=False),
+             H.leaf_case(309, 500, 300), H.leaf_case(305, 63, 64, alphabet=AA, jc=False, tl=.3, tr=.2)]
+    imgs = [H.job_images(f) for f in cases]
+    bt = capi.Batch(imgs, capi.HX_LSE_TRUNC | capi.HX_KEEP_BACKWARD)
+    bt.forward()
+    bt.backward()
+    lt, st = bt.lp_end(), bt.lp_start()
+    for k, (x, y, hmm, md) in enumerate(imgs):
+        want = c_oracle.backward(x, y, hmm, md, true_math=2)
+        ref = c_oracle.backward(x, y, hmm, md)
+        got = bt.read_matrix(k, 1)
+        assert np.array_equal(np.isneginf(want["cells"]), np.isneginf(got))
+        fin = np.isfinite(got)
+        assert np.max(np.abs(want["cells"][fin] - got[fin]), initial=0.) < 1e-9
+        assert np.max(np.abs(ref["cells"][fin] - got[fin]), initial=0.) < 1e-6
+        assert abs(ref["lp_start"] - st[k]) <= 1e-9 * abs(st[k])
+        # the reference itself only has Forward == Backward to its table's accuracy (FWD_BACK_ERROR_TOLERANCE .01, src/forward.cpp:9)
+        assert abs(st[k] - lt[k]) <= 1e-6 * abs(lt[k])
+    bt.close()
+
+
+@pytest.mark.parametrize("ppw", [0, -3, 2])
+def test_banded_leaf_pairs_in_the_rotating_row_sweep(ppw, monkeypatch):
+    if ppw:
+        monkeypatch.setenv("HX_BAND_PPW", str(ppw))
+    cases = [H.leaf_case(401, 70, 66, band=5), H.leaf_case(402, 200, 90, band=12), H.leaf_case(403, 130, 150, band=3),
+             H.leaf_case(404, 300, 330, alphabet=AA, jc=False, band=20), H.leaf_case(405, 40, 45, band=0),
+             H.leaf_case(407, 500, 520, band=8)]
+    for flags in (0, capi.HX_SPARSE_ENVELOPE, capi.HX_BAND_COMPRESSED):
+        bt, imgs = check_forward(cases, flags, env_only=flags != 0)
+        be = capi.Batch(imgs, flags & ~capi.HX_BAND_COMPRESSED)
+        be.forward()
+        assert bt.best_trace() == be.best_trace()
+        if flags != capi.HX_BAND_COMPRESSED:
+            be.backward()
+            bt.backward()
+            for k, (x, y, hmm, md) in enumerate(imgs):
+                want = c_oracle.backward(x, y, hmm, md, true_math=2)
+                got = bt.read_matrix(k, 1)
+                inside = np.isfinite(want["cells"])
+                assert np.max(np.abs(want["cells"][inside] - got[inside]), initial=0.) < 1e-9, "job %d backward" % k
+                if not flags:
+                    assert np.array_equal(np.isneginf(want["cells"]), np.isneginf(got))
+        be.close()
+        bt.close()
+
+
+def test_general_profiles_run_as_the_table_policy():
+    # no truncating kernel for state DAGs yet: those classes take HX_LSE_FAST (which truncates as the reference does)
+    cases = [H.dag_case(71, n=90, samples=4), H.dag_case(72, n=150, band=6, samples=3)]
+    imgs = [H.job_images(f) for f in cases]
+    bt = capi.Batch(imgs, capi.HX_LSE_TRUNC)
+    bf = capi.Batch(imgs, capi.HX_LSE_FAST)
+    bt.forward()
+    bf.forward()
+    for k in range(len(imgs)):
+        H.assert_same_bits(bt.read_matrix(k, 0), bf.read_matrix(k, 0), "general profile under HX_LSE_TRUNC")
+    bt.close()
+    bf.close()

@@ -3,7 +3,7 @@ bit-identical"; reference src/forward.cpp:245-255,283-302).
 
 For N random leaf pairs (lengths 50-2000, DNA / protein / 4-component mixture, banded and unbanded, symmetric branch
 lengths included) the device-side best path (hx_batch_best_trace) of a fill in each arithmetic policy - exact, fast,
-linear - is compared with oracle/trace_oracle.best_trace over the matrix of the pinned plain-C oracle
+linear, trunc - is compared with oracle/trace_oracle.best_trace over the matrix of the pinned plain-C oracle
 (oracle_fill.c, the reference's table operator with its truncation).  Reports, per policy, how many paths differ and
 the largest relative lpEnd difference; the differing pairs are listed by their seed.
 
@@ -90,7 +90,9 @@ def main():
     from historian_amd import capi
     from oracle import c_oracle
     capi.init(0, c_oracle.table())
-    modes = {"exact": capi.HX_LSE_EXACT, "fast": capi.HX_LSE_FAST, "linear": capi.HX_LSE_LINEAR}
+    modes = {"exact": capi.HX_LSE_EXACT, "fast": capi.HX_LSE_FAST, "linear": capi.HX_LSE_LINEAR, "trunc": capi.HX_LSE_TRUNC}
+    if os.environ.get("HX_SWEEP_MODES"):
+        modes = {m: modes[m] for m in os.environ["HX_SWEEP_MODES"].split(",")}
     dev = {m: {} for m in modes}
     # device side: batches of pairs of one band class (a batch is banded or not), sorted by size
     order = sorted(range(n), key=lambda k: (specs[k]["band"] >= 0, specs[k]["lx"]))
