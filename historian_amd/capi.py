@@ -79,7 +79,7 @@ EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_cr
            "hx_host_free", "hx_quick_batch_create", "hx_quick_batch_destroy", "hx_quick_batch_run",
            "hx_quick_batch_results", "hx_quick_batch_layout", "hx_quick_batch_read_matrix",
            "hx_quick_batch_total_cells", "hx_quick_batch_last_kernel_ms", "hx_sumprod_columns", "hx_sumprod_last_kernel_ms",
-           "hx_batch_read_matrix_async", "hx_batch_wait_read", "hx_batch_indel_counts"]
+           "hx_batch_read_matrix_async", "hx_batch_wait_read", "hx_batch_indel_counts", "hx_batch_shared_wavefront_pairs"]
 
 
 class HxError(RuntimeError):
@@ -122,6 +122,7 @@ def load():
     lib.hx_batch_strip_windows.argtypes = [vp, C.c_int32, _i32p, C.POINTER(C.c_int64)]
     lib.hx_batch_job_kernel.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.hx_batch_total_cells.argtypes = [vp]
+    lib.hx_batch_shared_wavefront_pairs.argtypes = [vp]
     lib.hx_batch_total_cells.restype = C.c_int64
     lib.hx_batch_last_kernel_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
     lib.hx_quick_batch_create.argtypes = [C.POINTER(HxQuickJob), C.c_int32, C.POINTER(vp)]
@@ -311,6 +312,13 @@ class Batch:
         c, s = C.c_int32(0), C.c_int32(0)
         _check(load().hx_batch_job_kernel(self._h, job, C.byref(c), C.byref(s)))
         return c.value, bool(s.value)
+
+    def shared_wavefront_pairs(self):
+        """pairs whose banded fill runs two pairs per wavefront (hx_band2.hip)"""
+        n = load().hx_batch_shared_wavefront_pairs(self._h)
+        if n < 0:
+            _check(n)
+        return n
 
     def kernel_ms(self, which=0):
         ms = C.c_float()

@@ -520,6 +520,7 @@ enum KernelClass {
 struct ClassRange {
   int64_t agg_begin = 0, agg_doubles = 0;   // the class's part of hx_batch::d_agg (general-profile classes)
   bool bwd_band = false;      // KC_LEAF_ROT_BANDED: every pair of the class also has the Backward sweep's row records
+  int n_w32 = 0;              // KC_LEAF_ROT_BANDED: pairs of the class that may share a wavefront (DevJob::band_w32)
   int begin = 0, n = 0;       // positions in the class-ordered job table
   int max_rows = 0, max_cols = 0, max_cls = 0, yl_cols = 0, yl_emis = 0;
   int64_t mat_begin = 0, mat_doubles = 0;   // the class's matrices are contiguous: [mat_begin, mat_begin + mat_doubles)
@@ -850,6 +851,18 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
           jo.band_rows = ar.put(rows.data(), sizeof(int32_t) * rows.size());
           J.band_steps = n_steps;
           kc = kclass[k] = KC_LEAF_ROT_BANDED;
+          // two pairs per wavefront (hx_band2.hip): a lane is a row modulo 32 there, so rows i and i + 31 must never be alive
+          // together and a lane must be idle for a whole step pair between rows i and i + 32 - the conditions build_band_rows
+          // checks for 63 / 64, on both sweeps' records
+          auto ring32 = [&](const std::vector<int32_t>& rec) {
+            auto first = [&](int i) { return rec[2 * (size_t)i] & 0xFFFF; };
+            auto last = [&](int i) { return (rec[2 * (size_t)i] & 0xFFFF) + ((rec[2 * (size_t)i] >> 16) & 0xFFFF); };
+            for (int i = 0; i + 31 < J.n_rows; ++i) if (first(i + 31) < last(i) + 1) return false;
+            for (int i = 0; i + 32 < J.n_rows; ++i) if (first(i + 32) < last(i) + 3) return false;
+            return true;
+          };
+          J.band_w32 = (ring32(rows) && (jo.compressed || ring32(rows_b)) &&
+                        band2_kernel_fits(J.n_rows, J.n_cols, std::max(jo.x.n_cls, jo.y.n_cls))) ? 1 : 0;
           J.band_steps_bwd = 0;
           if (!jo.compressed) {
             jo.band_rows_bwd = ar.put(rows_b.data(), sizeof(int32_t) * rows_b.size());
@@ -877,6 +890,7 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
     if (jo.table_emission && pairs > b->max_cls_pairs) b->max_cls_pairs = (int)pairs;
     ClassRange& cr = b->cls[kc];
     cr.n++;
+    if (kc == KC_LEAF_ROT_BANDED && J.band_w32) cr.n_w32++;
     if (J.n_rows > cr.max_rows) cr.max_rows = J.n_rows;
     if (J.n_cols > cr.max_cols) cr.max_cols = J.n_cols;
     if (jo.x.n_cls > cr.max_cls) cr.max_cls = jo.x.n_cls;
@@ -1036,6 +1050,17 @@ int hx_batch_destroy(hx_batch* b) {
     if ((expr) != 0) return fail(HX_ERR_INVALID_ARG, "unsupported batch shape: %s", launch_error()); \
   } while (0)
 
+// Two pairs per wavefront (hx_band2.hip) for a class of banded leaf pairs: scaled-probability policies only, every pair of
+// the class admitted (DevJob::band_w32), and enough pairs that halving the wavefronts matters - below HX_BAND2_MIN_PAIRS a pair
+// per wavefront with a converting wavefront beside it (hx_band.hip) has the shorter critical path.  HX_BAND2 = 0 / 1: never /
+// whenever admissible (tests).
+#define HX_BAND2_MIN_PAIRS 512
+static bool band2_wanted(bool linear, int n, int n_w32) {
+  if (!linear || n_w32 != n) return false;
+  if (const char* v = getenv("HX_BAND2")) return atoi(v) != 0;
+  return n > HX_BAND2_MIN_PAIRS;
+}
+
 int hx_batch_forward(hx_batch* b, void* stream) {
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
   int rc;
@@ -1058,6 +1083,10 @@ int hx_batch_forward(hx_batch* b, void* stream) {
     switch (c) {
       case KC_LEAF_ROT_BANDED:
         if (!(b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED))) launch_fill_neg_inf(b->d_fwd + cr.mat_begin, cr.mat_doubles, st);
+        if (band2_wanted(linear, cr.n, cr.n_w32))
+          LAUNCH_TRY(launch_forward_band2(jobs, cr.n, trunc, cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab}, Tab16{D.log_tab},
+                                          (b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED)) != 0, st));
+        else
         LAUNCH_TRY(launch_forward_band(jobs, cr.n, linear ? (trunc ? 3 : 0) : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab},
                                        linear ? Tab16{D.log_tab} : lse_tab, (b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED)) != 0, st));
         break;
@@ -1153,7 +1182,10 @@ int hx_batch_backward(hx_batch* b, void* stream) {
       case KC_LEAF_LDS: case KC_LEAF_LDS_BANDED: case KC_LEAF_ROT_BANDED: case KC_LEAF: case KC_LEAF_BANDED: {
         if (banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_bwd + cr.mat_begin, cr.mat_doubles, st);
         const int leaf = (c == KC_LEAF_LDS || c == KC_LEAF_LDS_BANDED || c == KC_LEAF_ROT_BANDED) ? 2 : 1;
-        if (c == KC_LEAF_ROT_BANDED && cr.bwd_band)
+        if (c == KC_LEAF_ROT_BANDED && cr.bwd_band && band2_wanted(linear, cr.n, cr.n_w32))
+          LAUNCH_TRY(launch_backward_band2(jobs, cr.n, trunc, cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab}, Tab16{D.log_tab},
+                                           (b->flags & HX_SPARSE_ENVELOPE) != 0, st));
+        else if (c == KC_LEAF_ROT_BANDED && cr.bwd_band)
           // the rotating-row sweep in mirrored coordinates (hx_band.hip)
           LAUNCH_TRY(launch_backward_band(jobs, cr.n, linear ? (trunc ? 3 : 0) : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab},
                                           linear ? Tab16{D.log_tab} : lse_tab, (b->flags & HX_SPARSE_ENVELOPE) != 0, st));
@@ -1288,6 +1320,12 @@ int hx_batch_job_kernel(const hx_batch* b, int32_t job, int32_t* forward_class, 
       }
   }
   return fail(HX_ERR_INVALID_ARG, "job %d is in no kernel class", job);
+}
+
+int hx_batch_shared_wavefront_pairs(const hx_batch* b) {
+  if (!b) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  const ClassRange& cr = b->cls[KC_LEAF_ROT_BANDED];
+  return band2_wanted((b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR, cr.n, cr.n_w32) ? cr.n : 0;
 }
 
 static const double* matrix_of(hx_batch* b, int job, int which) {

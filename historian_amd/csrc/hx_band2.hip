@@ -7,8 +7,8 @@
 // band-20 envelope holds ~21 cells, so two thirds of every vector instruction of that sweep are idle lanes.  Here a
 // wavefront sweeps TWO pairs: lanes 0-31 are a ring of 32 rows (lane = row mod 32) of one pair, lanes 32-63 of another.
 // Nothing else changes in the recursion: left is the lane's own previous cell, up and diagonal are the previous lane's
-// cells of one and two steps ago, handed over inside each 32-lane ring (ds_bpermute: the LDS crossbar, no LDS memory - a
-// DPP rotation is a ring of 64).  A pair is admitted when rows i and i + 31 are never alive together (hx_api.hip:
+// cells of one and two steps ago, handed over inside each 32-lane ring (ds_swizzle's rotate mode: the LDS crossbar, no LDS
+// memory - a DPP rotation is a ring of 64).  A pair is admitted when rows i and i + 31 are never alive together (hx_api.hip:
 // band2_admits); the row records, store bases and step counts are those of hx_band.hip (build_band_rows).
 //
 // One wavefront does everything for its two pairs - the recursion, the five logarithms per cell, the stores - so there is
@@ -44,8 +44,11 @@ typedef int i2v __attribute__((ext_vector_type(2)));
 struct L5 { double imm, imd, idm, imi, iiw; int e; };
 __device__ __forceinline__ L5 l5_zero() { return L5{0., 0., 0., 0., 0., HXB2_EMIN}; }
 
-// value of the previous lane of the lane's 32-lane ring (lane 0 receives lane 31's, lane 32 lane 63's)
-__device__ __forceinline__ int rot(const int addr, const int v) { return __builtin_amdgcn_ds_bpermute(addr, v); }
+// value of the previous lane of the lane's 32-lane ring (lane 0 receives lane 31's, lane 32 lane 63's): ds_swizzle in its
+// rotate mode, which works on groups of 32 lanes (checked on the GPU: tools/probes/swizzle_rotate.hip,
+// profiles/r03/ds_swizzle_rotate_probe.txt).  It uses the LDS crossbar, not LDS memory, and no address register.
+#define HXB2_SWIZZLE_ROR1 (0xC000 | (1 << 10) | (1 << 5))      // swizzle(ROTATE, 1, 1)
+__device__ __forceinline__ int rot(const int, const int v) { return __builtin_amdgcn_ds_swizzle(v, HXB2_SWIZZLE_ROR1); }
 __device__ __forceinline__ double rot(const int addr, const double v) {
   return __hiloint2double(rot(addr, __double2hiint(v)), rot(addr, __double2loint(v)));
 }
@@ -260,7 +263,7 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
     // =======================================================================================================
     // the sweep: lane = row mod 32 inside the lane's half
     // =======================================================================================================
-    const int rot_addr = 4 * (((lane - 1) & 31) | (lane & 32));
+    const int rot_addr = 0;
     const int64_t plane2 = Jp->plane >> 1;
     const int blk = Jp->blk;
     HX_GLOBAL double* __restrict__ M = as_global(DIR ? Jp->bwd : Jp->fwd);

@@ -100,7 +100,7 @@ struct DevJob {
   const uint32_t* yword;      // [n_cols + 328] per-column words of the banded scaled-probability fill (hx_linear.hip), or nullptr
   int32_t blk;                // doubles per step-pair block of a strip: 128 (state planes apart), or 640 = the five states of a
                               // step pair adjacent (interleaved layout; plane is then 128 and strip_stride five times as large)
-  int32_t pad3_;
+  int32_t band_w32;           // hx_band.hip row records whose rows i and i + 31 are never alive together: the pair may share a wavefront (hx_band2.hip)
   int64_t matrix_doubles;     // doubles of one whole matrix (all five states)
   const uint32_t* yword_bwd;  // the same for the Backward sweep (mirrored column order, class of the state an absorbing move leads to)
   // banded rotating-row sweep (hx_band.hip): one 16-byte record per row + 64 sentinel records, and the number of

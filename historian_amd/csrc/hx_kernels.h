@@ -75,6 +75,14 @@ int launch_forward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows,
 int launch_backward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows, int max_cols, int max_cls, Tab8 tab, Tab16 pol_tab,
                          bool write_edges, hipStream_t st);
 
+// banded leaf-like pairs on scaled probabilities, two pairs per wavefront (hx_band2.hip): pairs whose rows i and i + 31 are
+// never alive together (DevJob::band_w32)
+bool band2_kernel_fits(int rows, int cols, int cls);
+int launch_forward_band2(const DevJob* d_jobs, int n_jobs, bool trunc, int max_rows, int max_cols, int max_cls, Tab8 tab, Tab16 log_tab,
+                         bool write_edges, hipStream_t st);
+int launch_backward_band2(const DevJob* d_jobs, int n_jobs, bool trunc, int max_rows, int max_cols, int max_cls, Tab8 tab, Tab16 log_tab,
+                          bool write_edges, hipStream_t st);
+
 void launch_indel_counts(const DevJob* d_jobs, int job, const double* d_tm, double* d_out, int64_t cells, Tab8 tab, bool plane_valid,
                          hipStream_t st);
 void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, Tab8 tab,

@@ -252,6 +252,10 @@ int64_t hx_batch_total_cells(const hx_batch* b);
  * sweep for it (class 2, dense planes), 0 when it runs the class's strip pipeline.  Either may be NULL. */
 int hx_batch_job_kernel(const hx_batch* b, int32_t job, int32_t* forward_class, int32_t* backward_sweep);
 
+/* Diagnostics: the number of pairs whose banded fill runs two pairs per wavefront (hx_band2.hip: scaled-probability policies,
+ * every banded leaf pair of the batch admitted, more than 512 such pairs or HX_BAND2=1), 0 when none does; negative: an error. */
+int hx_batch_shared_wavefront_pairs(const hx_batch* b);
+
 /* Duration in milliseconds of the most recent hx_batch_forward / hx_batch_backward
  * fill kernel (HIP events recorded around that kernel on its stream). */
 int hx_batch_last_kernel_ms(hx_batch* b, int32_t which, float* ms);
