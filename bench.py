@@ -9,13 +9,20 @@ profile pairs under WAG -- `--pairs` of them PER GPU (weak scaling: independent 
 nodes are farmed across ranks, no data-path collective; the only RCCL traffic is the
 one-off broadcast of the rate-model constant block).
 
+The line carries, beside the headline (the full, unbanded DP):
+  * `banded_mode`: the same kind of pairs inside a band-20 GuideAlignmentEnvelope - the reference's default mode and
+    north_star's own target ("the banded forward DP for 2x2000-residue profile pairs") - at 512 pairs and at a
+    batch large enough to fill the chip, in-envelope cells counted;
+  * for N > 1, `strong`: configs[3] as written - 512 pairs IN TOTAL dealt to the N ranks.
+
   python bench.py                      # 1 GPU, defaults finish in a few minutes
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+  python bench.py --gpus N             # starts N rank processes itself (torch.distributed.run), one per GPU
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N      # the driver's form
 """
 import argparse
 import json
-import math
 import os
+import subprocess
 import sys
 import time
 
@@ -27,6 +34,24 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BYTES_PER_CELL = 40          # 5 fp64 states written once per cell (reference forward.h:13-15,107)
+MODES = ("trunc", "fast", "exact", "linear")
+MODE_KEY = {"exact": "exact_mode", "fast": "fast_mode", "linear": "scaled_probability_mode",
+            "trunc": "truncating_scaled_probability_mode"}
+KERNELS = {("exact", False): "hx::k_fill_chain<0,...,ExactLse3>", ("fast", False): "hx::k_fill_chain<0,...,FastLse>",
+           ("linear", False): "hx::k_fill_leaf_linear<W>", ("trunc", False): "hx::k_fill_leaf_linear<W,...,TRUNC>",
+           ("exact", True): "hx::k_fill_band<exact>", ("fast", True): "hx::k_fill_band<fast>",
+           ("linear", True): "hx::k_fill_band<scaled> / hx::k_fill_band2<false> (two pairs per wavefront above 512 pairs)",
+           ("trunc", True): "hx::k_fill_band<truncating scaled> / hx::k_fill_band2<true> (two pairs per wavefront above 512 pairs)"}
+ARITH = {"exact": "the reference's table log-sum-exp, cells bit-identical to the reference recursion",
+         "fast": "LDS-table log-sum-exp with the reference's truncation (lpEnd within 1e-9 rel. of the reference's, best paths "
+                 "identical to the reference's: 2000 of 2000 pairs, profiles/r03/trace_identity_sweep_seed7.json)",
+         "trunc": "scaled-probability recursion with the reference's truncation: every pairwise sum of the reference's left-nested "
+                  "log_sum_exp drops a term that is at most e^-10 of the other, as the reference's table does (src/logsumexp.h:45); "
+                  "no table, log-probabilities at the store; lpEnd within 1e-9 rel. of the reference's, best paths identical to the "
+                  "reference's: 2000 of 2000 pairs (profiles/r03/trace_identity_sweep_seed7.json)",
+         "linear": "scaled-probability recursion (fp64 sums of probabilities with a per-cell exponent, log-probabilities at the "
+                   "store; no truncation of small terms: lpEnd within 1e-5 rel., best paths may differ at near-ties: 4 of 2000, "
+                   "profiles/r02/trace_identity_sweep.json)"}
 
 
 def parse():
@@ -37,7 +62,7 @@ def parse():
     ap.add_argument("--pairs", type=int, default=512, help="independent pair DPs per GPU (weak scaling) or in total (strong)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --pairs pair DPs on every GPU.  strong: BASELINE configs[3] as written, --pairs pair DPs in "
-                         "total dealt to the GPUs")
+                         "total dealt to the GPUs (with N > 1 the weak line carries a `strong` block anyway)")
     ap.add_argument("--len", type=int, default=2000, dest="length", help="residues per sequence")
     ap.add_argument("--model", default="wag")
     ap.add_argument("--tl", type=float, default=0.2)
@@ -45,18 +70,32 @@ def parse():
     ap.add_argument("--cpu-pairs", type=int, default=10, help="pairs timed by the CPU baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--band", type=int, default=-1,
-                    help="guide-alignment band (maxDistanceFromGuide); the guide is the pair's true alignment. "
-                         "-1 = full envelope (the headline configuration)")
-    ap.add_argument("--mode", choices=["exact", "fast", "linear", "trunc"], default="fast",
-                    help="arithmetic of the headline fill.  fast (default) = LDS-table log-sum-exp with the reference's truncation: "
-                         "best paths identical to the reference's on all 2000 pairs of tools/sweep_trace_identity.py.  exact = the "
-                         "reference's table bit for bit.  linear = scaled probabilities (HX_LSE_LINEAR): fastest, but without the "
-                         "truncation 4 of those 2000 best paths differ, so it is reported as a secondary line.  The other "
-                         "policies are timed too")
-    ap.add_argument("--single-mode", action="store_true", help="time only --mode")
+                    help="guide-alignment band (maxDistanceFromGuide) of the HEADLINE workload; the guide is the pair's true "
+                         "alignment.  -1 = full envelope (the headline configuration; the banded block is added to it)")
+    ap.add_argument("--mode", choices=list(MODES), default="trunc",
+                    help="arithmetic of the headline fill.  trunc (default) = scaled probabilities with the reference's truncation; "
+                         "fast = LDS-table log-sum-exp with the reference's truncation; both have best paths identical to the "
+                         "reference's on all 2000 pairs of tools/sweep_trace_identity.py.  exact = the reference's table bit for "
+                         "bit.  linear = scaled probabilities without the truncation (best paths may differ at near-ties).  The "
+                         "other policies are timed too")
+    ap.add_argument("--single-mode", action="store_true", help="time only --mode; no banded block, no strong block")
+    ap.add_argument("--banded-pairs", default="512,4096", help="batch sizes of the banded block (band 20), comma separated; '' = none")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a PMC run (default: profiles/traffic.json entry for this workload)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU) as fresh children - before
+    anything in this process touches the GPU - and pass rank 0's line through."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
 
 
 def _cpu_fill_worker(spec):
@@ -75,9 +114,17 @@ def _cpu_fill_worker(spec):
 
 def main():
     args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's rank count and --gpus must agree" % (args.gpus, world))
+    strong = args.scaling == "strong"
+    if strong and args.pairs < world:
+        raise SystemExit("bench.py: --scaling strong needs at least one pair per rank (--pairs %d, %d ranks)" % (args.pairs, world))
     import torch
     import torch.distributed as dist
 
@@ -101,47 +148,40 @@ def main():
 
     # ---- rate-model constant block: built on rank 0, broadcast over RCCL/xGMI ----------------
     model = hostmodel.RateModel.load(os.path.join(ROOT, "tests", "golden", "models", args.model + ".json"))
-    a, c = len(model.alphabet), model.components()
     block = farm.constant_block(model, args.tl, args.tr) if rank == 0 else None
     block = farm.broadcast_block(block, farm.block_len(model), rank, world, coll_dev)
     table, sub_l, sub_r = farm.split_block(model, block)
 
     capi.init(dev_index, table)
     hmm = hostmodel.make_hmm(model, args.tl, args.tr, sub_l, sub_r)
-    pi = np.asarray(model.root[0], dtype=float)
-    pi = pi / pi.sum()
-
-    # strong scaling: BASELINE configs[3] as written - `--pairs` pairs IN TOTAL, dealt to the ranks; weak: per rank
-    strong = args.scaling == "strong"
-    n_local, first = farm.deal(args.pairs, world, rank, strong)
-    triples = []
-    env_cells = 0
-    env_cells_of = []
-    for k in range(n_local):
-        rng = np.random.default_rng(farm.pair_seed(0, 0, first + k))       # seed = 1000 + global pair index
-        triples.append(workload.leaf_pair(rng, model, hmm, args.length, band=args.band))
-        if args.band >= 0:
-            # in-envelope cells (reference src/forward.h:92-98): within the band, or at an edge
-            n_in = workload.in_envelope_cells(triples[-1][0].env_pos, triples[-1][1].env_pos, args.band)
-            env_cells_of.append(n_in)
-            env_cells += n_in
-        if rank == 0 and n_local > 1024 and (k + 1) % 1024 == 0:
-            print("built %d of %d pairs" % (k + 1, n_local), file=sys.stderr, flush=True)
     stream = torch.cuda.current_stream().cuda_stream
+    flags_of = {"exact": capi.HX_LSE_EXACT, "fast": capi.HX_LSE_FAST, "linear": capi.HX_LSE_LINEAR, "trunc": capi.HX_LSE_TRUNC}
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    traces = {}
+    def build(n, first, band):
+        """pairs `first` .. `first + n` of the global sequence of pairs (seed = 1000 + global index); with a
+        band also each pair's in-envelope cells (reference src/forward.h:92-98: within the band, or at an edge)"""
+        triples, env = [], []
+        for k in range(n):
+            rng = np.random.default_rng(farm.pair_seed(0, 0, first + k))
+            triples.append(workload.leaf_pair(rng, model, hmm, args.length, band=band))
+            if band >= 0:
+                env.append(workload.in_envelope_cells(triples[-1][0].env_pos, triples[-1][1].env_pos, band))
+            if rank == 0 and n > 1024 and (k + 1) % 1024 == 0:
+                print("built %d of %d pairs" % (k + 1, n), file=sys.stderr, flush=True)
+        return triples, env
 
-    def run_mode(mode):
-        """K timed passes of the hot path in one fill mode; returns (seconds, kernel ms list, lp_end, cells)."""
+    def timed(triples, mode, band, keep_traces=0):
+        """W warm-up passes, then exactly K timed passes of the hot path between barrier + synchronize on both sides; the
+        time is the MAX over ranks."""
         # banded batches are stored band-compressed (per strip only the swept step windows): thousands of pairs fit
-        batch = capi.Batch(triples, {"exact": capi.HX_LSE_EXACT, "fast": capi.HX_LSE_FAST, "linear": capi.HX_LSE_LINEAR, "trunc": capi.HX_LSE_TRUNC}[mode] |
-                           (capi.HX_BAND_COMPRESSED if args.band >= 0 else 0))
+        batch = capi.Batch(triples, flags_of[mode] | (capi.HX_BAND_COMPRESSED if band >= 0 else 0))
         n_cells = batch.total_cells()
+        shared = batch.shared_wavefront_pairs()
         for _ in range(args.warmup):
             batch.forward(stream)
         barrier()
@@ -153,44 +193,63 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        dt = time.perf_counter() - t0
-        dt = farm.max_over_ranks(dt, world, coll_dev)
+        dt = farm.max_over_ranks(time.perf_counter() - t0, world, coll_dev)
         lp = batch.lp_end()
-        # outside the timed region: the device-side best-path traceback of every pair (hx_batch_best_trace); the first
-        # few paths are compared with the CPU oracle's below
-        tcells, tlen = batch.best_trace(raw=True)
-        n_keep = max(1, min(args.cpu_pairs, n_local))
-        traces[mode] = [[tuple(int(v) for v in c) for c in tcells[k, :tlen[k]]] for k in range(n_keep)]
+        traces = None
+        if keep_traces:
+            # outside the timed region: the device-side best-path traceback of every pair (hx_batch_best_trace); the first
+            # few paths are compared with the CPU oracle's below
+            tcells, tlen = batch.best_trace(raw=True)
+            traces = [[tuple(int(v) for v in c) for c in tcells[k, :tlen[k]]] for k in range(min(keep_traces, len(triples)))]
         batch.close()
         assert np.all(np.isfinite(lp)) or os.environ.get("HX_BENCH_NOCHECK"), "non-finite Forward log-likelihood"
-        return dt, k_ms, lp, n_cells
+        return dict(dt=dt, kernel_ms=float(np.mean(k_ms)), lp_end=lp, cells=n_cells, traces=traces, shared_wavefront_pairs=shared)
 
-    order = [args.mode] + ([m for m in ("trunc", "fast", "exact", "linear") if m != args.mode] if not args.single_mode else [])
-    runs = {m: run_mode(m) for m in order}
-    dt, kernel_ms, lp_end, cells = runs[args.mode]
+    # ---- the headline workload ------------------------------------------------------------------------------------
+    # strong scaling: BASELINE configs[3] as written - `--pairs` pairs IN TOTAL, dealt to the ranks; weak: per rank
+    n_local, first = farm.deal(args.pairs, world, rank, strong)
+    triples, env_cells_of = build(n_local, first, args.band)
+    order = [args.mode] + ([m for m in MODES if m != args.mode] if not args.single_mode else [])
+    runs = {m: timed(triples, m, args.band, keep_traces=args.cpu_pairs) for m in order}
+    head = runs[args.mode]
+    cells = sum(env_cells_of) if args.band >= 0 else head["cells"]      # the metric counts in-envelope cells
+    gcells = farm.sum_over_ranks(cells, world, coll_dev) if strong else cells * world
 
-    KERNELS = {("exact", False): "hx::k_fill_chain<0,...,ExactLse3>", ("fast", False): "hx::k_fill_chain<0,...,FastLse>",
-               ("linear", False): "hx::k_fill_leaf_linear<W>", ("exact", True): "hx::k_fill_band<exact>",
-               ("fast", True): "hx::k_fill_band<fast>", ("linear", True): "hx::k_fill_band<scaled>",
-               ("trunc", False): "hx::k_fill_leaf_linear<W,...,TRUNC>", ("trunc", True): "hx::k_fill_band<truncating scaled>"}
-    ARITH = {"exact": "the reference's table log-sum-exp, cells bit-identical to the reference recursion",
-             "fast": "LDS-table log-sum-exp with the reference's truncation (lpEnd within 1e-9 rel. of the reference's, best paths "
-                     "identical to the reference's: 2000 of 2000 pairs, profiles/r02/trace_identity_sweep.json)",
-             "trunc": "scaled-probability recursion with the reference's truncation (every pairwise sum of the reference's left-nested "
-                      "log_sum_exp drops a term that is at most e^-10 of the other, as the reference's table does; no table, "
-                      "log-probabilities at the store)",
-             "linear": "scaled-probability recursion (fp64 sums of probabilities with a per-cell exponent, log-probabilities at the "
-                       "store; no truncation of small terms: lpEnd within 1e-5 rel., 4 of 2000 best paths differ from the reference's)"}
+    # ---- the strong-scaling block (N > 1 under a weak headline): configs[3] as written, 512 pairs in total ----------
+    strong_block = None
+    if world > 1 and not strong and not args.single_mode and args.band < 0:
+        s_total = 512
+        s_local, s_first = farm.deal(s_total, world, rank, True)
+        # (rank 0's slice is a prefix of its weak batch; the other ranks build theirs)
+        s_triples = triples[:s_local] if (s_first == first and s_local <= n_local) else build(s_local, s_first, -1)[0]
+        r = timed(s_triples, args.mode, -1)
+        s_cells = farm.sum_over_ranks(r["cells"], world, coll_dev)
+        strong_block = {"workload": "BASELINE configs[3] as written: %d pairs in total dealt to the %d ranks" % (s_total, world),
+                        "pairs_total": s_total, "pairs_per_gpu": s_local, "value": s_cells * args.steps / r["dt"], "unit": "cells/s",
+                        "ms_per_step": r["dt"] / args.steps * 1e3, "scaling": "strong", "fill_mode": args.mode}
+
+    # ---- the banded block: band 20, the reference's default mode and north_star's own target ------------------------
+    banded_block = None
+    if args.band < 0 and not args.single_mode and args.banded_pairs:
+        banded_block = {"band": 20, "fill_mode": args.mode, "arithmetic": ARITH[args.mode], "kernel": KERNELS[(args.mode, True)],
+                        "cells_counted": "in-envelope cells (band + envelope edges), band-compressed storage", "unit": "cells/s",
+                        "scaling": "weak", "batches": []}
+        sizes = sorted(int(v) for v in args.banded_pairs.split(","))
+        # (weak: every rank its own pairs; a rank's smaller batch is a prefix of its larger one)
+        have, have_env = build(sizes[-1], rank * sizes[-1], 20)
+        for n_b in sizes:
+            b_env = have_env[:n_b]
+            r = timed(have[:n_b], args.mode, 20)
+            b_cells = sum(b_env)
+            banded_block["batches"].append({
+                "pairs_per_gpu": n_b, "in_envelope_cells_per_gpu": b_cells, "value": b_cells * world * args.steps / r["dt"],
+                "ms_per_step": r["dt"] / args.steps * 1e3, "kernel_ms": r["kernel_ms"],
+                "pairs_sharing_a_wavefront": r["shared_wavefront_pairs"],
+                "roofline_frac": b_cells * BYTES_PER_CELL / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS})
+
     if rank == 0:
-        if args.band >= 0:
-            cells = env_cells          # the metric counts in-envelope cells
-        gcells = farm.sum_over_ranks(cells, world, coll_dev) if strong else cells * world
-    elif strong:
-        farm.sum_over_ranks(env_cells if args.band >= 0 else cells, world, coll_dev)
-    if rank == 0:
-        total_cells = gcells * args.steps
-        value = total_cells / dt
-        k_ms = float(np.mean(kernel_ms))
+        dt, k_ms, lp_end = head["dt"], head["kernel_ms"], head["lp_end"]
+        value = gcells * args.steps / dt
         traffic = args.traffic
         if traffic is None:
             try:        # measured with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes), see DESIGN.md
@@ -219,16 +278,19 @@ def main():
             "fill_mode": args.mode,
             "lp_end_pair0": float(lp_end[0]),
         }
-        ref_lp = runs["exact"][2] if "exact" in runs else None
+        ref_lp = runs["exact"]["lp_end"] if "exact" in runs else None
         for m in order[1:]:
-            dt_m, k_list, lp_m, _ = runs[m]
-            k_m = float(np.mean(k_list))
-            out[{"exact": "exact_mode", "fast": "fast_mode", "linear": "scaled_probability_mode", "trunc": "truncating_scaled_probability_mode"}[m]] = {
+            r = runs[m]
+            out[MODE_KEY[m]] = {
                 "arithmetic": ARITH[m], "kernel": KERNELS[(m, args.band >= 0)],
-                "value": gcells * args.steps / dt_m, "unit": "cells/s", "ms_per_step": dt_m / args.steps * 1e3, "kernel_ms": k_m,
-                "roofline_frac": cells * BYTES_PER_CELL / (k_m * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                "value": gcells * args.steps / r["dt"], "unit": "cells/s", "ms_per_step": r["dt"] / args.steps * 1e3,
+                "kernel_ms": r["kernel_ms"], "roofline_frac": cells * BYTES_PER_CELL / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if ref_lp is not None:
-            out["lp_end_max_rel_diff_to_exact"] = {m: float(np.max(np.abs(runs[m][2] - ref_lp) / np.abs(ref_lp))) for m in order if m != "exact"}
+            out["lp_end_max_rel_diff_to_exact"] = {m: float(np.max(np.abs(runs[m]["lp_end"] - ref_lp) / np.abs(ref_lp))) for m in order if m != "exact"}
+        if banded_block is not None:
+            out["banded_mode"] = banded_block
+        if strong_block is not None:
+            out["strong"] = strong_block
         if world == 1 and not args.no_cpu_baseline:
             from oracle import c_oracle           # the checker, timed as the CPU baseline ("port")
             c_oracle.load()
@@ -247,8 +309,8 @@ def main():
                 # traceback identity: the reference's bestTrace over the CPU matrix vs the device's paths
                 cpu_dt += time.perf_counter() - t1
                 path = trace_oracle.best_trace(x, y, h, md, r)
-                for m in traces:
-                    same[m] = same.get(m, 0) + (traces[m][k] == path)
+                for m in runs:
+                    same[m] = same.get(m, 0) + (runs[m]["traces"][k] == path)
                 t1 = time.perf_counter()
             out["cpu_baseline"] = {"value": cpu_cells / cpu_dt, "unit": "cells/s", "cores": 1, "kind": "port",
                                    "sample": "first %d pair(s) of the same batch, oracle/oracle_fill.c "
@@ -276,7 +338,7 @@ def main():
             out["cpu_baseline"]["all_cores"] = {"value": (cpu_cells / n_cpu) * n_all / all_dt, "unit": "cells/s", "cores": n_proc,
                                                 "sample": "%d pairs of the same workload over %d processes, %.1f s" % (n_all, n_proc, all_dt)}
             out["lp_end_max_rel_err_vs_cpu"] = rel
-            out["best_trace_identical_to_cpu"] = {m: "%d of %d pairs" % (same.get(m, 0), n_cpu) for m in traces}
+            out["best_trace_identical_to_cpu"] = {m: "%d of %d pairs" % (same.get(m, 0), n_cpu) for m in runs}
             assert rel <= 1e-4, "Forward log-likelihoods outside north_star's tolerance of the CPU path: %g" % rel
         print(json.dumps(out))
     if world > 1:

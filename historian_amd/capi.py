@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HX_LIB_PATH") or os.path.join(_HERE, "lib", "libhistorian_hip.so")
 
 HX_LSE_TABLE_ENTRIES = 100002
-HX_LSE_EXACT, HX_LSE_FAST, HX_KEEP_BACKWARD, HX_FORCE_GENERIC, HX_SPARSE_ENVELOPE = 0, 1, 2, 4, 8
+HX_LSE_EXACT, HX_LSE_FAST, HX_KEEP_BACKWARD, HX_FORCE_GENERIC, HX_SPARSE_ENVELOPE = 128, 1, 2, 4, 8
+HX_LSE_DEFAULT = 256    # the library's default policy (flags without any policy bit: HX_LSE_TRUNC)
 HX_BAND_COMPRESSED = 32   # banded jobs keep only the swept step windows (include/historian_hip.h)
 HX_LSE_TRUNC = 81       # HX_LSE_LINEAR with the reference's truncation of terms at most e^-10 of their sum (include/historian_hip.h)
 HX_LSE_LINEAR = 17      # HX_LSE_FAST + scaled-probability Forward fill where it applies (include/historian_hip.h)
@@ -79,7 +80,7 @@ EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_cr
            "hx_host_free", "hx_quick_batch_create", "hx_quick_batch_destroy", "hx_quick_batch_run",
            "hx_quick_batch_results", "hx_quick_batch_layout", "hx_quick_batch_read_matrix",
            "hx_quick_batch_total_cells", "hx_quick_batch_last_kernel_ms", "hx_sumprod_columns", "hx_sumprod_last_kernel_ms",
-           "hx_batch_read_matrix_async", "hx_batch_wait_read", "hx_batch_indel_counts", "hx_batch_shared_wavefront_pairs"]
+           "hx_batch_read_matrix_async", "hx_batch_wait_read", "hx_batch_indel_counts", "hx_batch_shared_wavefront_pairs", "hx_batch_relaunches"]
 
 
 class HxError(RuntimeError):
@@ -123,6 +124,7 @@ def load():
     lib.hx_batch_job_kernel.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.hx_batch_total_cells.argtypes = [vp]
     lib.hx_batch_shared_wavefront_pairs.argtypes = [vp]
+    lib.hx_batch_relaunches.argtypes = [vp]
     lib.hx_batch_total_cells.restype = C.c_int64
     lib.hx_batch_last_kernel_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
     lib.hx_quick_batch_create.argtypes = [C.POINTER(HxQuickJob), C.c_int32, C.POINTER(vp)]
@@ -260,6 +262,13 @@ class Batch:
     """n independent pair DPs resident on the device."""
 
     def __init__(self, triples, flags=0, device=None):
+        """flags: HX_* bits.  This binding is what the parity tests drive, so WITHOUT a policy bit it asks for the bit-exact
+        policy (HX_LSE_EXACT) - unlike the C ABI itself, whose default is the fastest policy with the reference's best
+        paths (HX_LSE_TRUNC); pass HX_LSE_DEFAULT to get the library's default."""
+        if flags & HX_LSE_DEFAULT:
+            flags &= ~HX_LSE_DEFAULT
+        elif not flags & (HX_LSE_TRUNC | HX_LSE_EXACT):
+            flags |= HX_LSE_EXACT
         self._keep = triples
         self.n = len(triples)
         self._jobs = make_jobs(triples)
@@ -319,6 +328,10 @@ class Batch:
         if n < 0:
             _check(n)
         return n
+
+    def relaunches(self):
+        """fills repeated with one workgroup per pair after waves of a several-workgroups launch gave up"""
+        return int(load().hx_batch_relaunches(self._h))
 
     def kernel_ms(self, which=0):
         ms = C.c_float()

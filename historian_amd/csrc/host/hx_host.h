@@ -771,13 +771,13 @@ struct AlignGraph {
     Edge() : lp(-std::numeric_limits<double>::infinity()) {}
     bool operator<(const Edge& other) const { return lp < other.lp; }
   };
-  struct Partition {
-    size_t nSets;
-    vguard<set<size_t>> seqSet;
-    vguard<size_t> seqSetIdx;
-    explicit Partition(size_t nSequences);
-    void merge(const TrialEdge& edge);
-    bool inSameSet(const TrialEdge& edge) const;
+  struct Components {              // disjoint sets of sequences: union-find forest + each set's members in ascending order
+    vguard<size_t> up;
+    vguard<vguard<size_t>> members;
+    size_t count;
+    explicit Components(size_t nSequences);
+    size_t root(size_t sequence);
+    void join(size_t a, size_t b);
   };
 
   const RateModel& model;
@@ -790,6 +790,8 @@ struct AlignGraph {
   AlignGraph(const vguard<FastSeq>& seqs, const RateModel& model, const double time, const DiagEnvParams& diagEnvParams,
              ForwardMatrix::random_engine& generator);
   AlignGraph(const vguard<FastSeq>& sequences, const RateModel& rates, double branchLength, const DiagEnvParams& envelopeParams);
+  AlignGraph(const vguard<FastSeq>& sequences, const RateModel& rates, double branchLength, const DiagEnvParams& envelopeParams,
+             ForwardMatrix::random_engine* rngOrNull);
   void buildDenseGraph();
   void buildSparseRandomGraph(ForwardMatrix::random_engine& rng);
   void buildGraph(const list<TrialEdge>& candidates, const string& description);

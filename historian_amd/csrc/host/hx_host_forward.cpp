@@ -18,13 +18,13 @@ namespace historian {
 
 static const double NEG_INF = -std::numeric_limits<double>::infinity();
 
-static unsigned g_fillMode = HX_LSE_EXACT;
+static unsigned g_fillMode = HX_LSE_TRUNC;    // the library's default policy; HX_FILL_MODE=exact / setFillMode(HX_LSE_EXACT): bit-identical
 static std::mutex g_deviceMutex;                  // device initialisation and the pinned-buffer pool
 static bool g_deviceReady[32] = {false};
 static bool g_modeRead = false;
 static thread_local int t_device = -1;
 
-void DPMatrix::setFillMode(unsigned hxFlags) { g_fillMode = hxFlags & HX_LSE_TRUNC; }
+void DPMatrix::setFillMode(unsigned hxFlags) { g_fillMode = hxFlags & (HX_LSE_TRUNC | HX_LSE_EXACT); }
 static int g_deviceTraceback = -1;
 void DPMatrix::setDeviceTraceback(bool on) { g_deviceTraceback = on ? 1 : 0; }
 bool DPMatrix::deviceTraceback() {
@@ -49,7 +49,8 @@ static void ensureDevice(int ordinal) {
   std::lock_guard<std::mutex> lock(g_deviceMutex);
   Require(ordinal >= 0 && ordinal < 32, "device ordinal %d out of range", ordinal);
   if (!g_modeRead) {
-    const char* mode = getenv("HX_FILL_MODE");   // "fast" selects the fast log-sum-exp policy for this process
+    const char* mode = getenv("HX_FILL_MODE");   // exact | fast | linear | trunc (default): the arithmetic policy of this process's fills
+    if (mode && string(mode) == "exact") g_fillMode = HX_LSE_EXACT;
     if (mode && string(mode) == "fast") g_fillMode = HX_LSE_FAST;
     if (mode && string(mode) == "linear") g_fillMode = HX_LSE_LINEAR;
     if (mode && string(mode) == "trunc") g_fillMode = HX_LSE_TRUNC;

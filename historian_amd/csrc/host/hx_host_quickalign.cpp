@@ -25,29 +25,28 @@ UnvalidatedTokSeq unvalidatedTokens(const FastSeq& seq, const string& alphabet) 
   return tok;
 }
 
+// a window of k tokens is a k-mer when none of them lies outside the alphabet (token -1) ...
 bool kmerValid(SeqIdx k, vguard<int>::const_iterator tok) {
-  for (SeqIdx j = 0; j < k; ++j)
-    if (tok[j] < 0) return false;
-  return true;
+  return std::find_if(tok, tok + k, [](int token) { return token < 0; }) == tok + k;
 }
 
+// ... and its code is the window read as a base-|alphabet| number, first token most significant
 Kmer makeKmer(SeqIdx k, vguard<int>::const_iterator tok, AlphTok alphabetSize) {
-  Kmer kmer = 0, mul = 1;
-  for (SeqIdx j = 0; j < k; ++j) {
-    const int token = tok[k - j - 1];
-    Assert(token >= 0, "Invalid token in makeKmer");
-    kmer += mul * token;
-    mul *= alphabetSize;
+  Kmer code = 0;
+  for (auto t = tok; t != tok + k; ++t) {
+    Assert(*t >= 0, "Invalid token in makeKmer");
+    code = code * alphabetSize + (Kmer)*t;
   }
-  return kmer;
+  return code;
 }
 
 KmerIndex::KmerIndex(const FastSeq& seq, const string& alphabet, SeqIdx kmerLen) : kmerLen(kmerLen), alphabet(alphabet), seq(seq) {
+  // every window of kmerLen tokens that lies inside the alphabet, filed under its code by start position
   const UnvalidatedTokSeq tok = unvalidatedTokens(seq, alphabet);
-  const AlphTok alphabetSize = (AlphTok)alphabet.size();
-  const SeqIdx seqLen = seq.length();
-  for (SeqIdx j = 0; j + kmerLen <= seqLen; ++j)
-    if (kmerValid(kmerLen, tok.begin() + j)) kmerLocations[makeKmer(kmerLen, tok.begin() + j, alphabetSize)].push_back(j);
+  if (tok.size() < kmerLen) return;
+  for (auto window = tok.begin(); window + kmerLen <= tok.end(); ++window)
+    if (kmerValid(kmerLen, window))
+      kmerLocations[makeKmer(kmerLen, window, (AlphTok)alphabet.size())].push_back((SeqIdx)(window - tok.begin()));
 }
 
 void writeFastaSeqs(std::ostream& out, const vguard<FastSeq>& fastSeqs) {
@@ -125,17 +124,20 @@ bool DiagonalEnvelope::contains(SeqIdx i, SeqIdx j) const {
   return iter != diagonals.end() && *iter == diag;
 }
 
+// The x positions of column j's envelope cells, ascending: diagonals are kept sorted, and a diagonal d meets column j at row
+// d + j, inside the matrix for d in (-j, xLen - j] - a contiguous stretch of the sorted list.
 vguard<SeqIdx> DiagonalEnvelope::forward_i(SeqIdx j) const {
-  vguard<SeqIdx> i_vec;
-  i_vec.reserve(diagonals.size());
-  for (auto d : diagonals)
-    if (intersects(j, d)) i_vec.push_back(get_i(j, d));
-  return i_vec;
+  const auto lo = std::upper_bound(diagonals.begin(), diagonals.end(), -(int)j);
+  const auto hi = std::upper_bound(lo, diagonals.end(), (int)xLen - (int)j);
+  vguard<SeqIdx> rows(hi - lo);
+  std::transform(lo, hi, rows.begin(), [j](int d) { return (SeqIdx)(d + (int)j); });
+  return rows;
 }
 
 vguard<SeqIdx> DiagonalEnvelope::reverse_i(SeqIdx j) const {
-  const vguard<SeqIdx> f = forward_i(j);
-  return vguard<SeqIdx>(f.rbegin(), f.rend());
+  vguard<SeqIdx> rows = forward_i(j);
+  std::reverse(rows.begin(), rows.end());
+  return rows;
 }
 
 // ---- src/quickalign.cpp -----------------------------------------------------------------------
@@ -270,14 +272,9 @@ LogProb QuickAlignMatrix::getCell(SeqIdx i, SeqIdx j, unsigned int offset) const
 }
 
 LogProb QuickAlignMatrix::cellScore(SeqIdx i, SeqIdx j, State state) const {
-  LogProb cs = std::numeric_limits<double>::quiet_NaN();
-  switch (state) {
-    case Match: cs = mat(i, j); break;
-    case Insert: cs = ins(i, j); break;
-    case Delete: cs = del(i, j); break;
-    default: break;
-  }
-  return cs;
+  if (state == Match) return mat(i, j);
+  if (state == Insert) return ins(i, j);
+  return state == Delete ? del(i, j) : std::numeric_limits<double>::quiet_NaN();     // (Start has no cell)
 }
 
 const char* QuickAlignMatrix::stateToString(State state) {
@@ -291,11 +288,11 @@ const char* QuickAlignMatrix::stateToString(State state) {
   return "Unknown";
 }
 
-void QuickAlignMatrix::updateMax(double& currentMax, State& currentMaxIdx, double candidateMax, State candidateMaxIdx) {
-  if (candidateMax > currentMax) {
-    currentMax = candidateMax;
-    currentMaxIdx = candidateMaxIdx;
-  }
+// (a later candidate replaces the best so far only when strictly better: the first source in consideration order wins ties)
+void QuickAlignMatrix::updateMax(double& best, State& bestState, double candidate, State candidateState) {
+  const bool better = candidate > best;
+  best = better ? candidate : best;
+  bestState = better ? candidateState : bestState;
 }
 
 // Viterbi traceback (behaviour of reference src/quickalign.cpp:147-207).  Walks back from (xEnd, yEnd, Match),
@@ -361,11 +358,8 @@ AlignPath QuickAlignMatrix::alignPath() const {
 }
 
 AlignPath QuickAlignMatrix::alignPath(AlignRowIndex row1, AlignRowIndex row2) const {
-  AlignPath oldPath = alignPath();
-  AlignPath newPath;
-  newPath[row1] = oldPath[0];
-  newPath[row2] = oldPath[1];
-  return newPath;
+  const AlignPath two = alignPath();          // rows 0 (x) and 1 (y), renumbered
+  return AlignPath{{row1, two.at(0)}, {row2, two.at(1)}};
 }
 
 vguard<FastSeq> QuickAlignMatrix::gappedSeq() const {

@@ -175,66 +175,83 @@ size_t DiagEnvParams::effectiveMaxSize() const {
 }
 
 // ---- src/span.cpp --------------------------------------------------------------------------------
-// Disjoint sets of sequence indices; the union keeps the smaller set index, so seqSet.front() is always the
-// component of sequence 0 (the spanning tree below grows from it).
-AlignGraph::Partition::Partition(size_t n) : nSets(n), seqSet(n), seqSetIdx(n) {
+// Disjoint sets of sequence indices as a union-find forest: parent links with path halving, and at every root the set's
+// members in ascending order (the spanning tree below scans the members of sequence 0's set in that order, which is what
+// decides between equally good edges).
+AlignGraph::Components::Components(size_t n) : up(n), members(n), count(n) {
   for (size_t k = 0; k < n; ++k) {
-    seqSetIdx[k] = k;
-    seqSet[k].insert(k);
+    up[k] = k;
+    members[k].assign(1, k);
   }
 }
 
-bool AlignGraph::Partition::inSameSet(const AlignGraph::TrialEdge& e) const { return seqSetIdx[e.row1] == seqSetIdx[e.row2]; }
-
-void AlignGraph::Partition::merge(const AlignGraph::TrialEdge& e) {
-  if (inSameSet(e)) return;
-  const size_t keep = std::min(seqSetIdx[e.row1], seqSetIdx[e.row2]);
-  const size_t drop = std::max(seqSetIdx[e.row1], seqSetIdx[e.row2]);
-  for (size_t member : seqSet[drop]) {
-    seqSetIdx[member] = keep;
-    seqSet[keep].insert(member);
+size_t AlignGraph::Components::root(size_t k) {
+  while (up[k] != k) {
+    up[k] = up[up[k]];
+    k = up[k];
   }
-  seqSet[drop].clear();
-  --nSets;
+  return k;
 }
 
-AlignGraph::AlignGraph(const vguard<FastSeq>& seqs, const RateModel& model, const double time, const DiagEnvParams& diagEnvParams,
-                       ForwardMatrix::random_engine& generator)
-    : model(model), time(time), seqs(seqs), diagEnvParams(diagEnvParams), edges(seqs.size()), edgePath(seqs.size()) {
-  buildSparseRandomGraph(generator);
+void AlignGraph::Components::join(size_t a, size_t b) {
+  size_t big = root(a), small = root(b);
+  if (big == small) return;
+  if (members[big].size() < members[small].size()) std::swap(big, small);
+  vguard<size_t> both(members[big].size() + members[small].size());
+  std::merge(members[big].begin(), members[big].end(), members[small].begin(), members[small].end(), both.begin());
+  members[big].swap(both);
+  vguard<size_t>().swap(members[small]);
+  up[small] = big;
+  --count;
 }
 
-AlignGraph::AlignGraph(const vguard<FastSeq>& seqs, const RateModel& model, const double time, const DiagEnvParams& diagEnvParams)
-    : model(model), time(time), seqs(seqs), diagEnvParams(diagEnvParams), edges(seqs.size()), edgePath(seqs.size()) {
-  buildDenseGraph();
+AlignGraph::AlignGraph(const vguard<FastSeq>& sequences, const RateModel& rates, const double branchLength,
+                       const DiagEnvParams& envelopeParams, ForwardMatrix::random_engine& rng)
+    : AlignGraph(sequences, rates, branchLength, envelopeParams, &rng) {}
+
+AlignGraph::AlignGraph(const vguard<FastSeq>& sequences, const RateModel& rates, const double branchLength, const DiagEnvParams& envelopeParams)
+    : AlignGraph(sequences, rates, branchLength, envelopeParams, nullptr) {}
+
+// (with a generator: the sparse random graph; without: every pair)
+AlignGraph::AlignGraph(const vguard<FastSeq>& sequences, const RateModel& rates, const double branchLength, const DiagEnvParams& envelopeParams,
+                       ForwardMatrix::random_engine* rng)
+    : model(rates), time(branchLength), seqs(sequences), diagEnvParams(envelopeParams) {
+  edges.resize(seqs.size());
+  edgePath.resize(seqs.size());
+  if (rng) buildSparseRandomGraph(*rng);
+  else buildDenseGraph();
 }
 
+// every unordered pair once, lower index first, in row-major order
 void AlignGraph::buildDenseGraph() {
-  list<TrialEdge> e;
-  for (AlignRowIndex src = 0; src + 1 < seqs.size(); ++src)
-    for (AlignRowIndex dest = src + 1; dest < seqs.size(); ++dest) e.push_back(TrialEdge(src, dest));
-  buildGraph(e, "all-vs-all");
+  const size_t n = seqs.size();
+  list<TrialEdge> everyPair;
+  for (size_t k = 0; k < n * n; ++k)
+    if (k / n < k % n) everyPair.emplace_back(k / n, k % n);
+  buildGraph(everyPair, "all-vs-all");
 }
 
+// Random pairs until there are n log2(n) of them (or all) AND the graph is connected.  The draws are the reference's
+// (src/span.cpp:57-85): two indices per attempt from one uniform_int_distribution, ordered, attempts that repeat a pair or
+// hit the diagonal are drawn again - so the generator is left where the reference leaves it.
 void AlignGraph::buildSparseRandomGraph(ForwardMatrix::random_engine& generator) {
-  list<TrialEdge> trialEdges;
-  map<AlignRowIndex, set<AlignRowIndex> > targets;
-  Partition part(seqs.size());
-  const size_t nEdges = std::min((size_t)(seqs.size() * (seqs.size() - 1) / 2),
-                                 (size_t)ceil(log(seqs.size()) * (double)seqs.size() / log(2)));
-  std::uniform_int_distribution<size_t> dist(0, seqs.size() - 1);
-  for (size_t n = 0; n < nEdges || part.nSets > 1; ++n) {
-    size_t src, dest;
+  const size_t n = seqs.size();
+  const size_t wanted = std::min(n * (n - 1) / 2, (size_t)ceil(log((double)n) * (double)n / log(2)));
+  std::uniform_int_distribution<size_t> anySequence(0, n - 1);
+  std::set<std::pair<size_t, size_t>> taken;
+  Components linked(n);
+  list<TrialEdge> picked;
+  while (picked.size() < wanted || linked.count > 1) {
+    std::pair<size_t, size_t> p;
     do {
-      src = dist(generator);
-      dest = dist(generator);
-      if (dest < src) std::swap(src, dest);
-    } while (src == dest || targets[src].count(dest));
-    targets[src].insert(dest);
-    trialEdges.push_back(TrialEdge(src, dest));
-    part.merge(trialEdges.back());
+      p.first = anySequence(generator);
+      p.second = anySequence(generator);
+      if (p.second < p.first) std::swap(p.first, p.second);
+    } while (p.first == p.second || !taken.insert(p).second);
+    picked.emplace_back(p.first, p.second);
+    linked.join(p.first, p.second);
   }
-  buildGraph(trialEdges, std::to_string(trialEdges.size()) + " random pairs");
+  buildGraph(picked, std::to_string(picked.size()) + " random pairs");
 }
 
 // The reference aligns the pairs one after the other (src/span.cpp:92-120); here the envelopes are
@@ -260,12 +277,10 @@ void AlignGraph::buildGraph(const list<TrialEdge>& trialEdges, const string&) {
     const size_t src = trialEdge.row1, dest = trialEdge.row2;
     QuickAlignMatrix& mx = *mxs[k];
     edgePath[src][dest] = mx.alignPath(src, dest);
-    Edge e;
-    e.row1 = src;
-    e.row2 = dest;
-    e.lp = mx.end;
-    edges[src].push(e);
-    edges[dest].push(e);
+    Edge scored;                       // the pair's Viterbi score, queued at both of its sequences
+    static_cast<TrialEdge&>(scored) = trialEdge;
+    scored.lp = mx.end;
+    for (const size_t at : {src, dest}) edges[at].push(scored);
     delete mxs[k];
     delete envs[k];
     ++k;
@@ -277,30 +292,32 @@ void AlignGraph::buildGraph(const list<TrialEdge>& trialEdges, const string&) {
 // have become internal are discarded lazily).  Returns the alignments of the chosen edges in selection order.
 list<AlignPath> AlignGraph::minSpanTree() {
   list<AlignPath> chosen;
-  Partition components(seqs.size());
-  while (components.nSets > 1) {
+  Components components(seqs.size());
+  while (components.count > 1) {
     const Edge* best = NULL;
-    for (size_t member : components.seqSet.front()) {
+    for (size_t member : components.members[components.root(0)]) {
       std::priority_queue<Edge>& heap = edges[member];
-      while (!heap.empty() && components.inSameSet(heap.top())) heap.pop();
+      while (!heap.empty() && components.root(heap.top().row1) == components.root(heap.top().row2)) heap.pop();
       if (!heap.empty() && (best == NULL || *best < heap.top())) best = &heap.top();
     }
     Assert(best != NULL, "Found no valid edge");
     const Edge taken = *best;
     chosen.push_back(edgePath[taken.row1][taken.row2]);
-    components.merge(taken);
+    components.join(taken.row1, taken.row2);
     if (getenv("HX_DEBUG_SPAN")) fprintf(stderr, "mst %d %d %a\n", (int)taken.row1, (int)taken.row2, taken.lp);
   }
   return chosen;
 }
 
 AlignPath AlignGraph::mstPath() {
-  const list<AlignPath> pathList = minSpanTree();
-  const vguard<AlignPath> pathVec(pathList.begin(), pathList.end());
-  return alignPathMerge(pathVec);
+  const list<AlignPath> tree = minSpanTree();
+  return alignPathMerge(vguard<AlignPath>(tree.begin(), tree.end()));
 }
 
-Alignment AlignGraph::mstAlign() { return Alignment(seqs, mstPath()); }
+Alignment AlignGraph::mstAlign() {
+  const AlignPath merged = mstPath();
+  return Alignment(seqs, merged);
+}
 
 vguard<FastSeq> AlignGraph::mstGapped() { return mstAlign().gapped(); }
 

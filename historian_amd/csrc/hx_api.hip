@@ -547,6 +547,9 @@ struct hx_batch {
   size_t lp_end_off = 0, lp_start_off = 0;   // [n_jobs] doubles each in the arena, caller's order: one copy per read
   int64_t total_cells = 0;
   bool forward_done = false, backward_done = false;
+  bool used_multi[2] = {false, false};   // the last Forward / Backward launch dealt some pair to several workgroups
+  bool no_multi = false;                 // ... which once failed (waves gave up waiting for one another): one workgroup per pair from now on
+  int relaunches = 0;                    // fills repeated for that reason
   bool sub_scattered = false;        // subx / suby of table-emission jobs exist per state (k_scatter_sub, on demand)
   hipStream_t last_stream = nullptr;
   hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -861,7 +864,7 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
             for (int i = 0; i + 32 < J.n_rows; ++i) if (first(i + 32) < last(i) + 3) return false;
             return true;
           };
-          J.band_w32 = (ring32(rows) && (jo.compressed || ring32(rows_b)) &&
+          J.band_w32 = (J.blk == 2 * HX_STRIP && ring32(rows) && (jo.compressed || ring32(rows_b)) &&
                         band2_kernel_fits(J.n_rows, J.n_cols, std::max(jo.x.n_cls, jo.y.n_cls))) ? 1 : 0;
           J.band_steps_bwd = 0;
           if (!jo.compressed) {
@@ -1004,6 +1007,10 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
 }
 
 int hx_batch_create_on(int device, const hx_pair_job* jobs, int32_t n_jobs, uint32_t flags, hx_batch** out) {
+  // the arithmetic policy: HX_LSE_EXACT overrides the other policy bits; no policy bit at all = the default, HX_LSE_TRUNC.
+  // Inside the library "exact" is the absence of the fast / linear / truncating bits.
+  if (flags & HX_LSE_EXACT) flags &= ~(HX_LSE_EXACT | HX_LSE_TRUNC);
+  else if (!(flags & HX_LSE_TRUNC)) flags |= HX_LSE_TRUNC;
   try {
     return batch_create_impl(device, jobs, n_jobs, flags, out);
   } catch (const std::bad_alloc&) {         // (std::vector / Arena growth: nothing throws across the ABI)
@@ -1071,6 +1078,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   const bool trunc = (b->flags & HX_LSE_TRUNC) == HX_LSE_TRUNC;
   const Tab16 lse_tab{fast ? D.fast_tab : D.pair_tab};    // FastPiece table, or the exact mode's {f0, df} pairs
   LAUNCH_TRY(launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_cls, b->max_ca, b->max_cls_pairs, Tab8{D.tab}, st));
+  b->used_multi[0] = false;
   HIP_TRY(hipEventRecord(b->ev[0][0], st));
   // per-cell emission terms of the jobs without a class-pair table (general profiles).  Part of the fill:
   // the reference evaluates them inside its fill loop, so the launch is inside the timed region.
@@ -1099,8 +1107,9 @@ int hx_batch_forward(hx_batch* b, void* stream) {
         // HX_LSE_LINEAR on leaf pairs whose y side fits LDS: the recursion runs on scaled probabilities instead of
         // table log-sum-exps (hx_linear.hip)
         // a small batch of unbanded leaf pairs (one rank's share of a strong-scaling run): several workgroups per pair
-        int multi = (leaf == 2 && !banded && cr.n <= HX_MULTI_COUNTER_PAIRS) ? chain_multi_groups(cr.n, cr.max_rows, linear ? 64 : 128) : 1;
+        int multi = (leaf == 2 && !banded && cr.n <= HX_MULTI_COUNTER_PAIRS && !b->no_multi) ? chain_multi_groups(cr.n, cr.max_rows, linear ? 64 : 128) : 1;
         if (multi > 1) {
+          b->used_multi[0] = true;
           if (!b->d_multi && hipMalloc(reinterpret_cast<void**>(&b->d_multi), 2 * HX_MULTI_COUNTER_PAIRS * 256 * sizeof(int)) != hipSuccess)
             return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of the progress counters failed");
           HIP_TRY(hipMemsetAsync(b->d_multi, 0, (size_t)cr.n * 256 * sizeof(int), st));
@@ -1123,7 +1132,8 @@ int hx_batch_forward(hx_batch* b, void* stream) {
           // a lone pair (or two) of more than sixteen strips: dealt to several workgroups, as the Backward fill is (below)
           int multi = 1, multi_waves = 4;
           const char* min_strips = getenv("HX_DAG_MULTI_MIN_STRIPS");
-          if (cr.n <= HX_MULTI_MAX_PAIRS && cr.max_rows > (min_strips ? atoi(min_strips) : 16) * HX_STRIP && !getenv("HX_DAG_FWD_SINGLE")) {
+          if (cr.n <= HX_MULTI_MAX_PAIRS && cr.max_rows > (min_strips ? atoi(min_strips) : 16) * HX_STRIP && !getenv("HX_DAG_FWD_SINGLE") && !b->no_multi) {
+            b->used_multi[0] = true;
             const int strips = (cr.max_rows + HX_STRIP - 1) / HX_STRIP;
             if (const char* e = getenv("HX_DAG_MULTI_WAVES")) multi_waves = atoi(e);
             if (multi_waves != 8 && multi_waves != 2) multi_waves = 4;
@@ -1172,6 +1182,7 @@ int hx_batch_backward(hx_batch* b, void* stream) {
     // the Backward fill reads what the Forward launch prepared (and, for the posterior, follows it): order the streams
     HIP_TRY(hipStreamWaitEvent(st, b->ev[0][1], 0));
   }
+  b->used_multi[1] = false;
   HIP_TRY(hipEventRecord(b->ev[1][0], st));
   for (int c = 0; c < KC_COUNT; ++c) {
     const ClassRange& cr = b->cls[c];
@@ -1190,9 +1201,10 @@ int hx_batch_backward(hx_batch* b, void* stream) {
           LAUNCH_TRY(launch_backward_band(jobs, cr.n, linear ? (trunc ? 3 : 0) : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab},
                                           linear ? Tab16{D.log_tab} : lse_tab, (b->flags & HX_SPARSE_ENVELOPE) != 0, st));
         else {
-          int multi = (leaf == 2 && !banded && cr.n <= HX_MULTI_COUNTER_PAIRS) ? chain_multi_groups(cr.n, cr.max_rows, linear ? 64 : 128) : 1;
+          int multi = (leaf == 2 && !banded && cr.n <= HX_MULTI_COUNTER_PAIRS && !b->no_multi) ? chain_multi_groups(cr.n, cr.max_rows, linear ? 64 : 128) : 1;
           int* counters = nullptr;
           if (multi > 1) {
+            b->used_multi[1] = true;
             if (!b->d_multi && hipMalloc(reinterpret_cast<void**>(&b->d_multi), 2 * HX_MULTI_COUNTER_PAIRS * 256 * sizeof(int)) != hipSuccess)
               return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of the progress counters failed");
             counters = b->d_multi + HX_MULTI_COUNTER_PAIRS * 256;
@@ -1217,7 +1229,8 @@ int hx_batch_backward(hx_batch* b, void* stream) {
           // k_backward_dag_multi); their progress counters - the last 256 ints of each pair's scratch planes - start at zero
           int multi = 1, multi_waves = 4;
           const char* min_strips = getenv("HX_DAG_MULTI_MIN_STRIPS");      // tuning hook
-          if (records && cr.n <= HX_MULTI_MAX_PAIRS && cr.max_rows > (min_strips ? atoi(min_strips) : 16) * HX_STRIP && !getenv("HX_DAG_BWD_SINGLE")) {
+          if (records && cr.n <= HX_MULTI_MAX_PAIRS && cr.max_rows > (min_strips ? atoi(min_strips) : 16) * HX_STRIP && !getenv("HX_DAG_BWD_SINGLE") && !b->no_multi) {
+            b->used_multi[1] = true;
             const int strips = (cr.max_rows + HX_STRIP - 1) / HX_STRIP;
             if (const char* e = getenv("HX_DAG_MULTI_WAVES")) multi_waves = atoi(e);      // tuning hook: waves per workgroup (default 4: measured 1.24 / 1.13 / 1.02 / 1.01 s at one workgroup / 16 / 8 / 4 waves)
             if (multi_waves != 16 && multi_waves != 8 && multi_waves != 2) multi_waves = 4;
@@ -1269,21 +1282,51 @@ static int read_scalars(hx_batch* b, double* out, int which) {
   return HX_OK;
 }
 
+// A fill dealt to several workgroups per pair marks a pair whose waves gave up waiting for one another (a bounded number of
+// polls, never a hang: hx_chain.hip / hx_linear.hip / hx_dag.hip / hx_daglin.hip MULTI) with NaN; no fill produces NaN
+// otherwise.  That is a scheduling accident - not every workgroup of the launch was resident - and not the caller's problem:
+// the batch's fills are launched again with one workgroup per pair (from then on), once; only if NaN remains is it an error.
+static int first_nan(const hx_batch* b, const double* v) {
+  for (int k = 0; k < b->n_jobs; ++k)
+    if (v[k] != v[k]) return k;
+  return -1;
+}
+static int relaunch_single(hx_batch* b, bool backward_too) {
+  if (getenv("HX_NO_RELAUNCH")) return HX_ERR_HIP;      // (tests: see the raw outcome)
+  b->no_multi = true;
+  b->relaunches++;
+  int rc = hx_batch_forward(b, b->last_stream);
+  if (rc == HX_OK && backward_too) rc = hx_batch_backward(b, b->last_stream);
+  return rc;
+}
 int hx_batch_lp_end(hx_batch* b, double* out) {
-  const int rc = read_scalars(b, out, 0);
+  int rc = read_scalars(b, out, 0);
   if (rc != HX_OK) return rc;
-  for (int k = 0; k < b->n_jobs; ++k)      // (a fill dealt to several workgroups marks a pair it could not finish with NaN: hx_batch_lp_start)
-    if (out[k] != out[k]) return fail(HX_ERR_HIP, "the Forward fill of pair %d did not complete (workgroups lost one another)", k);
+  int k = first_nan(b, out);
+  if (k >= 0 && b->used_multi[0] && !b->no_multi) {
+    if ((rc = relaunch_single(b, b->backward_done)) != HX_OK) return fail(HX_ERR_HIP, "the Forward fill of pair %d did not complete (workgroups lost one another) and could not be launched again", k);
+    if ((rc = read_scalars(b, out, 0)) != HX_OK) return rc;
+    k = first_nan(b, out);
+  }
+  if (k >= 0) return fail(HX_ERR_HIP, "the Forward fill of pair %d did not complete (workgroups lost one another)", k);
   return HX_OK;
 }
 int hx_batch_lp_start(hx_batch* b, double* out) {
-  const int rc = read_scalars(b, out, 1);
+  int rc = read_scalars(b, out, 1);
   if (rc != HX_OK) return rc;
-  // a Backward fill dealt to several workgroups marks a pair whose waves gave up waiting for one another (hx_dag.hip
-  // k_backward_dag_multi: a bounded number of polls, never a hang) with NaN; no fill produces NaN otherwise
-  for (int k = 0; k < b->n_jobs; ++k)
-    if (out[k] != out[k]) return fail(HX_ERR_HIP, "the Backward fill of pair %d did not complete (workgroups lost one another)", k);
+  int k = first_nan(b, out);
+  if (k >= 0 && b->used_multi[1] && !b->no_multi) {
+    if ((rc = relaunch_single(b, true)) != HX_OK) return fail(HX_ERR_HIP, "the Backward fill of pair %d did not complete (workgroups lost one another) and could not be launched again", k);
+    if ((rc = read_scalars(b, out, 1)) != HX_OK) return rc;
+    k = first_nan(b, out);
+  }
+  if (k >= 0) return fail(HX_ERR_HIP, "the Backward fill of pair %d did not complete (workgroups lost one another)", k);
   return HX_OK;
+}
+
+int hx_batch_relaunches(const hx_batch* b) {
+  if (!b) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  return b->relaunches;
 }
 
 int hx_batch_layout(const hx_batch* b, int32_t job, int32_t which, hx_layout* out) {

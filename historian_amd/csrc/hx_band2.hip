@@ -5,10 +5,9 @@
 //
 // The rotating-row sweep of hx_band.hip gives a pair one 64-lane wavefront, lane = row mod 64; an anti-diagonal of a
 // band-20 envelope holds ~21 cells, so two thirds of every vector instruction of that sweep are idle lanes.  Here a
-// wavefront sweeps TWO pairs: lanes 0-31 are a ring of 32 rows (lane = row mod 32) of one pair, lanes 32-63 of another.
-// Nothing else changes in the recursion: left is the lane's own previous cell, up and diagonal are the previous lane's
-// cells of one and two steps ago, handed over inside each 32-lane ring (ds_swizzle's rotate mode: the LDS crossbar, no LDS
-// memory - a DPP rotation is a ring of 64).  A pair is admitted when rows i and i + 31 are never alive together (hx_api.hip:
+// wavefront sweeps TWO pairs: the even lanes are a ring of 32 rows (lane = 2 (row mod 32)) of one pair, the odd lanes of
+// another.  Nothing else changes in the recursion: left is the lane's own previous cell, up and diagonal are the cells of
+// one and two steps ago of the lane two below, handed over by two DPP wave_ror:1 moves per register.  A pair is admitted when rows i and i + 31 are never alive together (hx_api.hip:
 // band2_admits); the row records, store bases and step counts are those of hx_band.hip (build_band_rows).
 //
 // One wavefront does everything for its two pairs - the recursion, the five logarithms per cell, the stores - so there is
@@ -44,11 +43,13 @@ typedef int i2v __attribute__((ext_vector_type(2)));
 struct L5 { double imm, imd, idm, imi, iiw; int e; };
 __device__ __forceinline__ L5 l5_zero() { return L5{0., 0., 0., 0., 0., HXB2_EMIN}; }
 
-// value of the previous lane of the lane's 32-lane ring (lane 0 receives lane 31's, lane 32 lane 63's): ds_swizzle in its
-// rotate mode, which works on groups of 32 lanes (checked on the GPU: tools/probes/swizzle_rotate.hip,
-// profiles/r03/ds_swizzle_rotate_probe.txt).  It uses the LDS crossbar, not LDS memory, and no address register.
-#define HXB2_SWIZZLE_ROR1 (0xC000 | (1 << 10) | (1 << 5))      // swizzle(ROTATE, 1, 1)
-__device__ __forceinline__ int rot(const int, const int v) { return __builtin_amdgcn_ds_swizzle(v, HXB2_SWIZZLE_ROR1); }
+// value of the previous lane of the lane's ring.  The two rings are INTERLEAVED - lane = 2 (row mod 32) + (which pair) - so
+// the previous row sits two lanes down, all the way round the wavefront: two DPP wave_ror:1 moves per dword, on the vector
+// ALU of the wavefront's own SIMD.  (Halves as rings - lanes 0-31 / 32-63 - need a rotation inside 32 lanes, which only the
+// LDS crossbar offers (ds_swizzle rotate mode, checked in tools/probes/swizzle_rotate.hip): eleven LDS instructions per
+// step made the CU's one LDS pipeline the bound of the whole kernel - 3.5 ms for 2048 pairs whatever the arithmetic.)
+__device__ __forceinline__ int ror1(int v) { return __builtin_amdgcn_mov_dpp(v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ int rot(const int, const int v) { return ror1(ror1(v)); }
 __device__ __forceinline__ double rot(const int addr, const double v) {
   return __hiloint2double(rot(addr, __double2hiint(v)), rot(addr, __double2loint(v)));
 }
@@ -57,9 +58,12 @@ __device__ __forceinline__ L5 rot(const int addr, const L5& c) {
 }
 
 // (hx_linear.hip) one pairwise sum of the reference's log_sum_exp on probabilities
+// (a dropped term keeps its low word: a number below 2^-1042 that no sum of mantissas scaled to the cell's exponent feels -
+// one select instead of two)
 __device__ __forceinline__ double trunc_sum(double a, double b) {
   const double hi = vmax(a, b), lo = vmin(a, b);
-  return hi + (lo > hi * 4.5399929762484854e-05 ? lo : 0.0);
+  const int keep = lo > hi * 4.5399929762484854e-05 ? __double2hiint(lo) : 0;
+  return hi + __hiloint2double(keep, __double2loint(lo));
 }
 template <bool TRUNC> __device__ __forceinline__ double lin_acc(double m, double p, double acc) {
   if (TRUNC) return trunc_sum(acc, m * p);
@@ -67,11 +71,13 @@ template <bool TRUNC> __device__ __forceinline__ double lin_acc(double m, double
 }
 
 // log(m * 2^e), m >= 0 (hx_linear.hip log_scaled: frexp, one 16-byte table entry, a cubic)
-__device__ __forceinline__ double log_scaled(double m, int e, const HX_LDS double* ltab) {
+// The table sits at LDS address 0 (the kernel has no static LDS: the dynamic allocation starts there), so the entry's byte
+// offset IS its address.
+__device__ __forceinline__ double log_scaled(double m, int e) {
   const double f = __builtin_amdgcn_frexp_mant(m);
   const int k = __builtin_amdgcn_frexp_exp(m);
   const unsigned byte_off = ((unsigned)__double2hiint(f) >> 7) & 0x7FF0u;
-  const d2v ce = *(const HX_LDS d2v*)((const HX_LDS char*)ltab + byte_off);
+  const d2v ce = *(const HX_LDS d2v*)(uintptr_t)byte_off;
   const double r = __builtin_fma(f, ce.x, -1.0);
   double p = __builtin_fma(r, 1.0 / 3.0, -0.5);
   p = __builtin_fma(p, r, 1.0);
@@ -102,13 +108,12 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  const int half = lane >> 5, r32 = lane & 31;
+  const int half = lane & 1, r32 = lane >> 1;      // which of the wavefront's two pairs, and the lane's place in that pair's ring
   const bool edge_wave = wave == NW;
   double* ptab = reinterpret_cast<double*>(lds);
   // (entries 1..1023 of the logarithm table are never addressed)
   for (int k = threadIdx.x; k < 2; k += THREADS) ptab[k] = log_tab[k];
   for (int k = 2048 + threadIdx.x; k < 2 * HXB2_LOG_ENTRIES; k += THREADS) ptab[k] = log_tab[k];
-  const HX_LDS double* lt = (const HX_LDS double*)ptab;
   const int first_job = (int)blockIdx.x * 2 * NW;
 
   // ---- the sweeping wavefronts stage their two pairs' blocks (32 lanes per pair) ----
@@ -265,35 +270,47 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
     // =======================================================================================================
     const int rot_addr = 0;
     const int64_t plane2 = Jp->plane >> 1;
-    const int blk = Jp->blk;
     HX_GLOBAL double* __restrict__ M = as_global(DIR ? Jp->bwd : Jp->fwd);
     const HX_GLOBAL i2v* xrecG = (const HX_GLOBAL i2v*)as_global(rowsG);
     auto xrec_at = [&](const int i) -> i2v { return xrecG[i]; };
     // anti-diagonal steps: the longer of the wavefront's two pairs, in whole blocks of eight (extra steps own nothing)
     const int my_steps = live ? ((DIR ? Jp->band_steps_bwd : Jp->band_steps) + 7) & ~7 : 0;
-    const int s0 = __builtin_amdgcn_readlane(my_steps, 0), s1 = __builtin_amdgcn_readlane(my_steps, 32);
+    const int s0 = __builtin_amdgcn_readlane(my_steps, 0), s1 = __builtin_amdgcn_readlane(my_steps, 1);
     const int n_steps = s0 > s1 ? s0 : s1;
 
-    int i = r32, os, oe, as, ae, store;
-    unsigned eoff;
+    // The lane's row, decoded: owned steps [os, oe], in-envelope steps [as, as + span], the row's store pointer (cell of step k:
+    // rowp + (k >> 1) * 64 sixteen-byte units per state plane), its emission row and column bytes as LDS addresses (the byte of
+    // step k is at ycur + k), its x-side constants.  And the raw record of the row the lane takes next (i + 32), fetched a
+    // whole row ahead.
+    int i = r32, os, oe, as;
+    unsigned span;
+    HX_GLOBAL d2v* rowp;
+    unsigned erow;               // LDS address of the row's emission-table row
+    unsigned ycur;               // LDS address of the column byte of step 0 (may lie before the array: clamped at use)
     double xc_rs, xc_in;         // exp(rootsubx), exp(insx)
     int x_wait;                  // x state not ready: 2^29 (an exponent shift)
     i2v nrec;
     d2v nxc = d2v{0., 0.};
     int nstore = 0;
-    auto decode = [&](const i2v r, const d2v xc, const int sb) {
+    unsigned nerow = 0;
+    const unsigned ycol_lo = (unsigned)(uintptr_t)ycolL, ycol_hi = ycol_lo + (unsigned)(Cc - 1);
+    const unsigned elds_a = (unsigned)(uintptr_t)eldsL, yclass_a = (unsigned)(uintptr_t)yclassL;
+    auto decode = [&](const i2v r, const d2v xc, const int sb, const unsigned er) {
       os = r.x & 0xFFFF; oe = os + ((r.x >> 16) & 0xFFFF);
-      as = os + ((r.y >> 9) & 1); ae = oe - ((r.y >> 10) & 1);
-      if ((r.x & 0xFFFF) == 0xFFFF || !live) { os = 0x7FFFFFF0; oe = 0x7FFFFFF1; as = os; ae = oe; }     // sentinel: never owned
-      store = sb;
-      eoff = (unsigned)(r.y & 0xFF) * (unsigned)Ky1;
+      as = os + ((r.y >> 9) & 1);
+      span = (unsigned)((oe - ((r.y >> 10) & 1)) - as);
+      if ((r.x & 0xFFFF) == 0xFFFF || !live) { os = 0x7FFFFFF0; oe = 0x7FFFFFF1; as = os; span = 1; }     // sentinel: never owned
+      rowp = (HX_GLOBAL d2v*)(M + sb);
+      erow = er;
       x_wait = (r.y & 0x100) ? (1 << 29) : 0;
       xc_rs = xc.x; xc_in = xc.y;
+      ycur = ycol_lo - (unsigned)i;
     };
     auto store_base = [&](const int row) -> int { return sbaseL[row < R ? row >> 6 : 0] + 2 * (row & 63); };
+    auto emis_row = [&](const i2v r) -> unsigned { return elds_a + 8u * (unsigned)(r.y & 0xFF) * (unsigned)Ky1; };
     {
       const i2v r0 = xrec_at(r32 < R ? r32 : R);
-      decode(r0, xclassL[r0.y & 0xFF], store_base(r32));
+      decode(r0, xclassL[r0.y & 0xFF], store_base(r32), emis_row(r0));
       nrec = xrec_at(r32 + HXB2_W < R ? r32 + HXB2_W : R);
     }
     // the 18 transition probabilities the recursion reads (dest 5 = EEE is only read by lpEnd): per lane - the halves
@@ -320,19 +337,18 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
 
     // The y side of a step, fetched ahead (see hx_band.hip): the column's byte two steps ahead, the column's class constants
     // and the emission term one step ahead.  A lane that is about to change rows looks up the NEXT row's column.
-    auto word_at = [&](const int col) -> unsigned {
-      const int c = col < 0 ? 0 : (col >= Cc ? Cc - 1 : col);
-      return ycolL[c];
+    auto byte_at = [&](const unsigned addr) -> unsigned {       // (clamped to the pair's column bytes)
+      const int a = (int)addr < (int)ycol_lo ? (int)ycol_lo : ((int)addr > (int)ycol_hi ? (int)ycol_hi : (int)addr);
+      return *(const HX_LDS unsigned char*)(uintptr_t)(unsigned)a;
     };
-    unsigned neoff = 0;
-    unsigned w_cur = word_at(0 - i), w_nxt = word_at(1 - i);        // bytes of steps k, k + 1
+    unsigned w_cur = byte_at(ycur), w_nxt = byte_at(ycur + 1);     // bytes of steps k, k + 1
     d2v rc_cur = yclassL[w_cur & 0x7Fu];                            // class constants of step k
-    double em_cur = eldsL[eoff + (w_cur & 0x7Fu)];
+    double em_cur = *(const HX_LDS double*)(uintptr_t)(erow + 8u * (w_cur & 0x7Fu));
 
     auto roll_even = [&](const int k) {
       if (k > oe) {
         i += HXB2_W;
-        decode(nrec, nxc, nstore);
+        decode(nrec, nxc, nstore, nerow);
         nrec = xrec_at(i + HXB2_W < R ? i + HXB2_W : R);
       }
     };
@@ -340,17 +356,17 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
       if (k == oe) {
         nxc = xclassL[nrec.y & 0xFF];
         nstore = store_base(i + HXB2_W);
-        neoff = (unsigned)(nrec.y & 0xFF) * (unsigned)Ky1;
+        nerow = emis_row(nrec);
       }
     };
     struct YSide { unsigned w; d2v rc; double em; };
     auto y_side = [&](const int k) -> YSide {
       const YSide now{w_cur, rc_cur, em_cur};
       const unsigned c1 = w_nxt & 0x7Fu;
-      rc_cur = yclassL[c1];
-      em_cur = eldsL[((k + 1 > oe) ? neoff : eoff) + c1];
+      rc_cur = *(const HX_LDS d2v*)(uintptr_t)(yclass_a + 16u * c1);
+      em_cur = *(const HX_LDS double*)(uintptr_t)(((k + 1 > oe) ? nerow : erow) + 8u * c1);
       w_cur = w_nxt;
-      w_nxt = word_at(k + 2 - ((oe <= k + 1) ? i + HXB2_W : i));
+      w_nxt = byte_at(((oe <= k + 1) ? ycur - HXB2_W : ycur) + (unsigned)(k + 2));
       return now;
     };
 
@@ -360,8 +376,9 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
       const double em = ys.em;
       int E = left.e > u1.e ? left.e : u1.e;
       E = E > u2.e ? E : u2.e;
-      const int outside = (k >= as && k <= ae) ? 0 : (1 << 29);
-      const int du = ((u1.e - E) - y_wait) - outside, dl = ((left.e - E) - x_wait) - outside, dd = (u2.e - E) - outside;
+      // (a cell outside the envelope - src/forward.h:92-98 - is shifted to zero as a whole: the exponent it is brought to lies 2^29 higher)
+      const int Eo = E + ((unsigned)(k - as) <= span ? 0 : (1 << 29));
+      const int du = (u1.e - y_wait) - Eo, dl = (left.e - x_wait) - Eo, dd = u2.e - Eo;
       if (DIR == 1) {
         // Backward (src/forward.cpp:1018-1065 for leaf-like profiles): the five destination terms brought to the cell's
         // exponent (a move that may not be made, a cell outside the envelope: shifted out of range), then the sums in the
@@ -406,7 +423,7 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
         out.imm = __builtin_ldexp(s_imm * em, dd);
       }
       out.e = E;
-      if (renorm) {                                  // (compile-time: the first two steps of every block of eight)
+      if (renorm) {                                  // (compile-time: the first step of every block of eight)
         if (k == 0 && r32 == 0 && live) {
           if (DIR == 0) { out.imm = 1.0; out.e = 0; }   // cell (0,0): lpStart() = 0 (src/forward.cpp:73)
           else {
@@ -431,16 +448,15 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
     auto step_pair = [&](const int k, const bool renorm) {
       roll_even(k);
       const bool own = k >= os && k <= oe;           // (owned spans are whole step pairs)
-      const int sl = store + (k >> 1) * blk;
+      HX_GLOBAL d2v* M2 = rowp + ((k >> 1) << 6);     // (step-pair blocks of 128 doubles: hx_api.hip admits dense planes and compressed windows alike)
       step(k, renorm, lb, la, lua, lub, y_side(k));
-      const double l0 = log_scaled(la.imm, la.e, lt), l1 = log_scaled(la.imd, la.e, lt), l2 = log_scaled(la.idm, la.e, lt),
-                   l3 = log_scaled(la.imi, la.e, lt), l4 = log_scaled(la.iiw, la.e, lt);
+      const double l0 = log_scaled(la.imm, la.e), l1 = log_scaled(la.imd, la.e), l2 = log_scaled(la.idm, la.e),
+                   l3 = log_scaled(la.imi, la.e), l4 = log_scaled(la.iiw, la.e);
       roll_odd(k + 1);
-      step(k + 1, renorm, la, lb, lub, lua, y_side(k + 1));
-      const double h0 = log_scaled(lb.imm, lb.e, lt), h1 = log_scaled(lb.imd, lb.e, lt), h2 = log_scaled(lb.idm, lb.e, lt),
-                   h3 = log_scaled(lb.imi, lb.e, lt), h4 = log_scaled(lb.iiw, lb.e, lt);
+      step(k + 1, false, la, lb, lub, lua, y_side(k + 1));
+      const double h0 = log_scaled(lb.imm, lb.e), h1 = log_scaled(lb.imd, lb.e), h2 = log_scaled(lb.idm, lb.e),
+                   h3 = log_scaled(lb.imi, lb.e), h4 = log_scaled(lb.iiw, lb.e);
       if (own) {
-        HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
         // write-once data: non-temporal stores
         __builtin_nontemporal_store(d2v{l0, h0}, &M2[0]);
         __builtin_nontemporal_store(d2v{l1, h1}, &M2[plane2]);

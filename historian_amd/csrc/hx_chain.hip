@@ -717,13 +717,17 @@ static int launch_chain(const DevJob* d_jobs, int n_jobs, int max_rows, const do
 // HX_CHAIN_MULTI: 0 = never, n > 1 = that many workgroups per pair (tuning / test hook).
 // max_pairs: 128 for the table policies' kernel, 64 for the scaled-probability one (k_fill_leaf_linear: 128 pairs measured
 // 5.1 ms in the ordinary launch, 5.5 ms dealt out).
+// A pair owns 256 progress counters: one per wave of its workgroups (slot groups * W + wave, k_fill_chain) or one per workgroup
+// (k_fill_leaf_linear), and slot 255 is the pair's "a poll gave up" flag - so at most 255 / W workgroups per pair, however
+// few pairs and however many strips (a pair of more than ~16 000 rows would otherwise reach slot 255 and beyond).
 int chain_multi_groups(int n_jobs, int max_rows, int max_pairs) {
   const int strips = (max_rows + 63) / 64;
-  const int cap = (strips + HX_CHAIN_MULTI_WAVES - 1) / HX_CHAIN_MULTI_WAVES;
+  const int cap = std::min((strips + HX_CHAIN_MULTI_WAVES - 1) / HX_CHAIN_MULTI_WAVES, 255 / HX_CHAIN_MULTI_WAVES);
+  static_assert((255 / HX_CHAIN_MULTI_WAVES) * HX_CHAIN_MULTI_WAVES <= 255, "progress slots of a pair end below its gave-up flag");
   if (const char* e = getenv("HX_CHAIN_MULTI")) {
     const int forced = atoi(e);
     if (forced <= 1) return 1;
-    return std::max(1, std::min(std::min(forced, cap), 256 / HX_CHAIN_MULTI_WAVES));
+    return std::max(1, std::min(forced, cap));
   }
   if (n_jobs > max_pairs || strips <= 16) return 1;
   const int groups = std::min(cap, 256 / n_jobs);

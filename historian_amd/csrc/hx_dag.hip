@@ -566,11 +566,10 @@ __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_fill_dag(const DevJob
 // pair's lpStart then reads NaN and the host reports an error - never a hang.  All workgroups of the launch must be resident
 // at once (the caller launches at most sixteen).  State records as in k_fill_dag<.., REC>.
 // ---------------------------------------------------------------------------------------------------------------------
-#define HX_MULTI_PATIENCE (1 << 22)
 template <class LSE, bool FAST>
 __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_backward_dag_multi(const DevJob* __restrict__ jobs,
                                                                                 const double* __restrict__ exact_tab,
-                                                                                const double* __restrict__ fast_tab, const int G) {
+                                                                                const double* __restrict__ fast_tab, const int G, const int patience) {
   __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : 2];
   const int threads = blockDim.x, W = threads >> 6, WT = W * G;
   if (FAST)
@@ -634,10 +633,11 @@ __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_backward_dag_multi(co
           while (seen < need) {
             seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(gprog + prev_gw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (seen < need) {
-              if (++polls > HX_MULTI_PATIENCE) { dead = true; break; }
+              if (++polls > patience) { dead = true; break; }
               __builtin_amdgcn_s_sleep(2);
             }
           }
+          if (seen == HX_MULTI_POISON) dead = true;      // the wave above (or one above it) gave up
         }
         const int jm = t - lane;
         if (!dead && rvalid && jm >= 0 && jm < Cc) {
@@ -654,8 +654,11 @@ __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_backward_dag_multi(co
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           int done = t - 62;
           done = done > Cc ? Cc : done;
-          if (dead) done = Cc;                     // (let everyone below run out as well)
-          if (done > published) {
+          if (dead && published != HX_MULTI_POISON) {   // (everyone below runs out as well, and knows why)
+            published = HX_MULTI_POISON;
+            publish(HX_MULTI_POISON);
+          }
+          if (!dead && done > published) {
             published = done;
             publish(my_base + done);
           }
@@ -663,9 +666,12 @@ __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_backward_dag_multi(co
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int upto = (w == 0 && whi[1] > wlo[1]) ? wlo[1] - 63 : Cc;
-      int done = upto > Cc ? Cc : upto;
-      if (dead) done = Cc;
-      if (done > published) {
+      const int done = upto > Cc ? Cc : upto;
+      if (dead && published != HX_MULTI_POISON) {
+        published = HX_MULTI_POISON;
+        publish(HX_MULTI_POISON);
+      }
+      if (!dead && done > published) {
         published = done;
         publish(my_base + done);
       }
@@ -769,7 +775,8 @@ template <class LSE, bool FAST, bool MULTI = false>
 __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(const DevJob* __restrict__ jobs,
                                                                                const double* __restrict__ exact_tab,
                                                                                const double* __restrict__ fast_tab,
-                                                                               const int groups = 1, int* const counters = nullptr) {
+                                                                               const int groups = 1, int* const counters = nullptr,
+                                                                               const int patience = 0) {
   __shared__ volatile int prog[HX_DAGF_MAX_WAVES];
   __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : 2];
   // per wave: the column constants (FwdPack) of the 128 columns around the wave's position, as four
@@ -816,7 +823,8 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
   };
   const auto publish = [&](const int value) {
     if (lane != 0) return;
-    if (MULTI) __hip_atomic_store(gprog + gw, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a wave that gave up publishes the poison value: the waves below give up as well, down to the one that reports lpEnd)
+    if (MULTI) __hip_atomic_store(gprog + gw, dead ? HX_MULTI_POISON : value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else progp[wave] = value;
   };
   const double NI = HX_NEG_INF;
@@ -886,10 +894,11 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
             do {
               seen = __builtin_amdgcn_readfirstlane(read_progress(prev_wave));
               if (seen < need) {
-                if (MULTI && ++polls > HX_MULTI_PATIENCE) { dead = true; break; }
+                if (MULTI && ++polls > patience) { dead = true; break; }
                 __builtin_amdgcn_s_sleep(1);
               }
             } while (seen < need);
+            if (MULTI && seen == HX_MULTI_POISON) dead = true;      // the wave above (or one above it) gave up
             asm volatile("" ::: "memory");
           }
         }
@@ -1221,17 +1230,17 @@ int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8
   const double* fast_tab = tab16.p;
   if (multi > 1) {
     const dim3 gm(n_jobs * multi), bm(multi_waves * 64);
-    if (fast) hipLaunchKernelGGL((k_forward_dag_pipe<FastLse, true, true>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi, counters);
-    else hipLaunchKernelGGL((k_forward_dag_pipe<ExactLse3, false, true>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi, counters);
+    if (fast) hipLaunchKernelGGL((k_forward_dag_pipe<FastLse, true, true>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi, counters, multi_patience());
+    else hipLaunchKernelGGL((k_forward_dag_pipe<ExactLse3, false, true>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi, counters, multi_patience());
     return 0;
   }
   const dim3 g(n_jobs), b(dag_waves(max_rows, HX_DAGF_MAX_WAVES) * 64);
   if (fast) {
     HX_CHECK_LDS((k_forward_dag_pipe<FastLse, true>), 0, "k_forward_dag_pipe<fast>");
-    hipLaunchKernelGGL((k_forward_dag_pipe<FastLse, true>), g, b, 0, st, d_jobs, tab, fast_tab, 1, nullptr);
+    hipLaunchKernelGGL((k_forward_dag_pipe<FastLse, true>), g, b, 0, st, d_jobs, tab, fast_tab, 1, nullptr, 0);
   } else {
     HX_CHECK_LDS((k_forward_dag_pipe<ExactLse3, false>), 0, "k_forward_dag_pipe<exact>");
-    hipLaunchKernelGGL((k_forward_dag_pipe<ExactLse3, false>), g, b, 0, st, d_jobs, tab, fast_tab, 1, nullptr);
+    hipLaunchKernelGGL((k_forward_dag_pipe<ExactLse3, false>), g, b, 0, st, d_jobs, tab, fast_tab, 1, nullptr, 0);
   }
   return 0;
 }
@@ -1247,8 +1256,8 @@ int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab
   // the progress counters
   if (records && multi > 1) {
     const dim3 gm(n_jobs * multi), bm((multi_waves > 0 ? multi_waves : HX_DAG_MAX_WAVES) * 64);
-if (fast) hipLaunchKernelGGL((k_backward_dag_multi<FastLse, true>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi);
-    else hipLaunchKernelGGL((k_backward_dag_multi<ExactLse3, false>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi);
+if (fast) hipLaunchKernelGGL((k_backward_dag_multi<FastLse, true>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi, multi_patience());
+    else hipLaunchKernelGGL((k_backward_dag_multi<ExactLse3, false>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi, multi_patience());
     return 0;
   }
   if (records) {

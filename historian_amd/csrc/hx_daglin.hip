@@ -31,7 +31,6 @@ namespace hx {
 namespace {
 
 #define HXD_MAX_WAVES 8
-#define HXD_MULTI_PATIENCE (1 << 22)   // MULTI launch: polls of another workgroup's progress before a wave gives up (lp_end = NaN)
 #define HXD_EMIN (-(1 << 28))      // exponent of a zero: loses every max()
 #define HXD_LOG_ENTRIES 1536       // the logarithm table of hx_linear.hip (build_log_table)
 #define HXD_EXP_ENTRIES 512
@@ -221,7 +220,8 @@ __global__ void k_lin_clear(const DevJob* __restrict__ jobs) {
 
 template <bool MULTI>
 __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab,
-                                                                           const double* __restrict__ log_tab, const int groups, int* const counters) {
+                                                                           const double* __restrict__ log_tab, const int groups, int* const counters,
+                                                                           const int patience) {
   __shared__ volatile int prog[HXD_MAX_WAVES];
   __shared__ __attribute__((aligned(16))) double ltab_s[HXD_LOG_ENTRIES * 2];
   __shared__ double etab_s[HXD_EXP_ENTRIES];
@@ -273,7 +273,8 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
   };
   const auto publish = [&](const int value) {
     if (lane != 0) return;
-    if (MULTI) __hip_atomic_store(gprog + gw, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a wave that gave up publishes the poison value: the waves below give up as well, down to the one that reports lpEnd)
+    if (MULTI) __hip_atomic_store(gprog + gw, dead ? HX_MULTI_POISON : value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else progp[wave] = value;
   };
   // transition probabilities of the pair HMM: in LDS, read as broadcasts where the outgoing sums are formed (36 scalar
@@ -385,10 +386,11 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
             do {
               seen = __builtin_amdgcn_readfirstlane(read_progress(prev_wave));
               if (seen < need) {
-                if (MULTI && ++polls > HXD_MULTI_PATIENCE) { dead = true; break; }
+                if (MULTI && ++polls > patience) { dead = true; break; }
                 __builtin_amdgcn_s_sleep(1);
               }
             } while (seen < need);
+            if (MULTI && seen == HX_MULTI_POISON) dead = true;      // the wave above (or one above it) gave up
             asm volatile("" ::: "memory");
           }
         }
@@ -784,11 +786,11 @@ int launch_forward_dag_linear(const DevJob* d_jobs, int n_jobs, int max_rows, Ta
   if (multi > 1) {
     if (multi_waves > HXD_MAX_WAVES) multi_waves = HXD_MAX_WAVES;
     HX_CHECK_LDS(k_forward_dag_linear<true>, 0, "k_forward_dag_linear<multi>");
-    hipLaunchKernelGGL(k_forward_dag_linear<true>, dim3(n_jobs * multi), dim3(multi_waves * 64), 0, st, d_jobs, tab8.p, log_tab.p, multi, counters);
+    hipLaunchKernelGGL(k_forward_dag_linear<true>, dim3(n_jobs * multi), dim3(multi_waves * 64), 0, st, d_jobs, tab8.p, log_tab.p, multi, counters, multi_patience());
     return 0;
   }
   HX_CHECK_LDS(k_forward_dag_linear<false>, 0, "k_forward_dag_linear");
-  hipLaunchKernelGGL(k_forward_dag_linear<false>, dim3(n_jobs), dim3(w * 64), 0, st, d_jobs, tab8.p, log_tab.p, 1, nullptr);
+  hipLaunchKernelGGL(k_forward_dag_linear<false>, dim3(n_jobs), dim3(w * 64), 0, st, d_jobs, tab8.p, log_tab.p, 1, nullptr, 0);
   return 0;
 }
 

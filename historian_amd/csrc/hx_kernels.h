@@ -1,5 +1,6 @@
 // Kernel launchers (implemented in hx_kernels.hip / hx_chain.hip).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "hx_device.h"
 
@@ -82,6 +83,16 @@ int launch_forward_band2(const DevJob* d_jobs, int n_jobs, bool trunc, int max_r
                          bool write_edges, hipStream_t st);
 int launch_backward_band2(const DevJob* d_jobs, int n_jobs, bool trunc, int max_rows, int max_cols, int max_cls, Tab8 tab, Tab16 log_tab,
                           bool write_edges, hipStream_t st);
+
+// Several-workgroups-per-pair launches of the general-profile fills (hx_dag.hip, hx_daglin.hip): polls of another workgroup's
+// progress before a wave gives up (HX_MULTI_PATIENCE overrides; 0 makes every unsatisfied wait give up - the tests' way of
+// forcing the error path), and the progress value a wave that gave up publishes: every wave that waits on it - directly or
+// through the waves in between - gives up as well, down to the wave of the last strip, which reports NaN.
+#define HX_MULTI_POISON 0x7FFFFFFF
+inline int multi_patience() {
+  const char* e = getenv("HX_MULTI_PATIENCE");
+  return e ? atoi(e) : (1 << 22);
+}
 
 void launch_indel_counts(const DevJob* d_jobs, int job, const double* d_tm, double* d_out, int64_t cells, Tab8 tab, bool plane_valid,
                          hipStream_t st);

@@ -51,9 +51,13 @@ enum { HX_IMM = 0, HX_IMD = 1, HX_IDM = 2, HX_IMI = 3, HX_IIW = 4, HX_STATES = 5
  * (log(1+exp(-n*1e-4)), reference src/logsumexp.cpp:8-16): device libm differs. */
 #define HX_LSE_TABLE_ENTRIES 100002
 
-/* ---- fill modes (hx_batch_create flags) ---------------------------------- */
-#define HX_LSE_EXACT 0u  /* table + linear interpolation + d>=10 truncation: every cell
-                            bit-identical to the reference recursion (default)        */
+/* ---- fill modes (hx_batch_create flags) ----------------------------------
+ * Without a policy bit a batch runs the DEFAULT policy, HX_LSE_TRUNC: the fastest arithmetic whose best paths are the
+ * reference's (0 of 2000 random pairs differ, profiles/r03/trace_identity_sweep_seed7.json) and whose log-likelihoods agree
+ * with the reference's to ~1e-11 relative.  HX_LSE_EXACT asks for the reference's table arithmetic bit for bit (2-3x slower)
+ * and overrides the other policy bits. */
+#define HX_LSE_EXACT 128u /* table + linear interpolation + d>=10 truncation: every cell
+                            bit-identical to the reference recursion                  */
 #define HX_LSE_FAST  1u  /* same truncation, higher-order LDS-resident table; cells
                             differ from HX_LSE_EXACT by <= ~1e-9 per op               */
 #define HX_LSE_LINEAR 17u /* HX_LSE_FAST, and the Forward fill of leaf-profile batches (the headline workload,
@@ -255,6 +259,12 @@ int hx_batch_job_kernel(const hx_batch* b, int32_t job, int32_t* forward_class, 
 /* Diagnostics: the number of pairs whose banded fill runs two pairs per wavefront (hx_band2.hip: scaled-probability policies,
  * every banded leaf pair of the batch admitted, more than 512 such pairs or HX_BAND2=1), 0 when none does; negative: an error. */
 int hx_batch_shared_wavefront_pairs(const hx_batch* b);
+
+/* Diagnostics: how often the batch's fills were launched again with one workgroup per pair because, in a launch that deals a
+ * pair's strips to several workgroups (small batches of large pairs), waves gave up waiting for one another - possible only
+ * when not all of that launch's workgroups were resident.  hx_batch_lp_end / hx_batch_lp_start do this by themselves, once;
+ * HX_ERR_HIP is returned only if the repeated fill fails too.  Negative: an error. */
+int hx_batch_relaunches(const hx_batch* b);
 
 /* Duration in milliseconds of the most recent hx_batch_forward / hx_batch_backward
  * fill kernel (HIP events recorded around that kernel on its stream). */

@@ -7,6 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The C ABI and the host mirror default to the fastest policy with the reference's best paths (HX_LSE_TRUNC).  The parity
+# tests are about bit-identity first: processes they start (bin/hxrecon, the test mains) run the bit-exact policy unless a
+# test names another one (HX_FILL_MODE in the environment it passes).
+os.environ.setdefault("HX_FILL_MODE", "exact")
+
 GOLDEN = os.path.join(ROOT, "tests", "golden", "reference_data")
 MODELS = os.path.join(ROOT, "tests", "golden", "models")
 

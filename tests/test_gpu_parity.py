@@ -696,6 +696,45 @@ def test_a_small_batch_of_general_pairs_dealt_to_several_workgroups(monkeypatch)
                 H.assert_same_bits(got[0][1][k], c_oracle.backward(x, y, hmm, md)["cells"], "job %d Backward cells vs oracle" % k)
 
 
+@pytest.mark.parametrize("flags", [capi.HX_LSE_EXACT, capi.HX_LSE_FAST, capi.HX_LSE_LINEAR])
+def test_a_wave_that_gives_up_never_yields_a_wrong_number(flags, monkeypatch):
+    # Several workgroups per pair: a wave whose poll of the strip above runs out of patience stops computing.  It publishes a
+    # poison value as its progress, so every wave below gives up too, down to the wave of the last strip, which reports NaN
+    # - never a finite number computed from cells that were not.  hx_batch_lp_end / lp_start then launch the batch's fills
+    # again with one workgroup per pair and return THAT result (hx_batch_relaunches counts it); with HX_NO_RELAUNCH the raw
+    # outcome is an error code.
+    # HX_MULTI_PATIENCE=0: the first unsatisfied wait of any wave gives up (six strips over 2-wave workgroups: some wave
+    # always has to wait for the strip above).
+    monkeypatch.setenv("HX_DAG_MULTI_MIN_STRIPS", "2")
+    monkeypatch.setenv("HX_DAG_MULTI_WAVES", "2")
+    imgs = [H.job_images(H.dag_case(86, n=400, samples=3))]
+    ref = capi.Batch(imgs, flags | capi.HX_KEEP_BACKWARD)
+    ref.forward()
+    ref.backward()
+    want = (ref.lp_end(), ref.lp_start(), ref.read_matrix(0, 0), ref.read_matrix(0, 1))
+    assert ref.relaunches() == 0
+    ref.close()
+    monkeypatch.setenv("HX_MULTI_PATIENCE", "0")
+    monkeypatch.setenv("HX_NO_RELAUNCH", "1")
+    b = capi.Batch(imgs, flags | capi.HX_KEEP_BACKWARD)
+    b.forward()
+    with pytest.raises(capi.HxError) as e:
+        b.lp_end()
+    assert e.value.code == -4              # HX_ERR_HIP
+    b.close()
+    monkeypatch.delenv("HX_NO_RELAUNCH")
+    b = capi.Batch(imgs, flags | capi.HX_KEEP_BACKWARD)
+    b.forward()
+    H.assert_same_bits(b.lp_end(), want[0], "lpEnd after the relaunch")
+    assert b.relaunches() == 1
+    b.backward()                           # (one workgroup per pair from now on)
+    H.assert_same_bits(b.lp_start(), want[1], "lpStart")
+    H.assert_same_bits(b.read_matrix(0, 0), want[2], "Forward cells after the relaunch")
+    H.assert_same_bits(b.read_matrix(0, 1), want[3], "Backward cells")
+    assert b.relaunches() == 1
+    b.close()
+
+
 @pytest.mark.parametrize("groups", ["2", "3", "64"])
 def test_a_small_batch_of_leaf_pairs_dealt_to_several_workgroups(groups, monkeypatch):
     # Few unbanded leaf pairs of many strips (one rank's share of a strong-scaling run) get several workgroups of four waves

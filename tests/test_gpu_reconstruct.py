@@ -189,7 +189,7 @@ def test_posterior_profiles_in_linear_fill_mode(tmp_path):
 from tests import test_oracle_testhist as TH
 
 
-@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("mode", ["exact", "fast", "trunc"])
 @pytest.mark.parametrize("name", sorted(TH.CASES))
 def test_hxrecon_reproduces_the_references_testhist_output(tmp_path, name, mode):
     # posterior-profile mode (cases 1, 2: Forward + Backward + threshold scan at every node) and sampling mode with

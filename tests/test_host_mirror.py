@@ -21,13 +21,25 @@ def run(args, env=None):
 
 
 def test_testseqprofile_host_only():
-    assert run(["testseqprofile", "ACGT", "AAGCT"]) == open(G + "testseqprofile.aagct.json").read()
+    assert run(["hxtest", "seqprofile", "ACGT", "AAGCT"]) == open(G + "testseqprofile.aagct.json").read()
+
+
+def test_substitution_matrix_is_the_oracles_bit_for_bit():
+    # exp(R t) is an input of every DP parity definition: the mirror's restatement of GSL's series (hx_host_base.cpp) and the
+    # oracle's (historian_oracle.sub_prob_matrix_ss) perform the same IEEE operations in the same order
+    from oracle import historian_oracle as ho
+    for model_file in (G + "testamino.json", os.path.join(ROOT, "tests", "golden", "models", "prot4.json")):
+        model = ho.RateModel.from_file(model_file)
+        for t in (1e-9, 0.0254, 0.17, 1.0, 12.0):
+            got = [[float.fromhex(v) for v in line.split()] for line in run(["hxtest", "expm", model_file, t]).splitlines()]
+            want = [row for sr in model.sub_rate for row in ho.sub_prob_matrix_ss(sr.tolist(), t)]
+            assert got == want, (model_file, t)
 
 
 def test_testlogsumexp_host_only():
     want = open(G + "logsumexp.txt").read()
-    assert run(["testlogsumexp", "-fast"]) == want
-    assert run(["testlogsumexp", "-slow"]) == want
+    assert run(["hxtest", "logsumexp", "-fast"]) == want
+    assert run(["hxtest", "logsumexp", "-slow"]) == want
 
 
 GPU_CASES = {
@@ -51,12 +63,13 @@ def test_reference_golden_file_through_the_gpu(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fast", "trunc"])
 @pytest.mark.parametrize("name", sorted(GPU_CASES))
-def test_reference_golden_file_through_the_gpu_fast_mode(name):
-    # 6-decimal fixtures: the fast fill mode reproduces them too.  (testbackward prints cells with
-    # posterior 1 in priority-queue order; with a fast Forward and an exact Backward fill those exact
-    # ties become 1e-12 near-ties, so their order is compared as a set.)
-    got, want = run(GPU_CASES[name], {"HX_FILL_MODE": "fast"}), open(G + name).read()
+def test_reference_golden_file_through_the_gpu_fast_mode(name, mode):
+    # 6-decimal fixtures: the fast fill mode and the library's default, the truncating scaled-probability mode, reproduce
+    # them too.  (testbackward prints cells with posterior 1 in priority-queue order; with a fast Forward and an exact
+    # Backward fill those exact ties become 1e-12 near-ties, so their order is compared as a set.)
+    got, want = run(GPU_CASES[name], {"HX_FILL_MODE": mode}), open(G + name).read()
     if name.startswith("testbackward"):
         assert sorted(got.splitlines()) == sorted(want.splitlines())
     else:
@@ -81,7 +94,7 @@ def test_reference_golden_file_through_the_gpu_linear_mode(name):
 @pytest.mark.gpu
 def test_testquickalign_golden_file_through_the_gpu():
     # reference Makefile:278-279
-    got = run(["testquickalign", G + "PF16593.pair.fa", G + "testamino.json", 1])
+    got = run(["hxtest", "quickalign", G + "PF16593.pair.fa", G + "testamino.json", 1])
     assert got == open(G + "testquickalign.out.fa").read()
 
 
