@@ -423,7 +423,10 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
         out.imm = __builtin_ldexp(s_imm * em, dd);
       }
       out.e = E;
-      if (renorm) {                                  // (compile-time: the first step of every block of eight)
+      // (compile-time: the first TWO steps of every block of eight.  A cell takes the largest exponent of its three sources,
+      // and the sources of step k + 2 are cells of steps k and k + 1: renormalising one step only would leave the stale
+      // exponent alive in the cells of the other parity for ever)
+      if (renorm) {
         if (k == 0 && r32 == 0 && live) {
           if (DIR == 0) { out.imm = 1.0; out.e = 0; }   // cell (0,0): lpStart() = 0 (src/forward.cpp:73)
           else {
@@ -453,7 +456,7 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
       const double l0 = log_scaled(la.imm, la.e), l1 = log_scaled(la.imd, la.e), l2 = log_scaled(la.idm, la.e),
                    l3 = log_scaled(la.imi, la.e), l4 = log_scaled(la.iiw, la.e);
       roll_odd(k + 1);
-      step(k + 1, false, la, lb, lub, lua, y_side(k + 1));
+      step(k + 1, renorm, la, lb, lub, lua, y_side(k + 1));
       const double h0 = log_scaled(lb.imm, lb.e), h1 = log_scaled(lb.imd, lb.e), h2 = log_scaled(lb.idm, lb.e),
                    h3 = log_scaled(lb.imi, lb.e), h4 = log_scaled(lb.iiw, lb.e);
       if (own) {

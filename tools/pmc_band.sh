@@ -1,18 +1,24 @@
 #!/bin/bash
-# usage: tools/pmc_linear.sh <tag> [bench.py arguments]  -- shader-side counters of the banded rotating-row fill (hx_band.hip)
+# usage: tools/pmc_band.sh <tag> [bench.py arguments]  -- shader-side counters of the banded fills (hx_band.hip / hx_band2.hip)
 # (few counters per pass; kernel-trace and PMC never combined with other trace domains)
 tag=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export TMPDIR=/tmp
+cd "$R" || exit 1
+mkdir -p gpurun_out
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
            "SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
-           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM"; do
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES" \
+           "SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" \
+           "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
   i=$((i+1))
-  timeout -k 5 240 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmcb_${tag}_$i -- python bench.py --no-cpu-baseline --single-mode --steps 1 --warmup 0 "$@" > gpurun_out/pmcb_${tag}_$i.log 2>&1 || { echo "pass $i failed"; grep -m2 -i "error\|exceeds" gpurun_out/pmcb_${tag}_$i.log; exit 1; }
+  timeout -k 5 300 rocprofv3 --pmc $set --output-format csv -d gpurun_out/pmcb_${tag}_$i -- python bench.py --no-cpu-baseline --single-mode --steps 1 --warmup 0 "$@" > gpurun_out/pmcb_${tag}_$i.log 2>&1 || { echo "pass $i failed"; grep -m2 -i "error\|exceeds" gpurun_out/pmcb_${tag}_$i.log; exit 1; }
 done
 python - <<PY
 import csv,glob,collections
-for i in range(1,4):
+for i in range(1,7):
     for f in glob.glob("gpurun_out/pmcb_${tag}_%d/*/*counter_collection.csv"%i):
         agg=collections.defaultdict(float); n=collections.defaultdict(int)
         for r in csv.DictReader(open(f)):
