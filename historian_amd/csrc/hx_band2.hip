@@ -513,7 +513,9 @@ int launch_band2_dir(const DevJob* d_jobs, int n_jobs, bool trunc, int max_rows,
   if (max_cls + 1 > 127) return launch_fail("%d emission classes exceed the two-pairs-per-wavefront sweep's column bytes", max_cls);
   const char* v = getenv("HX_BAND2_NW");           // tuning / test hook: sweeping wavefronts per workgroup (1, 2 or 4)
   int nw = v ? atoi(v) : 0;
-  if (nw != 1 && nw != 2 && nw != 4) nw = n_jobs > 1024 ? 2 : 1;
+  // (measured, tools/band2_sweep.sh: four sweeping wavefronts per workgroup are fastest from 2048 pairs on - 2048 pairs 3.5 ms
+  // against 4.5 / 4.7 ms with two / one; smaller batches need more workgroups than that leaves)
+  if (nw != 1 && nw != 2 && nw != 4) nw = n_jobs >= 2048 ? 4 : 2;
   const int we = write_edges ? 1 : 0;
 #define HXB2_GO(NW_) do { const Band2Plan p = plan_band2(NW_, max_rows, max_cols, max_cls); \
     return trunc ? launch_b2<true, NW_, DIR>(d_jobs, n_jobs, p, tab8.p, log_tab.p, we, st) \
