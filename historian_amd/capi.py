@@ -60,6 +60,13 @@ class HxQuickJob(C.Structure):
                 ("submat", C.POINTER(C.c_double)), ("diagonals", C.POINTER(C.c_int32)), ("scores", C.c_double * 11)]
 
 
+class HxBranchJob(C.Structure):
+    _fields_ = [("x_len", C.c_int32), ("y_len", C.c_int32), ("components", C.c_int32), ("alphabet", C.c_int32),
+                ("x_pwm", C.POINTER(C.c_double)), ("y_sub", C.POINTER(C.c_double)), ("y_emit", C.POINTER(C.c_double)),
+                ("trans", (C.c_double * 4) * 3), ("x_env", C.POINTER(C.c_int32)), ("y_env", C.POINTER(C.c_int32)),
+                ("max_distance", C.c_int32)]
+
+
 class HxSumprodModel(C.Structure):
     _fields_ = [("alph_size", C.c_int32), ("components", C.c_int32), ("n_nodes", C.c_int32), ("parent", _i32p),
                 ("ins_prob", _f64p), ("log_cpt_weight", _f64p), ("branch_sub", _f64p),
@@ -80,7 +87,9 @@ EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_cr
            "hx_host_free", "hx_quick_batch_create", "hx_quick_batch_destroy", "hx_quick_batch_run",
            "hx_quick_batch_results", "hx_quick_batch_layout", "hx_quick_batch_read_matrix",
            "hx_quick_batch_total_cells", "hx_quick_batch_last_kernel_ms", "hx_sumprod_columns", "hx_sumprod_last_kernel_ms",
-           "hx_batch_read_matrix_async", "hx_batch_wait_read", "hx_batch_indel_counts", "hx_batch_shared_wavefront_pairs", "hx_batch_relaunches"]
+           "hx_batch_read_matrix_async", "hx_batch_wait_read", "hx_batch_indel_counts", "hx_batch_shared_wavefront_pairs", "hx_batch_relaunches",
+           "hx_branch_batch_create", "hx_branch_batch_destroy", "hx_branch_batch_run", "hx_branch_batch_results",
+           "hx_branch_batch_read_matrix", "hx_branch_batch_total_cells", "hx_branch_batch_last_kernel_ms"]
 
 
 class HxError(RuntimeError):
@@ -128,6 +137,14 @@ def load():
     lib.hx_batch_total_cells.restype = C.c_int64
     lib.hx_batch_last_kernel_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_float)]
     lib.hx_quick_batch_create.argtypes = [C.POINTER(HxQuickJob), C.c_int32, C.POINTER(vp)]
+    lib.hx_branch_batch_create.argtypes = [C.POINTER(HxBranchJob), C.c_int32, C.POINTER(vp)]
+    lib.hx_branch_batch_destroy.argtypes = [vp]
+    lib.hx_branch_batch_run.argtypes = [vp, C.c_int32, vp]
+    lib.hx_branch_batch_results.argtypes = [vp, _f64p]
+    lib.hx_branch_batch_read_matrix.argtypes = [vp, C.c_int32, _f64p]
+    lib.hx_branch_batch_total_cells.argtypes = [vp]
+    lib.hx_branch_batch_total_cells.restype = C.c_int64
+    lib.hx_branch_batch_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.hx_quick_batch_destroy.argtypes = [vp]
     lib.hx_quick_batch_run.argtypes = [vp, vp]
     lib.hx_quick_batch_results.argtypes = [vp, _f64p, _i32p, _i32p]
@@ -424,6 +441,71 @@ class Batch:
             else:
                 out.append([tuple(int(v) for v in c) for c in cells[k, :n_cells[k]]])
         return out
+
+
+class BranchBatch:
+    """n independent per-branch pair DPs (Refiner::BranchMatrix / Sampler::BranchMatrix) resident on the device.
+    jobs: list of (x_pwm [x_len][C][A], y_sub [y_len][C][A], y_emit [y_len], trans [3][4], x_env or None, y_env or None,
+    max_distance)."""
+
+    def __init__(self, jobs):
+        self.n = len(jobs)
+        self._keep = []
+        arr = (HxBranchJob * self.n)()
+        for k, (xp, ys, ye, trans, xenv, yenv, md) in enumerate(jobs):
+            xp = np.ascontiguousarray(xp, dtype=np.float64)
+            ys = np.ascontiguousarray(ys, dtype=np.float64)
+            ye = np.ascontiguousarray(ye, dtype=np.float64)
+            xe = None if xenv is None else np.ascontiguousarray(xenv, dtype=np.int32)
+            yv = None if yenv is None else np.ascontiguousarray(yenv, dtype=np.int32)
+            self._keep.append((xp, ys, ye, xe, yv))
+            j = arr[k]
+            j.x_len, j.y_len = xp.shape[0] if xp.ndim == 3 else 0, ys.shape[0] if ys.ndim == 3 else 0
+            ref = xp if xp.ndim == 3 and xp.shape[0] else ys
+            j.components, j.alphabet = (ref.shape[1], ref.shape[2]) if ref.ndim == 3 else (1, 1)
+            j.x_pwm, j.y_sub, j.y_emit = _p(xp, _f64p), _p(ys, _f64p), _p(ye, _f64p)
+            for s in range(3):
+                for d in range(4):
+                    j.trans[s][d] = trans[s][d]
+            j.x_env = C.cast(None, _i32p) if xe is None else xe.ctypes.data_as(_i32p)
+            j.y_env = C.cast(None, _i32p) if yv is None else yv.ctypes.data_as(_i32p)
+            j.max_distance = md
+        self._jobs = arr
+        self.shapes = [(j.x_len + 1, j.y_len + 1) for j in arr]
+        self._h = C.c_void_p()
+        _check(load().hx_branch_batch_create(arr, self.n, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load().hx_branch_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, viterbi=True, stream=None):
+        _check(load().hx_branch_batch_run(self._h, 1 if viterbi else 0, C.c_void_p(stream or 0)))
+
+    def lp_end(self):
+        out = np.empty(self.n)
+        _check(load().hx_branch_batch_results(self._h, _p(out, _f64p)))
+        return out
+
+    def read_matrix(self, job):
+        out = np.empty(self.shapes[job] + (3,))
+        _check(load().hx_branch_batch_read_matrix(self._h, job, _p(out, _f64p)))
+        return out
+
+    def total_cells(self):
+        return int(load().hx_branch_batch_total_cells(self._h))
+
+    def kernel_ms(self):
+        ms = C.c_float()
+        _check(load().hx_branch_batch_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
 
 
 class QuickBatch:

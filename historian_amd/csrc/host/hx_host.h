@@ -801,4 +801,70 @@ struct AlignGraph {
   vguard<FastSeq> mstGapped();
 };
 
+// ---- src/sampler.h:19-215, src/refiner.h:8-18: the per-branch pair DPs ----------------
+// Parent profile x against child profile y across one branch: three states per cell (Match, Insert, Delete), the lattice of
+// TreeAlignFuncs::SparseDPMatrix<3> inside a GuideAlignmentEnvelope.  The fill runs on the device (hx_branch.hip through the
+// C ABI hx_branch_batch_*): Viterbi for Refiner::BranchMatrix, the reference's log_sum_exp for Sampler::BranchMatrix; the
+// matrix comes back dense and cell(), best() walk it on the host as the reference does.
+struct TreeAlignFuncs {
+  typedef vguard<vguard<vguard<LogProb>>> PosWeightMatrix;      // pwm[pos][cpt][tok]
+  enum State { Start = 0, Match = 0, Insert = 1, Delete = 2, End = 3 };   // ProbModel::State (src/model.h:135-137)
+  static double transProb(const ProbModel& probs, State src, State dest);                       // src/model.cpp:400-447
+  static PosWeightMatrix preMultiply(const PosWeightMatrix& child, const vguard<Mat>& logSubProb);    // src/sampler.cpp:452-463
+  static vguard<LogProb> calcInsProbs(const PosWeightMatrix& child, const vguard<vguard<LogProb>>& logInsProb,
+                                      const vguard<LogProb>& logCptWeight);                     // src/sampler.cpp:465-476
+  static PosWeightMatrix leafPWM(const FastSeq& seq, const string& alphabet, int components);   // a sequence as certain columns (0 / -inf)
+
+  class BranchMatrixBase {
+  public:
+    struct CellCoords { SeqIdx xpos, ypos; unsigned int state; };
+    const RateModel& model;
+    const ProbModel probModel;
+    const LogProbModel logProbModel;
+    LogProb mm, mi, md, me, im, ii, id, ie, dm, dd, de;
+    AlignRowIndex xRow, yRow;
+    const PosWeightMatrix& xSeq;
+    const PosWeightMatrix ySub;
+    const vguard<LogProb> yEmit;
+    const SeqIdx xSize, ySize;
+    LogProb lpEnd;
+
+    BranchMatrixBase(const RateModel& rates, const PosWeightMatrix& parent, const PosWeightMatrix& child, double branchLength,
+                     const GuideAlignmentEnvelope& envelope, const vguard<SeqIdx>& xEnvelopePos, const vguard<SeqIdx>& yEnvelopePos,
+                     AlignRowIndex parentRow, AlignRowIndex childRow, bool viterbi);
+    LogProb cell(SeqIdx xpos, SeqIdx ypos, unsigned int state) const;   // -inf outside the envelope; state End: lpEnd at the last cell
+    bool inEnvelope(SeqIdx xpos, SeqIdx ypos) const;
+    LogProb logMatch(SeqIdx xpos, SeqIdx ypos) const;
+    LogProb lpTrans(State src, State dest) const;
+    LogProb lpEmit(const CellCoords& at) const;
+    static void getColumn(const CellCoords& at, bool& xUngapped, bool& yUngapped);
+  private:
+    const GuideAlignmentEnvelope& env;
+    const vguard<SeqIdx>& xEnvPos;
+    const vguard<SeqIdx>& yEnvPos;
+    vguard<double> cells;      // dense [xSize][ySize][3] copy of the device matrix
+  };
+};
+
+struct Refiner : TreeAlignFuncs {
+  class BranchMatrix : public BranchMatrixBase {          // src/refiner.cpp:10-104
+  public:
+    BranchMatrix(const RateModel& rates, const PosWeightMatrix& parent, const PosWeightMatrix& child, double branchLength,
+                 const GuideAlignmentEnvelope& envelope, const vguard<SeqIdx>& xEnvelopePos, const vguard<SeqIdx>& yEnvelopePos,
+                 AlignRowIndex parentRow, AlignRowIndex childRow)
+        : BranchMatrixBase(rates, parent, child, branchLength, envelope, xEnvelopePos, yEnvelopePos, parentRow, childRow, true) {}
+    AlignPath best() const;
+  };
+};
+
+struct Sampler : TreeAlignFuncs {
+  class BranchMatrix : public BranchMatrixBase {          // src/sampler.cpp:1034-1084 (the fill; the sampling moves are not built)
+  public:
+    BranchMatrix(const RateModel& rates, const PosWeightMatrix& parent, const PosWeightMatrix& child, double branchLength,
+                 const GuideAlignmentEnvelope& envelope, const vguard<SeqIdx>& xEnvelopePos, const vguard<SeqIdx>& yEnvelopePos,
+                 AlignRowIndex parentRow, AlignRowIndex childRow)
+        : BranchMatrixBase(rates, parent, child, branchLength, envelope, xEnvelopePos, yEnvelopePos, parentRow, childRow, false) {}
+  };
+};
+
 }  // namespace historian

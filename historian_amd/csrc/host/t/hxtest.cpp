@@ -4,6 +4,8 @@
 //   hxtest seqprofile <alphabet> <sequence>        leaf Profile as JSON (Makefile:239-240)
 //   hxtest quickalign <pair.fa> <model.json> <t>   guide-alignment Viterbi of two sequences as gapped FASTA (Makefile:278-279)
 //   hxtest expm <model.json> <t>                   exp(R t) of every mixture component as hex floats, row by row
+//   hxtest branch <pair.fa> <model.json> <t>       the two sequences as parent and child of one branch (next row N4): Viterbi
+//                                                  and Forward log-likelihoods as hex floats, then the best alignment
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,11 +64,35 @@ int substitutionMatrix(int, char** args) {
   return 0;
 }
 
+int branchPair(int, char** args) {
+  const vguard<FastSeq> two = readFastSeqs(args[0]);
+  Require(two.size() == 2, "Sequence file must have exactly two sequences");
+  RateModel rates;
+  rates.readFile(args[1]);
+  const int C = (int)rates.subRate.size();
+  const auto parent = TreeAlignFuncs::leafPWM(two[0], rates.alphabet, C), child = TreeAlignFuncs::leafPWM(two[1], rates.alphabet, C);
+  vguard<SeqIdx> xPos(parent.size() + 1), yPos(child.size() + 1);
+  for (size_t k = 0; k < xPos.size(); ++k) xPos[k] = (SeqIdx)k;
+  for (size_t k = 0; k < yPos.size(); ++k) yPos[k] = (SeqIdx)k;
+  const GuideAlignmentEnvelope everywhere;
+  const Refiner::BranchMatrix viterbi(rates, parent, child, atof(args[2]), everywhere, xPos, yPos, 0, 1);
+  const Sampler::BranchMatrix forward(rates, parent, child, atof(args[2]), everywhere, xPos, yPos, 0, 1);
+  printf("viterbi %a\nforward %a\n", viterbi.lpEnd, forward.lpEnd);
+  const AlignPath best = viterbi.best();
+  for (AlignRowIndex row = 0; row < 2; ++row) {
+    size_t next = 0;
+    for (bool here : best.at(row)) putchar(here ? two[row].seq[next++] : '-');
+    putchar('\n');
+  }
+  return 0;
+}
+
 const Command commands[] = {
     {"logsumexp", 0, 1, "[-slow|-fast]", lseGrid},
     {"seqprofile", 2, 2, "<alphabet> <sequence>", leafProfileJson},
     {"quickalign", 3, 3, "<seqfile> <modelfile> <time>", guidePair},
     {"expm", 2, 2, "<modelfile> <time>", substitutionMatrix},
+    {"branch", 3, 3, "<seqfile> <modelfile> <time>", branchPair},
 };
 
 }  // namespace

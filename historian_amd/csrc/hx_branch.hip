@@ -1,0 +1,363 @@
+// Per-branch pair DPs: the three-state (Match / Insert / Delete) alignment of a parent sequence
+// profile with a child sequence profile across one tree branch, inside a GuideAlignmentEnvelope.
+//
+// Reference: Refiner::BranchMatrix::BranchMatrix (src/refiner.cpp:10-60: Viterbi, what `historian reconstruct -refine` runs on
+// every branch) and Sampler::BranchMatrix::BranchMatrix (src/sampler.cpp:1034-1084: the same lattice with log_sum_exp, the
+// MCMC sampler's branch move); cell storage and envelope of TreeAlignFuncs::SparseDPMatrix<3> (src/sampler.h:66-166), the
+// per-cell emission BranchMatrixBase::logMatch (src/sampler.h:207-209).
+//
+// Two kernels.  k_branch_emission evaluates logMatch(i, j) = logInnerProduct(xSeq[i-1], ySub[j-1]) for every in-envelope cell
+// up front - it does not depend on DP values, is fully parallel, and uses the reference's table log_sum_exp bit for bit.
+// k_branch_fill sweeps a pair with ONE wavefront: 64-row strips one after the other, lane <-> row, step <-> anti-diagonal; a
+// cell's left source is the lane's own previous cell, up and diagonal are the previous lane's cells of one and two steps ago
+// (DPP wave_shr:1); lane 0's come from the strip above's last row, which the same wavefront stored earlier: 64 columns of it
+// are block-loaded every 64 steps and handed out by v_readlane.  The batch supplies the parallelism: a refinement sweep aligns
+// every branch of a tree (2 N - 2 pairs), the sampler many moves.  Max-plus is exact in any order, the log_sum_exp form uses
+// the reference's operator in the reference's left-nested order: cells and lpEnd are bit-identical to the restatement
+// (oracle/branch_oracle.py) in both forms.
+//
+// Storage: three state planes per pair, strip-skewed like the Forward matrices (hx_device.h cell_slot), -inf outside the
+// envelope; hx_branch_batch_read_matrix returns the dense [x_len + 1][y_len + 1][3] array.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "hx_device.h"
+#include "hx_lse.h"
+#include "hx_common.h"
+#include "hx_policy.h"
+#include "hx_kernels.h"
+#include "../../include/historian_hip.h"
+
+namespace hx {
+
+int api_fail(int code, const char* what);                  // hx_api.hip: sets hx_last_error()
+const double* device_lse_table(int device);               // hx_api.hip: the table hx_init uploaded, or nullptr
+
+namespace {
+
+struct DevBranch {
+  int32_t X, Y;                 // positions 0 .. x_len, 0 .. y_len
+  int32_t CA;                   // components * alphabet
+  int32_t max_dist;             // < 0: no band
+  const double* x_pwm;          // [x_len][CA]
+  const double* y_sub;          // [y_len][CA]
+  const double* y_emit;         // [y_len]
+  const int32_t* x_env;         // [X] or nullptr
+  const int32_t* y_env;         // [Y]
+  double T[3][4];
+  double* cells;                // [3][plane]
+  double* emis;                 // [plane]: logMatch in the matrix layout
+  int64_t plane, strip_stride;
+  double* lp_end;
+};
+
+__device__ __forceinline__ bool branch_in_env(const DevBranch& J, const int i, const int j) {
+  // TreeAlignFuncs::SparseDPMatrix::inEnvelope (src/sampler.h:146-149)
+  if (i == 0 || j == 0 || i == J.X - 1 || j == J.Y - 1 || J.max_dist < 0) return true;
+  int d = J.x_env[i] - J.y_env[j];
+  d = d < 0 ? -d : d;
+  return d <= J.max_dist;
+}
+
+// logMatch for every in-envelope cell with i, j >= 1: the nested logInnerProduct of src/logsumexp.h:132-151 - over the
+// components, of the sum over the residues - in the reference's table arithmetic.  grid (jobs, row slices)
+__global__ void k_branch_emission(const DevBranch* __restrict__ jobs, const double* __restrict__ tab, const int C) {
+  const DevBranch& J = jobs[blockIdx.x];
+  const int A = J.CA / C;
+  const int64_t n = (int64_t)J.X * J.Y;
+  for (int64_t c = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.y * blockDim.x) {
+    const int i = (int)(c / J.Y), j = (int)(c % J.Y);
+    if (i == 0 || j == 0 || !branch_in_env(J, i, j)) continue;
+    const double* xs = J.x_pwm + (size_t)(i - 1) * J.CA;
+    const double* ys = J.y_sub + (size_t)(j - 1) * J.CA;
+    double lip = HX_NEG_INF;
+    for (int cpt = 0; cpt < C; ++cpt) {
+      double inner = HX_NEG_INF;
+      for (int a = 0; a < A; ++a) inner = lse(inner, xs[cpt * A + a] + ys[cpt * A + a], tab);
+      lip = lse(lip, inner, tab);
+    }
+    J.emis[cell_slot(J.strip_stride, i, j)] = lip;
+  }
+}
+
+__global__ void k_branch_clear(const DevBranch* __restrict__ jobs) {
+  const DevBranch& J = jobs[blockIdx.x];
+  const int64_t n = 3 * J.plane;
+  for (int64_t c = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.y * blockDim.x) J.cells[c] = HX_NEG_INF;
+}
+
+struct B3 { double m, i, d; };
+
+// value of lane `src` (wave-uniform)
+__device__ __forceinline__ double read_lane64(const double v, const int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+template <bool VITERBI>
+__device__ __forceinline__ double combine(const double a, const double b, const double* __restrict__ tab) {
+  return VITERBI ? vmax(a, b) : lse(a, b, tab);
+}
+
+// one wavefront per pair
+template <bool VITERBI>
+__global__ void __launch_bounds__(64) k_branch_fill(const DevBranch* __restrict__ jobs, const double* __restrict__ tab) {
+  const DevBranch& J = jobs[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int X = J.X, Y = J.Y;
+  const int64_t plane = J.plane, ss = J.strip_stride;
+  HX_GLOBAL double* __restrict__ M = as_global(J.cells);
+  const HX_GLOBAL double* __restrict__ E = as_global((const double*)J.emis);
+  const double mm = J.T[0][0], mi = J.T[0][1], md = J.T[0][2], im = J.T[1][0], ii = J.T[1][1], id = J.T[1][2], dm = J.T[2][0],
+               dd = J.T[2][2];
+  const int n_strips = (X + 63) >> 6;
+  const B3 none{HX_NEG_INF, HX_NEG_INF, HX_NEG_INF};
+  for (int s = 0; s < n_strips; ++s) {
+    const int i = (s << 6) + lane;
+    const bool rvalid = i < X;
+    const int xe = (rvalid && J.max_dist >= 0) ? J.x_env[i] : 0;
+    const bool xedge = i == 0 || i == X - 1;
+    B3 left = none, up = none, diag = none;        // (i, j-1); (i-1, j) and (i-1, j-1) of the step being computed
+    B3 bnd = none;                                  // lane l: cell (row above the strip, column c0 + l) of the current block of 64 columns
+    for (int t = 0; t < Y + 63; ++t) {
+      if (s > 0 && (t & 63) == 0) {
+        // the strip above's last row, 64 columns at a time (stored by this wavefront; agent-scope loads: served by L2)
+        const int c = t + lane;
+        bnd = none;
+        if (c < Y) {
+          const int64_t sl = cell_slot(ss, (s << 6) - 1, c);
+          bnd.m = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bnd.i = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bnd.d = __hip_atomic_load(M + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      // lane 0's upper neighbour of this step is column t of the row above: lane (t & 63) of the block
+      if (s > 0) {
+        const int src = t & 63;
+        const double bm = read_lane64(bnd.m, src), bi = read_lane64(bnd.i, src), bd = read_lane64(bnd.d, src);
+        if (lane == 0) up = t < Y ? B3{bm, bi, bd} : none;
+      }
+      const int j = t - lane;
+      B3 now = none;
+      if (rvalid && j >= 0 && j < Y) {
+        const bool in = xedge || j == 0 || j == Y - 1 || J.max_dist < 0 ||
+                        (xe - J.y_env[j] <= J.max_dist && J.y_env[j] - xe <= J.max_dist);
+        if (in) {
+          const int64_t sl = cell_slot(ss, i, j);
+          // src/refiner.cpp:24-50 / src/sampler.cpp:1049-1072: a source outside the envelope reads as -inf, which is what
+          // the cell's state then is - the reference leaves it unassigned
+          if (i > 0) now.d = combine<VITERBI>(combine<VITERBI>(up.m + md, up.i + id, tab), up.d + dd, tab);
+          if (j > 0) now.i = J.y_emit[j - 1] + combine<VITERBI>(left.m + mi, left.i + ii, tab);
+          if (i > 0 && j > 0) now.m = E[sl] + combine<VITERBI>(combine<VITERBI>(diag.m + mm, diag.i + im, tab), diag.d + dm, tab);
+          if (i == 0 && j == 0) now.m = 0.0;        // lpStart() = 0
+          M[sl] = now.m; M[plane + sl] = now.i; M[2 * plane + sl] = now.d;
+        }
+      }
+      // next step: the lane's own cell is its left source; the previous lane's cell of this step its upper, of the last its diagonal
+      diag = up;
+      left = now;
+      up = B3{wave_shr1(now.m), wave_shr1(now.i), wave_shr1(now.d)};
+      if (lane == 0) up = none;                     // (row 0 has no row above; strips below take it from the block)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (lane == 0) {
+    const int64_t sl = cell_slot(ss, X - 1, Y - 1);
+    const double em = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double ei = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double ed = __hip_atomic_load(M + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *J.lp_end = combine<VITERBI>(combine<VITERBI>(em + J.T[0][3], ei + J.T[1][3], tab), ed + J.T[2][3], tab);
+  }
+}
+
+// the skewed planes of one pair -> dense [X][Y][3]
+__global__ void k_branch_dense(const DevBranch* __restrict__ jobs, const int job, double* __restrict__ out) {
+  const DevBranch& J = jobs[job];
+  const int64_t n = (int64_t)J.X * J.Y;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t sl = cell_slot(J.strip_stride, (int)(c / J.Y), (int)(c % J.Y));
+    for (int s = 0; s < 3; ++s) out[3 * c + s] = J.cells[s * J.plane + sl];
+  }
+}
+
+}  // namespace
+}  // namespace hx
+
+using namespace hx;
+
+struct hx_branch_batch {
+  int device = 0, n_jobs = 0, components = 1;
+  std::vector<DevBranch> jobs;
+  DevBranch* d_jobs = nullptr;
+  char* d_arena = nullptr;          // inputs + lpEnd
+  double* d_cells = nullptr;        // matrices + emission planes
+  size_t lp_off = 0;
+  int64_t max_cells = 0;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  hipStream_t last_stream = nullptr;
+  bool done = false;
+};
+
+extern "C" {
+
+int hx_branch_batch_destroy(hx_branch_batch* b) {
+  if (!b) return HX_OK;
+  (void)hipSetDevice(b->device);
+  (void)hipDeviceSynchronize();
+  for (int e = 0; e < 2; ++e)
+    if (b->ev[e]) (void)hipEventDestroy(b->ev[e]);
+  if (b->d_jobs) (void)hipFree(b->d_jobs);
+  if (b->d_arena) (void)hipFree(b->d_arena);
+  if (b->d_cells) (void)hipFree(b->d_cells);
+  delete b;
+  return HX_OK;
+}
+
+int hx_branch_batch_create(const hx_branch_job* jobs, int32_t n_jobs, hx_branch_batch** out) {
+  if (out) *out = nullptr;
+  if (!jobs || !out || n_jobs < 1) return api_fail(HX_ERR_INVALID_ARG, "hx_branch_batch_create: need at least one job");
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return api_fail(HX_ERR_NO_DEVICE, "no HIP device");
+  if (!device_lse_table(device)) return api_fail(HX_ERR_NOT_INITIALIZED, "hx_init has not been called for the current device");
+  hx_branch_batch* b = new (std::nothrow) hx_branch_batch;
+  if (!b) return api_fail(HX_ERR_OUT_OF_MEMORY, "host allocation failed");
+  b->device = device;
+  b->n_jobs = n_jobs;
+  b->components = jobs[0].components;
+  std::vector<char> host;
+  auto put = [&](const void* p, size_t bytes) -> size_t {
+    const size_t off = (host.size() + 15) & ~(size_t)15;
+    host.resize(off + bytes);
+    if (bytes) memcpy(host.data() + off, p, bytes);
+    return off;
+  };
+  struct Off { size_t x, y, e, xe, ye; bool env; };
+  std::vector<Off> offs(n_jobs);
+  int64_t cells_total = 0;
+  try {
+    b->jobs.resize(n_jobs);
+    for (int k = 0; k < n_jobs; ++k) {
+      const hx_branch_job& j = jobs[k];
+      if (j.x_len < 0 || j.y_len < 0 || j.components < 1 || j.alphabet < 1 || j.components != b->components ||
+          (j.x_len && !j.x_pwm) || (j.y_len && (!j.y_sub || !j.y_emit)) || (j.max_distance >= 0 && (!j.x_env || !j.y_env))) {
+        hx_branch_batch_destroy(b);
+        return api_fail(HX_ERR_INVALID_ARG, "hx_branch_batch_create: inconsistent job (lengths, components, missing arrays)");
+      }
+      DevBranch& J = b->jobs[k];
+      memset(&J, 0, sizeof(J));
+      J.X = j.x_len + 1; J.Y = j.y_len + 1;
+      J.CA = j.components * j.alphabet;
+      J.max_dist = j.max_distance;
+      for (int s = 0; s < 3; ++s)
+        for (int d = 0; d < 4; ++d) J.T[s][d] = j.trans[s][d];
+      J.strip_stride = strip_stride_for(J.Y);
+      J.plane = (int64_t)((J.X + HX_STRIP - 1) / HX_STRIP) * J.strip_stride;
+      offs[k].x = put(j.x_pwm, sizeof(double) * (size_t)j.x_len * J.CA);
+      offs[k].y = put(j.y_sub, sizeof(double) * (size_t)j.y_len * J.CA);
+      offs[k].e = put(j.y_emit, sizeof(double) * (size_t)j.y_len);
+      offs[k].env = j.max_distance >= 0;
+      offs[k].xe = offs[k].env ? put(j.x_env, sizeof(int32_t) * (size_t)J.X) : 0;
+      offs[k].ye = offs[k].env ? put(j.y_env, sizeof(int32_t) * (size_t)J.Y) : 0;
+      cells_total += 4 * J.plane;
+      if ((int64_t)J.X * J.Y > b->max_cells) b->max_cells = (int64_t)J.X * J.Y;
+    }
+    b->lp_off = put(nullptr, 0);
+    host.resize(b->lp_off + sizeof(double) * n_jobs);
+  } catch (const std::bad_alloc&) {
+    hx_branch_batch_destroy(b);
+    return api_fail(HX_ERR_OUT_OF_MEMORY, "host allocation failed while building the batch");
+  }
+  if (hipMalloc(reinterpret_cast<void**>(&b->d_arena), host.size()) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&b->d_cells), sizeof(double) * (size_t)cells_total) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&b->d_jobs), sizeof(DevBranch) * n_jobs) != hipSuccess) {
+    hx_branch_batch_destroy(b);
+    return api_fail(HX_ERR_OUT_OF_MEMORY, "hx_branch_batch_create: device allocation failed");
+  }
+  int64_t at = 0;
+  for (int k = 0; k < n_jobs; ++k) {
+    DevBranch& J = b->jobs[k];
+    J.x_pwm = reinterpret_cast<const double*>(b->d_arena + offs[k].x);
+    J.y_sub = reinterpret_cast<const double*>(b->d_arena + offs[k].y);
+    J.y_emit = reinterpret_cast<const double*>(b->d_arena + offs[k].e);
+    J.x_env = offs[k].env ? reinterpret_cast<const int32_t*>(b->d_arena + offs[k].xe) : nullptr;
+    J.y_env = offs[k].env ? reinterpret_cast<const int32_t*>(b->d_arena + offs[k].ye) : nullptr;
+    J.cells = b->d_cells + at;
+    J.emis = b->d_cells + at + 3 * J.plane;
+    at += 4 * J.plane;
+    J.lp_end = reinterpret_cast<double*>(b->d_arena + b->lp_off) + k;
+  }
+  if (hipMemcpy(b->d_arena, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(b->d_jobs, b->jobs.data(), sizeof(DevBranch) * n_jobs, hipMemcpyHostToDevice) != hipSuccess ||
+      hipEventCreate(&b->ev[0]) != hipSuccess || hipEventCreate(&b->ev[1]) != hipSuccess) {
+    hx_branch_batch_destroy(b);
+    return api_fail(HX_ERR_HIP, "hx_branch_batch_create: copy to the device failed");
+  }
+  *out = b;
+  return HX_OK;
+}
+
+int hx_branch_batch_run(hx_branch_batch* b, int32_t viterbi, void* stream) {
+  if (!b) return api_fail(HX_ERR_INVALID_ARG, "batch is null");
+  if (hipSetDevice(b->device) != hipSuccess) return api_fail(HX_ERR_HIP, "hipSetDevice failed");
+  const double* tab = device_lse_table(b->device);
+  if (!tab) return api_fail(HX_ERR_NOT_INITIALIZED, "hx_init has not been called for the batch's device");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int j0 = 0; j0 < b->n_jobs; j0 += 16384) {        // (grid.x of at most 16384 jobs per launch)
+    const int n = b->n_jobs - j0 < 16384 ? b->n_jobs - j0 : 16384;
+    hipLaunchKernelGGL(k_branch_clear, dim3(n, 16), dim3(256), 0, st, b->d_jobs + j0);
+    hipLaunchKernelGGL(k_branch_emission, dim3(n, 16), dim3(256), 0, st, b->d_jobs + j0, tab, b->components);
+  }
+  if (hipEventRecord(b->ev[0], st) != hipSuccess) return api_fail(HX_ERR_HIP, "hipEventRecord failed");
+  for (int j0 = 0; j0 < b->n_jobs; j0 += 65536) {
+    const int n = b->n_jobs - j0 < 65536 ? b->n_jobs - j0 : 65536;
+    if (viterbi) hipLaunchKernelGGL(k_branch_fill<true>, dim3(n), dim3(64), 0, st, b->d_jobs + j0, tab);
+    else hipLaunchKernelGGL(k_branch_fill<false>, dim3(n), dim3(64), 0, st, b->d_jobs + j0, tab);
+  }
+  if (hipEventRecord(b->ev[1], st) != hipSuccess || hipGetLastError() != hipSuccess) return api_fail(HX_ERR_HIP, "hx_branch_batch_run: launch failed");
+  b->done = true;
+  b->last_stream = st;
+  return HX_OK;
+}
+
+int hx_branch_batch_results(hx_branch_batch* b, double* lp_end) {
+  if (!b || !lp_end) return api_fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (!b->done) return api_fail(HX_ERR_STATE, "hx_branch_batch_run has not been launched");
+  if (hipSetDevice(b->device) != hipSuccess || hipStreamSynchronize(b->last_stream) != hipSuccess ||
+      hipMemcpy(lp_end, b->d_arena + b->lp_off, sizeof(double) * b->n_jobs, hipMemcpyDeviceToHost) != hipSuccess)
+    return api_fail(HX_ERR_HIP, "hx_branch_batch_results: HIP call failed");
+  return HX_OK;
+}
+
+int hx_branch_batch_read_matrix(hx_branch_batch* b, int32_t job, double* out) {
+  if (!b || !out) return api_fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (job < 0 || job >= b->n_jobs) return api_fail(HX_ERR_RANGE, "job out of range");
+  if (!b->done) return api_fail(HX_ERR_STATE, "hx_branch_batch_run has not been launched");
+  const DevBranch& J = b->jobs[job];
+  const size_t bytes = sizeof(double) * 3 * (size_t)J.X * J.Y;
+  double* dense = nullptr;
+  if (hipSetDevice(b->device) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&dense), bytes) != hipSuccess)
+    return api_fail(HX_ERR_OUT_OF_MEMORY, "hx_branch_batch_read_matrix: device allocation failed");
+  hipLaunchKernelGGL(k_branch_dense, dim3(256), dim3(256), 0, b->last_stream, b->d_jobs, job, dense);
+  const bool ok = hipStreamSynchronize(b->last_stream) == hipSuccess && hipMemcpy(out, dense, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(dense);
+  return ok ? HX_OK : api_fail(HX_ERR_HIP, "hx_branch_batch_read_matrix: HIP call failed");
+}
+
+int64_t hx_branch_batch_total_cells(const hx_branch_batch* b) {
+  if (!b) return 0;
+  int64_t n = 0;
+  for (const DevBranch& J : b->jobs) n += (int64_t)J.X * J.Y;
+  return n;
+}
+
+int hx_branch_batch_last_kernel_ms(hx_branch_batch* b, float* ms) {
+  if (!b || !ms) return api_fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (!b->done) return api_fail(HX_ERR_STATE, "hx_branch_batch_run has not been launched");
+  if (hipSetDevice(b->device) != hipSuccess || hipEventSynchronize(b->ev[1]) != hipSuccess ||
+      hipEventElapsedTime(ms, b->ev[0], b->ev[1]) != hipSuccess)
+    return api_fail(HX_ERR_HIP, "hx_branch_batch_last_kernel_ms: HIP call failed");
+  return HX_OK;
+}
+
+}  // extern "C"

@@ -351,6 +351,38 @@ int hx_sumprod_last_kernel_ms(float* ms);
 int hx_host_alloc(size_t bytes, void** out);
 int hx_host_free(void* p);
 
+/* ---- next row N4: per-branch pair DPs -----------------------------------------------------------
+ * The three-state (Match / Insert / Delete) alignment of a parent sequence profile x with a child sequence profile y
+ * across one tree branch inside a GuideAlignmentEnvelope: Refiner::BranchMatrix (reference src/refiner.cpp:10-60, Viterbi;
+ * `historian reconstruct -refine` runs it on every branch) and Sampler::BranchMatrix (src/sampler.cpp:1034-1084, the same
+ * lattice with log_sum_exp).  A batch is a set of independent branches (all branches of a tree in a refinement sweep).
+ * Cells and lpEnd are bit-identical to the reference recursion for the same inputs in both forms. */
+typedef struct hx_branch_job {
+  int32_t x_len, y_len;      /* positions of the parent / child profile; the matrix has (x_len + 1) x (y_len + 1) cells   */
+  int32_t components;        /* mixture components C (the same for every job of a batch)                                 */
+  int32_t alphabet;          /* A                                                                                        */
+  const double* x_pwm;       /* [x_len][C][A] log weights of the parent profile (PosWeightMatrix xSeq)                   */
+  const double* y_sub;       /* [y_len][C][A] the child profile left-multiplied by the branch's log substitution matrix
+                                (BranchMatrixBase::ySub = TreeAlignFuncs::preMultiply, src/sampler.cpp:452-463)          */
+  const double* y_emit;      /* [y_len] insertion scores (BranchMatrixBase::yEmit = calcInsProbs, src/sampler.cpp:465-476) */
+  double trans[3][4];        /* log ProbModel::transProb(src, dest): src Match, Insert, Delete; dest ... and End (3)      */
+  const int32_t* x_env;      /* [x_len + 1] envelope coordinate of every position: cumulativeMatches[row1PosToCol[xEnvPos[i]]]
+                                of the GuideAlignmentEnvelope (src/alignpath.h:56-61); NULL with max_distance < 0          */
+  const int32_t* y_env;      /* [y_len + 1]                                                                              */
+  int32_t max_distance;      /* GuideAlignmentEnvelope::maxDistance; < 0: no band (every cell in the envelope)           */
+} hx_branch_job;
+typedef struct hx_branch_batch hx_branch_batch;
+
+int hx_branch_batch_create(const hx_branch_job* jobs, int32_t n_jobs, hx_branch_batch** out);   /* on the current device */
+int hx_branch_batch_destroy(hx_branch_batch* b);
+/* viterbi != 0: the max-plus fill of Refiner::BranchMatrix; 0: the log_sum_exp fill of Sampler::BranchMatrix */
+int hx_branch_batch_run(hx_branch_batch* b, int32_t viterbi, void* stream);
+int hx_branch_batch_results(hx_branch_batch* b, double* lp_end /* [n_jobs] */);
+/* dense [x_len + 1][y_len + 1][3] (Match, Insert, Delete); -inf outside the envelope, as SparseDPMatrix::cell() returns */
+int hx_branch_batch_read_matrix(hx_branch_batch* b, int32_t job, double* out);
+int64_t hx_branch_batch_total_cells(const hx_branch_batch* b);
+int hx_branch_batch_last_kernel_ms(hx_branch_batch* b, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -181,3 +181,34 @@ def test_testspan_random_graph_runs_and_is_a_valid_alignment():
     seqs = dict(read_fasta(G + "PF16593.fa"))
     assert set(rows) == set(seqs) and len({len(r) for r in rows.values()}) == 1
     assert all(rows[n].replace("-", "") == seqs[n] for n in seqs)
+
+
+@pytest.mark.gpu
+def test_branch_matrices_of_the_mirror_against_the_oracle():
+    # next row N4: Refiner::BranchMatrix / Sampler::BranchMatrix of the host mirror (fills on the device) on the reference's
+    # PF16593 pair as parent and child of one branch - Viterbi and Forward log-likelihoods bit for bit, the best alignment
+    # equal to the restatement's (oracle/branch_oracle.py, pinned by enumeration in tests/test_oracle_branch.py)
+    from oracle import branch_oracle as bo
+    from oracle import historian_oracle as ho
+    from oracle.ref_mains import read_fasta
+    (_, xs), (_, ys) = read_fasta(G + "PF16593.pair.fa")
+    model = ho.RateModel.from_file(G + "testamino.json")
+    t = 0.7
+    pm = ho.ProbModel(model, t, [ho.sub_prob_matrix_ss(sr.tolist(), t) for sr in model.sub_rate])
+    lpm = ho.LogProbModel(pm)
+    neg = float("-inf")
+    def pwm(seq):
+        return [[[0. if model.alphabet[a] == ch.lower() else neg for a in range(len(model.alphabet))]] for ch in seq]
+    x, y = pwm(xs), pwm(ys)
+    log_sub = [[[ho.safe_log(v) for v in row] for row in m] for m in pm.sub_mat]
+    ysub, yemit = bo.pre_multiply(y, log_sub), bo.calc_ins_probs(y, lpm.log_ins_prob, lpm.log_cpt_weight)
+    T = bo.trans_scores(pm.ins, pm.dele, pm.ins_ext, pm.del_ext)
+    vit = bo.BranchMatrix(x, ysub, yemit, T, viterbi=True)
+    fwd = bo.BranchMatrix(x, ysub, yemit, T, viterbi=False)
+    out = run(["hxtest", "branch", G + "PF16593.pair.fa", G + "testamino.json", t]).split()
+    assert float.fromhex(out[1]) == vit.lp_end and float.fromhex(out[3]) == fwd.lp_end
+    xrow, yrow = vit.best()
+    def gapped(seq, row):
+        it = iter(seq)
+        return "".join(next(it) if b else "-" for b in row)
+    assert out[4:] == [gapped(xs, xrow), gapped(ys, yrow)]

@@ -1,14 +1,16 @@
 #!/bin/bash
 # Round profile of the default bench: kernel-trace stats + HBM traffic counters (separate PMC passes,
 # as /opt/skills/guides/MI355X_MICROARCH.md prescribes).  Run on the GPU box; copy summaries to profiles/.
-tag=${1:-r01}
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+tag=${1:-r03}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export TMPDIR=/tmp
+cd "$R" || exit 1
 mkdir -p gpurun_out/$tag
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/trace -- python bench.py --steps 3 --warmup 1 > gpurun_out/$tag/bench.log 2>&1
 cp $(find gpurun_out/$tag/trace -name "*kernel_stats.csv" | head -1) gpurun_out/$tag/kernel_stats.csv
 grep '^{' gpurun_out/$tag/bench.log > gpurun_out/$tag/bench.json
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/$tag/pmc_$c -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/$tag/pmc_$c.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/$tag/pmc_$c -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --banded-pairs '' > gpurun_out/$tag/pmc_$c.log 2>&1
 done
 python - <<PY
 import csv,glob,collections,json
@@ -18,7 +20,7 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
         agg=collections.defaultdict(lambda: [0.0,0])
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"]!=c: continue
-            if "k_fill_leaf_linear" in r["Kernel_Name"]: key="linear"
+            if "k_fill_leaf_linear" in r["Kernel_Name"]: key="trunc" if r["Kernel_Name"].split("(")[0].rstrip().endswith("true>") else "linear"
             elif "k_fill_chain<0" in r["Kernel_Name"]: key="fast" if "FastLse" in r["Kernel_Name"] else "exact"
             else: continue
             agg[key][0]+=float(r["Counter_Value"]); agg[key][1]+=1
