@@ -39,7 +39,7 @@ namespace {
 
 struct DevBranch {
   int32_t X, Y;                 // positions 0 .. x_len, 0 .. y_len
-  int32_t CA;                   // components * alphabet
+  int32_t CA, C;                // components * alphabet; components
   int32_t max_dist;             // < 0: no band
   const double* x_pwm;          // [x_len][CA]
   const double* y_sub;          // [y_len][CA]
@@ -63,9 +63,9 @@ __device__ __forceinline__ bool branch_in_env(const DevBranch& J, const int i, c
 
 // logMatch for every in-envelope cell with i, j >= 1: the nested logInnerProduct of src/logsumexp.h:132-151 - over the
 // components, of the sum over the residues - in the reference's table arithmetic.  grid (jobs, row slices)
-__global__ void k_branch_emission(const DevBranch* __restrict__ jobs, const double* __restrict__ tab, const int C) {
+__global__ void k_branch_emission(const DevBranch* __restrict__ jobs, const double* __restrict__ tab) {
   const DevBranch& J = jobs[blockIdx.x];
-  const int A = J.CA / C;
+  const int C = J.C, A = J.CA / C;
   const int64_t n = (int64_t)J.X * J.Y;
   for (int64_t c = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.y * blockDim.x) {
     const int i = (int)(c / J.Y), j = (int)(c % J.Y);
@@ -187,7 +187,7 @@ __global__ void k_branch_dense(const DevBranch* __restrict__ jobs, const int job
 using namespace hx;
 
 struct hx_branch_batch {
-  int device = 0, n_jobs = 0, components = 1;
+  int device = 0, n_jobs = 0;
   std::vector<DevBranch> jobs;
   DevBranch* d_jobs = nullptr;
   char* d_arena = nullptr;          // inputs + lpEnd
@@ -224,7 +224,6 @@ int hx_branch_batch_create(const hx_branch_job* jobs, int32_t n_jobs, hx_branch_
   if (!b) return api_fail(HX_ERR_OUT_OF_MEMORY, "host allocation failed");
   b->device = device;
   b->n_jobs = n_jobs;
-  b->components = jobs[0].components;
   std::vector<char> host;
   auto put = [&](const void* p, size_t bytes) -> size_t {
     const size_t off = (host.size() + 15) & ~(size_t)15;
@@ -239,7 +238,7 @@ int hx_branch_batch_create(const hx_branch_job* jobs, int32_t n_jobs, hx_branch_
     b->jobs.resize(n_jobs);
     for (int k = 0; k < n_jobs; ++k) {
       const hx_branch_job& j = jobs[k];
-      if (j.x_len < 0 || j.y_len < 0 || j.components < 1 || j.alphabet < 1 || j.components != b->components ||
+      if (j.x_len < 0 || j.y_len < 0 || j.components < 1 || j.alphabet < 1 ||
           (j.x_len && !j.x_pwm) || (j.y_len && (!j.y_sub || !j.y_emit)) || (j.max_distance >= 0 && (!j.x_env || !j.y_env))) {
         hx_branch_batch_destroy(b);
         return api_fail(HX_ERR_INVALID_ARG, "hx_branch_batch_create: inconsistent job (lengths, components, missing arrays)");
@@ -248,6 +247,7 @@ int hx_branch_batch_create(const hx_branch_job* jobs, int32_t n_jobs, hx_branch_
       memset(&J, 0, sizeof(J));
       J.X = j.x_len + 1; J.Y = j.y_len + 1;
       J.CA = j.components * j.alphabet;
+      J.C = j.components;
       J.max_dist = j.max_distance;
       for (int s = 0; s < 3; ++s)
         for (int d = 0; d < 4; ++d) J.T[s][d] = j.trans[s][d];
@@ -306,7 +306,7 @@ int hx_branch_batch_run(hx_branch_batch* b, int32_t viterbi, void* stream) {
   for (int j0 = 0; j0 < b->n_jobs; j0 += 16384) {        // (grid.x of at most 16384 jobs per launch)
     const int n = b->n_jobs - j0 < 16384 ? b->n_jobs - j0 : 16384;
     hipLaunchKernelGGL(k_branch_clear, dim3(n, 16), dim3(256), 0, st, b->d_jobs + j0);
-    hipLaunchKernelGGL(k_branch_emission, dim3(n, 16), dim3(256), 0, st, b->d_jobs + j0, tab, b->components);
+    hipLaunchKernelGGL(k_branch_emission, dim3(n, 16), dim3(256), 0, st, b->d_jobs + j0, tab);
   }
   if (hipEventRecord(b->ev[0], st) != hipSuccess) return api_fail(HX_ERR_HIP, "hipEventRecord failed");
   for (int j0 = 0; j0 < b->n_jobs; j0 += 65536) {

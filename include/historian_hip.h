@@ -359,7 +359,7 @@ int hx_host_free(void* p);
  * Cells and lpEnd are bit-identical to the reference recursion for the same inputs in both forms. */
 typedef struct hx_branch_job {
   int32_t x_len, y_len;      /* positions of the parent / child profile; the matrix has (x_len + 1) x (y_len + 1) cells   */
-  int32_t components;        /* mixture components C (the same for every job of a batch)                                 */
+  int32_t components;        /* mixture components C                                                                     */
   int32_t alphabet;          /* A                                                                                        */
   const double* x_pwm;       /* [x_len][C][A] log weights of the parent profile (PosWeightMatrix xSeq)                   */
   const double* y_sub;       /* [y_len][C][A] the child profile left-multiplied by the branch's log substitution matrix
