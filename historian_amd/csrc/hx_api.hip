@@ -908,7 +908,11 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
   // The general-profile classes need scratch planes next to the matrices: the five outgoing sums of every cell
   // (hx_dag.hip), or - HX_LSE_LINEAR, when every such job's planes fit 32-bit byte offsets - the cells in the
   // scaled-probability fill's own format (hx_daglin.hip).
-  b->dag_linear = (flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && !(flags & HX_FORCE_GENERIC);
+  // (General profiles under the truncating policy run as HX_LSE_FAST, which truncates as the reference does.  The scaled-
+  // probability pipeline of hx_daglin.hip with truncating sums was built and withdrawn in round 3: it sums a state's fourth and
+  // further in-transitions out of the reference's order, and with truncation the order of a sum matters at the 4.5e-5 level -
+  // cells downstream of such a state moved by up to 6e-5 where the leaf kernels hold 1e-7.)
+  b->dag_linear = (flags & HX_LSE_LINEAR) == HX_LSE_LINEAR && (flags & HX_LSE_TRUNC) != HX_LSE_TRUNC && !(flags & HX_FORCE_GENERIC);
   for (int k = 0; k < n_jobs && b->dag_linear; ++k)
     if ((kclass[k] == KC_DAG || kclass[k] == KC_DAG_BANDED) && !dag_linear_fits(b->jobs[k].plane)) b->dag_linear = false;
   int64_t mat_total = 0, agg_total = 0;
@@ -1142,7 +1146,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
             HIP_TRY(hipMemsetAsync(b->d_multi, 0, HX_MULTI_MAX_PAIRS * 256 * sizeof(int), st));
           }
           if (b->dag_linear)
-            LAUNCH_TRY(launch_forward_dag_linear(jobs, cr.n, cr.max_rows, Tab8{D.tab}, Tab16{D.log_tab}, multi, multi_waves, b->d_multi, trunc, st));
+            LAUNCH_TRY(launch_forward_dag_linear(jobs, cr.n, cr.max_rows, Tab8{D.tab}, Tab16{D.log_tab}, multi, multi_waves, b->d_multi, st));
           else
             LAUNCH_TRY(launch_forward_dag_pipe(jobs, cr.n, cr.max_rows, Tab8{D.tab}, lse_tab, fast, multi, multi_waves, b->d_multi, st));
         }

@@ -91,36 +91,21 @@ __device__ __forceinline__ double log_scaled(const double m, const int e, const 
   return __builtin_fma((double)(e + k), 0.693147180559945309417, lf);
 }
 
-// One pairwise sum of the reference's log_sum_exp on probabilities (hx_linear.hip trunc_sum): the smaller term is dropped when
-// it is at most e^-10 of the larger, as the reference's table does for differences >= 10 (src/logsumexp.h:45).  TRUNC = the
-// HX_LSE_TRUNC policy; without it sums are plain multiply-adds (HX_LSE_LINEAR).
-__device__ __forceinline__ double trunc_sum(double a, double b) {
-  const double hi = vmax(a, b), lo = vmin(a, b);
-  const int keep = lo > hi * 4.5399929762484854e-05 ? __double2hiint(lo) : 0;
-  return hi + __hiloint2double(keep, __double2loint(lo));
-}
-template <bool TRUNC> __device__ __forceinline__ double lin_acc(const double m, const double p, const double acc) {
-  if (TRUNC) return trunc_sum(acc, m * p);
-  return __builtin_fma(m, p, acc);
-}
-
 // a running sum of terms with their own exponents: (s, E) += m * 2^e * w
 struct Acc1 { double s; int E; };
 struct Acc2 { double a, b; int E; };
-template <bool TRUNC>
 __device__ __forceinline__ void add1(Acc1& A, const double m, const int e, const double w) {
   const int te = m > 0. ? e : HXD_EMIN;
   const int En = te > A.E ? te : A.E;
-  A.s = lin_acc<TRUNC>(ldexp_fast(m, te - En), w, ldexp_fast(A.s, A.E - En));
+  A.s = __builtin_fma(ldexp_fast(m, te - En), w, ldexp_fast(A.s, A.E - En));
   A.E = En;
 }
-template <bool TRUNC>
 __device__ __forceinline__ void add2(Acc2& A, const double ma, const double mb, const int e, const double w) {
   const int te = (ma > 0. || mb > 0.) ? e : HXD_EMIN;
   const int En = te > A.E ? te : A.E;
   const int dn = te - En, dp = A.E - En;
-  A.a = lin_acc<TRUNC>(ldexp_fast(ma, dn), w, ldexp_fast(A.a, dp));
-  A.b = lin_acc<TRUNC>(ldexp_fast(mb, dn), w, ldexp_fast(A.b, dp));
+  A.a = __builtin_fma(ldexp_fast(ma, dn), w, ldexp_fast(A.a, dp));
+  A.b = __builtin_fma(ldexp_fast(mb, dn), w, ldexp_fast(A.b, dp));
   A.E = En;
 }
 
@@ -233,7 +218,7 @@ __global__ void k_lin_clear(const DevJob* __restrict__ jobs) {
   for (int64_t k = first; k < ne; k += stride) ex[k] = HXD_EMIN;
 }
 
-template <bool MULTI, bool TRUNC>
+template <bool MULTI>
 __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab,
                                                                            const double* __restrict__ log_tab, const int groups, int* const counters,
                                                                            const int patience) {
@@ -522,8 +507,8 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
           Acc1 am = Acc1{0., HXD_EMIN};                       // IMM
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            if (xgo && xdeg > k) add2<TRUNC>(ax, xa[k], xb[k], xe[k], wxs[k]);      // x-absorbing (or x-null) moves: IMD, IIW
-            if (ygo && ydeg > k) add2<TRUNC>(ay, ya[k], yb[k], ye[k], wys[k]);      // y-absorbing (or y-null) moves: IDM, IMI
+            if (xgo && xdeg > k) add2(ax, xa[k], xb[k], xe[k], wxs[k]);      // x-absorbing (or x-null) moves: IMD, IIW
+            if (ygo && ydeg > k) add2(ay, ya[k], yb[k], ye[k], wys[k]);      // y-absorbing (or y-null) moves: IDM, IMI
           }
           if (mode == 1) {
             // transition pairs (reference src/forward.cpp:98-116): the source's outgoing sum into IMM
@@ -531,15 +516,15 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
             for (int a = 0; a < 3; ++a)
 #pragma unroll
               for (int b = 0; b < 3; ++b)
-                if (xdeg > a && ydeg > b) add1<TRUNC>(am, mv[a * 3 + b], me[a * 3 + b], wxs[a] * wys[b]);
+                if (xdeg > a && ydeg > b) add1(am, mv[a * 3 + b], me[a * 3 + b], wxs[a] * wys[b]);
           } else if (mode == 2) {
 #pragma unroll
             for (int b = 0; b < 3; ++b)
-              if (ydeg > b) add1<TRUNC>(am, mv[b], me[b], wys[b]);
+              if (ydeg > b) add1(am, mv[b], me[b], wys[b]);
           } else if (mode == 3) {
 #pragma unroll
             for (int a = 0; a < 3; ++a)
-              if (xdeg > a) add1<TRUNC>(am, mv[a], me[a], wxs[a]);
+              if (xdeg > a) add1(am, mv[a], me[a], wxs[a]);
           }
           HXD_TR(6);     // (the inline transitions are summed)
           // ---- second batch: the cells of in-transitions 3 .. 7 of the row and of the column, all loads first ----
@@ -573,12 +558,12 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
                 xa2[q] = xnull ? up_imd : up_g0; xb2[q] = xnull ? up_iiw : up_g1; xe2[q] = up_E;
                 if (mode == 3) mx2[q * 3] = up_imm;
               }
-              if (hx && xgo) add2<TRUNC>(ax, xa2[q], xb2[q], xe2[q], xwx[q]);
-              if (hx && mode == 3) add1<TRUNC>(am, mx2[q * 3], xe2[q], xwx[q]);
+              if (hx && xgo) add2(ax, xa2[q], xb2[q], xe2[q], xwx[q]);
+              if (hx && mode == 3) add1(am, mx2[q * 3], xe2[q], xwx[q]);
               if (mode == 1) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                  if (hx && ydeg > k) add1<TRUNC>(am, mx2[q * 3 + k], mxe[q * 3 + k], xwx[q] * wys[k]);
+                  if (hx && ydeg > k) add1(am, mx2[q * 3 + k], mxe[q * 3 + k], xwx[q] * wys[k]);
               }
             }
           }
@@ -612,12 +597,12 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
                 ya2[q] = ynull ? pv.v[V_IDM] : pv.v[V_G2]; yb2[q] = ynull ? pv.v[V_IMI] : pv.v[V_G3]; ye2[q] = pv.E;
                 if (mode == 2) my2[q * 3] = pv.v[V_IMM];
               }
-              if (hy && ygo) add2<TRUNC>(ay, ya2[q], yb2[q], ye2[q], ywx[q]);
-              if (hy && mode == 2) add1<TRUNC>(am, my2[q * 3], ye2[q], ywx[q]);
+              if (hy && ygo) add2(ay, ya2[q], yb2[q], ye2[q], ywx[q]);
+              if (hy && mode == 2) add1(am, my2[q * 3], ye2[q], ywx[q]);
               if (mode == 1) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                  if (hy && xdeg > k) add1<TRUNC>(am, my2[q * 3 + k], mye[q * 3 + k], wxs[k] * ywx[q]);
+                  if (hy && xdeg > k) add1(am, my2[q * 3 + k], mye[q * 3 + k], wxs[k] * ywx[q]);
               }
             }
           }
@@ -630,7 +615,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
                 const unsigned rb = (unsigned)(srcx >> 6) * ssB + ((unsigned)(srcx & 63) << 3);
                 for (int b = HX_DAG_INLINE; b < ydeg; ++b) {
                   const unsigned sl = rb + col_part(yin_src[Y.in_b + b] + (srcx & 63));
-                  add1<TRUNC>(am, ldg<MULTI>(LIN, V_G4 * planeB + sl), ldgi<MULTI>(EX, sl >> 1), wxa * yin_w[Y.in_b + b]);
+                  add1(am, ldg<MULTI>(LIN, V_G4 * planeB + sl), ldgi<MULTI>(EX, sl >> 1), wxa * yin_w[Y.in_b + b]);
                 }
               }
             for (int a = HX_DAG_INLINE + HXD_EXTRA; a < xdeg; ++a) {
@@ -640,17 +625,17 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
               const unsigned sl = rb + col_part(jc + (src & 63));
               const bool adj = lane > 0 && src == i - 1;
               if (xgo) {
-                if (adj) add2<TRUNC>(ax, xnull ? up_imd : up_g0, xnull ? up_iiw : up_g1, up_E, wa);
-                else add2<TRUNC>(ax, ldg<MULTI>(LIN, vXa + sl), ldg<MULTI>(LIN, vXb + sl), ldgi<MULTI>(EX, sl >> 1), wa);
+                if (adj) add2(ax, xnull ? up_imd : up_g0, xnull ? up_iiw : up_g1, up_E, wa);
+                else add2(ax, ldg<MULTI>(LIN, vXa + sl), ldg<MULTI>(LIN, vXb + sl), ldgi<MULTI>(EX, sl >> 1), wa);
               }
               if (mode == 3) {
-                if (adj) add1<TRUNC>(am, up_imm, up_E, wa);
-                else add1<TRUNC>(am, ldg<MULTI>(LIN, sl), ldgi<MULTI>(EX, sl >> 1), wa);
+                if (adj) add1(am, up_imm, up_E, wa);
+                else add1(am, ldg<MULTI>(LIN, sl), ldgi<MULTI>(EX, sl >> 1), wa);
               }
               if (mode == 1)
                 for (int b = 0; b < (ydeg < HX_DAG_INLINE ? ydeg : HX_DAG_INLINE); ++b) {
                   const unsigned sp = rb + col_part((b == 0 ? Y.s0 : (b == 1 ? Y.s1 : Y.s2)) + (src & 63));
-                  add1<TRUNC>(am, ldg<MULTI>(LIN, V_G4 * planeB + sp), ldgi<MULTI>(EX, sp >> 1), wa * (b == 0 ? Y.w0 : (b == 1 ? Y.w1 : Y.w2)));
+                  add1(am, ldg<MULTI>(LIN, V_G4 * planeB + sp), ldgi<MULTI>(EX, sp >> 1), wa * (b == 0 ? Y.w0 : (b == 1 ? Y.w1 : Y.w2)));
                 }
             }
             for (int b = HX_DAG_INLINE + HXD_EXTRA; b < ydeg; ++b) {
@@ -659,17 +644,17 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
               const unsigned sl = ownB + col_part(src + lane);
               const bool adj = src == j - 1;
               if (ygo) {
-                if (adj) add2<TRUNC>(ay, ynull ? pv.v[V_IDM] : pv.v[V_G2], ynull ? pv.v[V_IMI] : pv.v[V_G3], pv.E, wb);
-                else add2<TRUNC>(ay, ldg<MULTI>(LIN, vYa + sl), ldg<MULTI>(LIN, vYb + sl), ldgi<MULTI>(EX, sl >> 1), wb);
+                if (adj) add2(ay, ynull ? pv.v[V_IDM] : pv.v[V_G2], ynull ? pv.v[V_IMI] : pv.v[V_G3], pv.E, wb);
+                else add2(ay, ldg<MULTI>(LIN, vYa + sl), ldg<MULTI>(LIN, vYb + sl), ldgi<MULTI>(EX, sl >> 1), wb);
               }
               if (mode == 2) {
-                if (adj) add1<TRUNC>(am, pv.v[V_IMM], pv.E, wb);
-                else add1<TRUNC>(am, ldg<MULTI>(LIN, sl), ldgi<MULTI>(EX, sl >> 1), wb);
+                if (adj) add1(am, pv.v[V_IMM], pv.E, wb);
+                else add1(am, ldg<MULTI>(LIN, sl), ldgi<MULTI>(EX, sl >> 1), wb);
               }
               if (mode == 1)
                 for (int a = 0; a < (xdeg < HX_DAG_INLINE ? xdeg : HX_DAG_INLINE); ++a) {
                   const unsigned sp = (a == 0 ? xrB0 : (a == 1 ? xrB1 : xrB2)) + col_part(src + (a == 0 ? xl0 : (a == 1 ? xl1 : xl2)));
-                  add1<TRUNC>(am, ldg<MULTI>(LIN, V_G4 * planeB + sp), ldgi<MULTI>(EX, sp >> 1), (a == 0 ? X.w0 : (a == 1 ? X.w1 : X.w2)) * wb);
+                  add1(am, ldg<MULTI>(LIN, V_G4 * planeB + sp), ldgi<MULTI>(EX, sp >> 1), (a == 0 ? X.w0 : (a == 1 ? X.w1 : X.w2)) * wb);
                 }
             }
           }
@@ -714,12 +699,11 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
           const double idm = ldexp_fast(m_idm, (m_idm > 0. ? e_idm : HXD_EMIN) - E), imi = ldexp_fast(m_imi, (m_imi > 0. ? e_imi : HXD_EMIN) - E);
           const double iiw = ldexp_fast(m_iiw, (m_iiw > 0. ? e_iiw : HXD_EMIN) - E);
           pv.v[V_IMM] = imm; pv.v[V_IMD] = imd; pv.v[V_IDM] = idm; pv.v[V_IMI] = imi; pv.v[V_IIW] = iiw;
-          // the five outgoing sums, left-nested as the reference's n-ary log_sum_exp (src/logsumexp.h:86-100)
-          pv.v[V_G0] = lin_acc<TRUNC>(imi, P31, lin_acc<TRUNC>(idm, P21, lin_acc<TRUNC>(imd, P11, imm * P01)));
-          pv.v[V_G1] = lin_acc<TRUNC>(iiw, P44, lin_acc<TRUNC>(imi, P34, imm * P04));
-          pv.v[V_G2] = lin_acc<TRUNC>(iiw, P42, lin_acc<TRUNC>(idm, P22, lin_acc<TRUNC>(imd, P12, imm * P02)));
-          pv.v[V_G3] = lin_acc<TRUNC>(imi, P33, imm * P03);
-          pv.v[V_G4] = lin_acc<TRUNC>(iiw, P40, lin_acc<TRUNC>(imi, P30, lin_acc<TRUNC>(idm, P20, lin_acc<TRUNC>(imd, P10, imm * P00))));
+          pv.v[V_G0] = __builtin_fma(imi, P31, __builtin_fma(idm, P21, __builtin_fma(imd, P11, imm * P01)));
+          pv.v[V_G1] = __builtin_fma(iiw, P44, __builtin_fma(imi, P34, imm * P04));
+          pv.v[V_G2] = __builtin_fma(iiw, P42, __builtin_fma(idm, P22, __builtin_fma(imd, P12, imm * P02)));
+          pv.v[V_G3] = __builtin_fma(imi, P33, imm * P03);
+          pv.v[V_G4] = __builtin_fma(iiw, P40, __builtin_fma(imi, P30, __builtin_fma(idm, P20, __builtin_fma(imd, P10, imm * P00))));
           pv.E = E;
           pv.slot = own_slot;
           up_imm = wave_shr1(imm); up_imd = wave_shr1(imd); up_iiw = wave_shr1(iiw);
@@ -795,28 +779,18 @@ bool dag_linear_fits(int64_t plane) { return (V_PLANES + 1) * plane * 8 < ((int6
 // multi > 1: one or two pairs of many strips, each dealt to `multi` workgroups of `multi_waves` waves (MULTI instantiation);
 // `counters`: 256 zeroed ints per pair
 int launch_forward_dag_linear(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 log_tab, int multi, int multi_waves,
-                              int* counters, bool trunc, hipStream_t st) {
+                              int* counters, hipStream_t st) {
   int w = (max_rows + 63) / 64;
   w = w < 1 ? 1 : (w > HXD_MAX_WAVES ? HXD_MAX_WAVES : w);
   hipLaunchKernelGGL(k_lin_pack, dim3(n_jobs), dim3(256), 0, st, d_jobs);
   if (multi > 1) {
     if (multi_waves > HXD_MAX_WAVES) multi_waves = HXD_MAX_WAVES;
-    if (trunc) {
-      HX_CHECK_LDS((k_forward_dag_linear<true, true>), 0, "k_forward_dag_linear<multi, trunc>");
-      hipLaunchKernelGGL((k_forward_dag_linear<true, true>), dim3(n_jobs * multi), dim3(multi_waves * 64), 0, st, d_jobs, tab8.p, log_tab.p, multi, counters, multi_patience());
-    } else {
-      HX_CHECK_LDS((k_forward_dag_linear<true, false>), 0, "k_forward_dag_linear<multi>");
-      hipLaunchKernelGGL((k_forward_dag_linear<true, false>), dim3(n_jobs * multi), dim3(multi_waves * 64), 0, st, d_jobs, tab8.p, log_tab.p, multi, counters, multi_patience());
-    }
+    HX_CHECK_LDS(k_forward_dag_linear<true>, 0, "k_forward_dag_linear<multi>");
+    hipLaunchKernelGGL(k_forward_dag_linear<true>, dim3(n_jobs * multi), dim3(multi_waves * 64), 0, st, d_jobs, tab8.p, log_tab.p, multi, counters, multi_patience());
     return 0;
   }
-  if (trunc) {
-    HX_CHECK_LDS((k_forward_dag_linear<false, true>), 0, "k_forward_dag_linear<trunc>");
-    hipLaunchKernelGGL((k_forward_dag_linear<false, true>), dim3(n_jobs), dim3(w * 64), 0, st, d_jobs, tab8.p, log_tab.p, 1, nullptr, 0);
-  } else {
-    HX_CHECK_LDS((k_forward_dag_linear<false, false>), 0, "k_forward_dag_linear");
-    hipLaunchKernelGGL((k_forward_dag_linear<false, false>), dim3(n_jobs), dim3(w * 64), 0, st, d_jobs, tab8.p, log_tab.p, 1, nullptr, 0);
-  }
+  HX_CHECK_LDS(k_forward_dag_linear<false>, 0, "k_forward_dag_linear");
+  hipLaunchKernelGGL(k_forward_dag_linear<false>, dim3(n_jobs), dim3(w * 64), 0, st, d_jobs, tab8.p, log_tab.p, 1, nullptr, 0);
   return 0;
 }
 

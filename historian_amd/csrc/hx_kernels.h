@@ -47,7 +47,7 @@ void launch_fill_neg_inf(double* p, int64_t n, hipStream_t st);
 int64_t dag_linear_scratch_doubles(int64_t plane, int nx, int ny, int tx, int ty);
 bool dag_linear_fits(int64_t plane);
 int launch_forward_dag_linear(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 log_tab, int multi, int multi_waves,
-                              int* counters, bool trunc, hipStream_t st);
+                              int* counters, hipStream_t st);
 void launch_dag_linear_clear(const DevJob* d_jobs, int n_jobs, hipStream_t st);
 int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 fast_tab,
                             bool fast, int multi, int multi_waves, int* counters, hipStream_t st);

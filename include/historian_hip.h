@@ -72,8 +72,7 @@ enum { HX_IMM = 0, HX_IMD = 1, HX_IDM = 2, HX_IMI = 3, HX_IIW = 4, HX_STATES = 5
                             that is at most e^-10 of the larger - what the reference's table does for differences >= 10
                             (src/logsumexp.h:45) - instead of adding it.  No table, no logarithm until the store.  Cells agree
                             with HX_LSE_EXACT to the interpolation error of the reference's table (~3e-10 per operation), as
-                            HX_LSE_FAST does; best paths are the reference's.  General profiles: the Forward fill likewise
-                            (hx_daglin.hip), the Backward fill as HX_LSE_FAST.                                                */
+                            HX_LSE_FAST does; best paths are the reference's.  General profiles run as HX_LSE_FAST.           */
 #define HX_KEEP_BACKWARD 2u /* pre-allocate the Backward matrices at hx_batch_create        */
 #define HX_FORCE_GENERIC 4u /* always use the general (DAG) kernels, even for chain profiles */
 #define HX_SPARSE_ENVELOPE 8u /* banded jobs: do not pre-fill the matrices with -inf.  Cells outside the
