@@ -195,3 +195,64 @@ def event_counts_json(alphabet, indel, root, sub):
         lines.append(component(root[0], sub[0], 2) + ",")
     lines += [" \"logLikelihood\": %s" % _g(indel["lp"]), "}", ""]
     return "\n".join(lines)
+
+
+# ---- `historian count` without -recon: the substitution half of BackwardMatrix::getCounts (src/forward.cpp:897-973, 1183-1214) ----
+
+def dp_posterior_substitution_counts(batch, job, x_cols, y_cols, x_null, y_null, parent_row, counter):
+    """Expected substitution events of a pair DP whose Forward and Backward matrices are on the device (capi.Batch with
+    HX_KEEP_BACKWARD, both fills done): every in-envelope cell's alignment column - ForwardMatrix::getAlignmentColumn, the
+    columns of the two profile states plus, for an absorbing cell, the parent as a wildcard - through the tree's sum-product
+    (ColumnCounter: the device kernel of hx_sumprod.hip), weighted with the cell's posterior probability
+    exp(F + B - lpEnd).  The reference evaluates one column per cell (and caches those of cells that change one side only,
+    cachedCellEigenCounts); here the cells are grouped by column first - an IMD cell's column depends on its row only, an IDM
+    cell's on its column, insertions likewise - so the device sees (Nx-2)(Ny-2) + O(Nx + Ny) weighted columns in one launch.
+
+    x_cols [Nx][N], y_cols [Ny][N]: int8 tokens of every profile state's alignment column over the N tree nodes
+    (Profile::alignColumn: residue token, -1 wildcard for an ancestor's row, -2 where the state has no residue of that
+    row; null states: what their alignPath holds); x_null / y_null [Nx], [Ny]: ProfileState::isNull(); parent_row: the tree
+    node the pair's parent profile belongs to.  -> dict(root_counts, eigen_counts, counts) as ColumnCounter.run."""
+    fm, bm = batch.read_matrix(job, 0), batch.read_matrix(job, 1)
+    lp_end = batch.lp_end()[job]
+    with np.errstate(invalid="ignore"):
+        w = np.exp(fm + bm - lp_end)                       # [Nx-1][Ny-1][5]; -inf cells (outside the envelope) -> 0
+    w[~np.isfinite(w)] = 0.
+    w[0, :, :] = 0.                                        # getAlignmentColumn: no column for xpos == 0 or ypos == 0
+    w[:, 0, :] = 0.
+    x_cols, y_cols = np.asarray(x_cols, dtype=np.int8), np.asarray(y_cols, dtype=np.int8)
+    nx1, ny1 = w.shape[0], w.shape[1]
+    xc, yc = x_cols[:nx1], y_cols[:ny1]
+    xn, yn = np.asarray(x_null, dtype=bool)[:nx1], np.asarray(y_null, dtype=bool)[:ny1]
+    IMM, IMD, IDM, IMI, IIW = 0, 1, 2, 3, 4
+    tokens, weight = [], []
+
+    def add(cols, ws):
+        keep = (ws > 0) & (cols != GAP).any(axis=1)
+        if keep.any():
+            tokens.append(cols[keep])
+            weight.append(ws[keep])
+
+    def with_parent(cols):
+        out = cols.copy()
+        out[:, parent_row] = WILD
+        return out
+
+    # IMM, both states absorbing: the two columns merged (a row present in both keeps x's), the parent a wildcard
+    ii, jj = np.nonzero((w[:, :, IMM] > 0) & ~xn[:, None] & ~yn[None, :])
+    if len(ii):
+        merged = np.where(xc[ii] != GAP, xc[ii], yc[jj])
+        merged[:, parent_row] = WILD
+        add(merged, w[ii, jj, IMM])
+    # per-row columns: IMD (with the parent when x absorbs), IIW, and the IMM / IMD cells of null x states
+    wx_imd, wx_iiw = w[:, :, IMD].sum(axis=1), w[:, :, IIW].sum(axis=1)
+    wx_imm_null = (w[:, :, IMM] * xn[:, None]).sum(axis=1)
+    add(with_parent(xc), np.where(xn, 0., wx_imd))
+    add(xc, wx_iiw + np.where(xn, wx_imd + wx_imm_null, 0.))
+    # per-column columns: IDM (with the parent when y absorbs), IMI, and the IMM cells of a null y state under an emitting x
+    wy_idm, wy_imi = w[:, :, IDM].sum(axis=0), w[:, :, IMI].sum(axis=0)
+    wy_imm_null = (w[:, :, IMM] * (~xn)[:, None] * yn[None, :]).sum(axis=0)
+    add(with_parent(yc), np.where(yn, 0., wy_idm))
+    add(yc, wy_imi + np.where(yn, wy_idm, 0.) + wy_imm_null)
+    if not tokens:
+        raise ValueError("no cell of the pair has a posterior probability")
+    return counter.run(np.concatenate(tokens), np.concatenate(weight))

@@ -72,3 +72,49 @@ def test_leaf_pairs_against_the_restatement(flags):
         nb.indel_counts(0, _times(tm))
     assert e.value.code == -7
     nb.close()
+
+
+def test_substitution_counts_of_a_root_pair_against_the_restatement():
+    # The substitution half of BackwardMatrix::getCounts (src/forward.cpp:897-973, 1183-1214) through the device: Forward and
+    # Backward fills of the root pair, posterior weights, the cells' alignment columns grouped and sent through the sum-product
+    # kernel in one launch (historian_amd/counts.dp_posterior_substitution_counts) - against oracle/counts_dp_oracle, which
+    # evaluates one column per cell as the reference does and is pinned by enumeration (tests/test_oracle_counts_dp.py).
+    # A four-leaf tree ((a, b) u, (c, d) v) root: both children of the root are internal-node profiles (null states included).
+    from historian_amd import counts, hostmodel
+    from oracle import sumprod_oracle as so
+    model = ho.RateModel.from_file(G + "testforward.jukescantor.json")
+    t = .15
+    names = ["a", "b", "u", "c", "d", "v", "root"]
+    parent = [2, 2, 6, 5, 5, 6, -1]
+    tree = so.Tree(parent, [t] * 6 + [0.], names)
+    pm = ho.ProbModel(model, t)
+    hmm = ho.PairHMM(pm, pm, model.ins_prob)
+    seqs = {0: "acgtacgta", 1: "acgaacta", 3: "aggtacgt", 4: "acgtaagtt"}
+    leaf = {n: ho.Profile.from_seq(1, model.alphabet, s, n, names[n]) for n, s in seqs.items()}
+    gen = ho.MT19937(5489)
+    u = ho.ForwardMatrix(leaf[0], leaf[1], hmm, 2, ho.GuideAlignmentEnvelope()).sample_profile(gen, 6, 0, ho.DPMatrix.CollapseChains | ho.DPMatrix.IncludeBestTrace)
+    v = ho.ForwardMatrix(leaf[3], leaf[4], hmm, 5, ho.GuideAlignmentEnvelope()).sample_profile(gen, 6, 0, ho.DPMatrix.CollapseChains | ho.DPMatrix.IncludeBestTrace)
+    fwd = ho.ForwardMatrix(u, v, hmm, 6, ho.GuideAlignmentEnvelope())
+    bwd = ho.BackwardMatrix(fwd)
+    sp = so.SumProduct(model, tree)
+    want_root, want_eig = cd.get_subst_counts(bwd, sp)
+
+    def columns(prof):
+        out = np.full((prof.size(), len(parent)), counts.GAP, dtype=np.int8)
+        for s in range(prof.size()):
+            for row, ch in cd.profile_align_column(prof, s).items():
+                out[s, row] = model.alphabet.find(ch) if ch != cd.WILDCARD else counts.WILD
+        return out
+    hm = hostmodel.RateModel.load(G + "testforward.jukescantor.json")
+    counter = counts.ColumnCounter(hm, parent, [t] * 6 + [0.], branch_sub=[[np.asarray(m) for m in pm.sub_mat]] * 7)
+    b = capi.Batch([H.job_images(fwd)], capi.HX_KEEP_BACKWARD)
+    b.forward()
+    b.backward()
+    got = counts.dp_posterior_substitution_counts(b, 0, columns(u), columns(v), [s.is_null() for s in u.state], [s.is_null() for s in v.state], 6, counter)
+    b.close()
+    for cpt in range(sp.C):
+        assert np.max(np.abs(got["root_counts"][cpt] - want_root[cpt])) <= 1e-9 * max(1., float(np.max(np.abs(want_root[cpt]))))
+        assert np.max(np.abs(got["eigen_counts"][cpt] - want_eig[cpt])) <= 1e-8 * max(1., float(np.max(np.abs(want_eig[cpt]))))
+    # the columns' residues: four leaves are certain in every column they take part in, so the root counts sum to the expected
+    # number of columns with a root
+    assert float(np.sum(got["root_counts"])) > 0
