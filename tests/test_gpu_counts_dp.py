@@ -103,7 +103,7 @@ def test_substitution_counts_of_a_root_pair_against_the_restatement():
         out = np.full((prof.size(), len(parent)), counts.GAP, dtype=np.int8)
         for s in range(prof.size()):
             for row, ch in cd.profile_align_column(prof, s).items():
-                out[s, row] = model.alphabet.find(ch) if ch != cd.WILDCARD else counts.WILD
+                out[s, row] = model.alphabet.lower().find(ch.lower()) if ch != cd.WILDCARD else counts.WILD
         return out
     hm = hostmodel.RateModel.load(G + "testforward.jukescantor.json")
     counter = counts.ColumnCounter(hm, parent, [t] * 6 + [0.], branch_sub=[[np.asarray(m) for m in pm.sub_mat]] * 7)
