@@ -13,14 +13,15 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d gpurun_out/$tag/pmc_$c -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --banded-pairs '' > gpurun_out/$tag/pmc_$c.log 2>&1
 done
 python - <<PY
-import csv,glob,collections,json
+import csv,glob,collections,json,re
 res={}
 for c in ("FETCH_SIZE","WRITE_SIZE"):
     for f in glob.glob("gpurun_out/$tag/pmc_%s/*/*counter_collection.csv"%c):
         agg=collections.defaultdict(lambda: [0.0,0])
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"]!=c: continue
-            if "k_fill_leaf_linear" in r["Kernel_Name"]: key="trunc" if r["Kernel_Name"].split("(")[0].rstrip().endswith("true>") else "linear"
+            m=re.search(r"k_fill_leaf_linear<([^>]*)>",r["Kernel_Name"])
+            if m: key="trunc" if m.group(1).replace(" ","").endswith("true") else "linear"
             elif "k_fill_chain<0" in r["Kernel_Name"]: key="fast" if "FastLse" in r["Kernel_Name"] else "exact"
             else: continue
             agg[key][0]+=float(r["Counter_Value"]); agg[key][1]+=1
