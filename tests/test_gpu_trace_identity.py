@@ -4,7 +4,8 @@ reference src/forward.cpp:245-255,283-302), per arithmetic policy, on randomised
 lengths included.  The pairs are the first ones of tools/sweep_trace_identity.py's generator, shortened; the full
 sweep (2000 pairs, lengths 50-2000) is profiles/r02/trace_identity_sweep.json.
 
-exact and fast must reproduce every path.  The scaled-probability policy (HX_LSE_LINEAR) does not carry the reference's
+exact, fast and trunc (the default: scaled probabilities WITH the reference's truncation, round 3; its full sweep is
+profiles/r03/trace_identity_sweep_seed7.json) must reproduce every path.  The scaled-probability policy (HX_LSE_LINEAR) does not carry the reference's
 truncation of log-sum-exp terms below e^-10, so a near-tie can resolve differently (4 of 2000 paths in the sweep): its
 lpEnd must be within north_star's 1e-4, its paths are counted, and it is not the arithmetic bench.py headlines."""
 import os
@@ -45,7 +46,7 @@ def test_best_paths_identical_to_table_arithmetic():
         r = c_oracle.forward(x, y, h, md)
         want.append((r["lp_end"], trace_oracle.best_trace(x, y, h, md, r)))
     differ = {}
-    for mode, flag in (("exact", capi.HX_LSE_EXACT), ("fast", capi.HX_LSE_FAST), ("linear", capi.HX_LSE_LINEAR)):
+    for mode, flag in (("exact", capi.HX_LSE_EXACT), ("fast", capi.HX_LSE_FAST), ("trunc", capi.HX_LSE_TRUNC), ("linear", capi.HX_LSE_LINEAR)):
         differ[mode] = 0
         for banded, storage in ((False, 0), (True, 0), (True, capi.HX_SPARSE_ENVELOPE), (True, capi.HX_BAND_COMPRESSED)):
             ids = [k for k, s in enumerate(specs) if (s["band"] >= 0) == banded]
@@ -68,12 +69,13 @@ def test_best_paths_identical_to_table_arithmetic():
 def test_a_known_near_tie_separates_the_policies():
     """Pair 1166 of the sweep (42/51-residue mixture pair, t = 0.1/0.1, band 5): two source cells of the last
     xy-absorbing move are 1e-4 apart in the reference's arithmetic and swap order without its truncation.  exact and
-    fast follow the reference; the scaled-probability policy is allowed to differ here and only here."""
+    fast follow the reference, and so does the truncating scaled-probability policy - the truncation is what decides this pair;
+    the untruncated scaled-probability policy is allowed to differ here and only here."""
     spec = dict(id=1166, seed=745984089, kind="mixture", lx=51, ly=42, tl=.1, tr=.1, band=5, sub=.4, indel=.02)
     x, y, h, md = sweep.job_of(spec)
     r = c_oracle.forward(x, y, h, md)
     want = trace_oracle.best_trace(x, y, h, md, r)
-    for flag in (capi.HX_LSE_EXACT, capi.HX_LSE_FAST):
+    for flag in (capi.HX_LSE_EXACT, capi.HX_LSE_FAST, capi.HX_LSE_TRUNC):
         b = capi.Batch([(x, y, h, md)], flag)
         b.forward()
         assert b.best_trace()[0] == want
