@@ -467,13 +467,8 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
           ep[k] = epad[XL[k].eoff + (unsigned)yecls[(unsigned)jc + 1]];
           continue;
         }
-#if HX_ABLATE == 9 || HX_ABLATE == 10
-        Yp[k] = d4v{0.0, -1.5 + jc * 1e-9, -2.5, 0.0};
-        ep[k] = -3.0;
-#else
         Yp[k] = ypack[(unsigned)jc];
         ep[k] = epad[XL[k].eoff + (unsigned)yecls[(unsigned)jc]];
-#endif
       }
     };
     d4v Ya[RPT], Yb[RPT];
@@ -528,17 +523,9 @@ __global__ void __launch_bounds__(W * PPW * 64, MINW) k_fill_chain(const DevJob*
         prefetch(t + 3, Yb, eb);
       }
       const int t64 = t + t_off;                   // even: j + (i & 63) of the first of the two steps
-#if HX_ABLATE == 3 || HX_ABLATE == 9 || HX_ABLATE == 10
-      if (t64 == 123456789) {
-#else
       if (t64 >= 0 && t64 < Cc + 63 && store_rows) {
-#endif
         typedef double d2v __attribute__((ext_vector_type(2)));
-#if HX_ABLATE == 8
-        const int64_t sl = (store_base2 + ((int64_t)(t64 >> 1) << 7)) & 0xFFFF;   // stay in L2
-#else
         const int64_t sl = sbase ? cstore_base + ((int64_t)((t - cstore_t0) >> 1) << 7) : store_base2 + ((int64_t)(t64 >> 1) << 7);
-#endif
         HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
         const int64_t plane2 = plane >> 1;
 #pragma unroll

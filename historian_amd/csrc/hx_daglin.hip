@@ -77,9 +77,6 @@ __device__ __forceinline__ void exp_split(const double lp, const HX_LDS double* 
 
 // log(m * 2^e), m >= 0 (see hx_linear.hip: frexp, {c, -log c} table entry, cubic log1p); m == 0 gives -inf
 __device__ __forceinline__ double log_scaled(const double m, const int e, const HX_LDS double* ltab) {
-#if HX_ABLATE == 35      // timing only: no logarithm
-  return m + (double)e;
-#endif
   const double f = __builtin_amdgcn_frexp_mant(m);
   const int k = __builtin_amdgcn_frexp_exp(m);
   const unsigned byte_off = ((unsigned)__double2hiint(f) >> 7) & 0x7FF0u;
@@ -113,9 +110,6 @@ __device__ __forceinline__ void add2(Acc2& A, const double ma, const double mb, 
 // scratch access is `sc1` - stores write through, loads bypass the L1
 template <bool COH = false>
 __device__ __forceinline__ double ldg(const HX_GLOBAL double* base, const unsigned byte_off) {
-#if HX_ABLATE == 33      // timing only: no source loads
-  return 1e-3 * (double)(byte_off & 1023u);
-#endif
   HX_GLOBAL double* p = (HX_GLOBAL double*)((HX_GLOBAL char*)const_cast<HX_GLOBAL double*>(base) + byte_off);
   if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return *p;
@@ -128,9 +122,6 @@ __device__ __forceinline__ int ldgi(const HX_GLOBAL int* base, const unsigned by
 }
 template <bool COH = false>
 __device__ __forceinline__ void stg(HX_GLOBAL double* base, const unsigned byte_off, const double v) {
-#if HX_ABLATE == 32      // timing only: stores only where the value is NaN (never)
-  if (v != v)
-#endif
   {
     HX_GLOBAL double* p = (HX_GLOBAL double*)((HX_GLOBAL char*)base + byte_off);
     if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -330,7 +321,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
     const bool rvalid = i < R;
     const int ir = rvalid ? i : 0;
     const ColRec X = load_col(xpk, xlp, ir);
-    const int xf = X.meta & 0xff, xdeg = HX_ABLATE == 36 ? ((X.meta >> 8) > 1 ? 1 : (X.meta >> 8)) : X.meta >> 8;
+    const int xf = X.meta & 0xff, xdeg = X.meta >> 8;
     const bool xnull = xf & F_NULL, xok = (xf & F_READY) || xempty, xeos = xf & F_EMIT_OR_START;
     const unsigned ownB = (unsigned)s * ssB + ((unsigned)lane << 3), ownB_m = (unsigned)s * ssB + ((unsigned)lane << 4);
     // the rows of the first three in-transitions: byte offset of the row inside a plane, and the row's lane
@@ -398,7 +389,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
         if (t > wlo[w] && ((t - wlo[w]) & 63) == 0) stage(t);
         const int j = t - lane;
         const ColRec Y = column(j);
-        const int yf = Y.meta & 0xff, ydeg = HX_ABLATE == 36 ? ((Y.meta >> 8) > 1 ? 1 : (Y.meta >> 8)) : Y.meta >> 8;
+        const int yf = Y.meta & 0xff, ydeg = Y.meta >> 8;
         bool act = rvalid && j >= 0 && j < Cc && !dead;
         if (banded) {
           int dd = X.env - Y.env;
@@ -528,7 +519,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
           }
           HXD_TR(6);     // (the inline transitions are summed)
           // ---- second batch: the cells of in-transitions 3 .. 7 of the row and of the column, all loads first ----
-          if (HX_ABLATE != 34 && xdeg > HX_DAG_INLINE) {
+          if (xdeg > HX_DAG_INLINE) {
             // the row's further transitions: their cells at this column, and their pairs with the column's inline transitions
             double xa2[HXD_EXTRA], xb2[HXD_EXTRA], mx2[HXD_EXTRA * 3];
             int xe2[HXD_EXTRA], mxe[HXD_EXTRA * 3];
@@ -567,7 +558,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
               }
             }
           }
-          if (HX_ABLATE != 34 && ydeg > HX_DAG_INLINE) {
+          if (ydeg > HX_DAG_INLINE) {
             // the column's further transitions: their cells in this row, and their pairs with the row's inline transitions
             double ya2[HXD_EXTRA], yb2[HXD_EXTRA], my2[HXD_EXTRA * 3];
             int ye2[HXD_EXTRA], mye[HXD_EXTRA * 3];
@@ -606,7 +597,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
               }
             }
           }
-          if (HX_ABLATE != 34 && (xdeg > HX_DAG_INLINE || ydeg > HX_DAG_INLINE)) {
+          if (xdeg > HX_DAG_INLINE || ydeg > HX_DAG_INLINE) {
             // ---- what is left: pairs of two transitions beyond the inline ones, transitions beyond the eighth ----
             if (mode == 1 && xdeg > HX_DAG_INLINE && ydeg > HX_DAG_INLINE)
               for (int a = HX_DAG_INLINE; a < xdeg; ++a) {
@@ -714,9 +705,7 @@ __global__ void __launch_bounds__(HXD_MAX_WAVES * 64) k_forward_dag_linear(const
         // ---- publish, every 8th step: drain, then all stores issued so far (the cells of steps <= t - 1) are in memory,
         // i.e. all 64 rows have completed the columns up to t - 1 - 63
         if ((t & 7) == 7) {
-#if HX_ABLATE != 31
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
           int done = t - 63;
           done = (dead || done > Cc) ? Cc : done;
           if (done > published) {

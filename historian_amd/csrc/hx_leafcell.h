@@ -22,12 +22,6 @@ __device__ __forceinline__ C5 leaf_cell(const double (*T)[6], const LSE& L, cons
                                         double e, double pj, const C5& up, const C5& left, const C5& diag) {
   // the five left-nested n-ary sums of reference src/forward.cpp:103-115,139-150,171-180,
   // evaluated level by level: 5 + 4 + 3 + 1 look-ups, each level's fetches issued together
-#if HX_ABLATE == 11
-  const double TT[5][6] = {{T[0][0], T[0][0], T[0][0], T[0][0], T[0][0], 0}, {T[0][0], T[0][0], T[0][0], T[0][0], T[0][0], 0},
-                           {T[0][0], T[0][0], T[0][0], T[0][0], T[0][0], 0}, {T[0][0], T[0][0], T[0][0], T[0][0], T[0][0], 0},
-                           {T[0][0], T[0][0], T[0][0], T[0][0], T[0][0], 0}};
-#define T TT
-#endif
   typename LSE::Prep p0 = L.prep(up.imm + T[0][1], up.imd + T[1][1]);
   typename LSE::Prep p1 = L.prep(up.imm + T[0][4], up.imi + T[3][4]);
   typename LSE::Prep p2 = L.prep(left.imm + T[0][2], left.imd + T[1][2]);
@@ -68,9 +62,6 @@ __device__ __forceinline__ C5 leaf_cell(const double (*T)[6], const LSE& L, cons
   r.idm = ((a_idm + Y.x) + Y.y) + q2;
   r.imi = ((a_imi + Y.x) + Y.z) + q2;
   r.imm = ((a_imm + X.lp + Y.x) + e) + pj;
-#if HX_ABLATE == 11
-#undef T
-#endif
   return r;
 }
 

@@ -77,9 +77,6 @@ __device__ __forceinline__ L5 dpp_shr1_old(const L5& o, const L5& c) {
 #define HXL_LOG_ENTRIES 1536
 __device__ __forceinline__ double log_scaled(double m, int e, const HX_LDS double* ltab) {
   typedef double d2v __attribute__((ext_vector_type(2)));
-#if HX_ABLATE == 22      // no logarithm
-  return m + (double)e;
-#endif
   const double f = __builtin_amdgcn_frexp_mant(m);           // [0.5, 1), or 0
   const int k = __builtin_amdgcn_frexp_exp(m);
   const unsigned byte_off = ((unsigned)__double2hiint(f) >> 7) & 0x7FF0u;
@@ -285,11 +282,7 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
       }
     }
     L5 ca = l5_zero(), cb = l5_zero(), ua = l5_zero(), ub = l5_zero();
-#if HX_ABLATE == 24      // no exchange between strips at all (wrong results): what the synchronisation machinery costs
-    const bool has_above = false, has_below = false;
-#else
     const bool has_above = s > 0, has_below = s + 1 < n_strips;
-#endif
     const bool wrap_in = has_above && wave == 0;             // the strip above went through memory (W > 1: s >= W)
     const bool wrap_out = has_below && wave == W - 1;        // this strip's last row is read back from memory
     const bool ring_out = has_below && !wrap_out;
@@ -556,15 +549,6 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
         const int64_t sl = store_base2 + (int64_t)((t - store_t0) >> 1) * blk;
         HX_GLOBAL d2v* M2 = (HX_GLOBAL d2v*)(M + sl);
         const int64_t plane2 = plane >> 1;
-#if HX_ABLATE == 21      // no stores (keeps the values alive)
-        if (l0 + l1 + l2 + l3 + l4 + h0 + h1 + h2 + h3 + h4 == 12345.678) M2[0] = d2v{l0, h0};
-#elif HX_ABLATE == 23    // plain stores
-        M2[0] = d2v{l0, h0};
-        M2[plane2] = d2v{l1, h1};
-        M2[2 * plane2] = d2v{l2, h2};
-        M2[3 * plane2] = d2v{l3, h3};
-        M2[4 * plane2] = d2v{l4, h4};
-#else
         // write-once data that this kernel never reads again (the wrap-around link reads 1/64 of it, from L2 or
         // memory): non-temporal stores - 17.4 -> 15.8 ms on the headline workload with separate state planes; with the
         // interleaved layout (5 KiB contiguous per iteration) they measure the same as plain stores
@@ -583,7 +567,6 @@ k_fill_leaf_linear(const DevJob* __restrict__ jobs, const double* __restrict__ e
         __builtin_nontemporal_store(d2v{l3, h3}, &M2[3 * plane2]);
         __builtin_nontemporal_store(d2v{l4, h4}, &M2[4 * plane2]);
         }
-#endif
       }
       if (wrap_out && !BANDED) {
         // wrap-around link: a column counts once its stores have left the wave.  Vector-memory operations retire in

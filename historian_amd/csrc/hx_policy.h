@@ -7,9 +7,6 @@
 
 namespace hx {
 
-#ifndef HX_ABLATE
-#define HX_ABLATE 0
-#endif
 
 // global-address-space views of pointers that were loaded from the job table (the compiler
 // would otherwise have to use flat_* instructions, which tie up both memory counters)
@@ -49,20 +46,11 @@ struct FastLse {
     Prep p;
     p.mx = vmax(a, b);
     const double d = a - b;
-#if HX_ABLATE == 5
-    p.k = 3; p.t = d * 1e-9; return p;
-#endif
     const double s = vmin(__builtin_fabs(d) * (HX_FAST_INTERVALS / 10.0), (double)HX_FAST_INTERVALS);
     p.k = (int)s;
     p.t = __builtin_amdgcn_fract(s);
     return p;
   }
-#ifndef HX_ABLATE
-#define HX_ABLATE 0
-#endif
-#if HX_ABLATE == 2 || HX_ABLATE == 9
-  __device__ __forceinline__ Piece fetch(const Prep& p) const { return Piece{0.6931 + p.k * 1e-9, -0.0049f, 3e-6f}; }
-#else
   __device__ __forceinline__ Piece fetch(const Prep& p) const {
     // exactly one 16-byte LDS access (ds_read_b128): c0 is the first double, the two fp32
     // coefficients are the halves of the second
@@ -74,7 +62,6 @@ struct FastLse {
     c.c2 = __uint_as_float((unsigned)__double2hiint(v.y));
     return c;
   }
-#endif
   __device__ __forceinline__ double finish(const Prep& p, const Piece& c) const {
     return p.mx + __builtin_fma(__builtin_fma((double)c.c2, p.t, (double)c.c1), p.t, c.c0);
   }
