@@ -595,14 +595,18 @@ int hx_version(void) { return 1; }
 const char* hx_last_error(void) { return g_err; }
 
 namespace {
-void free_tables(DeviceTables& t) {
+// keep_stream: hx_init on an ordinal that is already initialised replaces the tables only - batches created before keep the
+// device's copy stream (hx_batch::copy_stream) and their events on it
+void free_tables(DeviceTables& t, bool keep_stream = false) {
   if (t.tab) (void)hipFree(t.tab);
   if (t.fast_tab) (void)hipFree(t.fast_tab);
   if (t.log_tab) (void)hipFree(t.log_tab);
   if (t.pair_tab) (void)hipFree(t.pair_tab);
-  if (t.copy_stream) (void)hipStreamDestroy(t.copy_stream);
   t.tab = t.fast_tab = t.log_tab = t.pair_tab = nullptr;
-  t.copy_stream = nullptr;
+  if (!keep_stream) {
+    if (t.copy_stream) (void)hipStreamDestroy(t.copy_stream);
+    t.copy_stream = nullptr;
+  }
   t.ready = false;
 }
 int upload(double** dst, const std::vector<double>& src) {
@@ -627,7 +631,7 @@ int hx_init(int device_ordinal, const double* lse_table, size_t n_entries) {
     return fail(HX_ERR_NO_DEVICE, "device %d out of range (%d devices)", device_ordinal, n_dev);
   if (hipSetDevice(device_ordinal) != hipSuccess) return fail(HX_ERR_NO_DEVICE, "hipSetDevice(%d) failed", device_ordinal);
   DeviceTables& D = g_dev[device_ordinal];
-  free_tables(D);
+  free_tables(D, /*keep_stream*/ true);
   try {
     int rc;
     if ((rc = upload(&D.tab, std::vector<double>(lse_table, lse_table + n_entries))) != HX_OK) { free_tables(D); return rc; }

@@ -728,8 +728,12 @@ int hx_sumprod_columns(const hx_sumprod_model* hm, const int8_t* tokens, const d
     return api_fail(HX_ERR_HIP, "hx_sumprod_columns: HIP call failed");
   const size_t lds = sizeof(double) * (size_t)parts * A * (HX_SP_TILE + 1);
   if (lds > HX_LDS_LIMIT) return api_fail(HX_ERR_INVALID_ARG, "hx_sumprod_columns: basis tile exceeds the LDS of a CU");
-  hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return api_fail(HX_ERR_HIP, "hx_sumprod_columns: HIP call failed");
+  struct Events {                                   // destroyed on every way out
+    hipEvent_t a = nullptr, b = nullptr;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return api_fail(HX_ERR_HIP, "hx_sumprod_columns: HIP call failed");
+  const hipEvent_t e0 = ev.a, e1 = ev.b;
   (void)hipEventRecord(e0, st);
   for (long long first = 0; first < n_cols; first += chunk) {
     const long long nc = n_cols - first < chunk ? n_cols - first : chunk;
@@ -786,8 +790,6 @@ int hx_sumprod_columns(const hx_sumprod_model* hm, const int8_t* tokens, const d
   int rc = HX_OK;
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = HX_ERR_HIP;
   if (rc == HX_OK) (void)hipEventElapsedTime(&g_sp_ms, e0, e1);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   if (rc != HX_OK) return api_fail(rc, "hx_sumprod_columns: kernel launch or execution failed");
 #define DOWN(dst, src, n) if (hipMemcpy(dst, src, (n) * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return api_fail(HX_ERR_HIP, "hx_sumprod_columns: copy failed")
   DOWN(col_log_like, d_cll, (size_t)n_cols);

@@ -1,7 +1,10 @@
 #!/bin/bash
 # usage: tools/pmc.sh <tag> <bench args...>   -- collects two PMC passes for the forward kernel
 tag=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export TMPDIR=/tmp
+cd "$R" || exit 1
+mkdir -p gpurun_out
 timeout -k 10 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_SCA --output-format csv -d gpurun_out/pmc_${tag}_1 -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > gpurun_out/pmc_${tag}_1.log 2>&1
 timeout -k 10 400 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_BUSY_CYCLES --output-format csv -d gpurun_out/pmc_${tag}_2 -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > gpurun_out/pmc_${tag}_2.log 2>&1
 python - <<PY

@@ -2,7 +2,10 @@
 # usage: tools/pmc_dag.sh <tag> <kernel-name-substring>  -- shader-side counters of a general-profile Forward fill on
 # tools/dag_bench.py 32 (unbanded batch only).  Few counters per pass; PMC never combined with other trace domains.
 tag=$1; kern=$2
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export TMPDIR=/tmp
+cd "$R" || exit 1
+mkdir -p gpurun_out
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
            "SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \

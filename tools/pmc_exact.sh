@@ -1,6 +1,9 @@
 #!/bin/bash
 # memory-side counters of the exact-table Forward fill on the headline workload (what bounds it?)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export TMPDIR=/tmp
+cd "$R" || exit 1
+mkdir -p gpurun_out
 i=0
 for set in "TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY TCP_PENDING_STALL_CYCLES TCP_TOTAL_CACHE_ACCESSES" \
            "TA_TA_BUSY TA_TOTAL_WAVEFRONTS GRBM_GUI_ACTIVE TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES"; do

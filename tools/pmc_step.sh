@@ -2,7 +2,10 @@
 # usage: tools/pmc_step.sh <tag> <lx> <ly> <jobs>  -- memory-side counters of the general Forward pipeline
 # (few counters per pass: the TCP block has 4 counter slots)
 tag=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+export TMPDIR=/tmp
+cd "$R" || exit 1
+mkdir -p gpurun_out
 i=0
 for set in "TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT TCP_TCC_READ_REQ TCP_TCC_READ_REQ_LATENCY" \
            "TCP_PENDING_STALL_CYCLES TCP_TOTAL_CACHE_ACCESSES TCP_TCC_WRITE_REQ TCP_TCC_WRITE_REQ_LATENCY" \

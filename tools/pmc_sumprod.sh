@@ -12,7 +12,7 @@ for set in "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT
            "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM" \
            "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TA_BUSY_avr TCP_TA_DATA_STALL_CYCLES_sum"; do
   i=$((i+1))
-  timeout -k 5 200 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/sp_pmc_$i -- python3 $R/tools/sumprod_bench.py "$@" > $R/gpurun_out/sp_pmc_$i.log 2>&1 || { echo "pass $i failed"; tail -3 $R/gpurun_out/sp_pmc_$i.log; continue; }
+  timeout -k 5 200 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/sp_pmc_$i -- python3 $R/tools/sumprod_bench.py "$@" > $R/gpurun_out/sp_pmc_$i.log 2>&1 || { echo "pass $i failed"; tail -3 $R/gpurun_out/sp_pmc_$i.log; exit 1; }
   f=$(find $R/gpurun_out/sp_pmc_$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 - "$f" <<'PY'
 import csv, sys, collections
