@@ -48,6 +48,8 @@ struct DeviceTables {
   // which costs a caller that makes a batch per fill (a reconstruction's internal nodes) a millisecond or two per matrix
   hipStream_t copy_stream = nullptr;
   std::mutex copy_mutex;
+  // side stream of the fills: the two-pairs-per-wavefront banded sweep's edge kernel runs beside the sweep (hx_batch_forward)
+  hipStream_t side_stream = nullptr;
   bool ready = false;
 };
 DeviceTables g_dev[HX_MAX_DEVICES];
@@ -553,6 +555,7 @@ struct hx_batch {
   bool sub_scattered = false;        // subx / suby of table-emission jobs exist per state (k_scatter_sub, on demand)
   hipStream_t last_stream = nullptr;
   hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  hipEvent_t ev_side[2] = {nullptr, nullptr};   // fork / join of the device's side stream (banded sweep's edge kernel)
   bool dag_linear = false;                      // general-profile classes run the scaled-probability fill (hx_daglin.hip)
   hipStream_t copy_stream = nullptr;            // hx_batch_read_matrix_async: the device's copy stream (DeviceTables)
   int* d_multi = nullptr;                       // progress counters of a pair dealt to several workgroups (hx_dag.hip MULTI)
@@ -605,7 +608,8 @@ void free_tables(DeviceTables& t, bool keep_stream = false) {
   t.tab = t.fast_tab = t.log_tab = t.pair_tab = nullptr;
   if (!keep_stream) {
     if (t.copy_stream) (void)hipStreamDestroy(t.copy_stream);
-    t.copy_stream = nullptr;
+    if (t.side_stream) (void)hipStreamDestroy(t.side_stream);
+    t.copy_stream = t.side_stream = nullptr;
   }
   t.ready = false;
 }
@@ -842,10 +846,47 @@ static int batch_create_impl(int device, const hx_pair_job* jobs, int32_t n_jobs
       const std::vector<uint8_t> yf(ar.host.data() + jo.y.flags, ar.host.data() + jo.y.flags + jo.y.n);
       const std::vector<int32_t> xecls(reinterpret_cast<const int32_t*>(ar.host.data() + jo.x.ecls),
                                        reinterpret_cast<const int32_t*>(ar.host.data() + jo.x.ecls) + jo.x.n);
-      if (band_kernel_fits(pol, J.n_rows, J.n_cols, std::max(jo.x.n_cls, jo.y.n_cls)) &&
+      // Band-compressed planes of such a pair need not hold the always-in-envelope column (the y state feeding END) away
+      // from the band: below row 1 those cells are -inf (no x-absorbing move enters that column from a cell that is not
+      // itself in it, and the column's only finite cell off the band is (1, Ny-2): see hx_band.hip), and a cell that is not
+      // stored reads as -inf (hx_batch_read_cells, the traceback, lpEnd).  A strip's second window is that column whenever
+      // it is apart from the band's window, which also says that no row of the strip has a band that reaches it.  Without
+      // those windows a pair's planes are about half the size, and the fill no longer writes 5 x 8 bytes of -inf into a
+      // cache line of its own for every row (a fifth of the sweep's time at 4096 pairs).
+      std::vector<int32_t> twin;
+      std::vector<int64_t> tbase;
+      int64_t tplane = 0;
+      if (jo.compressed) {
+        twin = cwin_keep;
+        const int n_strips = (J.n_rows + HX_STRIP - 1) / HX_STRIP;
+        tbase.assign(2 * (size_t)n_strips, 0);
+        int64_t off = 0;
+        for (int q = 0; q < n_strips; ++q) {
+          int32_t* o = &twin[4 * (size_t)q];
+          if (q >= 1 && o[3] > o[2]) o[2] = o[3] = 0;
+          for (int w = 0; w < 2; ++w) {
+            tbase[2 * (size_t)q + w] = off;
+            off += (int64_t)((o[2 * w + 1] - o[2 * w]) >> 1) * (2 * HX_STRIP);
+          }
+        }
+        tplane = (off + 1) & ~(int64_t)1;
+      }
+      const bool fits = band_kernel_fits(pol, J.n_rows, J.n_cols, std::max(jo.x.n_cls, jo.y.n_cls));
+      bool trimmed = fits && jo.compressed && !getenv("HX_BAND_KEEP_EDGE_COLUMN") &&
+                     build_band_rows(pj.x->env_pos, pj.y->env_pos, xf.data(), yf.data(), xecls.data(), jo.x.empty != 0, J.n_rows, J.n_cols,
+                                     pj.max_distance, J.strip_stride, J.blk, twin.data(), tbase.data(), rows, n_steps);
+      if (trimmed) {
+        jo.fwd_windows = ar.put(twin.data(), sizeof(int32_t) * twin.size());
+        jo.strip_base = ar.put(tbase.data(), sizeof(int64_t) * tbase.size());
+        jo.compact_plane = tplane;
+        J.plane = tplane;
+        J.matrix_doubles = 5 * J.plane;
+      }
+      if (trimmed ||
+          (fits &&
           build_band_rows(pj.x->env_pos, pj.y->env_pos, xf.data(), yf.data(), xecls.data(), jo.x.empty != 0, J.n_rows, J.n_cols,
                           pj.max_distance, J.strip_stride, J.blk, jo.compressed ? cwin_keep.data() : nullptr,
-                          jo.compressed ? cbase_keep.data() : nullptr, rows, n_steps)) {
+                          jo.compressed ? cbase_keep.data() : nullptr, rows, n_steps))) {
         // the Backward sweep of the same kernel (dense planes: band-compressed batches have no Backward).  A pair the
         // Backward sweep cannot take (fewer than three rows or columns) stays out of the class altogether, so that the
         // class never falls back to the strip pipeline because of one such pair.
@@ -1040,6 +1081,8 @@ int hx_batch_destroy(hx_batch* b) {
   for (int w = 0; w < 2; ++w)
     for (int e = 0; e < 2; ++e)
       if (b->ev[w][e]) (void)hipEventDestroy(b->ev[w][e]);
+  for (int e = 0; e < 2; ++e)
+    if (b->ev_side[e]) (void)hipEventDestroy(b->ev_side[e]);
   for (int w = 0; w < 2; ++w)
     for (hipEvent_t e : b->copied[w])
       if (e) (void)hipEventDestroy(e);
@@ -1068,11 +1111,32 @@ int hx_batch_destroy(hx_batch* b) {
 // the class admitted (DevJob::band_w32), and enough pairs that halving the wavefronts matters - below HX_BAND2_MIN_PAIRS a pair
 // per wavefront with a converting wavefront beside it (hx_band.hip) has the shorter critical path.  HX_BAND2 = 0 / 1: never /
 // whenever admissible (tests).
-#define HX_BAND2_MIN_PAIRS 512
+#define HX_BAND2_MIN_PAIRS 1024
 static bool band2_wanted(bool linear, int n, int n_w32) {
   if (!linear || n_w32 != n) return false;
   if (const char* v = getenv("HX_BAND2")) return atoi(v) != 0;
   return n > HX_BAND2_MIN_PAIRS;
+}
+
+// The two-pairs-per-wavefront banded sweep leaves a CU's memory pipeline mostly idle (it is bound by vector issue), while its
+// edge kernel - row 0 beyond the band: one 16-byte cell per kilobyte of a plane - is bound by the number of cache lines it
+// touches.  The edge kernel therefore runs BESIDE the sweep, on the device's side stream: fork behind the preparation
+// kernels, join before anything that follows the sweep on the caller's stream.  Without a side stream (creation failed) the
+// two run one after the other on the caller's stream.
+static hipStream_t side_fork(hx_batch* b, hipStream_t st) {
+  DeviceTables& D = g_dev[b->device];
+  if (getenv("HX_NO_SIDE_STREAM")) return st;
+  if (!D.side_stream && hipStreamCreateWithFlags(&D.side_stream, hipStreamNonBlocking) != hipSuccess) { D.side_stream = nullptr; return st; }
+  for (int e = 0; e < 2; ++e)
+    if (!b->ev_side[e] && hipEventCreateWithFlags(&b->ev_side[e], hipEventDisableTiming) != hipSuccess) { b->ev_side[e] = nullptr; return st; }
+  if (hipEventRecord(b->ev_side[0], st) != hipSuccess || hipStreamWaitEvent(D.side_stream, b->ev_side[0], 0) != hipSuccess) return st;
+  return D.side_stream;
+}
+static int side_join(hx_batch* b, hipStream_t st, hipStream_t side) {
+  if (side == st) return HX_OK;
+  HIP_TRY(hipEventRecord(b->ev_side[1], side));
+  HIP_TRY(hipStreamWaitEvent(st, b->ev_side[1], 0));
+  return HX_OK;
 }
 
 int hx_batch_forward(hx_batch* b, void* stream) {
@@ -1098,10 +1162,13 @@ int hx_batch_forward(hx_batch* b, void* stream) {
     switch (c) {
       case KC_LEAF_ROT_BANDED:
         if (!(b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED))) launch_fill_neg_inf(b->d_fwd + cr.mat_begin, cr.mat_doubles, st);
-        if (band2_wanted(linear, cr.n, cr.n_w32))
+        if (band2_wanted(linear, cr.n, cr.n_w32)) {
+          const hipStream_t side = side_fork(b, st);
           LAUNCH_TRY(launch_forward_band2(jobs, cr.n, trunc, cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab}, Tab16{D.log_tab},
-                                          (b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED)) != 0, st));
-        else
+                                          (b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED)) != 0, st, side));
+          if ((rc = side_join(b, st, side)) != HX_OK) return rc;
+          launch_band2_result(jobs, cr.n, 0, Tab8{D.tab}, st);
+        } else
         LAUNCH_TRY(launch_forward_band(jobs, cr.n, linear ? (trunc ? 3 : 0) : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab},
                                        linear ? Tab16{D.log_tab} : lse_tab, (b->flags & (HX_SPARSE_ENVELOPE | HX_BAND_COMPRESSED)) != 0, st));
         break;
@@ -1200,10 +1267,13 @@ int hx_batch_backward(hx_batch* b, void* stream) {
       case KC_LEAF_LDS: case KC_LEAF_LDS_BANDED: case KC_LEAF_ROT_BANDED: case KC_LEAF: case KC_LEAF_BANDED: {
         if (banded && !(b->flags & HX_SPARSE_ENVELOPE)) launch_fill_neg_inf(b->d_bwd + cr.mat_begin, cr.mat_doubles, st);
         const int leaf = (c == KC_LEAF_LDS || c == KC_LEAF_LDS_BANDED || c == KC_LEAF_ROT_BANDED) ? 2 : 1;
-        if (c == KC_LEAF_ROT_BANDED && cr.bwd_band && band2_wanted(linear, cr.n, cr.n_w32))
+        if (c == KC_LEAF_ROT_BANDED && cr.bwd_band && band2_wanted(linear, cr.n, cr.n_w32)) {
+          const hipStream_t side = side_fork(b, st);
           LAUNCH_TRY(launch_backward_band2(jobs, cr.n, trunc, cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab}, Tab16{D.log_tab},
-                                           (b->flags & HX_SPARSE_ENVELOPE) != 0, st));
-        else if (c == KC_LEAF_ROT_BANDED && cr.bwd_band)
+                                           (b->flags & HX_SPARSE_ENVELOPE) != 0, st, side));
+          if ((rc = side_join(b, st, side)) != HX_OK) return rc;
+          launch_band2_result(jobs, cr.n, 1, Tab8{D.tab}, st);
+        } else if (c == KC_LEAF_ROT_BANDED && cr.bwd_band)
           // the rotating-row sweep in mirrored coordinates (hx_band.hip)
           LAUNCH_TRY(launch_backward_band(jobs, cr.n, linear ? (trunc ? 3 : 0) : (fast ? 1 : 2), cr.max_rows, cr.max_cols, cr.max_cls, Tab8{D.tab},
                                           linear ? Tab16{D.log_tab} : lse_tab, (b->flags & HX_SPARSE_ENVELOPE) != 0, st));

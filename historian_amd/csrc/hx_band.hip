@@ -45,6 +45,7 @@
 #include "hx_policy.h"
 #include "hx_leafcell.h"
 #include "hx_kernels.h"
+#include "hx_bandedge.h"
 
 namespace hx {
 
@@ -277,12 +278,18 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
     double d_idm = HX_NEG_INF, d_imi = HX_NEG_INF;                     // cell (0, Ny-3): the diagonal source of (1, Ny-2)
     if (own0 < Cc - 1 || row1_edge) {
       double idm = HX_NEG_INF, imi = HX_NEG_INF;                       // (the chain's value in every lane)
+      double carry_idm = 0., carry_imi = 0.;                            // (scaled-probability policies: the prefix sums' carries)
       for (int j0 = 0; j0 < Cc; j0 += 64) {
         const int jl = j0 + lane < Cc ? j0 + lane : Cc - 1;
         const unsigned w = ycolL[jl];
         const double lrs = LIN ? J.y.pack[4 * (size_t)jl + 1] : yclassL[w & 0xFFu].x;
         const double lin = LIN ? J.y.pack[4 * (size_t)jl + 2] : yclassL[w & 0xFFu].y;
         double kidm = HX_NEG_INF, kimi = HX_NEG_INF;
+        if (LIN) {
+          // as a prefix sum (hx_bandedge.h; the same function as the two-pairs-per-wavefront sweep's edge kernel: same bits)
+          row0_chain_block(j0, lane, Cc, lrs, lin, T02, T03, T22, T33, pen0, carry_idm, carry_imi, kidm, kimi);
+          if (Cc - 2 >= j0 && Cc - 2 < j0 + 64) { d_idm = read_lane(kidm, Cc - 2 - j0); d_imi = read_lane(kimi, Cc - 2 - j0); }
+        } else
 #pragma unroll 2
         for (int m = 0; m < 64; ++m) {
           const int j = j0 + m;                                         // (wave-uniform)

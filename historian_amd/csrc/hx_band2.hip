@@ -10,9 +10,9 @@
 // one and two steps ago of the lane two below, handed over by two DPP wave_ror:1 moves per register.  A pair is admitted when rows i and i + 31 are never alive together (hx_api.hip:
 // band2_admits); the row records, store bases and step counts are those of hx_band.hip (build_band_rows).
 //
-// One wavefront does everything for its two pairs - the recursion, the five logarithms per cell, the stores - so there is
-// no ring between a sweeping and a converting wave and no flow control; a workgroup is NW such wavefronts plus one that
-// writes the one-dimensional envelope edges of the workgroup's pairs (row 0 beyond the band, the column feeding END).
+// One wavefront does everything for its two pairs - the one-dimensional envelope edges (row 0 beyond the band, the column
+// feeding END) first, then the recursion, the five logarithms per cell, the stores - so there is no ring between a sweeping
+// and a converting wave and no flow control; a workgroup is NW such wavefronts sharing the logarithm table.
 // Per-pair constants that are wave-uniform in hx_band.hip (the 18 transition probabilities, plane bases, LDS block) are
 // per-lane here, since the two halves belong to different pairs.
 //
@@ -26,6 +26,7 @@
 #include "hx_common.h"
 #include "hx_policy.h"
 #include "hx_kernels.h"
+#include "hx_bandedge.h"
 
 namespace hx {
 
@@ -39,6 +40,8 @@ typedef int i2v __attribute__((ext_vector_type(2)));
 #define HXB2_HOLE_BEGIN 16         // bytes [16, 16384) of the table are never addressed: pair blocks live there
 #define HXB2_HOLE_END 16384
 #define HXB2_W 32                  // rows per ring
+#define HXB2_INFLIGHT 30           // vector-memory operations that may be outstanding when a lane reads its next row's record ...
+#define HXB2_LONG_ROW 16           // ... at the end of a row of at least this many owned steps: 5 stores in each of its first 7 step pairs
 
 struct L5 { double imm, imd, idm, imi, iiw; int e; };
 __device__ __forceinline__ L5 l5_zero() { return L5{0., 0., 0., 0., 0., HXB2_EMIN}; }
@@ -98,18 +101,162 @@ __device__ __forceinline__ int block_offset(const Band2Plan& p, const int pair) 
   return pair < p.in_hole ? HXB2_HOLE_BEGIN + pair * p.stride : 16 * HXB2_LOG_ENTRIES + (pair - p.in_hole) * p.stride;
 }
 
-// NW sweeping wavefronts (two pairs each) + one edge wavefront per workgroup.  DIR = 1: the Backward fill as the same sweep
+// The envelope's one-dimensional edges of a pair (see hx_band.hip): row 0 beyond the band and the column feeding END
+// (Forward), the first column and the last row (Backward).  One wavefront per pair, four pairs per workgroup, a launch of its
+// own in front of the sweep: nothing here is read by the sweep, and the sweep's 176 registers per lane leave a CU no room for
+// wavefronts that only write edges (as a fifth wavefront of the sweep's workgroups they kept a second workgroup off the CU; run
+// by the sweeping wavefronts in front of their sweeps they were a third of a millisecond of dependent additions per pair in
+// front of every sweep).
+template <bool TRUNC, int DIR>
+__global__ void __launch_bounds__(256)
+k_band2_edges(const DevJob* __restrict__ jobs, const int n_jobs, const int write_edges) {
+  const int lane = threadIdx.x & 63;
+  const int job = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (job >= n_jobs) return;
+  const DevJob J = jobs[job];                      // (a copy: the stores below cannot alias it)
+  const int Re = J.n_rows, Ce = J.n_cols;
+  const int nse = (Re + 63) >> 6;
+  const int64_t plane = J.plane;
+  const int blk = J.blk;
+  HX_GLOBAL double* __restrict__ M = as_global(DIR ? J.bwd : J.fwd);
+  const HX_GLOBAL i2v* xrecG = (const HX_GLOBAL i2v*)as_global(reinterpret_cast<const i2v*>(DIR ? J.band_rows_bwd : J.band_rows));
+  if (DIR == 1) {
+    const int64_t ssd = J.strip_stride;
+    const int lo_last = reinterpret_cast<const int*>(reinterpret_cast<const i2v*>(J.band_rows_bwd) + (Re + 64))[nse];   // first column the sweep owns on the last row
+    auto put_inf = [&](const int ip, const int jp) {
+      const int64_t sl = cell_slot_blk(ssd, blk, ip, jp);
+      M[sl] = HX_NEG_INF; M[plane + sl] = HX_NEG_INF; M[2 * plane + sl] = HX_NEG_INF; M[3 * plane + sl] = HX_NEG_INF;
+      M[4 * plane + sl] = HX_NEG_INF;
+    };
+    if (write_edges) {
+      for (int ip = 1 + lane; ip < Re; ip += 64) {
+        const i2v rec = xrecG[ip];
+        if ((rec.x & 0xFFFF) + ((rec.y >> 9) & 1) - ip > 0) put_inf(ip, 0);      // (the sweep owns the row from a later column on)
+      }
+      for (int jp = 1 + lane; jp < lo_last; jp += 64) put_inf(Re - 1, jp);
+    }
+    {
+      // a first row whose band does not reach column 0: the END-feeding cell itself (src/forward.cpp:981-995)
+      const i2v rec = xrecG[0];
+      if (lane == 0 && (rec.x & 0xFFFF) + ((rec.y >> 9) & 1) > 0) {
+        const double lpe = J.x.pack[4 * (size_t)Re] + J.y.pack[4 * (size_t)Ce];
+        const int64_t sl = cell_slot_blk(ssd, blk, 0, 0);
+        for (int st = 0; st < 5; ++st) M[st * plane + sl] = lpe + J.T[st][5];
+      }
+    }
+  } else {
+    // row 0 beyond what the sweep owns: the chain in log space
+    const int own0 = (xrecG[0].x >> 16) & 0xFFFF;                    // row 0 is owned from step 0 to this step = column
+    const i2v rec1 = xrecG[1];
+    const bool row1_edge = ((rec1.x & 0xFFFF) + ((rec1.x >> 16) & 0xFFFF) - 1) < Ce - 1;   // row 1 does not own column Ny-2
+    const double T02 = J.T[0][2], T03 = J.T[0][3], T22 = J.T[2][2], T33 = J.T[3][3];
+    const double pen0 = J.x.pack[3];                                 // x START ready (or x empty): 0, else -inf
+    double d_idm = HX_NEG_INF, d_imi = HX_NEG_INF;                   // cell (0, Ny-3): the diagonal source of (1, Ny-2)
+    if (own0 < Ce - 1 || row1_edge) {
+      // the chain as a prefix sum (hx_bandedge.h)
+      // row 0's slots: strip 0's windows (band-compressed planes) or the dense layout, fetched once
+      const bool packed = J.strip_base != nullptr;
+      const int w0 = packed ? J.fwd_windows[0] : 0, w1 = packed ? J.fwd_windows[1] : 0, w2 = packed ? J.fwd_windows[2] : 0,
+                w3 = packed ? J.fwd_windows[3] : 0;
+      const int64_t b0 = packed ? J.strip_base[0] : 0, b1 = packed ? J.strip_base[1] : 0;
+      auto row0_slot = [&](const int j) -> int64_t {
+        if (!packed) return cell_slot_blk(J.strip_stride, J.blk, 0, j);
+        if (j >= w0 && j < w1) return b0 + ((int64_t)((j - w0) >> 1) << 7) + (j & 1);
+        if (j >= w2 && j < w3) return b1 + ((int64_t)((j - w2) >> 1) << 7) + (j & 1);
+        return -1;
+      };
+      const HX_GLOBAL double* ypack = as_global(J.y.pack);
+      // first even column from which on rows 1-3 own nothing (a row's last owned step: first + count of its record)
+      int full_from = own0 + 1;
+      for (int l = 1; l < 4 && l < Re; ++l) {
+        const i2v r = xrecG[l];
+        if ((r.x & 0xFFFF) != 0xFFFF) full_from = max(full_from, (r.x & 0xFFFF) + ((r.x >> 16) & 0xFFFF) + 1);
+      }
+      full_from = (full_from + 1) & ~1;
+      double carry_idm = 0., carry_imi = 0.;                          // the sums up to the block in front
+      for (int j0 = 0; j0 < Ce; j0 += 64) {
+        const int j = j0 + lane;
+        const size_t jl = 4 * (size_t)(j < Ce ? j : Ce - 1);
+        const double lrs = ypack[jl + 1], lin = ypack[jl + 2];
+        double kidm, kimi;
+        row0_chain_block(j0, lane, Ce, lrs, lin, T02, T03, T22, T33, pen0, carry_idm, carry_imi, kidm, kimi);
+        if (Ce - 2 >= j0 && Ce - 2 < j0 + 64) { d_idm = read_lane(kidm, Ce - 2 - j0); d_imi = read_lane(kimi, Ce - 2 - j0); }
+        // Row 0's cells lie one to a kilobyte of a plane (lane 0 of strip 0's step-pair blocks): written alone, every pair of
+        // them is a 16-byte piece of a 64-byte line of its own - five read-modify-writes per two columns.  The rest of such a
+        // line are the cells of rows 1-3 on the same two steps, which beyond those rows' bands lie outside the envelope: they
+        // hold -inf (pre-filled planes) or anything (sparse / band-compressed planes), so the line is written whole, -inf
+        // around the two cells.  Two stores per plane and block of 64 columns: lane t writes piece t & 3 of line t >> 2 (+ 16).
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int line = (lane >> 2) + 16 * half, piece = lane & 3;
+          const int je = j0 + 2 * line;                                 // the line's even column
+          const double e_idm = __shfl(kidm, 2 * line, 64), o_idm = __shfl(kidm, 2 * line + 1, 64);
+          const double e_imi = __shfl(kimi, 2 * line, 64), o_imi = __shfl(kimi, 2 * line + 1, 64);
+          const int64_t sl = je + 1 < Ce ? row0_slot(je) : -1;
+          if (je >= full_from && sl >= 0) {
+            const d2v ninf = d2v{HX_NEG_INF, HX_NEG_INF};
+            HX_GLOBAL d2v* L = (HX_GLOBAL d2v*)(M + sl) + piece;
+            const int64_t plane2 = plane >> 1;
+            L[0] = ninf; L[plane2] = ninf; L[4 * plane2] = ninf;
+            L[2 * plane2] = piece == 0 ? d2v{e_idm, o_idm} : ninf;
+            L[3 * plane2] = piece == 0 ? d2v{e_imi, o_imi} : ninf;
+          }
+        }
+        // (the few columns next to the band, and an odd last one: cell by cell)
+        if (j > own0 && j < Ce && ((j & ~1) < full_from || (j | 1) >= Ce)) {
+          const int64_t sl = row0_slot(j);
+          if (sl >= 0) {
+            M[sl] = HX_NEG_INF; M[plane + sl] = HX_NEG_INF; M[2 * plane + sl] = kidm; M[3 * plane + sl] = kimi; M[4 * plane + sl] = HX_NEG_INF;
+          }
+        }
+      }
+    }
+    // cell (1, Ny-2) when row 1's band does not reach it (see hx_band.hip): the nested sum over the diagonal cell
+    // (0, Ny-3), in libm arithmetic (with the reference's truncation under HX_LSE_TRUNC), written as a log-probability
+    if (row1_edge) {
+      double dv[5] = {HX_NEG_INF, HX_NEG_INF, HX_NEG_INF, HX_NEG_INF, HX_NEG_INF};
+      if (Ce - 2 == 0) dv[0] = 0.0; else { dv[2] = d_idm; dv[3] = d_imi; }
+      const unsigned c = (unsigned)J.y.ecls[Ce - 1] & 0x7Fu;
+      const unsigned eo = (unsigned)(rec1.y & 0xFF) * (unsigned)(J.y.n_cls + 1);
+      double acc = HX_NEG_INF;
+      for (int q = 0; q < 5; ++q) {
+        const double t = dv[q] + J.T[q][0];
+        const double hi = vmax(acc, t), lo = vmin(acc, t);
+        const bool add = hi > HX_NEG_INF && lo > HX_NEG_INF && (!TRUNC || hi - lo < 10.0);
+        acc = add ? hi + log1p(exp(lo - hi)) : hi;
+      }
+      const double imm = acc > HX_NEG_INF ? acc + J.emis_pad[eo + c] : HX_NEG_INF;
+      const int64_t sl = stored_slot(J, 1, Ce - 1);
+      if (lane == 0 && sl >= 0) {
+        M[sl] = imm; M[plane + sl] = HX_NEG_INF; M[2 * plane + sl] = HX_NEG_INF; M[3 * plane + sl] = HX_NEG_INF; M[4 * plane + sl] = HX_NEG_INF;
+      }
+    }
+    // the rest of column Ny-2 away from the band: -inf (only where the matrix was not pre-filled)
+    if (write_edges)
+      for (int i = 2 + lane; i < Re; i += 64) {
+        const i2v rec = xrecG[i];
+        const int last_col = (rec.x & 0xFFFF) + ((rec.x >> 16) & 0xFFFF) - i;   // column of the row's last owned step
+        if (last_col < Ce - 1) {
+          const int64_t sl = stored_slot(J, i, Ce - 1);
+          if (sl >= 0) {
+            M[sl] = HX_NEG_INF; M[plane + sl] = HX_NEG_INF; M[2 * plane + sl] = HX_NEG_INF; M[3 * plane + sl] = HX_NEG_INF; M[4 * plane + sl] = HX_NEG_INF;
+          }
+        }
+      }
+  }
+}
+
+// NW sweeping wavefronts (two pairs each) per workgroup.  DIR = 1: the Backward fill as the same sweep
 // in mirrored coordinates (see hx_band.hip).
 template <bool TRUNC, int NW, int DIR>
-__global__ void __launch_bounds__((NW + 1) * 64)
+__global__ void __launch_bounds__(NW * 64, 2)
 k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const double* __restrict__ log_tab,
-             const Band2Plan plan, const int n_jobs, const int write_edges) {
-  constexpr int THREADS = (NW + 1) * 64;
+             const Band2Plan plan, const int n_jobs) {
+  constexpr int THREADS = NW * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int half = lane & 1, r32 = lane >> 1;      // which of the wavefront's two pairs, and the lane's place in that pair's ring
-  const bool edge_wave = wave == NW;
   double* ptab = reinterpret_cast<double*>(lds);
   // (entries 1..1023 of the logarithm table are never addressed)
   for (int k = threadIdx.x; k < 2; k += THREADS) ptab[k] = log_tab[k];
@@ -117,9 +264,9 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
   const int first_job = (int)blockIdx.x * 2 * NW;
 
   // ---- the sweeping wavefronts stage their two pairs' blocks (32 lanes per pair) ----
-  const int my_pair = edge_wave ? 0 : 2 * wave + half;
+  const int my_pair = 2 * wave + half;
   const int my_job = first_job + my_pair;
-  const bool live = !edge_wave && my_job < n_jobs;
+  const bool live = my_job < n_jobs;
   const DevJob* __restrict__ Jp = jobs + (my_job < n_jobs ? my_job : 0);
   unsigned char* blkp = lds + block_offset(plan, my_pair);
   HX_LDS int* sbaseL = (HX_LDS int*)(blkp + plan.sbase);
@@ -154,117 +301,7 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
   }
   __syncthreads();
 
-  if (edge_wave) {
-    // =====================================================================================================
-    // the envelope's one-dimensional edges of every pair of the workgroup (see hx_band.hip).  Nothing here is read by
-    // the sweeps.
-    // =====================================================================================================
-    for (int p = 0; p < 2 * NW; ++p) {
-      const int job = first_job + p;
-      if (job >= n_jobs) break;
-      const DevJob& J = jobs[job];
-      const unsigned char* bp = lds + block_offset(plan, p);
-      const HX_LDS unsigned char* ycolE = (const HX_LDS unsigned char*)(bp + plan.ycol);
-      const int Re = J.n_rows, Ce = J.n_cols;
-      const int nse = (Re + 63) >> 6;
-      const int64_t plane = J.plane;
-      const int blk = J.blk;
-      HX_GLOBAL double* __restrict__ M = as_global(DIR ? J.bwd : J.fwd);
-      const HX_GLOBAL i2v* xrecG = (const HX_GLOBAL i2v*)as_global(reinterpret_cast<const i2v*>(DIR ? J.band_rows_bwd : J.band_rows));
-      if (DIR == 1) {
-        const int64_t ssd = J.strip_stride;
-        const int lo_last = reinterpret_cast<const int*>(reinterpret_cast<const i2v*>(J.band_rows_bwd) + (Re + 64))[nse];   // first column the sweep owns on the last row
-        auto put_inf = [&](const int ip, const int jp) {
-          const int64_t sl = cell_slot_blk(ssd, blk, ip, jp);
-          M[sl] = HX_NEG_INF; M[plane + sl] = HX_NEG_INF; M[2 * plane + sl] = HX_NEG_INF; M[3 * plane + sl] = HX_NEG_INF;
-          M[4 * plane + sl] = HX_NEG_INF;
-        };
-        if (write_edges) {
-          for (int ip = 1 + lane; ip < Re; ip += 64) {
-            const i2v rec = xrecG[ip];
-            if ((rec.x & 0xFFFF) + ((rec.y >> 9) & 1) - ip > 0) put_inf(ip, 0);      // (the sweep owns the row from a later column on)
-          }
-          for (int jp = 1 + lane; jp < lo_last; jp += 64) put_inf(Re - 1, jp);
-        }
-        {
-          // a first row whose band does not reach column 0: the END-feeding cell itself (src/forward.cpp:981-995)
-          const i2v rec = xrecG[0];
-          if (lane == 0 && (rec.x & 0xFFFF) + ((rec.y >> 9) & 1) > 0) {
-            const double lpe = J.x.pack[4 * (size_t)Re] + J.y.pack[4 * (size_t)Ce];
-            const int64_t sl = cell_slot_blk(ssd, blk, 0, 0);
-            for (int st = 0; st < 5; ++st) M[st * plane + sl] = lpe + J.T[st][5];
-          }
-        }
-      } else {
-        // row 0 beyond what the sweep owns: the chain in log space
-        const int own0 = (xrecG[0].x >> 16) & 0xFFFF;                    // row 0 is owned from step 0 to this step = column
-        const i2v rec1 = xrecG[1];
-        const bool row1_edge = ((rec1.x & 0xFFFF) + ((rec1.x >> 16) & 0xFFFF) - 1) < Ce - 1;   // row 1 does not own column Ny-2
-        const double T02 = J.T[0][2], T03 = J.T[0][3], T22 = J.T[2][2], T33 = J.T[3][3];
-        const double pen0 = J.x.pack[3];                                 // x START ready (or x empty): 0, else -inf
-        double d_idm = HX_NEG_INF, d_imi = HX_NEG_INF;                   // cell (0, Ny-3): the diagonal source of (1, Ny-2)
-        if (own0 < Ce - 1 || row1_edge) {
-          double idm = HX_NEG_INF, imi = HX_NEG_INF;                     // (the chain's value in every lane)
-          for (int j0 = 0; j0 < Ce; j0 += 64) {
-            const int jl = j0 + lane < Ce ? j0 + lane : Ce - 1;
-            const double lrs = J.y.pack[4 * (size_t)jl + 1];
-            const double lin = J.y.pack[4 * (size_t)jl + 2];
-            double kidm = HX_NEG_INF, kimi = HX_NEG_INF;
-#pragma unroll 2
-            for (int m = 0; m < 64; ++m) {
-              const int j = j0 + m;                                       // (wave-uniform)
-              const double rr = read_lane(lrs, m), nn = read_lane(lin, m);
-              if (j >= 1) {
-                idm = (((j == 1 ? T02 : idm + T22) + 0.0) + rr) + pen0;
-                imi = (((j == 1 ? T03 : imi + T33) + 0.0) + nn) + pen0;
-              }
-              if (j == Ce - 2) { d_idm = idm; d_imi = imi; }
-              if (lane == m) { kidm = idm; kimi = imi; }
-            }
-            const int j = j0 + lane;
-            if (j > own0 && j < Ce) {
-              const int64_t sl = stored_slot(J, 0, j);
-              if (sl >= 0) {
-                M[sl] = HX_NEG_INF; M[plane + sl] = HX_NEG_INF; M[2 * plane + sl] = kidm; M[3 * plane + sl] = kimi; M[4 * plane + sl] = HX_NEG_INF;
-              }
-            }
-          }
-        }
-        // cell (1, Ny-2) when row 1's band does not reach it (see hx_band.hip): the nested sum over the diagonal cell
-        // (0, Ny-3), in libm arithmetic (with the reference's truncation under HX_LSE_TRUNC), written as a log-probability
-        if (row1_edge) {
-          double dv[5] = {HX_NEG_INF, HX_NEG_INF, HX_NEG_INF, HX_NEG_INF, HX_NEG_INF};
-          if (Ce - 2 == 0) dv[0] = 0.0; else { dv[2] = d_idm; dv[3] = d_imi; }
-          const unsigned c = ycolE[Ce - 1] & 0x7Fu;
-          const unsigned eo = (unsigned)(rec1.y & 0xFF) * (unsigned)(J.y.n_cls + 1);
-          double acc = HX_NEG_INF;
-          for (int q = 0; q < 5; ++q) {
-            const double t = dv[q] + J.T[q][0];
-            const double hi = vmax(acc, t), lo = vmin(acc, t);
-            const bool add = hi > HX_NEG_INF && lo > HX_NEG_INF && (!TRUNC || hi - lo < 10.0);
-            acc = add ? hi + log1p(exp(lo - hi)) : hi;
-          }
-          const double imm = acc > HX_NEG_INF ? acc + J.emis_pad[eo + c] : HX_NEG_INF;
-          const int64_t sl = stored_slot(J, 1, Ce - 1);
-          if (lane == 0 && sl >= 0) {
-            M[sl] = imm; M[plane + sl] = HX_NEG_INF; M[2 * plane + sl] = HX_NEG_INF; M[3 * plane + sl] = HX_NEG_INF; M[4 * plane + sl] = HX_NEG_INF;
-          }
-        }
-        // the rest of column Ny-2 away from the band: -inf (only where the matrix was not pre-filled)
-        if (write_edges)
-          for (int i = 2 + lane; i < Re; i += 64) {
-            const i2v rec = xrecG[i];
-            const int last_col = (rec.x & 0xFFFF) + ((rec.x >> 16) & 0xFFFF) - i;   // column of the row's last owned step
-            if (last_col < Ce - 1) {
-              const int64_t sl = stored_slot(J, i, Ce - 1);
-              if (sl >= 0) {
-                M[sl] = HX_NEG_INF; M[plane + sl] = HX_NEG_INF; M[2 * plane + sl] = HX_NEG_INF; M[3 * plane + sl] = HX_NEG_INF; M[4 * plane + sl] = HX_NEG_INF;
-              }
-            }
-          }
-      }
-    }
-  } else {
+  {
     // =======================================================================================================
     // the sweep: lane = row mod 32 inside the lane's half
     // =======================================================================================================
@@ -273,6 +310,32 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
     HX_GLOBAL double* __restrict__ M = as_global(DIR ? Jp->bwd : Jp->fwd);
     const HX_GLOBAL i2v* xrecG = (const HX_GLOBAL i2v*)as_global(rowsG);
     auto xrec_at = [&](const int i) -> i2v { return xrecG[i]; };
+    // The record of the row a lane takes NEXT is fetched when the lane takes its current row and first read on that row's last
+    // step.  Left to the compiler that read costs an `s_waitcnt vmcnt(0)` in every step - some lane of the wavefront is always
+    // about to change rows - i.e. every step waited for the acknowledgement of the stores issued just before it and for the
+    // fetch another lane had issued a few hundred instructions earlier (shader counters: the wavefronts waited 40-55 % of
+    // their cycles, and the fill took the same time with 138 as with 239 vector instructions per step).  Vector-memory
+    // operations retire in issue order, and between a lane's fetch and its first read of the result the lane owns cells in
+    // every step pair of the row, so the five stores of each of those pairs were issued behind the fetch: for a row of at
+    // least HXB2_LONG_ROW owned steps the fetch has retired once at most HXB2_INFLIGHT operations are outstanding.  The fetch
+    // is therefore issued by hand into a register pair the compiler only ever sees READ (`landing`: defined once, in front
+    // of the loop; nothing makes the compiler copy or move it), and the value is taken out of it behind a counted wait; a
+    // wavefront in which a shorter row is ending (the band's corners) waits for everything.  tests/test_band2_isa.py checks the
+    // compiled loop: one landing register pair, read only behind the waits.
+    i2v landing;
+    asm volatile("; landing registers of the row-record fetches: %0" : "=v"(landing));
+    auto xrec_fetch = [&](const int i) {
+      const HX_GLOBAL i2v* a = xrecG + i;
+      asm volatile("global_load_dwordx2 %0, %1, off" : : "v"(landing), "v"(a) : "memory");
+    };
+    auto xrec_take = [&](const bool short_row) -> i2v {
+      int x, y;
+      if (__builtin_amdgcn_ballot_w64(short_row) != 0)
+        asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(x), "=&v"(y) : "v"(landing.x), "v"(landing.y) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%4)\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(x), "=&v"(y) : "v"(landing.x), "v"(landing.y), "n"(HXB2_INFLIGHT) : "memory");
+      return i2v{x, y};
+    };
     // anti-diagonal steps: the longer of the wavefront's two pairs, in whole blocks of eight (extra steps own nothing)
     const int my_steps = live ? ((DIR ? Jp->band_steps_bwd : Jp->band_steps) + 7) & ~7 : 0;
     const int s0 = __builtin_amdgcn_readlane(my_steps, 0), s1 = __builtin_amdgcn_readlane(my_steps, 1);
@@ -311,7 +374,8 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
     {
       const i2v r0 = xrec_at(r32 < R ? r32 : R);
       decode(r0, xclassL[r0.y & 0xFF], store_base(r32), emis_row(r0));
-      nrec = xrec_at(r32 + HXB2_W < R ? r32 + HXB2_W : R);
+      nrec = i2v{0xFFFF, 0};
+      xrec_fetch(r32 + HXB2_W < R ? r32 + HXB2_W : R);
     }
     // the 18 transition probabilities the recursion reads (dest 5 = EEE is only read by lpEnd): per lane - the halves
     // belong to different pairs
@@ -348,12 +412,13 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
     auto roll_even = [&](const int k) {
       if (k > oe) {
         i += HXB2_W;
-        decode(nrec, nxc, nstore, nerow);
-        nrec = xrec_at(i + HXB2_W < R ? i + HXB2_W : R);
+        decode(nrec, nxc, nstore, nerow);                 // (nrec was taken on the last step of the row that ended)
+        xrec_fetch(i + HXB2_W < R ? i + HXB2_W : R);
       }
     };
     auto roll_odd = [&](const int k) {
       if (k == oe) {
+        nrec = xrec_take(oe - os < HXB2_LONG_ROW - 1);
         nxc = xclassL[nrec.y & 0xFF];
         nstore = store_base(i + HXB2_W);
         nerow = emis_row(nrec);
@@ -475,13 +540,20 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
       step_pair(k + 6, false);
     }
   }
-  // lpEnd reads cell (Nx-2, Ny-2): the sweep's last cell, or - a one-row band - an edge cell
+  // (the drain tools/check_landing_regs.py looks for: every hand-issued fetch has retired)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (live && r32 == 0) {
-    if (DIR == 0) *Jp->lp_end = forward_lp_end(*Jp, ExactLse{exact_tab});
-    else *Jp->lp_start = Jp->bwd[cell_slot_blk(Jp->strip_stride, Jp->blk, R - 1, Cc - 1)];   // B(START, START).IMM: the sweep's last cell
-  }
+}
+
+// lpEnd / lpStart of the pairs, behind the sweep AND the edge kernel (which may run beside the sweep on another stream):
+// lpEnd reads cell (Nx-2, Ny-2) - the sweep's last cell or, with a one-row band, an edge cell.
+template <int DIR>
+__global__ void __launch_bounds__(64)
+k_band2_result(const DevJob* __restrict__ jobs, const double* __restrict__ exact_tab, const int n_jobs) {
+  const int job = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (job >= n_jobs) return;
+  const DevJob& J = jobs[job];
+  if (DIR == 0) *J.lp_end = forward_lp_end(J, ExactLse{exact_tab});
+  else *J.lp_start = J.bwd[cell_slot_blk(J.strip_stride, J.blk, J.n_rows - 1, J.n_cols - 1)];   // B(START, START).IMM: the sweep's last cell
 }
 
 Band2Plan plan_band2(int nw, int max_rows, int max_cols, int max_cls) {
@@ -500,26 +572,29 @@ Band2Plan plan_band2(int nw, int max_rows, int max_cols, int max_cls) {
 }
 
 template <bool TRUNC, int NW, int DIR>
-int launch_b2(const DevJob* d_jobs, int n_jobs, const Band2Plan& p, const double* tab, const double* log_tab, int write_edges, hipStream_t st) {
+int launch_b2(const DevJob* d_jobs, int n_jobs, const Band2Plan& p, const double* tab, const double* log_tab, int write_edges, hipStream_t st,
+              hipStream_t edge_st) {
   if (p.total > HX_LDS_LIMIT) return launch_fail("k_fill_band2<%d> needs %d bytes of LDS (limit %d)", NW, p.total, HX_LDS_LIMIT);
-  hipLaunchKernelGGL((k_fill_band2<TRUNC, NW, DIR>), dim3((n_jobs + 2 * NW - 1) / (2 * NW)), dim3((NW + 1) * 64), p.total, st, d_jobs, tab,
-                     log_tab, p, n_jobs, write_edges);
+  // the sweep first: it takes two workgroups' worth of every CU, the edge kernel's wavefronts fit beside them
+  hipLaunchKernelGGL((k_fill_band2<TRUNC, NW, DIR>), dim3((n_jobs + 2 * NW - 1) / (2 * NW)), dim3(NW * 64), p.total, st, d_jobs, tab,
+                     log_tab, p, n_jobs);
+  hipLaunchKernelGGL((k_band2_edges<TRUNC, DIR>), dim3((n_jobs + 3) / 4), dim3(256), 0, edge_st, d_jobs, n_jobs, write_edges);
   return 0;
 }
 
 template <int DIR>
 int launch_band2_dir(const DevJob* d_jobs, int n_jobs, bool trunc, int max_rows, int max_cols, int max_cls, Tab8 tab8, Tab16 log_tab,
-                     bool write_edges, hipStream_t st) {
+                     bool write_edges, hipStream_t st, hipStream_t edge_st) {
   if (max_cls + 1 > 127) return launch_fail("%d emission classes exceed the two-pairs-per-wavefront sweep's column bytes", max_cls);
   const char* v = getenv("HX_BAND2_NW");           // tuning / test hook: sweeping wavefronts per workgroup (1, 2 or 4)
   int nw = v ? atoi(v) : 0;
-  // (measured, tools/band2_sweep.sh: four sweeping wavefronts per workgroup are fastest from 2048 pairs on - 2048 pairs 3.5 ms
-  // against 4.5 / 4.7 ms with two / one; smaller batches need more workgroups than that leaves)
-  if (nw != 1 && nw != 2 && nw != 4) nw = n_jobs >= 2048 ? 4 : 2;
+  // (four: a workgroup is then one wavefront per SIMD of its CU and two workgroups fill the CU; workgroups of two wavefronts are
+  // placed two to a SIMD pair - 2048 pairs 3.3 ms with four, 4.4 ms with two)
+  if (nw != 1 && nw != 2 && nw != 4) nw = 4;
   const int we = write_edges ? 1 : 0;
 #define HXB2_GO(NW_) do { const Band2Plan p = plan_band2(NW_, max_rows, max_cols, max_cls); \
-    return trunc ? launch_b2<true, NW_, DIR>(d_jobs, n_jobs, p, tab8.p, log_tab.p, we, st) \
-                 : launch_b2<false, NW_, DIR>(d_jobs, n_jobs, p, tab8.p, log_tab.p, we, st); } while (0)
+    return trunc ? launch_b2<true, NW_, DIR>(d_jobs, n_jobs, p, tab8.p, log_tab.p, we, st, edge_st) \
+                 : launch_b2<false, NW_, DIR>(d_jobs, n_jobs, p, tab8.p, log_tab.p, we, st, edge_st); } while (0)
   if (nw == 4) HXB2_GO(4);
   if (nw == 2) HXB2_GO(2);
   HXB2_GO(1);
@@ -532,13 +607,18 @@ bool band2_kernel_fits(int rows, int cols, int cls) {
   return cls + 1 <= 127 && plan_band2(1, rows, cols, cls).total <= HX_LDS_LIMIT;
 }
 
+void launch_band2_result(const DevJob* d_jobs, int n_jobs, int dir, Tab8 tab8, hipStream_t st) {
+  if (dir == 0) hipLaunchKernelGGL(k_band2_result<0>, dim3((n_jobs + 63) / 64), dim3(64), 0, st, d_jobs, tab8.p, n_jobs);
+  else hipLaunchKernelGGL(k_band2_result<1>, dim3((n_jobs + 63) / 64), dim3(64), 0, st, d_jobs, tab8.p, n_jobs);
+}
+
 int launch_forward_band2(const DevJob* d_jobs, int n_jobs, bool trunc, int max_rows, int max_cols, int max_cls, Tab8 tab8, Tab16 log_tab,
-                         bool write_edges, hipStream_t st) {
-  return launch_band2_dir<0>(d_jobs, n_jobs, trunc, max_rows, max_cols, max_cls, tab8, log_tab, write_edges, st);
+                         bool write_edges, hipStream_t st, hipStream_t edge_st) {
+  return launch_band2_dir<0>(d_jobs, n_jobs, trunc, max_rows, max_cols, max_cls, tab8, log_tab, write_edges, st, edge_st);
 }
 int launch_backward_band2(const DevJob* d_jobs, int n_jobs, bool trunc, int max_rows, int max_cols, int max_cls, Tab8 tab8, Tab16 log_tab,
-                          bool write_edges, hipStream_t st) {
-  return launch_band2_dir<1>(d_jobs, n_jobs, trunc, max_rows, max_cols, max_cls, tab8, log_tab, write_edges, st);
+                          bool write_edges, hipStream_t st, hipStream_t edge_st) {
+  return launch_band2_dir<1>(d_jobs, n_jobs, trunc, max_rows, max_cols, max_cls, tab8, log_tab, write_edges, st, edge_st);
 }
 
 }  // namespace hx

@@ -80,9 +80,11 @@ int launch_backward_band(const DevJob* d_jobs, int n_jobs, int pol, int max_rows
 // never alive together (DevJob::band_w32)
 bool band2_kernel_fits(int rows, int cols, int cls);
 int launch_forward_band2(const DevJob* d_jobs, int n_jobs, bool trunc, int max_rows, int max_cols, int max_cls, Tab8 tab, Tab16 log_tab,
-                         bool write_edges, hipStream_t st);
+                         bool write_edges, hipStream_t st, hipStream_t edge_st);
+// lpEnd (dir 0) / lpStart (dir 1) of the pairs: behind the sweep and the edge kernel of launch_*_band2
+void launch_band2_result(const DevJob* d_jobs, int n_jobs, int dir, Tab8 tab, hipStream_t st);
 int launch_backward_band2(const DevJob* d_jobs, int n_jobs, bool trunc, int max_rows, int max_cols, int max_cls, Tab8 tab, Tab16 log_tab,
-                          bool write_edges, hipStream_t st);
+                          bool write_edges, hipStream_t st, hipStream_t edge_st);
 
 // Several-workgroups-per-pair launches of the general-profile fills (hx_dag.hip, hx_daglin.hip): polls of another workgroup's
 // progress before a wave gives up (HX_MULTI_PATIENCE overrides; 0 makes every unsatisfied wait give up - the tests' way of
