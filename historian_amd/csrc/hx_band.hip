@@ -69,7 +69,7 @@ struct L5 { double imm, imd, idm, imi, iiw; int e; };
 __device__ __forceinline__ L5 l5_zero() { return L5{0., 0., 0., 0., 0., HXB_EMIN}; }
 // (hx_linear.hip) the reference's pairwise log_sum_exp on probabilities: the smaller term is dropped when it is at most e^-10 of the larger
 __device__ __forceinline__ double trunc_sum(double a, double b) {
-  const double hi = vmax(a, b), lo = vmin(a, b);
+  const double hi = fmax_plain(a, b), lo = fmin_plain(a, b);
   // (a dropped term keeps its low word: a number below 2^-1042 that no sum of mantissas scaled to the cell's exponent feels - one select instead of two)
   const int keep = lo > hi * 4.5399929762484854e-05 ? __double2hiint(lo) : 0;
   return hi + __hiloint2double(keep, __double2loint(lo));

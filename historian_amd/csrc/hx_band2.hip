@@ -56,15 +56,22 @@ __device__ __forceinline__ int rot(const int, const int v) { return ror1(ror1(v)
 __device__ __forceinline__ double rot(const int addr, const double v) {
   return __hiloint2double(rot(addr, __double2hiint(v)), rot(addr, __double2loint(v)));
 }
-__device__ __forceinline__ L5 rot(const int addr, const L5& c) {
-  return L5{rot(addr, c.imm), rot(addr, c.imd), rot(addr, c.idm), rot(addr, c.imi), rot(addr, c.iiw), rot(addr, c.e)};
+// a whole cell: the eleven first moves, then the eleven second ones - a move that reads the result of the move in front of it
+// waits two issue slots (the compiler, left alone, pairs them up that way and pads every pair)
+__device__ __forceinline__ double ror1(const double v) { return __hiloint2double(ror1(__double2hiint(v)), ror1(__double2loint(v))); }
+__device__ __forceinline__ L5 rot(const int, const L5& c) {
+  const L5 t{ror1(c.imm), ror1(c.imd), ror1(c.idm), ror1(c.imi), ror1(c.iiw), ror1(c.e)};
+  __builtin_amdgcn_sched_barrier(0);
+  const L5 r{ror1(t.imm), ror1(t.imd), ror1(t.idm), ror1(t.imi), ror1(t.iiw), ror1(t.e)};
+  __builtin_amdgcn_sched_barrier(0);
+  return r;
 }
 
 // (hx_linear.hip) one pairwise sum of the reference's log_sum_exp on probabilities
 // (a dropped term keeps its low word: a number below 2^-1042 that no sum of mantissas scaled to the cell's exponent feels -
 // one select instead of two)
 __device__ __forceinline__ double trunc_sum(double a, double b) {
-  const double hi = vmax(a, b), lo = vmin(a, b);
+  const double hi = fmax_plain(a, b), lo = fmin_plain(a, b);
   const int keep = lo > hi * 4.5399929762484854e-05 ? __double2hiint(lo) : 0;
   return hi + __hiloint2double(keep, __double2loint(lo));
 }

@@ -42,7 +42,7 @@ struct L5 { double imm, imd, idm, imi, iiw; int e; };
 // (HX_LSE_TRUNC) from plain multiply-adds: the dropped terms are the 4.5e-5-per-operation bias that moves near-tied best paths.
 #define HXL_EXP_M10 4.5399929762484854e-05      // e^-10
 __device__ __forceinline__ double trunc_sum(double a, double b) {
-  const double hi = vmax(a, b), lo = vmin(a, b);
+  const double hi = fmax_plain(a, b), lo = fmin_plain(a, b);
   // (a dropped term keeps its low word: a number below 2^-1042 that no sum of mantissas scaled to the cell's exponent feels - one select instead of two)
   const int keep = lo > hi * HXL_EXP_M10 ? __double2hiint(lo) : 0;
   return hi + __hiloint2double(keep, __double2loint(lo));

@@ -32,6 +32,12 @@ __device__ __forceinline__ double vmin(double a, double b) {
   return r;
 }
 
+// The same two instructions through the compiler's own operations, for operands that are results of arithmetic (never a
+// signalling NaN: no canonicalising move is added).  Behind an inline-asm instruction the compiler pads every first use of the
+// result with an s_nop - nine issue slots per step in the truncating sums of the scaled-probability fills.
+__device__ __forceinline__ double fmax_plain(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ double fmin_plain(double a, double b) { return __builtin_fmin(a, b); }
+
 // A log-sum-exp policy is used in three phases so that the independent table look-ups of a
 // cell can be issued back to back:  prep (index arithmetic) -> fetch (the memory access) ->
 // finish (interpolation + add).  operator() runs the three in sequence.

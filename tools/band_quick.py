@@ -24,7 +24,7 @@ def main():
     hmm = hostmodel.make_hmm(model, 0.2, 0.3)
     capi.init(0)
     base = [workload.leaf_pair(np.random.default_rng(1000 + k), model, hmm, length, band=band) for k in range(min(64, pairs))]
-    env = [workload.in_envelope_cells(t[0].env_pos, t[1].env_pos, band) for t in base]
+    env = [workload.in_envelope_cells(t[0].env_pos, t[1].env_pos, band) if band >= 0 else 0 for t in base]
     triples = [base[k % len(base)] for k in range(pairs)]
     cells = sum(env[k % len(base)] for k in range(pairs))
     b = capi.Batch(triples, flags | (capi.HX_BAND_COMPRESSED if band >= 0 else 0))
