@@ -79,7 +79,7 @@ def parse():
                          "bit.  linear = scaled probabilities without the truncation (best paths may differ at near-ties).  The "
                          "other policies are timed too")
     ap.add_argument("--single-mode", action="store_true", help="time only --mode; no banded block, no strong block")
-    ap.add_argument("--banded-pairs", default="512,4096", help="batch sizes of the banded block (band 20), comma separated; '' = none")
+    ap.add_argument("--banded-pairs", default="512,2560,4096", help="batch sizes of the banded block (band 20), comma separated; '' = none")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a PMC run (default: profiles/traffic.json entry for this workload)")
     return ap.parse_args()

@@ -497,6 +497,9 @@ public:
   Path bestTrace();
   Path bestTrace(const CellCoords& from);
   Path sampleTrace(random_engine& rng);
+  // sampled walks made on the device (HX_DEVICE_SAMPLING=1, hx_batch_sample_traces); see hx_host_walk.cpp
+  static bool deviceSampling();
+  bool sampleTracesOnDevice(const random_engine& generator, size_t walks, vguard<Path>& paths, vguard<long long>& draws);
   AlignPath bestAlignPath();
 
   Profile makeProfile(const set<CellCoords>& chosen, ProfilingStrategy how = CollapseChains);

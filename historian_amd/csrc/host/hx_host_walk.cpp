@@ -563,6 +563,42 @@ Profile ForwardMatrix::sampleProfile(random_engine& generator, size_t profileSam
   return makeProfile(sampleCells(generator, profileSamples, maxCells, strategy, minLen, maxLen), strategy);
 }
 
+// The walks sampleTrace would make from the generator's present state, made on the device in the matrix where it is
+// (hx_batch_sample_traces; HX_DEVICE_SAMPLING=1): the generator's canonical uniforms are drawn from a COPY of it, and the
+// caller advances the generator itself by what the walks it keeps have used (two 32-bit draws per step).  Empty when a walk
+// could not be made there: the caller then samples on the host as before, from the untouched generator.
+bool ForwardMatrix::deviceSampling() {
+  static const bool on = getenv("HX_DEVICE_SAMPLING") != NULL && atoi(getenv("HX_DEVICE_SAMPLING")) != 0;
+  return on;
+}
+bool ForwardMatrix::sampleTracesOnDevice(const random_engine& generator, size_t walks, vguard<Path>& paths, vguard<long long>& draws) {
+  paths.clear();
+  draws.clear();
+  if (!batch || haveHostCells || walks == 0) return false;
+  const double t0 = wallSeconds();
+  const long long cap = (long long)xSize + ySize + 4;
+  random_engine ahead(generator);
+  vguard<double> uniforms((size_t)cap * walks);
+  for (double& u : uniforms) u = std::generate_canonical<double, 53>(ahead);
+  vguard<hx_trace_cell> cells((size_t)cap * walks);
+  vguard<int32_t> len(walks, 0);
+  vguard<int64_t> used(walks, 0);
+  detail::check(hx_batch_sample_traces(batch, jobIndex, (int32_t)walks, uniforms.data(), (int64_t)uniforms.size(), cells.data(), cap,
+                                 len.data(), used.data()), "hx_batch_sample_traces");
+  for (size_t w = 0; w < walks; ++w)
+    if (len[w] <= 0) return false;
+  paths.resize(walks);
+  draws.resize(walks);
+  for (size_t w = 0; w < walks; ++w) {
+    const hx_trace_cell* tc = cells.data() + (size_t)cap * w;
+    for (int k = 0; k < len[w]; ++k) paths[w].emplace_back(tc[k].xpos, tc[k].ypos, (State)tc[k].state);
+    draws[w] = used[w];
+  }
+  fillTiming.deviceTrace += wallSeconds() - t0;
+  fillTiming.deviceTraces += 1;
+  return true;
+}
+
 set<ForwardMatrix::CellCoords> ForwardMatrix::sampleCells(random_engine& generator, size_t profileSamples, size_t maxCells,
                                                           ProfilingStrategy strategy, size_t minLen, size_t maxLen) {
   Require((strategy & IncludeBestTrace) || profileSamples > 0, "Must allow at least one sample path in the profile");
@@ -574,7 +610,17 @@ set<ForwardMatrix::CellCoords> ForwardMatrix::sampleCells(random_engine& generat
   set<CellCoords> keep;
   // sampled traces walk the matrix on the host, so it is coming over anyway: the best trace then walks it there too
   // (a thousand-odd steps) instead of waiting for a device traceback kernel
-  if (profileSamples > 0 && batch) ensureHostCells();
+  vguard<Path> devicePaths;
+  vguard<long long> deviceDraws;
+  const bool onDevice = profileSamples > 0 && deviceSampling() && sampleTracesOnDevice(generator, profileSamples, devicePaths, deviceDraws);
+  if (profileSamples > 0 && batch && !onDevice) ensureHostCells();
+  // the next walk: the device's, in order, or one more walk on the host; the generator moves past the walks taken
+  size_t taken = 0;
+  const auto nextWalk = [&]() -> Path {
+    if (!onDevice) return sampleTrace(generator);
+    generator.discard(2 * (unsigned long long)(deviceDraws[taken] - (taken ? deviceDraws[taken - 1] : 0)));
+    return devicePaths[taken++];
+  };
   if (maxCells == 0) {
     // no cell budget: every visited cell stays, so the visits need not be counted - collect, sort, drop repeats
     vguard<CellCoords> seen;
@@ -583,7 +629,7 @@ set<ForwardMatrix::CellCoords> ForwardMatrix::sampleCells(random_engine& generat
       seen.assign(best.begin(), best.end());
     }
     for (size_t accepted = 0; accepted < profileSamples; ++accepted) {
-      const Path sampled = sampleTrace(generator);
+      const Path sampled = nextWalk();
       const size_t ancestral = ancestralLength(sampled);
       if (ancestral < minLen || ancestral > maxLen) break;
       seen.insert(seen.end(), sampled.begin(), sampled.end());
@@ -602,7 +648,7 @@ set<ForwardMatrix::CellCoords> ForwardMatrix::sampleCells(random_engine& generat
     ++traces;
   }
   for (size_t accepted = 0; accepted < profileSamples && visits.size() < maxCells; ++accepted) {
-    const Path sampled = sampleTrace(generator);
+    const Path sampled = nextWalk();
     const size_t ancestral = ancestralLength(sampled);
     if (ancestral < minLen || ancestral > maxLen) break;
     for (const CellCoords& c : sampled) ++visits[c];

@@ -1793,6 +1793,48 @@ int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t*
   return HX_OK;
 }
 
+int hx_batch_sample_traces(hx_batch* b, int32_t job, int32_t n_walks, const double* uniforms, int64_t n_uniforms,
+                           hx_trace_cell* cells, int64_t cap, int32_t* n_cells, int64_t* draws_used) {
+  if (!b || !uniforms || !cells || !n_cells || !draws_used || n_walks < 1 || n_uniforms < 0 || cap < 1)
+    return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);
+  if (!b->forward_done) return fail(HX_ERR_STATE, "hx_batch_sample_traces needs a previous hx_batch_forward");
+  { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
+  struct Dev {                                       // released on every way out
+    void* p = nullptr;
+    ~Dev() { if (p) (void)hipFree(p); }
+  } d_u, d_paths, d_n, d_draws;
+  const size_t path_ints = 3 * (size_t)cap * (size_t)n_walks;
+  if (hipMalloc(&d_u.p, sizeof(double) * (size_t)(n_uniforms > 0 ? n_uniforms : 1)) != hipSuccess ||
+      hipMalloc(&d_paths.p, sizeof(int32_t) * path_ints) != hipSuccess ||
+      hipMalloc(&d_n.p, sizeof(int32_t) * (size_t)n_walks) != hipSuccess ||
+      hipMalloc(&d_draws.p, sizeof(int64_t) * (size_t)n_walks) != hipSuccess)
+    return fail(HX_ERR_OUT_OF_MEMORY, "allocating the buffers of %d sampled walks failed", n_walks);
+  hipStream_t st = b->last_stream;
+  HIP_TRY(hipMemcpyAsync(d_u.p, uniforms, sizeof(double) * (size_t)n_uniforms, hipMemcpyHostToDevice, st));
+  launch_sample_traces(b->d_jobs, job, n_walks, static_cast<const double*>(d_u.p), n_uniforms, static_cast<int32_t*>(d_paths.p), cap,
+                       static_cast<int32_t*>(d_n.p), static_cast<int64_t*>(d_draws.p), Tab8{g_dev[b->device].tab},
+                       !(b->flags & HX_FORCE_GENERIC), st);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(n_cells, d_n.p, sizeof(int32_t) * (size_t)n_walks, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(draws_used, d_draws.p, sizeof(int64_t) * (size_t)n_walks, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  // the kernel walks from the END cell backwards; the reference's Path starts at the start cell
+  std::vector<int32_t> raw;
+  for (int w = 0; w < n_walks; ++w) {
+    const int n = n_cells[w];
+    if (n <= 0) continue;
+    raw.resize(3 * (size_t)n);
+    HIP_TRY(hipMemcpy(raw.data(), static_cast<const int32_t*>(d_paths.p) + 3 * (size_t)cap * w, sizeof(int32_t) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+    hx_trace_cell* dst = cells + (size_t)cap * w;
+    for (int c = 0; c < n; ++c) {
+      const int32_t* t = &raw[3 * (size_t)(n - 1 - c)];
+      dst[c].xpos = t[0]; dst[c].ypos = t[1]; dst[c].state = t[2];
+    }
+  }
+  return HX_OK;
+}
+
 int hx_batch_indel_counts(hx_batch* b, int32_t job, const double* branch_times, double* out) {
   if (!b || !branch_times || !out) return fail(HX_ERR_INVALID_ARG, "bad arguments");
   if (job < 0 || job >= b->n_jobs) return fail(HX_ERR_RANGE, "job %d out of range", job);

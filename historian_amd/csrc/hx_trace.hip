@@ -257,6 +257,154 @@ __global__ __launch_bounds__(256) void k_indel_counts(const DevJob* __restrict__
   if (threadIdx.x < 6) atomicAdd(&out[threadIdx.x], part[threadIdx.x][0]);
 }
 
+// Sampled tracebacks of ONE pair: ForwardMatrix::sampleTrace (reference src/forward.cpp:257-276) with sampleCell (:225-243),
+// n_walks walks one after the other.  The reference draws one uniform_real_distribution<double>(0, ptot) value per step from the
+// generator it shares with everything else; the host hands over the canonical uniforms that generator would produce (two
+// 32-bit draws each, std::generate_canonical) and discards what the walks used: step k of the concatenated walks takes
+// uniforms[k].  A step is what sampleCell does, in its order: the source cells as the reference's std::map holds them (sorted
+// by (x, y, state), a cell produced twice keeps the later value), lpmax, ptot = the sum of exp(lp - lpmax) in that order, the
+// draw u * ptot, and the first cell at which the running remainder is used up.  One wavefront: candidates are evaluated a
+// lane each, the two sums run over them in order (every lane the same).  What is NOT the reference's bit for bit is exp():
+// this is the device library's, glibc's differs from it in the last place for some arguments, so a walk can leave the
+// reference's only where a draw falls within an ulp of a boundary between two cells' shares (~1e-16 per step).
+//
+// paths: [n_walks][cap][3], a walk's cells from the END cell backwards; n_cells[w] = cells of walk w, or < 0: -1 lpEnd = -inf,
+// -2 a cell without sources, -3 cap too small, -4 more than HX_SAMPLE_MAX_SOURCES source cells, -5 the remainder never used up
+// (the reference aborts), -6 out of uniforms; walks behind a failed one are not run (n_cells 0).  draws[w] = uniforms used up
+// to and including walk w.
+#define HX_SAMPLE_MAX_SOURCES 1024
+__global__ __launch_bounds__(64) void k_sample_traces(const DevJob* __restrict__ jobs, const int job, const int n_walks,
+                                                      const double* __restrict__ uniforms, const int64_t n_uniforms,
+                                                      int32_t* __restrict__ paths, const int64_t cap, int32_t* __restrict__ n_cells,
+                                                      int64_t* __restrict__ draws, const double* __restrict__ tab, const int plane_valid) {
+  __shared__ unsigned long long ckey[HX_SAMPLE_MAX_SOURCES], skey[HX_SAMPLE_MAX_SOURCES];
+  __shared__ double cval[HX_SAMPLE_MAX_SOURCES], sval[HX_SAMPLE_MAX_SOURCES];
+  __shared__ unsigned char alive[HX_SAMPLE_MAX_SOURCES];
+  const DevJob& J = jobs[job];
+  const int lane = threadIdx.x;
+  const int Nx = J.x.n, Ny = J.y.n;
+  int64_t used = 0;
+  bool failed = false;
+  for (int w = 0; w < n_walks; ++w) {
+    int32_t* out = paths + (int64_t)w * cap * 3;
+    if (failed) { if (lane == 0) { n_cells[w] = 0; draws[w] = used; } continue; }
+    int status = 0;
+    if (!(*J.lp_end > HX_NEG_INF)) status = -1;
+    int dx = Nx - 1, dy = Ny - 1, ds = 5;
+    int64_t n = 0;
+    if (status == 0) {
+      if (cap < 1) status = -3;
+      else if (lane == 0) { out[0] = dx; out[1] = dy; out[2] = ds; }
+      n = 1;
+    }
+    while (status == 0) {
+      // ---- the source cells of (dx, dy, ds), as k_best_trace enumerates them ----
+      const FwdPack xp = J.x.fpack[dx], yp = J.y.fpack[dy];
+      const int xf = xp.meta & 0xFF, yf = yp.meta & 0xFF;
+      const bool x_null = xf & F_NULL, y_null = yf & F_NULL;
+      const bool x_ready = (xf & F_READY) || J.x.empty, y_ready = (yf & F_READY) || J.y.empty;
+      bool move_x = false, move_y = false, hmm = false, any = false;
+      double lp_abs = 0.;
+      if (ds == 1 || ds == 4) {
+        move_x = true;
+        if (x_null) any = y_ready && dx < Nx - 1;
+        else { any = y_ready; hmm = true; lp_abs = ds == 1 ? xp.rootsub : xp.ins; }
+      } else if (ds == 2 || ds == 3) {
+        move_y = true;
+        if (y_null) any = dy < Ny - 1;
+        else { any = x_ready; hmm = true; lp_abs = ds == 2 ? yp.rootsub : yp.ins; }
+      } else if (ds == 0) {
+        if (y_null && (xf & F_EMIT_OR_START)) { move_y = true; any = dy < Ny - 1; }
+        else if (x_null) { move_x = true; any = y_ready && dx < Nx - 1; }
+        else if (!y_null) {
+          move_x = move_y = hmm = any = true;
+          if (J.emis) {
+            const int cx = xp.cls, cy = yp.cls;
+            lp_abs = (cx < 0 || cy < 0) ? HX_NEG_INF : J.emis[(size_t)cx * J.y.n_cls + cy];
+          } else if (plane_valid)
+            lp_abs = J.emis_plane[cell_slot(J.strip_stride, dx, dy)];
+          else
+            lp_abs = emission(J, dx, dy, tab);
+        }
+      } else {
+        move_x = move_y = hmm = any = true;
+      }
+      const int nx = move_x ? (xp.meta >> 8) : 1;
+      const int ny = move_y ? (yp.meta >> 8) : 1;
+      const int ns = hmm ? 5 : 1;
+      const int total = any ? nx * ny * ns : 0;
+      if (total == 0) { status = -2; break; }
+      if (total > HX_SAMPLE_MAX_SOURCES) { status = -4; break; }
+      __syncthreads();                                   // (the arrays of the step in front are done with)
+      for (int c = lane; c < total; c += 64) {
+        const int si = c % ns, r = c / ns, yi = r % ny, xi = r / ny;
+        int sx = dx, sy = dy;
+        double xlp = 0., ylp = 0.;
+        if (move_x) {
+          if (xi < HX_DAG_INLINE) { sx = xi == 0 ? xp.s0 : xi == 1 ? xp.s1 : xp.s2; xlp = xi == 0 ? xp.lp0 : xi == 1 ? xp.lp1 : xp.lp2; }
+          else { sx = J.x.in_src[xp.in_b + xi]; xlp = J.x.in_lp[xp.in_b + xi]; }
+        }
+        if (move_y) {
+          if (yi < HX_DAG_INLINE) { sy = yi == 0 ? yp.s0 : yi == 1 ? yp.s1 : yp.s2; ylp = yi == 0 ? yp.lp0 : yi == 1 ? yp.lp1 : yp.lp2; }
+          else { sy = J.y.in_src[yp.in_b + yi]; ylp = J.y.in_lp[yp.in_b + yi]; }
+        }
+        const int st = hmm ? si : ds;
+        const double h = hmm ? J.T[si][ds] : 0.;
+        cval[c] = (((h + xlp) + ylp) + lp_abs) + forward_cell(J, sx, sy, st);
+        ckey[c] = ((unsigned long long)(unsigned)sx << 32) | ((unsigned long long)(unsigned)sy << 3) | (unsigned)st;
+      }
+      __syncthreads();
+      // ---- the std::map: a cell produced twice keeps its later value; cells in (x, y, state) order ----
+      for (int c = lane; c < total; c += 64) {
+        const unsigned long long k = ckey[c];
+        bool a = true;
+        for (int c2 = c + 1; c2 < total; ++c2) a = a && ckey[c2] != k;
+        alive[c] = a ? 1 : 0;
+      }
+      __syncthreads();
+      for (int c = lane; c < total; c += 64)
+        if (alive[c]) {
+          const unsigned long long k = ckey[c];
+          int rank = 0;
+          for (int c2 = 0; c2 < total; ++c2) rank += (alive[c2] && ckey[c2] < k) ? 1 : 0;
+          skey[rank] = k; sval[rank] = cval[c];
+        }
+      int m = 0;
+      for (int c = 0; c < total; ++c) m += alive[c];      // (every lane the same)
+      __syncthreads();
+      // ---- sampleCell ----
+      double lpmax = HX_NEG_INF;
+      for (int k = 0; k < m; ++k) lpmax = sval[k] > lpmax ? sval[k] : lpmax;
+      for (int k = lane; k < m; k += 64) cval[k] = exp(sval[k] - lpmax);
+      __syncthreads();
+      double ptot = 0.;
+      for (int k = 0; k < m; ++k) ptot += cval[k];
+      if (used >= n_uniforms) { status = -6; break; }
+      const double p0 = uniforms[used] * (ptot - 0.0) + 0.0;   // uniform_real_distribution<double>(0, ptot)
+      ++used;
+      double p = p0;
+      int pick = -1;
+      for (int k = 0; k < m; ++k)
+        if ((p -= cval[k]) <= 0) { pick = k; break; }
+      if (pick < 0) { status = -5; break; }
+      const unsigned long long bkey = skey[pick];
+      dx = (int)(bkey >> 32); dy = (int)((bkey & 0xffffffffull) >> 3); ds = (int)(bkey & 7);
+      if (n >= cap) { status = -3; break; }
+      if (lane == 0) { out[3 * n] = dx; out[3 * n + 1] = dy; out[3 * n + 2] = ds; }
+      ++n;
+      if (dx == 0 && dy == 0) break;
+    }
+    if (lane == 0) { n_cells[w] = status < 0 ? status : (int32_t)n; draws[w] = used; }
+    failed = status < 0;
+  }
+}
+
+void launch_sample_traces(const DevJob* d_jobs, int job, int n_walks, const double* d_uniforms, int64_t n_uniforms, int32_t* d_paths,
+                          int64_t cap, int32_t* d_n_cells, int64_t* d_draws, Tab8 tab8, bool plane_valid, hipStream_t st) {
+  hipLaunchKernelGGL(k_sample_traces, dim3(1), dim3(64), 0, st, d_jobs, job, n_walks, d_uniforms, n_uniforms, d_paths, cap, d_n_cells,
+                     d_draws, tab8.p, plane_valid ? 1 : 0);
+}
+
 void launch_indel_counts(const DevJob* d_jobs, int job, const double* d_tm, double* d_out, int64_t cells, Tab8 tab8, bool plane_valid,
                          hipStream_t st) {
   int64_t blocks = (cells + 255) / 256;

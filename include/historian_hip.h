@@ -244,6 +244,23 @@ typedef struct hx_trace_cell {
 } hx_trace_cell;
 int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t* n_cells);
 
+/* Sampled tracebacks of job `job` in the device-resident Forward matrix: ForwardMatrix::sampleTrace (reference
+ * src/forward.cpp:257-276) with DPMatrix::sampleCell (:225-243), n_walks walks one after the other, so that a host which
+ * only needs the sampled paths (profile building) copies no matrix.  The reference draws one
+ * uniform_real_distribution<double>(0, ptot) value per step from the generator it shares with every other node of the tree;
+ * the caller passes the canonical uniforms in [0, 1) that generator produces from its current state
+ * (std::generate_canonical<double, 53>: two draws of the 32-bit engine each) and afterwards discards what the walks used:
+ * step k of the concatenated walks takes uniforms[k].  cells: [n_walks][cap], a walk's cells start cell first as the
+ * reference's Path; n_cells[w] = its length, or < 0 for the walk that failed (-1 lpEnd = -inf, -2 a cell without source
+ * cells - both "traceback failure" in the reference -, -3 cap too small, -4 more than 1024 source cells in one step, -5 the
+ * reference's "sampleCell fail", -6 out of uniforms) and 0 for the walks behind it, which are not run; draws_used[w] =
+ * uniforms consumed up to and including walk w.  Additions and comparisons are the reference's in the reference's order;
+ * exp() is the device library's, which differs from glibc's in the last place for some arguments: a walk can leave the
+ * reference's only when a draw falls within an ulp of the boundary between two source cells' shares.
+ * One wavefront walks them all (the draws order the steps): ~2 microseconds per step. */
+int hx_batch_sample_traces(hx_batch* b, int32_t job, int32_t n_walks, const double* uniforms, int64_t n_uniforms,
+                           hx_trace_cell* cells, int64_t cap, int32_t* n_cells, int64_t* draws_used);
+
 /* HX_BAND_COMPRESSED jobs: the step windows [n_strips][4] and their plane offsets [n_strips][2] (see hx_layout). */
 int hx_batch_strip_windows(const hx_batch* b, int32_t job, int32_t* windows, int64_t* bases);
 
