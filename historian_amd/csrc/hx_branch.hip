@@ -19,6 +19,8 @@
 // Storage: three state planes per pair, strip-skewed like the Forward matrices (hx_device.h cell_slot), -inf outside the
 // envelope; hx_branch_batch_read_matrix returns the dense [x_len + 1][y_len + 1][3] array.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <climits>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -51,6 +53,7 @@ struct DevBranch {
   double* emis;                 // [plane]: logMatch in the matrix layout
   int64_t plane, strip_stride;
   double* lp_end;
+  const int32_t* win;           // banded: [n_strips][3][2] step windows of the strips (half-open, merged, in order; empty ones last), or nullptr
 };
 
 __device__ __forceinline__ bool branch_in_env(const DevBranch& J, const int i, const int j) {
@@ -100,11 +103,27 @@ __device__ __forceinline__ double combine(const double a, const double b, const 
   return VITERBI ? vmax(a, b) : lse(a, b, tab);
 }
 
-// one wavefront per pair
-template <bool VITERBI>
-__global__ void __launch_bounds__(64) k_branch_fill(const DevBranch* __restrict__ jobs, const double* __restrict__ tab) {
+// One workgroup per branch; its 64-row strips are dealt to the workgroup's wavefronts round-robin, each wavefront sweeps its
+// strip on its own clock (lane <-> row, step <-> anti-diagonal, up / diagonal from the lane above by DPP), and what a strip
+// needs of the strip above - that strip's last row - it reads from the matrix, HXBR_BLK columns at a time, once the wavefront
+// above has said that those columns are stored: a monotonic column count per strip in LDS, published behind a drain of the
+// producer's stores (the consumer's loads are agent-scope: served by L2, where the stores are by then).  A strip therefore
+// starts ~HXBR_BLK + 64 steps behind the one above, and a branch of S strips takes columns + ~80 (S - 1) steps instead of the
+// S (columns + 63) of one wavefront per branch.  Waits cannot form a cycle: strip s waits for strip s - 1 only.
+#define HXBR_BLK 16
+#define HXBR_MAX_STRIPS 1024
+// YL: the child side of a step - insertion score and envelope coordinate of its column - out of LDS (staged once per
+// workgroup; the launcher checks that the longest child profile of the launch fits), not fetched from memory inside the step;
+// the step's emission term is fetched one step ahead either way.
+template <bool VITERBI, bool YL>
+__global__ void __launch_bounds__(1024) k_branch_fill(const DevBranch* __restrict__ jobs, const double* __restrict__ tab, const int y_cap) {
+  __shared__ int progress[HXBR_MAX_STRIPS];         // columns of the strip's last row that are stored
+  extern __shared__ __attribute__((aligned(16))) unsigned char ydyn[];
+  double* yemitL = reinterpret_cast<double*>(ydyn);                 // [y_cap]
+  int* yenvL = reinterpret_cast<int*>(ydyn + 8 * (size_t)y_cap);    // [y_cap]
   const DevBranch& J = jobs[blockIdx.x];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = (int)(blockDim.x >> 6);
   const int X = J.X, Y = J.Y;
   const int64_t plane = J.plane, ss = J.strip_stride;
   HX_GLOBAL double* __restrict__ M = as_global(J.cells);
@@ -112,62 +131,131 @@ __global__ void __launch_bounds__(64) k_branch_fill(const DevBranch* __restrict_
   const double mm = J.T[0][0], mi = J.T[0][1], md = J.T[0][2], im = J.T[1][0], ii = J.T[1][1], id = J.T[1][2], dm = J.T[2][0],
                dd = J.T[2][2];
   const int n_strips = (X + 63) >> 6;
+  for (int q = threadIdx.x; q < n_strips && q < HXBR_MAX_STRIPS; q += blockDim.x) progress[q] = 0;
+  if (YL)
+    for (int j = threadIdx.x; j < Y; j += blockDim.x) {
+      yemitL[j] = j > 0 ? J.y_emit[j - 1] : 0.0;    // (the score of entering column j: yEmit of child position j - 1)
+      yenvL[j] = J.max_dist >= 0 ? J.y_env[j] : 0;
+    }
+  __syncthreads();
+  volatile int* prog = progress;
   const B3 none{HX_NEG_INF, HX_NEG_INF, HX_NEG_INF};
-  for (int s = 0; s < n_strips; ++s) {
+  for (int s = wave; s < n_strips; s += n_waves) {
     const int i = (s << 6) + lane;
     const bool rvalid = i < X;
     const int xe = (rvalid && J.max_dist >= 0) ? J.x_env[i] : 0;
     const bool xedge = i == 0 || i == X - 1;
+    const bool feeds = s + 1 < n_strips;            // a strip below reads this strip's last row
     B3 left = none, up = none, diag = none;        // (i, j-1); (i-1, j) and (i-1, j-1) of the step being computed
-    B3 bnd = none;                                  // lane l: cell (row above the strip, column c0 + l) of the current block of 64 columns
-    for (int t = 0; t < Y + 63; ++t) {
-      if (s > 0 && (t & 63) == 0) {
-        // the strip above's last row, 64 columns at a time (stored by this wavefront; agent-scope loads: served by L2)
-        const int c = t + lane;
+    B3 bnd = none;                                  // lane l < HXBR_BLK: cell (row above the strip, column c0 + l) of the current block of columns
+    int seen = 0;
+    // logMatch of the lane's cell of the NEXT step (column t + 1 - lane), fetched a step ahead
+    auto emis_at = [&](const int jj) -> double {
+      return (rvalid && i > 0 && jj > 0 && jj < Y) ? E[cell_slot(ss, i, jj)] : 0.0;
+    };
+    // a banded strip sweeps its step windows only (hx_branch_batch_create: branch_windows); between them nothing of the
+    // strip is inside the envelope, so a window starts from -inf registers, and the strip below is told that the columns up
+    // to the next window are final (they hold the -inf the planes were cleared to)
+    const int32_t* wn = J.win ? J.win + 6 * s : nullptr;
+    for (int wi = 0; wi < (wn ? 3 : 1); ++wi) {
+    const int t0 = wn ? wn[2 * wi] : 0, t1 = wn ? wn[2 * wi + 1] : Y + 63;
+    if (t1 <= t0) break;
+    left = none; up = none; diag = none;
+    if (s > 0 && t0 >= 1 && t0 - 1 < Y) {
+      // ... except lane 0's diagonal source of the window's first step: cell (row above, column t0 - 1) belongs to the strip
+      // above, whose band may well hold it
+      while (seen < t0) {
+        seen = __builtin_amdgcn_readfirstlane(prog[s - 1]);
+        if (seen < t0) __builtin_amdgcn_s_sleep(2);
+      }
+      asm volatile("" ::: "memory");
+      if (lane == 0) {
+        const int64_t sl = cell_slot(ss, (s << 6) - 1, t0 - 1);
+        diag.m = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        diag.i = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        diag.d = __hip_atomic_load(M + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    double e_next = emis_at(t0 - lane);
+    for (int t = t0; t < t1; ++t) {
+      const double e_now = e_next;
+      e_next = emis_at(t + 1 - lane);
+      if (s > 0 && ((t & (HXBR_BLK - 1)) == 0 || t == t0) && t < Y) {
+        // the strip above's last row, HXBR_BLK columns at a time
+        const int c0 = t & ~(HXBR_BLK - 1);
+        const int need = c0 + HXBR_BLK < Y ? c0 + HXBR_BLK : Y;
+        while (seen < need) {
+          seen = __builtin_amdgcn_readfirstlane(prog[s - 1]);
+          if (seen < need) __builtin_amdgcn_s_sleep(2);
+        }
+        asm volatile("" ::: "memory");
+        const int c = c0 + lane;
         bnd = none;
-        if (c < Y) {
+        if (lane < HXBR_BLK && c < Y) {
           const int64_t sl = cell_slot(ss, (s << 6) - 1, c);
           bnd.m = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           bnd.i = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           bnd.d = __hip_atomic_load(M + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      // lane 0's upper neighbour of this step is column t of the row above: lane (t & 63) of the block
+      // lane 0's upper neighbour of this step is column t of the row above: lane t mod HXBR_BLK of the block
       if (s > 0) {
-        const int src = t & 63;
+        const int src = t & (HXBR_BLK - 1);
         const double bm = read_lane64(bnd.m, src), bi = read_lane64(bnd.i, src), bd = read_lane64(bnd.d, src);
         if (lane == 0) up = t < Y ? B3{bm, bi, bd} : none;
       }
+      // The cell, straight-line: sources that do not exist (row / column -1, cells outside the envelope) are -inf in the
+      // registers they come from, and -inf through the sums is what the reference's unassigned cell is
+      // (src/refiner.cpp:24-50 / src/sampler.cpp:1049-1072); only the stores are conditional.
       const int j = t - lane;
-      B3 now = none;
-      if (rvalid && j >= 0 && j < Y) {
-        const bool in = xedge || j == 0 || j == Y - 1 || J.max_dist < 0 ||
-                        (xe - J.y_env[j] <= J.max_dist && J.y_env[j] - xe <= J.max_dist);
-        if (in) {
-          const int64_t sl = cell_slot(ss, i, j);
-          // src/refiner.cpp:24-50 / src/sampler.cpp:1049-1072: a source outside the envelope reads as -inf, which is what
-          // the cell's state then is - the reference leaves it unassigned
-          if (i > 0) now.d = combine<VITERBI>(combine<VITERBI>(up.m + md, up.i + id, tab), up.d + dd, tab);
-          if (j > 0) now.i = J.y_emit[j - 1] + combine<VITERBI>(left.m + mi, left.i + ii, tab);
-          if (i > 0 && j > 0) now.m = E[sl] + combine<VITERBI>(combine<VITERBI>(diag.m + mm, diag.i + im, tab), diag.d + dm, tab);
-          if (i == 0 && j == 0) now.m = 0.0;        // lpStart() = 0
-          M[sl] = now.m; M[plane + sl] = now.i; M[2 * plane + sl] = now.d;
-        }
+      const bool jv = rvalid && j >= 0 && j < Y;
+      const int jc = j < 0 ? 0 : (j < Y ? j : Y - 1);
+      const int ye = J.max_dist < 0 ? 0 : (YL ? yenvL[jc] : J.y_env[jc]);
+      const double yem = YL ? yemitL[jc] : (jc > 0 ? J.y_emit[jc - 1] : 0.0);
+      const int dxy = xe - ye;
+      const bool in = jv && (xedge || j == 0 || j == Y - 1 || J.max_dist < 0 || (dxy <= J.max_dist && -dxy <= J.max_dist));
+      B3 now;
+      now.d = combine<VITERBI>(combine<VITERBI>(up.m + md, up.i + id, tab), up.d + dd, tab);
+      now.i = yem + combine<VITERBI>(left.m + mi, left.i + ii, tab);
+      now.m = e_now + combine<VITERBI>(combine<VITERBI>(diag.m + mm, diag.i + im, tab), diag.d + dm, tab);
+      if (i == 0 && j == 0) now.m = 0.0;            // lpStart() = 0
+      if (!in) now = none;
+      if (in) {
+        const int64_t sl = cell_slot(ss, i, j);
+        M[sl] = now.m; M[plane + sl] = now.i; M[2 * plane + sl] = now.d;
       }
       // next step: the lane's own cell is its left source; the previous lane's cell of this step its upper, of the last its diagonal
       diag = up;
       left = now;
       up = B3{wave_shr1(now.m), wave_shr1(now.i), wave_shr1(now.d)};
       if (lane == 0) up = none;                     // (row 0 has no row above; strips below take it from the block)
+      // the last row's columns 0 .. t - 63 are computed; say so once their stores have left the wavefront
+      if (feeds) {
+        const int done = t - 63 + 1;                // columns of lane 63's row computed so far
+        if (done > 0 && ((done & (HXBR_BLK - 1)) == 0 || done >= Y)) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) prog[s] = done < Y ? done : Y;
+        }
+      }
+    }
+    // behind a window: the last row is final up to where the next window takes it up
+    {
+      const int nt0 = (wn && wi + 1 < 3 && wn[2 * wi + 3] > wn[2 * wi + 2]) ? wn[2 * wi + 2] : Y + 63;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int fin = nt0 - 63;
+      fin = fin < 0 ? 0 : (fin > Y ? Y : fin);
+      if (feeds && lane == 0 && fin > 0) prog[s] = fin;
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  if (lane == 0) {
-    const int64_t sl = cell_slot(ss, X - 1, Y - 1);
-    const double em = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double ei = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double ed = __hip_atomic_load(M + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *J.lp_end = combine<VITERBI>(combine<VITERBI>(em + J.T[0][3], ei + J.T[1][3], tab), ed + J.T[2][3], tab);
+    if (feeds && lane == 0) prog[s] = Y;
+    if (s == n_strips - 1 && lane == 0) {
+      const int64_t sl = cell_slot(ss, X - 1, Y - 1);
+      const double em = __hip_atomic_load(M + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double ei = __hip_atomic_load(M + plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double ed = __hip_atomic_load(M + 2 * plane + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *J.lp_end = combine<VITERBI>(combine<VITERBI>(em + J.T[0][3], ei + J.T[1][3], tab), ed + J.T[2][3], tab);
+    }
   }
 }
 
@@ -194,10 +282,61 @@ struct hx_branch_batch {
   double* d_cells = nullptr;        // matrices + emission planes
   size_t lp_off = 0;
   int64_t max_cells = 0;
+  int max_x = 0, max_y = 0;         // rows / columns of the longest branch
   hipEvent_t ev[2] = {nullptr, nullptr};
   hipStream_t last_stream = nullptr;
   bool done = false;
 };
+
+namespace {
+// Step windows of a banded branch's strips (steps t = column + row-in-strip): what is always inside the envelope - the first
+// and the last column (SparseDPMatrix::inEnvelope, src/sampler.h:146-149) - and the band, as up to three half-open ranges that
+// together hold every in-envelope cell of the strip's rows (supersets are harmless: a cell is tested again).  The strips of
+// the first and the last row sweep everything.  Any envelope coordinates (not only non-decreasing ones): the columns of a
+// coordinate value are bracketed once, a row takes the brackets of the values within max_distance of its own.
+std::vector<int32_t> branch_windows(const int32_t* xenv, const int32_t* yenv, int X, int Y, int band) {
+  const int n_strips = (X + HX_STRIP - 1) / HX_STRIP, nsteps = Y + HX_STRIP - 1;
+  std::vector<int32_t> w(6 * (size_t)n_strips, 0);
+  int V = 0;
+  for (int j = 0; j < Y; ++j) V = std::max(V, (int)yenv[j]);
+  std::vector<int> minj(V + 1, INT_MAX), maxj(V + 1, -1);
+  for (int j = 0; j < Y; ++j) {
+    const int v = yenv[j] < 0 ? 0 : yenv[j];
+    minj[v] = std::min(minj[v], j);
+    maxj[v] = std::max(maxj[v], j);
+  }
+  // (prefix brackets would make a row O(1); bands are tens of values wide)
+  for (int s = 0; s < n_strips; ++s) {
+    int32_t* o = &w[6 * (size_t)s];
+    const int rows = std::min(HX_STRIP, X - s * HX_STRIP);
+    if (s == 0 || s == n_strips - 1) { o[0] = 0; o[1] = nsteps; continue; }
+    int lo = INT_MAX, hi = -1;
+    for (int l = 0; l < rows; ++l) {
+      const int xe = xenv[s * HX_STRIP + l] < 0 ? 0 : xenv[s * HX_STRIP + l];
+      int jmin = INT_MAX, jmax = -1;
+      for (int v = std::max(0, xe - band); v <= std::min(V, xe + band); ++v) {
+        jmin = std::min(jmin, minj[v]);
+        jmax = std::max(jmax, maxj[v]);
+      }
+      if (jmax < 0) continue;
+      lo = std::min(lo, jmin + l);
+      hi = std::max(hi, jmax + l);
+    }
+    std::pair<int, int> r[3] = {{0, rows}, {lo, hi + 1}, {Y - 1, Y - 1 + rows}};
+    if (hi < 0) r[1] = {INT_MAX, INT_MAX};         // (no band cell in the strip)
+    // in order, merged where they touch
+    std::sort(r, r + 3);
+    int n = 0;
+    for (int k = 0; k < 3; ++k) {
+      if (r[k].second <= r[k].first) continue;
+      if (n > 0 && r[k].first <= o[2 * (n - 1) + 1]) o[2 * (n - 1) + 1] = std::max(o[2 * (n - 1) + 1], r[k].second);
+      else { o[2 * n] = r[k].first; o[2 * n + 1] = r[k].second; ++n; }
+    }
+    for (int k = 0; k < n; ++k) o[2 * k + 1] = std::min(o[2 * k + 1], nsteps);
+  }
+  return w;
+}
+}  // namespace
 
 extern "C" {
 
@@ -231,13 +370,17 @@ int hx_branch_batch_create(const hx_branch_job* jobs, int32_t n_jobs, hx_branch_
     if (bytes) memcpy(host.data() + off, p, bytes);
     return off;
   };
-  struct Off { size_t x, y, e, xe, ye; bool env; };
+  struct Off { size_t x, y, e, xe, ye, win; bool env; };
   std::vector<Off> offs(n_jobs);
   int64_t cells_total = 0;
   try {
     b->jobs.resize(n_jobs);
     for (int k = 0; k < n_jobs; ++k) {
       const hx_branch_job& j = jobs[k];
+      if (j.x_len >= 64 * HXBR_MAX_STRIPS) {
+        hx_branch_batch_destroy(b);
+        return api_fail(HX_ERR_RANGE, "hx_branch_batch_create: a parent profile of more than 65535 positions");
+      }
       if (j.x_len < 0 || j.y_len < 0 || j.components < 1 || j.alphabet < 1 ||
           (j.x_len && !j.x_pwm) || (j.y_len && (!j.y_sub || !j.y_emit)) || (j.max_distance >= 0 && (!j.x_env || !j.y_env))) {
         hx_branch_batch_destroy(b);
@@ -259,8 +402,15 @@ int hx_branch_batch_create(const hx_branch_job* jobs, int32_t n_jobs, hx_branch_
       offs[k].env = j.max_distance >= 0;
       offs[k].xe = offs[k].env ? put(j.x_env, sizeof(int32_t) * (size_t)J.X) : 0;
       offs[k].ye = offs[k].env ? put(j.y_env, sizeof(int32_t) * (size_t)J.Y) : 0;
+      offs[k].win = 0;
+      if (offs[k].env && !getenv("HX_BRANCH_NO_WINDOWS")) {
+        const std::vector<int32_t> w = branch_windows(j.x_env, j.y_env, J.X, J.Y, j.max_distance);
+        offs[k].win = put(w.data(), sizeof(int32_t) * w.size()) + 1;      // (+1: 0 means none)
+      }
       cells_total += 4 * J.plane;
       if ((int64_t)J.X * J.Y > b->max_cells) b->max_cells = (int64_t)J.X * J.Y;
+      if (J.X > b->max_x) b->max_x = J.X;
+      if (J.Y > b->max_y) b->max_y = J.Y;
     }
     b->lp_off = put(nullptr, 0);
     host.resize(b->lp_off + sizeof(double) * n_jobs);
@@ -282,6 +432,7 @@ int hx_branch_batch_create(const hx_branch_job* jobs, int32_t n_jobs, hx_branch_
     J.y_emit = reinterpret_cast<const double*>(b->d_arena + offs[k].e);
     J.x_env = offs[k].env ? reinterpret_cast<const int32_t*>(b->d_arena + offs[k].xe) : nullptr;
     J.y_env = offs[k].env ? reinterpret_cast<const int32_t*>(b->d_arena + offs[k].ye) : nullptr;
+    J.win = offs[k].win ? reinterpret_cast<const int32_t*>(b->d_arena + (offs[k].win - 1)) : nullptr;
     J.cells = b->d_cells + at;
     J.emis = b->d_cells + at + 3 * J.plane;
     at += 4 * J.plane;
@@ -311,8 +462,20 @@ int hx_branch_batch_run(hx_branch_batch* b, int32_t viterbi, void* stream) {
   if (hipEventRecord(b->ev[0], st) != hipSuccess) return api_fail(HX_ERR_HIP, "hipEventRecord failed");
   for (int j0 = 0; j0 < b->n_jobs; j0 += 65536) {
     const int n = b->n_jobs - j0 < 65536 ? b->n_jobs - j0 : 65536;
-    if (viterbi) hipLaunchKernelGGL(k_branch_fill<true>, dim3(n), dim3(64), 0, st, b->d_jobs + j0, tab);
-    else hipLaunchKernelGGL(k_branch_fill<false>, dim3(n), dim3(64), 0, st, b->d_jobs + j0, tab);
+    // wavefronts per branch: as many as the longest branch has strips, at most 16 (a workgroup of 1024) - fewer when the
+    // batch alone fills the chip (~8 wavefronts per SIMD)
+    int waves = (b->max_x + 63) / 64;
+    waves = waves < 1 ? 1 : (waves > 16 ? 16 : waves);
+    if (const char* e = getenv("HX_BRANCH_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 16) waves = v; }
+    else while (waves > 1 && (int64_t)n * waves > 8192 * 2) waves = (waves + 1) / 2;
+    // the child sides in LDS when the longest one fits (12 bytes per position beside the progress counters)
+    const bool yl = (size_t)b->max_y * 12 <= 96 * 1024;
+    const size_t dyn = yl ? (size_t)b->max_y * 12 + 16 : 0;
+    const int y_cap = yl ? (b->max_y + 1) & ~1 : 0;
+    if (viterbi && yl) hipLaunchKernelGGL((k_branch_fill<true, true>), dim3(n), dim3(64 * waves), dyn, st, b->d_jobs + j0, tab, y_cap);
+    else if (viterbi) hipLaunchKernelGGL((k_branch_fill<true, false>), dim3(n), dim3(64 * waves), 0, st, b->d_jobs + j0, tab, 0);
+    else if (yl) hipLaunchKernelGGL((k_branch_fill<false, true>), dim3(n), dim3(64 * waves), dyn, st, b->d_jobs + j0, tab, y_cap);
+    else hipLaunchKernelGGL((k_branch_fill<false, false>), dim3(n), dim3(64 * waves), 0, st, b->d_jobs + j0, tab, 0);
   }
   if (hipEventRecord(b->ev[1], st) != hipSuccess || hipGetLastError() != hipSuccess) return api_fail(HX_ERR_HIP, "hx_branch_batch_run: launch failed");
   b->done = true;
