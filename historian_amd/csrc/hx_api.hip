@@ -560,6 +560,7 @@ struct hx_batch {
   hipStream_t copy_stream = nullptr;            // hx_batch_read_matrix_async: the device's copy stream (DeviceTables)
   int* d_multi = nullptr;                       // progress counters of a pair dealt to several workgroups (hx_dag.hip MULTI)
   std::vector<hipEvent_t> copied[2];            // per job: the event behind its asynchronous matrix copy, or null
+  bool records_valid = false;        // the per-state records (FwdPack) of the device job tables are built (launch_prep / ensure_state_records)
   int32_t* d_trace = nullptr;        // hx_batch_best_trace: path buffers, kept between calls
   int64_t* d_trace_n = nullptr;
   void* h_trace = nullptr;
@@ -1139,6 +1140,14 @@ static int side_join(hx_batch* b, hipStream_t st, hipStream_t side) {
   return HX_OK;
 }
 
+// The 80-byte state records that the traceback and counting kernels read (and the general-profile fills, which get them with
+// the preparation): built on first demand for a batch of leaf pairs, and with every preparation from then on.
+static void ensure_state_records(hx_batch* b, hipStream_t st) {
+  if (b->records_valid) return;
+  launch_state_records(b->d_jobs, b->n_jobs, b->max_states, st);
+  b->records_valid = true;
+}
+
 int hx_batch_forward(hx_batch* b, void* stream) {
   if (!b) return fail(HX_ERR_INVALID_ARG, "batch is null");
   int rc;
@@ -1148,7 +1157,12 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   const bool fast = (b->flags & HX_LSE_FAST) != 0, linear = (b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR;
   const bool trunc = (b->flags & HX_LSE_TRUNC) == HX_LSE_TRUNC;
   const Tab16 lse_tab{fast ? D.fast_tab : D.pair_tab};    // FastPiece table, or the exact mode's {f0, df} pairs
-  LAUNCH_TRY(launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_cls, b->max_ca, b->max_cls_pairs, Tab8{D.tab}, st));
+  // the state records: with the preparation when a general-profile class will read them in the fill, else when a traceback or
+  // counting kernel first asks (ensure_state_records)
+  const bool records_now = b->cls[KC_DAG].n > 0 || b->cls[KC_DAG_BANDED].n > 0 || b->cls[KC_GENERIC].n > 0 || b->records_valid ||
+                           (b->flags & HX_FORCE_GENERIC) != 0 || getenv("HX_FORCE_DAG") != nullptr;
+  LAUNCH_TRY(launch_prep(b->d_jobs, b->n_jobs, b->max_states, b->max_cls, b->max_ca, b->max_cls_pairs, Tab8{D.tab}, records_now, st));
+  b->records_valid = records_now;
   b->used_multi[0] = false;
   HIP_TRY(hipEventRecord(b->ev[0][0], st));
   // per-cell emission terms of the jobs without a class-pair table (general profiles).  Part of the fill:
@@ -1245,6 +1259,7 @@ int hx_batch_backward(hx_batch* b, void* stream) {
   const bool fast = (b->flags & HX_LSE_FAST) != 0, linear = (b->flags & HX_LSE_LINEAR) == HX_LSE_LINEAR;
   const bool trunc = (b->flags & HX_LSE_TRUNC) == HX_LSE_TRUNC;
   const Tab16 lse_tab{fast ? D.fast_tab : D.pair_tab};
+  ensure_state_records(b, st);                    // (the Backward fill of chain profiles runs the general pipeline, which reads them)
   if (!b->d_bwd) {
     // not pre-allocated with HX_KEEP_BACKWARD: allocate the Backward matrices now and re-publish the job tables
     HIP_TRY(hipStreamSynchronize(b->last_stream));
@@ -1770,6 +1785,7 @@ int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t*
   int64_t* d_off = b->d_trace_n + n;
   hipStream_t st = b->last_stream;
   // the per-cell emission plane is only filled by the strip pipelines (hx_batch_forward)
+  ensure_state_records(b, st);
   launch_best_trace(b->d_jobs, n, d_paths, cap, d_n, Tab8{g_dev[b->device].tab}, !(b->flags & HX_FORCE_GENERIC), st);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
       hipMemcpy(n_cells, d_n, sizeof(int32_t) * n, hipMemcpyDeviceToHost) != hipSuccess)
@@ -1812,6 +1828,7 @@ int hx_batch_sample_traces(hx_batch* b, int32_t job, int32_t n_walks, const doub
     return fail(HX_ERR_OUT_OF_MEMORY, "allocating the buffers of %d sampled walks failed", n_walks);
   hipStream_t st = b->last_stream;
   HIP_TRY(hipMemcpyAsync(d_u.p, uniforms, sizeof(double) * (size_t)n_uniforms, hipMemcpyHostToDevice, st));
+  ensure_state_records(b, st);
   launch_sample_traces(b->d_jobs, job, n_walks, static_cast<const double*>(d_u.p), n_uniforms, static_cast<int32_t*>(d_paths.p), cap,
                        static_cast<int32_t*>(d_n.p), static_cast<int64_t*>(d_draws.p), Tab8{g_dev[b->device].tab},
                        !(b->flags & HX_FORCE_GENERIC), st);
@@ -1849,6 +1866,7 @@ int hx_batch_indel_counts(hx_batch* b, int32_t job, const double* branch_times, 
   if (hipMemcpyAsync(d, host, sizeof(host), hipMemcpyHostToDevice, st) != hipSuccess) rc = HX_ERR_HIP;
   if (rc == HX_OK) {
     const DevJob& J = b->jobs[job];
+    ensure_state_records(b, st);
     launch_indel_counts(b->d_jobs, job, d, d + 6, (int64_t)J.n_rows * J.n_cols, Tab8{g_dev[b->device].tab}, !(b->flags & HX_FORCE_GENERIC), st);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d + 6, 6 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)

@@ -33,7 +33,9 @@ int launch_fail(const char* fmt, ...);
   } while (0)
 
 int launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, int max_ca, int max_cls_pairs,
-                Tab8 tab, hipStream_t st);
+                Tab8 tab, bool state_records, hipStream_t st);
+// the 80-byte state records alone (for a batch whose launch_prep left them out)
+void launch_state_records(const DevJob* d_jobs, int n_jobs, int max_states, hipStream_t st);
 void launch_scatter_sub(const DevJob* d_jobs, int n_jobs, int max_states, hipStream_t st);
 int launch_forward_dag(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, hipStream_t st);
 int launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 fast_tab,

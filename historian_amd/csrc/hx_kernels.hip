@@ -66,7 +66,11 @@ __global__ void k_ins_rootsub(const DevJob* __restrict__ jobs, const double* __r
   P.rootsubc[kc] = rs;
 }
 
-// one thread per state: scatter the class results, pack the chain kernels' per-state constants
+// one thread per state: scatter the class results, pack the chain kernels' per-state constants.  RECORDS: also the 80-byte
+// state records (FwdPack) that the general-profile fills and the traceback / counting kernels read - the leaf-pair fills do
+// not, and the records are two thirds of what this kernel writes, so a batch of leaf pairs only gets them when one of those
+// kernels is about to run (hx_api.hip: ensure_state_records).  RECORDS == 2: nothing but the records.
+template <int RECORDS>
 __global__ void k_scatter_prepared(const DevJob* __restrict__ jobs) {
   const DevJob& J = jobs[blockIdx.y >> 1];
   const int side = blockIdx.y & 1;
@@ -80,16 +84,19 @@ __global__ void k_scatter_prepared(const DevJob* __restrict__ jobs) {
   const double rs = emit ? P.rootsubc[kc] : HX_NEG_INF;
   // Per-state leftMultiply rows are only read on the device where there is no class-pair emission table (per-cell
   // emission terms, k_emission_plane); otherwise they are scattered when the host asks for them (k_scatter_sub).
-  if (!J.emis)
-    for (int k = 0; k < CA; ++k) P.sub[(size_t)i * CA + k] = kc >= 0 ? P.subc[(size_t)kc * CA + k] : HX_NEG_INF;
-  P.ins[i] = ins;
-  P.rootsub[i] = rs;
-  const bool ok = (P.flags[i] & F_READY) || P.empty;
-  double* pk = P.pack + 4 * (size_t)i;
-  pk[0] = (i > 0 && P.in_off[i + 1] > P.in_off[i]) ? P.in_lp[P.in_off[i]] : 0.0;
-  pk[1] = rs;
-  pk[2] = ins;
-  pk[3] = ok ? 0.0 : HX_NEG_INF;
+  if (RECORDS != 2) {
+    if (!J.emis)
+      for (int k = 0; k < CA; ++k) P.sub[(size_t)i * CA + k] = kc >= 0 ? P.subc[(size_t)kc * CA + k] : HX_NEG_INF;
+    P.ins[i] = ins;
+    P.rootsub[i] = rs;
+    const bool ok = (P.flags[i] & F_READY) || P.empty;
+    double* pk = P.pack + 4 * (size_t)i;
+    pk[0] = (i > 0 && P.in_off[i + 1] > P.in_off[i]) ? P.in_lp[P.in_off[i]] : 0.0;
+    pk[1] = rs;
+    pk[2] = ins;
+    pk[3] = ok ? 0.0 : HX_NEG_INF;
+  }
+  if (RECORDS == 0) return;
   FwdPack f;
   const int b = P.in_off[i], deg = P.in_off[i + 1] - b;
   f.lp0 = deg > 0 ? P.in_lp[b] : 0.0;
@@ -423,8 +430,17 @@ int launch_fail(const char* fmt, ...) {
 // The prep kernels put the job on grid.y (two blocks per job, x and y side); grid.y is limited to 65535, so large
 // batches are launched in chunks of HX_PREP_CHUNK jobs.
 #define HX_PREP_CHUNK 16384
+void launch_state_records(const DevJob* d_jobs, int n_jobs, int max_states, hipStream_t st) {
+  const int tpb = 256;
+  for (int j0 = 0; j0 < n_jobs; j0 += HX_PREP_CHUNK) {
+    const int n = n_jobs - j0 < HX_PREP_CHUNK ? n_jobs - j0 : HX_PREP_CHUNK;
+    dim3 grid((unsigned)((max_states + tpb - 1) / tpb), (unsigned)(2 * n));
+    hipLaunchKernelGGL(k_scatter_prepared<2>, grid, dim3(tpb), 0, st, d_jobs + j0);
+  }
+}
+
 int launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, int max_ca, int max_cls_pairs,
-                Tab8 tab8, hipStream_t st) {
+                Tab8 tab8, bool state_records, hipStream_t st) {
   const double* tab = tab8.p;
   const int tpb = 256;
   for (int j0 = 0; j0 < n_jobs; j0 += HX_PREP_CHUNK) {
@@ -438,7 +454,8 @@ int launch_prep(const DevJob* d_jobs, int n_jobs, int max_states, int max_cls, i
     }
     {
       dim3 grid((unsigned)((max_states + tpb - 1) / tpb), (unsigned)(2 * n));
-      hipLaunchKernelGGL(k_scatter_prepared, grid, dim3(tpb), 0, st, jobs);
+      if (state_records) hipLaunchKernelGGL(k_scatter_prepared<1>, grid, dim3(tpb), 0, st, jobs);
+      else hipLaunchKernelGGL(k_scatter_prepared<0>, grid, dim3(tpb), 0, st, jobs);
     }
     if (max_cls_pairs > 0) {
       dim3 grid((unsigned)((max_cls_pairs + tpb - 1) / tpb), (unsigned)n);
