@@ -88,6 +88,28 @@ def test_branch_matrices_bit_for_bit(viterbi):
     b.close()
 
 
+@pytest.mark.parametrize("waves, windows", [(1, True), (3, True), (16, True), (2, False), (16, False)])
+def test_strips_dealt_to_wavefronts_and_band_windows(monkeypatch, waves, windows):
+    # a branch's strips on 1 ... 16 wavefronts (the last row of a strip handed to the one below through the matrix), banded
+    # strips swept by their step windows or in full: the same bits either way.  Rows 300-400 are five to seven strips, with
+    # envelope coordinates that advance unevenly (runs of gaps), a band of 0 and a band wider than a strip.
+    monkeypatch.setenv("HX_BRANCH_WAVES", str(waves))
+    if not windows:
+        monkeypatch.setenv("HX_BRANCH_NO_WINDOWS", "1")
+    cases = [random_branch(51, 300, 330, 1, 4, 5, False), random_branch(52, 400, 290, 1, 4, 0, True), random_branch(53, 321, 321, 2, 4, 70, False),
+             random_branch(54, 257, 300, 1, 4, None, False), random_branch(55, 129, 64, 1, 4, 2, True)]
+    b = capi.BranchBatch([as_job(c) for c in cases])
+    for viterbi in (True, False):
+        b.run(viterbi=viterbi)
+        lp = b.lp_end()
+        for k, case in enumerate(cases):
+            x, ysub, yemit, T, xe, ye, md = case
+            want = bo.BranchMatrix(x, ysub, yemit, T, None if xe is None else list(xe), None if ye is None else list(ye), md, viterbi=viterbi)
+            H.assert_same_bits(b.read_matrix(k), dense(want), "job %d cells (%s, %d wavefronts)" % (k, "viterbi" if viterbi else "forward", waves))
+            H.assert_same_bits([lp[k]], [want.lp_end], "job %d lpEnd" % k)
+    b.close()
+
+
 def test_refiner_traceback_over_the_device_matrix():
     # Refiner::BranchMatrix::best (src/refiner.cpp:62-104) walks O(path) cells: over the device's matrix it finds the
     # alignment the restatement finds over its own
