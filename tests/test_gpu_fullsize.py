@@ -202,3 +202,62 @@ def test_config4_batch_banded_as_the_reference_runs_it(monkeypatch):
             monkeypatch.delenv("HX_BAND_BWD_OLD")
     assert np.max(np.abs(lp["fast"] - lp["exact"]) / np.abs(lp["exact"])) <= 1e-9
     assert np.max(np.abs(lp["linear"] - lp["exact"]) / np.abs(lp["exact"])) <= 1e-5
+
+
+def test_large_banded_batch_two_pairs_per_wavefront_default_policy():
+    """The driver-run bench's banded block at size: 2560 pairs of 2x2000 residues, band 20, band-compressed planes, the
+    library's default policy - above 1024 pairs the fill is two pairs per wavefront (hx_band2.hip) with its edge kernel on
+    the side stream.  128 distinct pairs, each twenty times over (the fill does not know): every copy's lpEnd the same bits;
+    against one pair per wavefront (HX_BAND2=0: hx_band.hip, same arithmetic) the same bits; against the libm-arithmetic
+    oracle with truncation within 1e-9 relative on sampled pairs; against the exact policy within 1e-9; the device's best
+    paths of the first 64 pairs those of the exact policy's matrices; and the in-envelope cells of one pair, read through
+    hx_batch_read_cells, within 1e-9 of the oracle's."""
+    import os
+    from historian_amd import hostmodel, workload
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = hostmodel.RateModel.load(os.path.join(root, "tests", "golden", "models", "wag.json"))
+    hmm = hostmodel.make_hmm(model, .2, .3)
+    base = [workload.leaf_pair(np.random.default_rng(7000 + k), model, hmm, 2000, band=20) for k in range(128)]
+    jobs = [base[k % 128] for k in range(2560)]
+    b = capi.Batch(jobs, capi.HX_LSE_TRUNC | capi.HX_BAND_COMPRESSED)
+    assert b.shared_wavefront_pairs() == 2560
+    b.forward()
+    lp = b.lp_end().copy()
+    assert np.all(np.isfinite(lp)) and np.all(lp < 0)
+    for k in range(128, 2560):
+        assert lp[k] == lp[k % 128], k
+    all_paths, all_len = b.best_trace(raw=True)
+    paths, plen = all_paths[:64].copy(), all_len[:64].copy()
+    # the oracle in libm arithmetic with the reference's truncation (true_math=2): three pairs
+    for k in (0, 77, 127):
+        x, y, h, md = base[k]
+        want = c_oracle.forward(x, y, h, md, true_math=2)
+        assert abs(want["lp_end"] - lp[k]) <= 1e-9 * abs(lp[k]), k
+        if k == 77:
+            mask = np.isfinite(want["cells"]).any(axis=2)
+            ii, jj = np.nonzero(mask)
+            sel = np.random.default_rng(1).choice(len(ii), size=20000, replace=False)
+            got = b.read_cells(k, np.stack([ii[sel], jj[sel]], axis=1))
+            ref = want["cells"][ii[sel], jj[sel]]
+            fin = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(got), fin)
+            assert np.max(np.abs(got[fin] - ref[fin])) < 1e-9
+    b.close()
+    os.environ["HX_BAND2"] = "0"
+    try:
+        one = capi.Batch(jobs[:128], capi.HX_LSE_TRUNC | capi.HX_BAND_COMPRESSED)
+        assert one.shared_wavefront_pairs() == 0
+        one.forward()
+        H.assert_same_bits(one.lp_end(), lp[:128], "one pair per wavefront vs two")
+        one.close()
+    finally:
+        del os.environ["HX_BAND2"]
+    ex = capi.Batch(jobs[:64], capi.HX_LSE_EXACT | capi.HX_BAND_COMPRESSED)
+    ex.forward()
+    le = ex.lp_end()
+    assert np.max(np.abs(le - lp[:64]) / np.abs(le)) <= 1e-9
+    epaths, elen = ex.best_trace(raw=True)
+    assert np.array_equal(elen, plen)
+    for k in range(64):
+        assert np.array_equal(epaths[k, :elen[k]], paths[k, :plen[k]]), "best path of pair %d" % k
+    ex.close()
