@@ -5,7 +5,7 @@ only ever sees read, and take the value out behind a counted `s_waitcnt vmcnt(N)
 keeps the pair where it is and never touches it itself.  This script reads the assembly listing (hipcc -S) and checks, for
 every kernel that announces its landing registers ("; landing registers of the row-record fetches: v[a:b]"):
   * every hand-issued fetch writes exactly that pair;
-  * between the announcement and the kernel's drain (the stand-alone inline `s_waitcnt vmcnt(0)` behind the sweep) nothing
+  * between the announcement and the first drain behind the last fetch (a stand-alone inline `s_waitcnt vmcnt(0)`) nothing
     else names either register, except the v_mov_b32 pair directly behind an s_waitcnt inside the same inline-asm block.
 usage: python tools/check_landing_regs.py file.s   (exit code 1 and a message per violation)"""
 import re
@@ -44,17 +44,19 @@ def check(path):
         land = {lo, hi}
         in_asm, waited = False, False
         fetches = takes = 0
-        # the pair is reserved from its announcement (in front of the first fetch) to the kernel's drain - the stand-alone
-        # inline `s_waitcnt vmcnt(0)` behind the sweep; in front of and behind that stretch (staging, the edge wavefront's code,
-        # lpEnd) the registers are anybody's
+        # the pair is reserved from its announcement (in front of the first fetch) to the first drain behind the last fetch - a
+        # stand-alone inline `s_waitcnt vmcnt(0)`; in front of and behind that stretch (staging, another wavefront's code, lpEnd)
+        # the registers are anybody's
         first = next(k for k, l in enumerate(body) if "landing registers of the row-record fetches" in l)
         drains = [k for k in range(first, len(body) - 2) if body[k].strip().startswith(";;#ASMSTART")
                   and body[k + 1].strip() == "s_waitcnt vmcnt(0)" and body[k + 2].strip().startswith(";;#ASMEND")]
-        if not drains:
-            problems.append("%s: no drain behind the sweep" % name)
+        last_fetch = max((k for k, l in enumerate(body) if l.strip().startswith("global_load_dwordx2 v[%d:%d]," % (lo, hi))), default=-1)
+        drains = [k for k in drains if k > last_fetch]
+        if not drains or last_fetch < 0:
+            problems.append("%s: no fetch, or no drain behind the last one" % name)
             continue
         for k, l in enumerate(body):
-            if k < first or k > drains[-1]:
+            if k < first or k > drains[0]:
                 continue
             t = l.strip()
             if t.startswith(";;#ASMSTART"):
