@@ -40,18 +40,18 @@ MODE_KEY = {"exact": "exact_mode", "fast": "fast_mode", "linear": "scaled_probab
 KERNELS = {("exact", False): "hx::k_fill_chain<0,...,ExactLse3>", ("fast", False): "hx::k_fill_chain<0,...,FastLse>",
            ("linear", False): "hx::k_fill_leaf_linear<W>", ("trunc", False): "hx::k_fill_leaf_linear<W,...,TRUNC>",
            ("exact", True): "hx::k_fill_band<exact>", ("fast", True): "hx::k_fill_band<fast>",
-           ("linear", True): "hx::k_fill_band<scaled> / hx::k_fill_band2<false> (two pairs per wavefront above 512 pairs)",
-           ("trunc", True): "hx::k_fill_band<truncating scaled> / hx::k_fill_band2<true> (two pairs per wavefront above 512 pairs)"}
+           ("linear", True): "hx::k_fill_band<scaled> / hx::k_fill_band2<false> (two pairs per wavefront above 1024 pairs)",
+           ("trunc", True): "hx::k_fill_band<truncating scaled> / hx::k_fill_band2<true> (two pairs per wavefront above 1024 pairs)"}
 ARITH = {"exact": "the reference's table log-sum-exp, cells bit-identical to the reference recursion",
          "fast": "LDS-table log-sum-exp with the reference's truncation (lpEnd within 1e-9 rel. of the reference's, best paths "
-                 "identical to the reference's: 2000 of 2000 pairs, profiles/r03/trace_identity_sweep_seed7.json)",
+                 "identical to the reference's: 10000 of 10000 pairs, profiles/r03/trace_identity_sweep_seed11.json)",
          "trunc": "scaled-probability recursion with the reference's truncation: every pairwise sum of the reference's left-nested "
                   "log_sum_exp drops a term that is at most e^-10 of the other, as the reference's table does (src/logsumexp.h:45); "
                   "no table, log-probabilities at the store; lpEnd within 1e-9 rel. of the reference's, best paths identical to the "
-                  "reference's: 2000 of 2000 pairs (profiles/r03/trace_identity_sweep_seed7.json)",
+                  "reference's: 10000 of 10000 pairs (profiles/r03/trace_identity_sweep_seed11.json)",
          "linear": "scaled-probability recursion (fp64 sums of probabilities with a per-cell exponent, log-probabilities at the "
-                   "store; no truncation of small terms: lpEnd within 1e-5 rel., best paths may differ at near-ties: 4 of 2000, "
-                   "profiles/r02/trace_identity_sweep.json)"}
+                   "store; no truncation of small terms: lpEnd within 3e-5 rel., best paths differ at near-ties: 14 of 10000, "
+                   "profiles/r03/trace_identity_sweep_seed11.json)"}
 
 
 def parse():
