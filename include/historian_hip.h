@@ -274,7 +274,7 @@ int64_t hx_batch_total_cells(const hx_batch* b);
 int hx_batch_job_kernel(const hx_batch* b, int32_t job, int32_t* forward_class, int32_t* backward_sweep);
 
 /* Diagnostics: the number of pairs whose banded fill runs two pairs per wavefront (hx_band2.hip: scaled-probability policies,
- * every banded leaf pair of the batch admitted, more than 512 such pairs or HX_BAND2=1), 0 when none does; negative: an error. */
+ * every banded leaf pair of the batch admitted, more than 1024 such pairs or HX_BAND2=1), 0 when none does; negative: an error. */
 int hx_batch_shared_wavefront_pairs(const hx_batch* b);
 
 /* Diagnostics: how often the batch's fills were launched again with one workgroup per pair because, in a launch that deals a
