@@ -398,13 +398,40 @@ bool build_band_rows(const int32_t* xenv, const int32_t* yenv, const uint8_t* xf
   const int n_strips = (R + HX_STRIP - 1) / HX_STRIP;
   out.assign(2 * (size_t)(R + 64) + (size_t)n_strips + 4, 0);
   int32_t* strip_store = &out[2 * (size_t)(R + 64)];
-  std::vector<int> os(R), oe(R);
+  std::vector<int> os(R), oe(R), as_(R), ae_(R);
   std::vector<char> have(n_strips, 0);
   n_steps = 0;
   for (int i = 0; i < R; ++i) {
-    int as = i + lo[i], ae = i + hi[i];
-    os[i] = as & ~1; oe[i] = ae | 1;
-    // row 0's pad cell is inside the envelope (unless it is past the last column): the sweep computes it
+    as_[i] = i + lo[i]; ae_[i] = i + hi[i];
+    os[i] = as_[i] & ~1; oe[i] = ae_[i] | 1;
+  }
+  // Whole cache lines: a step pair of a state plane holds rows 4g .. 4g + 3 of a strip in one 64-byte line, and a line that
+  // the sweep writes in part costs a read-modify-write (a build that simply dropped the partly written lines at both ends of
+  // a store ran a quarter faster).  So the four rows of such a group own the same steps - from the first row's first to the
+  // last row's last: the cells a row gains lie outside the envelope (the sweep computes them as zero cells and stores -inf,
+  // which is what they hold in pre-filled planes and "anything" in the others), except that nothing is gained in the
+  // always-in-envelope column: a row whose band does not reach it stops one column short (cell (1, Ny-2) there is the edge
+  // kernel's, the others are its -inf).  A group whose spread does not fit the record's three-bit pads keeps its own spans.
+  if (!getenv("HX_BAND_NO_LINE_GROUPS"))
+    for (int g = 0; g < R; g += 4) {
+      const int ge = std::min(g + 4, R);
+      int gos = INT_MAX, goe = -1;
+      for (int i = g; i < ge; ++i) { gos = std::min(gos, os[i]); goe = std::max(goe, oe[i]); }
+      bool fits = true;
+      std::vector<int> no(ge - g), ne(ge - g);
+      for (int i = g; i < ge; ++i) {
+        int e = goe;
+        if (hi[i] < Cc - 1) { int lim = i + Cc - 2; if (!(lim & 1)) --lim; e = std::min(e, std::max(lim, oe[i])); }
+        no[i - g] = gos; ne[i - g] = e;
+        if (as_[i] - gos > 7 || e - ae_[i] > 7) fits = false;
+      }
+      if (!fits) continue;
+      for (int i = g; i < ge; ++i) { os[i] = no[i - g]; oe[i] = ne[i - g]; }
+    }
+  for (int i = 0; i < R; ++i) {
+    const int as = as_[i];
+    int ae = ae_[i];
+    // row 0's pad cells are inside the envelope (unless they are past the last column): the sweep computes them
     if (i == 0) ae = std::min(oe[0], Cc - 1);
     // where the strip's cells live: slot(i, k) = strip_store[q] + 2 (i % 64) + (k >> 1) blk + (k & 1)
     const int q = i >> 6;
@@ -428,7 +455,8 @@ bool build_band_rows(const int32_t* xenv, const int32_t* yenv, const uint8_t* xf
     int32_t* o = &out[2 * (size_t)i];
     if (oe[i] - os[i] > 0xFFFF || os[i] >= 0xFFFF) return false;
     o[0] = os[i] | ((oe[i] - os[i]) << 16);
-    o[1] = (xecls[i] & 0xFF) | (ready ? 0 : 0x100) | ((as - os[i]) << 9) | ((oe[i] - ae) << 10);
+    if (as - os[i] > 7 || oe[i] - ae > 7 || as < os[i] || ae > oe[i]) return false;
+    o[1] = (xecls[i] & 0xFF) | (ready ? 0 : 0x100) | ((as - os[i]) << 9) | ((oe[i] - ae) << 12);
     n_steps = std::max(n_steps, oe[i] + 1);
   }
   // a lane must be idle for at least one whole step pair between two rows (its register window restarts from zero cells),
@@ -446,7 +474,7 @@ bool build_band_rows(const int32_t* xenv, const int32_t* yenv, const uint8_t* xf
 // Backward matrix).  What is always inside the envelope is now the LAST row (x START) and the FIRST column (the y state
 // feeding END): both are -inf away from the band (see below), written by the kernel's second wave; the sweep owns a row's band
 // cells, widened to column 0 where the band touches it, and on the last row from where the row above's band begins.
-//   x = first owned step | (owned steps - 1) << 16;  y = class of x state i + 1 | state i not ready << 8 | pads << 9, 10
+//   x = first owned step | (owned steps - 1) << 16;  y = class of x state i + 1 | state i not ready << 8 | pads << 9, 12 (three bits each)
 // followed by the per-strip store bases (dense planes only) and, last, one int: the first column the sweep owns on the last
 // row (0: the whole row).
 bool build_band_rows_bwd(const int32_t* xenv, const int32_t* yenv, const uint8_t* xf, const uint8_t* yf, const int32_t* xecls,
@@ -489,7 +517,7 @@ bool build_band_rows_bwd(const int32_t* xenv, const int32_t* yenv, const uint8_t
     int32_t* o = &out[2 * (size_t)i];
     if (oe[i] - os[i] > 0xFFFF || os[i] >= 0xFFFF) return false;
     o[0] = os[i] | ((oe[i] - os[i]) << 16);
-    o[1] = (xecls[ic + 1] & 0xFF) | (ready ? 0 : 0x100) | ((as - os[i]) << 9) | ((oe[i] - ae) << 10);
+    o[1] = (xecls[ic + 1] & 0xFF) | (ready ? 0 : 0x100) | ((as - os[i]) << 9) | ((oe[i] - ae) << 12);
     n_steps = std::max(n_steps, oe[i] + 1);
   }
   for (int i = 0; i + 63 < R; ++i) if (os[i + 63] < oe[i] + 1) return false;

@@ -108,7 +108,9 @@ struct BandPlan { int table, xrec, sbase, ycol, yclass, xclass, elds, ring, flag
 //   x = first owned step | (owned steps - 1) << 16     (owned: an even first and an odd last step - the two cells a row
 //       produces on steps 2m, 2m+1 are stored together; the lane is busy with the row from its first to its last owned step;
 //       0xFFFF in the low half: a sentinel row past the end, never owned)
-//   y = emission class | not ready << 8 | lead pad << 9 | tail pad << 10   (pads: owned steps that lie outside the envelope)
+//   y = emission class | not ready << 8 | lead pad << 9 (3 bits) | tail pad << 12 (3 bits)
+//       (pads: owned steps that lie outside the envelope - the widening to whole step pairs and, since round 3, to the steps
+//        of the row's group of four: hx_api.hip build_band_rows, "whole cache lines")
 // followed, after the Nx - 1 + 64 records, by one int32 per 64-row strip: the cell of row i, step k lives at
 //   strip_store[i / 64] + 2 * (i % 64) + (k >> 1) * blk + (k & 1)   in a state plane.
 
@@ -254,14 +256,14 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
       if (write_edges) {
         for (int ip = 1 + lane; ip < R; ip += 64) {
           const i2v rec = xrec_at(ip);
-          if ((rec.x & 0xFFFF) + ((rec.y >> 9) & 1) - ip > 0) put_inf(ip, 0);      // (the sweep owns the row from a later column on)
+          if ((rec.x & 0xFFFF) + ((rec.y >> 9) & 7) - ip > 0) put_inf(ip, 0);      // (the sweep owns the row from a later column on)
         }
         for (int jp = 1 + lane; jp < lo_last; jp += 64) put_inf(R - 1, jp);
       }
       {
         // a first row whose band does not reach column 0: the END-feeding cell itself (src/forward.cpp:981-995)
         const i2v rec = xrec_at(0);
-        if (lane == 0 && (rec.x & 0xFFFF) + ((rec.y >> 9) & 1) > 0) {
+        if (lane == 0 && (rec.x & 0xFFFF) + ((rec.y >> 9) & 7) > 0) {
           const double lpe = J.x.pack[4 * (size_t)R] + J.y.pack[4 * (size_t)Cc];
           const int64_t sl = cell_slot_blk(ssd, blk, 0, 0);
           for (int st = 0; st < 5; ++st) M[st * plane + sl] = lpe + J.T[st][5];
@@ -385,7 +387,7 @@ k_fill_band(const DevJob* __restrict__ jobs, const double* __restrict__ exact_ta
   int nstore = 0;
   auto decode = [&](const i2v r, const d2v xc, const int sb) {
     os = r.x & 0xFFFF; oe = os + ((r.x >> 16) & 0xFFFF);
-    as = os + ((r.y >> 9) & 1); ae = oe - ((r.y >> 10) & 1);
+    as = os + ((r.y >> 9) & 7); ae = oe - ((r.y >> 12) & 7);
     if ((r.x & 0xFFFF) == 0xFFFF) { os = 0x7FFFFFF0; oe = 0x7FFFFFF1; as = os; ae = oe; }     // sentinel: never owned
     store = sb;
     eoff = (unsigned)(r.y & 0xFF) * (unsigned)Ky1;

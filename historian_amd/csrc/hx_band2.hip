@@ -138,14 +138,14 @@ k_band2_edges(const DevJob* __restrict__ jobs, const int n_jobs, const int write
     if (write_edges) {
       for (int ip = 1 + lane; ip < Re; ip += 64) {
         const i2v rec = xrecG[ip];
-        if ((rec.x & 0xFFFF) + ((rec.y >> 9) & 1) - ip > 0) put_inf(ip, 0);      // (the sweep owns the row from a later column on)
+        if ((rec.x & 0xFFFF) + ((rec.y >> 9) & 7) - ip > 0) put_inf(ip, 0);      // (the sweep owns the row from a later column on)
       }
       for (int jp = 1 + lane; jp < lo_last; jp += 64) put_inf(Re - 1, jp);
     }
     {
       // a first row whose band does not reach column 0: the END-feeding cell itself (src/forward.cpp:981-995)
       const i2v rec = xrecG[0];
-      if (lane == 0 && (rec.x & 0xFFFF) + ((rec.y >> 9) & 1) > 0) {
+      if (lane == 0 && (rec.x & 0xFFFF) + ((rec.y >> 9) & 7) > 0) {
         const double lpe = J.x.pack[4 * (size_t)Re] + J.y.pack[4 * (size_t)Ce];
         const int64_t sl = cell_slot_blk(ssd, blk, 0, 0);
         for (int st = 0; st < 5; ++st) M[st * plane + sl] = lpe + J.T[st][5];
@@ -367,8 +367,8 @@ k_fill_band2(const DevJob* __restrict__ jobs, const double* __restrict__ exact_t
     const unsigned elds_a = (unsigned)(uintptr_t)eldsL, yclass_a = (unsigned)(uintptr_t)yclassL;
     auto decode = [&](const i2v r, const d2v xc, const int sb, const unsigned er) {
       os = r.x & 0xFFFF; oe = os + ((r.x >> 16) & 0xFFFF);
-      as = os + ((r.y >> 9) & 1);
-      span = (unsigned)((oe - ((r.y >> 10) & 1)) - as);
+      as = os + ((r.y >> 9) & 7);
+      span = (unsigned)((oe - ((r.y >> 12) & 7)) - as);
       if ((r.x & 0xFFFF) == 0xFFFF || !live) { os = 0x7FFFFFF0; oe = 0x7FFFFFF1; as = os; span = 1; }     // sentinel: never owned
       rowp = (HX_GLOBAL d2v*)(M + sb);
       erow = er;
