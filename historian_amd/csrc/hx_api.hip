@@ -420,8 +420,11 @@ bool build_band_rows(const int32_t* xenv, const int32_t* yenv, const uint8_t* xf
       bool fits = true;
       std::vector<int> no(ge - g), ne(ge - g);
       for (int i = g; i < ge; ++i) {
-        int e = goe;
+        // (never past the pad cell of the last column - the plane ends there -, and a row whose band does not reach the
+        // always-in-envelope column stops one column short of it)
+        int e = std::min(goe, (i + Cc - 1) | 1);
         if (hi[i] < Cc - 1) { int lim = i + Cc - 2; if (!(lim & 1)) --lim; e = std::min(e, std::max(lim, oe[i])); }
+        e = std::max(e, oe[i]);
         no[i - g] = gos; ne[i - g] = e;
         if (as_[i] - gos > 7 || e - ae_[i] > 7) fits = false;
       }
@@ -505,9 +508,25 @@ bool build_band_rows_bwd(const int32_t* xenv, const int32_t* yenv, const uint8_t
   int32_t* strip_store = &out[2 * (size_t)(R + 64)];
   std::vector<int> os(R), oe(R);
   n_steps = 0;
+  for (int i = 0; i < R; ++i) { os[i] = (i + lo[i]) & ~1; oe[i] = (i + hi[i]) | 1; }
+  // whole cache lines, as in build_band_rows: the four rows of a 64-byte group own the same steps.  What a row gains lies
+  // outside the envelope or - first column, last row away from the band - is -inf by the argument above, which is what the
+  // sweep stores for an owned cell outside its row's span.
+  if (!getenv("HX_BAND_NO_LINE_GROUPS"))
+    for (int g = 0; g < R; g += 4) {
+      const int ge = std::min(g + 4, R);
+      int gos = INT_MAX, goe = -1;
+      for (int i = g; i < ge; ++i) { gos = std::min(gos, os[i]); goe = std::max(goe, oe[i]); }
+      bool fits = true;
+      for (int i = g; i < ge; ++i) {
+        const int e = std::max(oe[i], std::min(goe, (i + Cc - 1) | 1));
+        if (i + lo[i] - gos > 7 || e - (i + hi[i]) > 7) fits = false;
+      }
+      if (!fits) continue;
+      for (int i = g; i < ge; ++i) { oe[i] = std::max(oe[i], std::min(goe, (i + Cc - 1) | 1)); os[i] = gos; }
+    }
   for (int i = 0; i < R; ++i) {
     const int as = i + lo[i], ae = i + hi[i];
-    os[i] = as & ~1; oe[i] = ae | 1;
     const int q = i >> 6;
     const int64_t A = (int64_t)q * ss - (int64_t)32 * q * blk;
     if (A < INT32_MIN / 2 || A > INT32_MAX / 2) return false;
@@ -517,6 +536,7 @@ bool build_band_rows_bwd(const int32_t* xenv, const int32_t* yenv, const uint8_t
     int32_t* o = &out[2 * (size_t)i];
     if (oe[i] - os[i] > 0xFFFF || os[i] >= 0xFFFF) return false;
     o[0] = os[i] | ((oe[i] - os[i]) << 16);
+    if (as - os[i] > 7 || oe[i] - ae > 7) return false;
     o[1] = (xecls[ic + 1] & 0xFF) | (ready ? 0 : 0x100) | ((as - os[i]) << 9) | ((oe[i] - ae) << 12);
     n_steps = std::max(n_steps, oe[i] + 1);
   }
