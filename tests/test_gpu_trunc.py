@@ -190,3 +190,56 @@ def test_two_banded_pairs_per_wavefront(nw, monkeypatch):
             b1.close()
             monkeypatch.setenv("HX_BAND2", "1")
             bt.close()
+
+
+@pytest.mark.parametrize("policy", ["trunc", "exact"])
+def test_line_groups_change_no_in_envelope_cell(policy, monkeypatch):
+    # build_band_rows gives the four rows of a 64-byte group the same owned steps, so that the sweeps write whole cache lines;
+    # what a row gains lies outside the envelope.  With and without (HX_BAND_NO_LINE_GROUPS=1): every in-envelope cell the same
+    # bits, Forward and Backward, lpEnd / lpStart the same bits, dense planes still -inf outside the envelope - one pair per
+    # wavefront and two, pre-filled, sparse and band-compressed planes, bands of 0 to 20, pairs whose ends come close to the
+    # last rows and columns (unequal lengths).
+    flag = capi.HX_LSE_TRUNC if policy == "trunc" else capi.HX_LSE_EXACT
+    cases = [H.leaf_case(501, 70, 66, band=5), H.leaf_case(502, 200, 90, band=12), H.leaf_case(503, 131, 150, band=3),
+             H.leaf_case(504, 300, 333, alphabet=AA, jc=False, band=20), H.leaf_case(505, 41, 45, band=0), H.leaf_case(506, 257, 256, band=9)]
+    imgs = [H.job_images(f) for f in cases]
+    for band2 in (("0", "1") if policy == "trunc" else ("0",)):
+        monkeypatch.setenv("HX_BAND2", band2)
+        for extra in (0, capi.HX_SPARSE_ENVELOPE, capi.HX_BAND_COMPRESSED):
+            got = {}
+            for groups in (True, False):
+                if groups:
+                    monkeypatch.delenv("HX_BAND_NO_LINE_GROUPS", raising=False)
+                else:
+                    monkeypatch.setenv("HX_BAND_NO_LINE_GROUPS", "1")
+                b = capi.Batch(imgs, flag | extra | (0 if extra == capi.HX_BAND_COMPRESSED else capi.HX_KEEP_BACKWARD))
+                assert all(b.job_kernel(k)[0] == 2 for k in range(len(imgs)))
+                b.forward()
+                res = {"lp_end": b.lp_end().copy()}
+                masks = []
+                for k, f in enumerate(cases):
+                    mask = H.envelope_mask(f)
+                    masks.append(mask)
+                    ii, jj = np.nonzero(mask)
+                    res["f%d" % k] = b.read_cells(k, np.stack([ii, jj], axis=1))
+                    if extra == 0:
+                        full = b.read_matrix(k, 0)
+                        assert np.all(np.isneginf(full[~mask])), "pre-filled planes: -inf outside the envelope"
+                if extra != capi.HX_BAND_COMPRESSED:
+                    b.backward()
+                    res["lp_start"] = b.lp_start().copy()
+                    for k in range(len(cases)):
+                        res["b%d" % k] = b.read_matrix(k, 1)[masks[k]]
+                b.close()
+                got[groups] = res
+            for key in got[True]:
+                a, c = np.asarray(got[True][key]), np.asarray(got[False][key])
+                what = "%s, band2 %s, flags %d: %s" % (policy, band2, extra, key)
+                if policy == "exact":
+                    H.assert_same_bits(a, c, what)
+                else:
+                    # the scaled-probability policies evaluate row 0 beyond the sweep's reach as a prefix sum (hx_bandedge.h):
+                    # where the sweep's reach on row 0 changes, the same cell is the same number to an ulp, not to the bit
+                    assert np.array_equal(np.isneginf(a), np.isneginf(c)), what
+                    fin = np.isfinite(a)
+                    assert np.all(np.abs(a[fin] - c[fin]) <= 1e-12 * np.abs(a[fin])), what
