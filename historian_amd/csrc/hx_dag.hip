@@ -861,6 +861,12 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
       adjx[k] = lane > 0 && xdeg > k && X.s[k] == i - 1;
     }
     const int64_t offXa = xnull ? plane : aggoff, offXb = xnull ? 4 * plane : aggoff + plane;
+    // the row's in-transitions K and K + 1 (CSR entries), kept for the whole strip: see "transitions beyond the inline ones"
+    int xs_first[2] = {0, 0};
+    double xl_first[2] = {0., 0.};
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (xdeg > K + q) { xs_first[q] = xin_src[X.in_b + K + q]; xl_first[q] = xin_lp[X.in_b + K + q]; }
     const int above_base = ((s - 1) / WT) * Cc;
     const int my_base = (s / WT) * Cc;
     int seen = 0, published = 0;
@@ -927,6 +933,12 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
           sXj[k] = slot_at(XR[k], jc);
           sOy[k] = slot_at(own, Y.s[k]);
         }
+        // the column's in-transitions K and K + 1 (CSR entries), in front of the step's loads
+        int ys_first[2] = {0, 0};
+        double yl_first[2] = {0., 0.};
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          if (act && ydeg > K + q) { ys_first[q] = yin_src[Y.in_b + K + q]; yl_first[q] = yin_lp[Y.in_b + K + q]; }
         // ---- this step's loads: the first transitions for every lane (absent ones have source state 0 in
         // the pack, so the address is valid and the value is discarded below), further ones only where they
         // exist.  xa/xb feed IMD/IIW, ya/yb feed IDM/IMI, mv[] feeds IMM: transition pairs when both states
@@ -993,7 +1005,10 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
           for (int k = 1; k < K; ++k)
             if (ygo && ydeg > k) { idm = L(idm, ya[k] + Y.lp[k]); imi = L(imi, yb[k] + Y.lp[k]); }
           double imm = NI;
-          const bool pairs_inline = mode == 1 && ydeg <= K;         // else (both emit, > K y transitions): generic loop below
+          // the transition pairs of IMM are summed row transition by row transition (reference src/forward.cpp:98-116): with at
+          // most one row transition that is the column's order, so the column's further transitions add their pair below;
+          // with at most K column transitions the row's further transitions add theirs; else the generic loop
+          const bool pairs_inline = mode == 1 && (ydeg <= K || xdeg <= 1);
           if (pairs_inline) {
             imm = (mv[0] + X.lp[0]) + Y.lp[0];
 #pragma unroll
@@ -1010,45 +1025,89 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
 #pragma unroll
             for (int k = 1; k < K; ++k) if (xdeg > k) imm = L(imm, mv[k] + X.lp[k]);
           }
-          // ---- transitions beyond the inline ones.  Rare, but a row that has them has them at every step and
-          // sets the pace of its strip (and through the pipeline of its pair): one round per transition reads its
-          // CSR entry once and fetches everything that hangs on it -- the two sums of the x (or y) part and, in
-          // the same round, its IMM sources -- before any of the dependent look-ups.
-          for (int a = K; a < xdeg; ++a) {
-            const int src = xin_src[X.in_b + a];
-            const double lp = xin_lp[X.in_b + a];
-            const bool adj = lane > 0 && src == i - 1;              // the previous lane's cell of the previous step
-            const RowRef rr = row_ref(ss, src);
-            const int64_t sl = slot_at(rr, j);
-            double va = upA, vb = upB, vm = up_imm, g[K];
-            if (xgo && !adj) { va = M[offXa + sl]; vb = M[offXb + sl]; }
-            if (mode == 3 && !adj) vm = M[sl];
-            if (pairs_inline) {                                      // (a pair's source is >= 2 steps old: in memory)
+          // ---- transitions beyond the inline ones.  Rare (half a percent of the states), but a row that has them has them at
+          // every step and sets the pace of its strip, and through the pipeline of its pair; and one of the 64 columns of a
+          // step has them at every third step.  They are taken two at a time: the two CSR entries are in registers before the
+          // round starts (the row's first two for the whole strip, the column's first two fetched in front of the step's
+          // loads, a later round's together with the loads of the round before), so a round is ONE batch of loads - the
+          // cells of both transitions and everything that hangs on them - and then the look-ups, in the reference's order.
+          if (xdeg > K) {
+            int e_src[2] = {xs_first[0], xs_first[1]};
+            double e_lp[2] = {xl_first[0], xl_first[1]};
+            const bool rpairs = mode == 1 && ydeg <= K;
+            for (int a = K; a < xdeg; a += 2) {
+              int n_src[2] = {0, 0};
+              double n_lp[2] = {0., 0.};
 #pragma unroll
-              for (int b = 0; b < K; ++b)
-                if (b < ydeg) g[b] = M[o4 + slot_at(rr, Y.s[b])];
-            }
-            if (xgo) { imd = L(imd, va + lp); iiw = L(iiw, vb + lp); }
-            if (mode == 3) imm = L(imm, vm + lp);
-            if (pairs_inline) {
+              for (int q = 0; q < 2; ++q)
+                if (a + 2 + q < xdeg) { n_src[q] = xin_src[X.in_b + a + 2 + q]; n_lp[q] = xin_lp[X.in_b + a + 2 + q]; }
+              double va[2], vb[2], vm[2], g[2][K];
 #pragma unroll
-              for (int b = 0; b < K; ++b)
-                if (b < ydeg) imm = L(imm, (g[b] + lp) + Y.lp[b]);
+              for (int q = 0; q < 2; ++q) {
+                va[q] = upA; vb[q] = upB; vm[q] = up_imm;
+                if (a + q < xdeg) {
+                  const bool adj = lane > 0 && e_src[q] == i - 1;     // the previous lane's cell of the previous step
+                  const RowRef rr = row_ref(ss, e_src[q]);
+                  const int64_t sl = slot_at(rr, j);
+                  if (xgo && !adj) { va[q] = M[offXa + sl]; vb[q] = M[offXb + sl]; }
+                  if (mode == 3 && !adj) vm[q] = M[sl];
+                  if (rpairs) {                                       // (a pair's source is >= 2 steps old: in memory)
+#pragma unroll
+                    for (int b = 0; b < K; ++b)
+                      if (b < ydeg) g[q][b] = M[o4 + slot_at(rr, Y.s[b])];
+                  }
+                }
+              }
+#pragma unroll
+              for (int q = 0; q < 2; ++q)
+                if (a + q < xdeg) {
+                  const double lp = e_lp[q];
+                  if (xgo) { imd = L(imd, va[q] + lp); iiw = L(iiw, vb[q] + lp); }
+                  if (mode == 3) imm = L(imm, vm[q] + lp);
+                  if (rpairs) {
+#pragma unroll
+                    for (int b = 0; b < K; ++b)
+                      if (b < ydeg) imm = L(imm, (g[q][b] + lp) + Y.lp[b]);
+                  }
+                }
+              e_src[0] = n_src[0]; e_src[1] = n_src[1]; e_lp[0] = n_lp[0]; e_lp[1] = n_lp[1];
             }
           }
-          for (int b = K; b < ydeg; ++b) {
-            const int src = yin_src[Y.in_b + b];
-            const double lp = yin_lp[Y.in_b + b];
-            const bool adj = src == j - 1;                          // the lane's own cell of the previous step
-            const int64_t sl = slot_at(own, src);
-            double va = ownA, vb = ownB, vm = own10.imm;
-            if (ygo && !adj) { va = M[offYa + sl]; vb = M[offYb + sl]; }
-            if (mode == 2 && !adj) vm = M[sl];
-            if (ygo) { idm = L(idm, va + lp); imi = L(imi, vb + lp); }
-            if (mode == 2) imm = L(imm, vm + lp);
+          if (ydeg > K) {
+            int e_src[2] = {ys_first[0], ys_first[1]};
+            double e_lp[2] = {yl_first[0], yl_first[1]};
+            const bool cpairs = mode == 1 && xdeg == 1;               // pair (the row's only transition, this one)
+            for (int b = K; b < ydeg; b += 2) {
+              int n_src[2] = {0, 0};
+              double n_lp[2] = {0., 0.};
+#pragma unroll
+              for (int q = 0; q < 2; ++q)
+                if (b + 2 + q < ydeg) { n_src[q] = yin_src[Y.in_b + b + 2 + q]; n_lp[q] = yin_lp[Y.in_b + b + 2 + q]; }
+              double va[2], vb[2], vm[2], g[2];
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                va[q] = ownA; vb[q] = ownB; vm[q] = own10.imm;
+                if (b + q < ydeg) {
+                  const bool adj = e_src[q] == j - 1;                 // the lane's own cell of the previous step
+                  const int64_t sl = slot_at(own, e_src[q]);
+                  if (ygo && !adj) { va[q] = M[offYa + sl]; vb[q] = M[offYb + sl]; }
+                  if (mode == 2 && !adj) vm[q] = M[sl];
+                  if (cpairs) g[q] = M[o4 + slot_at(XR[0], e_src[q])];
+                }
+              }
+#pragma unroll
+              for (int q = 0; q < 2; ++q)
+                if (b + q < ydeg) {
+                  const double lp = e_lp[q];
+                  if (ygo) { idm = L(idm, va[q] + lp); imi = L(imi, vb[q] + lp); }
+                  if (mode == 2) imm = L(imm, vm[q] + lp);
+                  if (cpairs) imm = L(imm, (g[q] + X.lp[0]) + lp);
+                }
+              e_src[0] = n_src[0]; e_src[1] = n_src[1]; e_lp[0] = n_lp[0]; e_lp[1] = n_lp[1];
+            }
           }
           if (mode == 1 && !pairs_inline) {
-            // both states emit and y has more than K in-transitions: all pairs in the reference's order
+            // both states emit, the row has several in-transitions and the column more than K: all pairs in the reference's order
             for (int a = 0; a < xdeg; ++a) {
               const RowRef rr = row_ref(ss, xin_src[X.in_b + a]);
               const double lpx = xin_lp[X.in_b + a];
