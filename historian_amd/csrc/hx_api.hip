@@ -1272,7 +1272,8 @@ int hx_batch_forward(hx_batch* b, void* stream) {
             b->used_multi[0] = true;
             const int strips = (cr.max_rows + HX_STRIP - 1) / HX_STRIP;
             if (const char* e = getenv("HX_DAG_MULTI_WAVES")) multi_waves = atoi(e);
-            if (multi_waves != 8 && multi_waves != 2) multi_waves = 4;
+            // (the table policies' kernel is built for at most four waves per workgroup in this launch: 512 registers per lane)
+            if ((multi_waves != 8 || !b->dag_linear) && multi_waves != 2) multi_waves = 4;
             multi = std::min(std::min(32, HX_MULTI_MAX_GROUPS / cr.n), (strips + multi_waves - 1) / multi_waves);
             if (!b->d_multi && hipMalloc(reinterpret_cast<void**>(&b->d_multi), 2 * HX_MULTI_COUNTER_PAIRS * 256 * sizeof(int)) != hipSuccess)
               return fail(HX_ERR_OUT_OF_MEMORY, "hipMalloc of the progress counters failed");

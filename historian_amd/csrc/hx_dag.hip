@@ -735,6 +735,7 @@ __device__ __forceinline__ int64_t slot_at(const RowRef& r, int c) {
 }
 
 #define HX_DAGF_MAX_WAVES 8     // Forward pipeline: up to 8 waves (512 threads) so that a wave may use 256 VGPRs
+#define HX_DAGF_MULTI_WAVES 4   // ... its several-workgroups launch: 4 waves, a wave may use 512
 
 // Trace builds (-DHX_DAG_TRACE): per-strip cycle sums of the phases of a step, printed by lane 0 at the end of
 // every strip (tools/dag_trace.sh).  The explicit waits a trace build adds perturb the schedule a little.
@@ -772,7 +773,7 @@ struct Fwd10 { double imm, imd, idm, imi, iiw, g0, g1, g2, g3, g4; };
 // MULTI: one pair's strips dealt to `groups` workgroups (one or two pairs of many strips: see k_backward_dag_multi for the
 // hand-off; the progress counters - 256 ints per pair - are a region the host passes in, zeroed before the launch).
 template <class LSE, bool FAST, bool MULTI = false>
-__global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(const DevJob* __restrict__ jobs,
+__global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(const DevJob* __restrict__ jobs,
                                                                                const double* __restrict__ exact_tab,
                                                                                const double* __restrict__ fast_tab,
                                                                                const int groups = 1, int* const counters = nullptr,
@@ -828,6 +829,14 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
     else progp[wave] = value;
   };
   const double NI = HX_NEG_INF;
+  // in-transitions beyond the inline ones are taken CHX (row) / CHY (column) at a time; EARLY: the first round's loads are
+  // issued with the step's own (the several-workgroups launch has four waves per workgroup, i.e. 512 registers per lane)
+  constexpr int CHX = MULTI ? 6 : 2, CHY = MULTI ? 4 : 2;
+  constexpr bool EARLY = MULTI;
+  // g / h: a further transition's pairs with the other side's inline transitions ([.][0] doubles as the IMM source when the
+  // other state is null); gg: the pairs of two further transitions
+  struct XRound { double va[CHX], vb[CHX], g[CHX][HX_DAG_INLINE], gg[CHX][CHY]; };
+  struct YRound { double va[CHY], vb[CHY], h[CHY][HX_DAG_INLINE]; };
   HX_LDS d2v* ring = (HX_LDS d2v*)&ycols[wave][0][0];
   // columns c0 .. c0+63 (clamped into the profile) -> ring; one coalesced 4 KiB read per call
   auto stage = [&](const int c0) {
@@ -861,12 +870,14 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
       adjx[k] = lane > 0 && xdeg > k && X.s[k] == i - 1;
     }
     const int64_t offXa = xnull ? plane : aggoff, offXb = xnull ? 4 * plane : aggoff + plane;
-    // the row's in-transitions K and K + 1 (CSR entries), kept for the whole strip: see "transitions beyond the inline ones"
-    int xs_first[2] = {0, 0};
-    double xl_first[2] = {0., 0.};
+    // the row's in-transitions K .. K + CHX - 1 (CSR entries), kept for the whole strip: see "transitions beyond the inline ones"
+    int xs_first[CHX];
+    double xl_first[CHX];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < CHX; ++q) {
+      xs_first[q] = 0; xl_first[q] = 0.;
       if (xdeg > K + q) { xs_first[q] = xin_src[X.in_b + K + q]; xl_first[q] = xin_lp[X.in_b + K + q]; }
+    }
     const int above_base = ((s - 1) / WT) * Cc;
     const int my_base = (s / WT) * Cc;
     int seen = 0, published = 0;
@@ -933,12 +944,14 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
           sXj[k] = slot_at(XR[k], jc);
           sOy[k] = slot_at(own, Y.s[k]);
         }
-        // the column's in-transitions K and K + 1 (CSR entries), in front of the step's loads
-        int ys_first[2] = {0, 0};
-        double yl_first[2] = {0., 0.};
+        // the column's in-transitions K .. K + CHY - 1 (CSR entries), in front of the step's loads
+        int ys_first[CHY];
+        double yl_first[CHY];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < CHY; ++q) {
+          ys_first[q] = 0; yl_first[q] = 0.;
           if (act && ydeg > K + q) { ys_first[q] = yin_src[Y.in_b + K + q]; yl_first[q] = yin_lp[Y.in_b + K + q]; }
+        }
         // ---- this step's loads: the first transitions for every lane (absent ones have source state 0 in
         // the pack, so the address is valid and the value is discarded below), further ones only where they
         // exist.  xa/xb feed IMD/IIW, ya/yb feed IDM/IMI, mv[] feeds IMM: transition pairs when both states
@@ -973,12 +986,67 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
           for (int k = 1; k < K; ++k) if (xdeg > k) mv[k] = M[sXj[k]];
         }
         if (X.cls < 0 || Y.cls < 0) e = NI;
+        // ---- a round of further in-transitions (see "transitions beyond the inline ones" below): the loads of up to CHX row
+        // transitions a0 .. / CHY column transitions b0 .. whose CSR entries are in registers, and later their look-ups
+        const bool rpairs = mode == 1 && ydeg <= K;                 // the row's further transitions carry their pairs
+        const bool cpairs = mode == 1 && xdeg == 1;                 // the column's do (pair with the row's only transition)
+        // several row transitions AND further column transitions, all of them among the entries in registers: one round each
+        // (only where there are registers for it: the several-workgroups launch; else such cells take the generic loop below)
+        const bool bpairs = EARLY && mode == 1 && xdeg > 1 && ydeg > K && xdeg <= K + CHX && ydeg <= K + CHY;
+        const double upA = xnull ? up_imd : up_g0, upB = xnull ? up_iiw : up_g1;
+        const double ownA = ynull ? own10.idm : own10.g2, ownB = ynull ? own10.imi : own10.g3;
+        XRound xv;
+        YRound yv;
+        const auto x_loads = [&](const int (&src)[CHX], const int a0) {
+#pragma unroll
+          for (int q = 0; q < CHX; ++q) {
+            xv.va[q] = upA; xv.vb[q] = upB; xv.g[q][0] = up_imm;
+            if (a0 + q < xdeg) {
+              const bool adj = lane > 0 && src[q] == i - 1;         // the previous lane's cell of the previous step
+              const RowRef rr = row_ref(ss, src[q]);
+              const int64_t sl = slot_at(rr, j);
+              if (xgo && !adj) { xv.va[q] = M[offXa + sl]; xv.vb[q] = M[offXb + sl]; }
+              if (mode == 3 && !adj) xv.g[q][0] = M[sl];
+              if (rpairs || bpairs) {                               // (a pair's source is >= 2 steps old: in memory)
+#pragma unroll
+                for (int b = 0; b < K; ++b)
+                  if (b < ydeg) xv.g[q][b] = M[o4 + slot_at(rr, Y.s[b])];
+              }
+              if (bpairs) {
+#pragma unroll
+                for (int r = 0; r < CHY; ++r)
+                  if (K + r < ydeg) xv.gg[q][r] = M[o4 + slot_at(rr, ys_first[r])];
+              }
+            }
+          }
+        };
+        const auto y_loads = [&](const int (&src)[CHY], const int b0) {
+#pragma unroll
+          for (int q = 0; q < CHY; ++q) {
+            yv.va[q] = ownA; yv.vb[q] = ownB; yv.h[q][0] = own10.imm;
+            if (b0 + q < ydeg) {
+              const bool adj = src[q] == j - 1;                     // the lane's own cell of the previous step
+              const int64_t sl = slot_at(own, src[q]);
+              if (ygo && !adj) { yv.va[q] = M[offYa + sl]; yv.vb[q] = M[offYb + sl]; }
+              if (mode == 2 && !adj) yv.h[q][0] = M[sl];
+              if (cpairs || bpairs) {
+#pragma unroll
+                for (int a = 0; a < K; ++a)
+                  if (a < xdeg) yv.h[q][a] = M[o4 + slot_at(XR[a], src[q])];
+              }
+            }
+          }
+        };
+        if (EARLY && act) {
+          // with registers to spare (the several-workgroups launch: four waves per workgroup) the first round's loads go out
+          // with the step's own, so that a step with up to K + CHX row and K + CHY column transitions is one round trip
+          if (xdeg > K) x_loads(xs_first, K);
+          if (ydeg > K) y_loads(ys_first, K);
+        }
         HX_TR(1);      // column record, addresses, load issue
         HX_TR_WAIT_LOADS();
         HX_TR(2);      // waiting for the loads
         // ---- values forwarded from the previous step, and -inf for what does not exist ----
-        const double upA = xnull ? up_imd : up_g0, upB = xnull ? up_iiw : up_g1;
-        const double ownA = ynull ? own10.idm : own10.g2, ownB = ynull ? own10.imi : own10.g3;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           if (adjx[k]) { xa[k] = upA; xb[k] = upB; }
@@ -1025,89 +1093,97 @@ __global__ void __launch_bounds__(HX_DAGF_MAX_WAVES * 64) k_forward_dag_pipe(con
 #pragma unroll
             for (int k = 1; k < K; ++k) if (xdeg > k) imm = L(imm, mv[k] + X.lp[k]);
           }
-          // ---- transitions beyond the inline ones.  Rare (half a percent of the states), but a row that has them has them at
-          // every step and sets the pace of its strip, and through the pipeline of its pair; and one of the 64 columns of a
-          // step has them at every third step.  They are taken two at a time: the two CSR entries are in registers before the
-          // round starts (the row's first two for the whole strip, the column's first two fetched in front of the step's
-          // loads, a later round's together with the loads of the round before), so a round is ONE batch of loads - the
-          // cells of both transitions and everything that hangs on them - and then the look-ups, in the reference's order.
-          if (xdeg > K) {
-            int e_src[2] = {xs_first[0], xs_first[1]};
-            double e_lp[2] = {xl_first[0], xl_first[1]};
-            const bool rpairs = mode == 1 && ydeg <= K;
-            for (int a = K; a < xdeg; a += 2) {
-              int n_src[2] = {0, 0};
-              double n_lp[2] = {0., 0.};
+          // ---- transitions beyond the inline ones.  Rare (half a percent of the states in gp120's profiles, two percent at
+          // 64 leaves), but a row that has them has them at every step and sets the pace of its strip, and through the pipeline
+          // of its pair; and one of the 64 columns of a step has them at every second or third step.  They are taken CHX / CHY
+          // at a time: a round's CSR entries are in registers before it starts (the row's first for the whole strip, the
+          // column's first fetched in front of the step's loads, a later round's together with the loads of the round before),
+          // so a round is ONE batch of loads - the cells of its transitions and everything that hangs on them - and then the
+          // look-ups, in the reference's order.
+          if (ydeg > K) {
+            int e_src[CHY];
+            double e_lp[CHY];
 #pragma unroll
-              for (int q = 0; q < 2; ++q)
-                if (a + 2 + q < xdeg) { n_src[q] = xin_src[X.in_b + a + 2 + q]; n_lp[q] = xin_lp[X.in_b + a + 2 + q]; }
-              double va[2], vb[2], vm[2], g[2][K];
+            for (int q = 0; q < CHY; ++q) { e_src[q] = ys_first[q]; e_lp[q] = yl_first[q]; }
+            for (int b = K; b < ydeg; b += CHY) {
+              int n_src[CHY];
+              double n_lp[CHY];
 #pragma unroll
-              for (int q = 0; q < 2; ++q) {
-                va[q] = upA; vb[q] = upB; vm[q] = up_imm;
-                if (a + q < xdeg) {
-                  const bool adj = lane > 0 && e_src[q] == i - 1;     // the previous lane's cell of the previous step
-                  const RowRef rr = row_ref(ss, e_src[q]);
-                  const int64_t sl = slot_at(rr, j);
-                  if (xgo && !adj) { va[q] = M[offXa + sl]; vb[q] = M[offXb + sl]; }
-                  if (mode == 3 && !adj) vm[q] = M[sl];
-                  if (rpairs) {                                       // (a pair's source is >= 2 steps old: in memory)
-#pragma unroll
-                    for (int b = 0; b < K; ++b)
-                      if (b < ydeg) g[q][b] = M[o4 + slot_at(rr, Y.s[b])];
-                  }
-                }
+              for (int q = 0; q < CHY; ++q) {
+                n_src[q] = 0; n_lp[q] = 0.;
+                if (b + CHY + q < ydeg) { n_src[q] = yin_src[Y.in_b + b + CHY + q]; n_lp[q] = yin_lp[Y.in_b + b + CHY + q]; }
               }
+              if (!EARLY || b > K) y_loads(e_src, b);
 #pragma unroll
-              for (int q = 0; q < 2; ++q)
+              for (int q = 0; q < CHY; ++q)
+                if (b + q < ydeg) {
+                  const double lp = e_lp[q];
+                  if (ygo) { idm = L(idm, yv.va[q] + lp); imi = L(imi, yv.vb[q] + lp); }
+                  if (mode == 2) imm = L(imm, yv.h[q][0] + lp);
+                  if (cpairs) imm = L(imm, (yv.h[q][0] + X.lp[0]) + lp);
+                }
+#pragma unroll
+              for (int q = 0; q < CHY; ++q) { e_src[q] = n_src[q]; e_lp[q] = n_lp[q]; }
+            }
+          }
+          if (bpairs) {
+            // the pairs of the row's inline transitions, row transition by row transition: with the column's inline transitions
+            // (loaded with the step's sources), then with its further ones (the round above)
+#pragma unroll
+            for (int a = 0; a < K; ++a)
+              if (a < xdeg) {
+#pragma unroll
+                for (int b = 0; b < K; ++b) imm = L(imm, (mv[a * K + b] + X.lp[a]) + Y.lp[b]);      // (K < ydeg)
+#pragma unroll
+                for (int r = 0; r < CHY; ++r)
+                  if (K + r < ydeg) imm = L(imm, (yv.h[r][a] + X.lp[a]) + yl_first[r]);
+              }
+          }
+          if (xdeg > K) {
+            int e_src[CHX];
+            double e_lp[CHX];
+#pragma unroll
+            for (int q = 0; q < CHX; ++q) { e_src[q] = xs_first[q]; e_lp[q] = xl_first[q]; }
+            for (int a = K; a < xdeg; a += CHX) {
+              int n_src[CHX];
+              double n_lp[CHX];
+#pragma unroll
+              for (int q = 0; q < CHX; ++q) {
+                n_src[q] = 0; n_lp[q] = 0.;
+                if (a + CHX + q < xdeg) { n_src[q] = xin_src[X.in_b + a + CHX + q]; n_lp[q] = xin_lp[X.in_b + a + CHX + q]; }
+              }
+              if (!EARLY || a > K) x_loads(e_src, a);
+#pragma unroll
+              for (int q = 0; q < CHX; ++q)
                 if (a + q < xdeg) {
                   const double lp = e_lp[q];
-                  if (xgo) { imd = L(imd, va[q] + lp); iiw = L(iiw, vb[q] + lp); }
-                  if (mode == 3) imm = L(imm, vm[q] + lp);
+                  if (xgo) { imd = L(imd, xv.va[q] + lp); iiw = L(iiw, xv.vb[q] + lp); }
+                  if (mode == 3) imm = L(imm, xv.g[q][0] + lp);
                   if (rpairs) {
 #pragma unroll
                     for (int b = 0; b < K; ++b)
-                      if (b < ydeg) imm = L(imm, (g[q][b] + lp) + Y.lp[b]);
+                      if (b < ydeg) imm = L(imm, (xv.g[q][b] + lp) + Y.lp[b]);
                   }
                 }
-              e_src[0] = n_src[0]; e_src[1] = n_src[1]; e_lp[0] = n_lp[0]; e_lp[1] = n_lp[1];
+#pragma unroll
+              for (int q = 0; q < CHX; ++q) { e_src[q] = n_src[q]; e_lp[q] = n_lp[q]; }
             }
           }
-          if (ydeg > K) {
-            int e_src[2] = {ys_first[0], ys_first[1]};
-            double e_lp[2] = {yl_first[0], yl_first[1]};
-            const bool cpairs = mode == 1 && xdeg == 1;               // pair (the row's only transition, this one)
-            for (int b = K; b < ydeg; b += 2) {
-              int n_src[2] = {0, 0};
-              double n_lp[2] = {0., 0.};
+          if (bpairs) {
+            // ... and those of the row's further transitions
 #pragma unroll
-              for (int q = 0; q < 2; ++q)
-                if (b + 2 + q < ydeg) { n_src[q] = yin_src[Y.in_b + b + 2 + q]; n_lp[q] = yin_lp[Y.in_b + b + 2 + q]; }
-              double va[2], vb[2], vm[2], g[2];
+            for (int q = 0; q < CHX; ++q)
+              if (K + q < xdeg) {
 #pragma unroll
-              for (int q = 0; q < 2; ++q) {
-                va[q] = ownA; vb[q] = ownB; vm[q] = own10.imm;
-                if (b + q < ydeg) {
-                  const bool adj = e_src[q] == j - 1;                 // the lane's own cell of the previous step
-                  const int64_t sl = slot_at(own, e_src[q]);
-                  if (ygo && !adj) { va[q] = M[offYa + sl]; vb[q] = M[offYb + sl]; }
-                  if (mode == 2 && !adj) vm[q] = M[sl];
-                  if (cpairs) g[q] = M[o4 + slot_at(XR[0], e_src[q])];
-                }
+                for (int b = 0; b < K; ++b) imm = L(imm, (xv.g[q][b] + xl_first[q]) + Y.lp[b]);
+#pragma unroll
+                for (int r = 0; r < CHY; ++r)
+                  if (K + r < ydeg) imm = L(imm, (xv.gg[q][r] + xl_first[q]) + yl_first[r]);
               }
-#pragma unroll
-              for (int q = 0; q < 2; ++q)
-                if (b + q < ydeg) {
-                  const double lp = e_lp[q];
-                  if (ygo) { idm = L(idm, va[q] + lp); imi = L(imi, vb[q] + lp); }
-                  if (mode == 2) imm = L(imm, vm[q] + lp);
-                  if (cpairs) imm = L(imm, (g[q] + X.lp[0]) + lp);
-                }
-              e_src[0] = n_src[0]; e_src[1] = n_src[1]; e_lp[0] = n_lp[0]; e_lp[1] = n_lp[1];
-            }
           }
-          if (mode == 1 && !pairs_inline) {
-            // both states emit, the row has several in-transitions and the column more than K: all pairs in the reference's order
+          if (mode == 1 && !pairs_inline && !bpairs) {
+            // both states emit, the row has several in-transitions and the column more than K + CHY (or the row more than
+            // K + CHX): all pairs in the reference's order, one at a time
             for (int a = 0; a < xdeg; ++a) {
               const RowRef rr = row_ref(ss, xin_src[X.in_b + a]);
               const double lpx = xin_lp[X.in_b + a];

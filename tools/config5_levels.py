@@ -35,7 +35,7 @@ with tempfile.TemporaryDirectory() as d:
         print("== %d leaves x %d residues, prot4 (4 components), no band, HX_FILL_MODE=%s: %.1f s wall, lpFinalFwd %.4f" %
               (n_leaves, length, mode, time.time() - t0, got["lpFinalFwd"]), flush=True)
         for line in out.stderr.decode().strip().splitlines():
-            if line.startswith("timing"):
+            if line.startswith("timing") or line.startswith("profile stats"):
                 print("   ", line, flush=True)
         rows = got["rows"]
         assert len({len(v) for v in rows.values()}) == 1, "ragged alignment"
