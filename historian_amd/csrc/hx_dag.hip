@@ -1284,7 +1284,7 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
     }
 #ifdef HX_DAG_TRACE
     if (lane == 0 && tr_steps > 0)
-      printf("trace job %d strip %d steps %d wait %lld issue %lld loads %lld accumulate %lld sums %lld rotate %lld\\n", (int)blockIdx.x, s, tr_steps,
+      printf("trace job %d strip %d steps %d wait %lld issue %lld loads %lld accumulate %lld sums %lld rotate %lld\n", (int)blockIdx.x, s, tr_steps,
              tr_sum[0] / tr_steps, tr_sum[1] / tr_steps, tr_sum[2] / tr_steps, tr_sum[3] / tr_steps, tr_sum[4] / tr_steps, tr_sum[5] / tr_steps);
 #endif
     // (a strip without any window still has to release the strip below)

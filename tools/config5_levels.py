@@ -34,6 +34,9 @@ with tempfile.TemporaryDirectory() as d:
         got = R.parse_hxrecon(out.stdout.decode())
         print("== %d leaves x %d residues, prot4 (4 components), no band, HX_FILL_MODE=%s: %.1f s wall, lpFinalFwd %.4f" %
               (n_leaves, length, mode, time.time() - t0, got["lpFinalFwd"]), flush=True)
+        for line in out.stdout.decode().splitlines():          # (a -DHX_DAG_TRACE build of the library: the kernels' phase lines)
+            if line.startswith("trace "):
+                print("   ", line, flush=True)
         for line in out.stderr.decode().strip().splitlines():
             if line.startswith("timing") or line.startswith("profile stats"):
                 print("   ", line, flush=True)
