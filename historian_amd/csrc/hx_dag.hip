@@ -725,13 +725,16 @@ __device__ __forceinline__ PackRegs load_pack(const HX_GLOBAL FwdPack* p) {
   return unpack(q[0], q[1], q[2], q[3], q[4]);
 }
 
-struct RowRef { int64_t base; int l; };
-__device__ __forceinline__ RowRef row_ref(int64_t ss, int r) {
-  return RowRef{(int64_t)(r >> 6) * ss + ((r & 63) << 1), r & 63};
+// Slots (offsets of a cell inside a plane, in doubles) are 32-bit and unsigned: a plane of 2^32 doubles is 32 GiB, more than a
+// pair's ten planes can have in 288 GB, and an address is then ONE 64-bit operation (plane pointer + zero-extended slot * 8)
+// where 64-bit slots took four or five per load - most of what a step issued in front of its loads.
+struct RowRef { unsigned base; int l; };
+__device__ __forceinline__ RowRef row_ref(unsigned ss, int r) {
+  return RowRef{(unsigned)(r >> 6) * ss + ((unsigned)(r & 63) << 1), r & 63};
 }
-__device__ __forceinline__ int64_t slot_at(const RowRef& r, int c) {
-  const int t = c + r.l;
-  return r.base + ((int64_t)(t >> 1) << 7) + (t & 1);
+__device__ __forceinline__ unsigned slot_at(const RowRef& r, int c) {
+  const unsigned t = (unsigned)(c + r.l);
+  return r.base + ((t >> 1) << 7) + (t & 1);
 }
 
 #define HX_DAGF_MAX_WAVES 8     // Forward pipeline: up to 8 waves (512 threads) so that a wave may use 256 VGPRs
@@ -766,6 +769,8 @@ struct PairPlanes {
     }
   };
   __device__ __forceinline__ Ref operator[](int64_t k) const { return Ref{p + k}; }
+  __device__ __forceinline__ Ref operator[](unsigned k) const { return Ref{p + k}; }
+  __device__ __forceinline__ PairPlanes at(int64_t off) const { return PairPlanes{p + off}; }      // another plane's view
 };
 
 struct Fwd10 { double imm, imd, idm, imi, iiw, g0, g1, g2, g3, g4; };
@@ -796,7 +801,8 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
   const DevJob& J = jobs[job];
   const double (*T)[6] = J.T;
   const int R = J.n_rows, Cc = J.n_cols;
-  const int64_t plane = J.plane, ss = J.strip_stride;
+  const int64_t plane = J.plane;
+  const unsigned ss = (unsigned)J.strip_stride;
   const PairPlanes<MULTI> M{as_global(J.fwd)};
   HX_GLOBAL int* gprog = MULTI ? (HX_GLOBAL int*)as_global(counters + 256 * job) : nullptr;
   const int64_t aggoff = J.agg - J.fwd;          // the outgoing-sum planes, addressed relative to the matrix
@@ -858,7 +864,7 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
     const PackRegs X = load_pack(xpk + (rvalid ? i : 0));
     const int xf = X.meta & 0xff, xdeg = X.meta >> 8;
     const bool xnull = xf & F_NULL, xok = (xf & F_READY) || xempty, xeos = xf & F_EMIT_OR_START;
-    const RowRef own = RowRef{(int64_t)s * ss + (lane << 1), lane};
+    const RowRef own = RowRef{(unsigned)s * ss + ((unsigned)lane << 1), lane};
     constexpr int K = HX_DAG_INLINE;
     RowRef XR[K];
     bool adjx[K];
@@ -869,7 +875,8 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
       // step: it is forwarded through registers (its store has not been issued yet, see below)
       adjx[k] = lane > 0 && xdeg > k && X.s[k] == i - 1;
     }
-    const int64_t offXa = xnull ? plane : aggoff, offXb = xnull ? 4 * plane : aggoff + plane;
+    const PairPlanes<MULTI> Xa = M.at(xnull ? plane : aggoff), Xb = M.at(xnull ? 4 * plane : aggoff + plane);
+    const PairPlanes<MULTI> G4 = M.at(aggoff + 4 * plane);
     // the row's in-transitions K .. K + CHX - 1 (CSR entries), kept for the whole strip: see "transitions beyond the inline ones"
     int xs_first[CHX];
     double xl_first[CHX];
@@ -902,7 +909,7 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
       Fwd10 own10 = Fwd10{NI, NI, NI, NI, NI, NI, NI, NI, NI, NI};
       double up_imm = NI, up_imd = NI, up_iiw = NI, up_g0 = NI, up_g1 = NI;
       // (the first step's store goes to the slot that step's own cell will overwrite one step later)
-      int64_t pend_slot = own.base + ((int64_t)(wlo[w] >> 1) << 7) + (wlo[w] & 1);
+      unsigned pend_slot = own.base + ((unsigned)(wlo[w] >> 1) << 7) + (unsigned)(wlo[w] & 1);
       for (int t = wlo[w]; t < whi[w]; ++t) {
         if (s > 0) {
           const int need = above_base + (t + 1 < Cc ? t + 1 : Cc);
@@ -932,12 +939,11 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
         }
         const bool ynull = yf & F_NULL, yok = (yf & F_READY) || yempty;
         const int mode = (!xnull && !ynull) ? 1 : ((ynull && xeos) ? 2 : (yok ? 3 : 0));
-        const int64_t offYa = ynull ? 2 * plane : aggoff + 2 * plane, offYb = ynull ? 3 * plane : aggoff + 3 * plane;
-        const int64_t o4 = aggoff + 4 * plane;
+        const PairPlanes<MULTI> Ya = M.at(ynull ? 2 * plane : aggoff + 2 * plane), Yb = M.at(ynull ? 3 * plane : aggoff + 3 * plane);
         const bool xgo = act && yok, ygo = act && (ynull || xok);
         const int jc = j < 0 ? 0 : (j >= Cc ? Cc - 1 : j);       // a valid column for the addresses of idle lanes
         bool adjy[K];
-        int64_t sXj[K], sOy[K];
+        unsigned sXj[K], sOy[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           adjy[k] = ydeg > k && Y.s[k] == j - 1;
@@ -961,23 +967,23 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
         for (int k = 0; k < K; ++k) { xa[k] = NI; xb[k] = NI; ya[k] = NI; yb[k] = NI; }
 #pragma unroll
         for (int k = 0; k < K * K; ++k) mv[k] = NI;
-        xa[0] = M[offXa + sXj[0]]; xb[0] = M[offXb + sXj[0]];
-        ya[0] = M[offYa + sOy[0]]; yb[0] = M[offYb + sOy[0]];
-        mv[0] = M[mode == 1 ? o4 + slot_at(XR[0], Y.s[0]) : (mode == 2 ? sOy[0] : sXj[0])];
+        xa[0] = Xa[sXj[0]]; xb[0] = Xb[sXj[0]];
+        ya[0] = Ya[sOy[0]]; yb[0] = Yb[sOy[0]];
+        mv[0] = (mode == 1 ? G4 : M)[mode == 1 ? slot_at(XR[0], Y.s[0]) : (mode == 2 ? sOy[0] : sXj[0])];
         double e;
         if (etab) e = etab[(int64_t)(X.cls < 0 ? 0 : X.cls) * Ky + (Y.cls < 0 ? 0 : Y.cls)];
         else e = eplane[slot_at(own, jc)];
 #pragma unroll
         for (int k = 1; k < K; ++k) {
-          if (xgo && xdeg > k) { xa[k] = M[offXa + sXj[k]]; xb[k] = M[offXb + sXj[k]]; }
-          if (ygo && ydeg > k) { ya[k] = M[offYa + sOy[k]]; yb[k] = M[offYb + sOy[k]]; }
+          if (xgo && xdeg > k) { xa[k] = Xa[sXj[k]]; xb[k] = Xb[sXj[k]]; }
+          if (ygo && ydeg > k) { ya[k] = Ya[sOy[k]]; yb[k] = Yb[sOy[k]]; }
         }
         if (act && mode == 1) {
 #pragma unroll
           for (int a = 0; a < K; ++a)
 #pragma unroll
             for (int b = 0; b < K; ++b)
-              if ((a | b) != 0 && xdeg > a && ydeg > b) mv[a * K + b] = M[o4 + slot_at(XR[a], Y.s[b])];
+              if ((a | b) != 0 && xdeg > a && ydeg > b) mv[a * K + b] = G4[slot_at(XR[a], Y.s[b])];
         } else if (act && mode == 2) {
 #pragma unroll
           for (int k = 1; k < K; ++k) if (ydeg > k) mv[k] = M[sOy[k]];
@@ -1004,18 +1010,18 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
             if (a0 + q < xdeg) {
               const bool adj = lane > 0 && src[q] == i - 1;         // the previous lane's cell of the previous step
               const RowRef rr = row_ref(ss, src[q]);
-              const int64_t sl = slot_at(rr, j);
-              if (xgo && !adj) { xv.va[q] = M[offXa + sl]; xv.vb[q] = M[offXb + sl]; }
+              const unsigned sl = slot_at(rr, j);
+              if (xgo && !adj) { xv.va[q] = Xa[sl]; xv.vb[q] = Xb[sl]; }
               if (mode == 3 && !adj) xv.g[q][0] = M[sl];
               if (rpairs || bpairs) {                               // (a pair's source is >= 2 steps old: in memory)
 #pragma unroll
                 for (int b = 0; b < K; ++b)
-                  if (b < ydeg) xv.g[q][b] = M[o4 + slot_at(rr, Y.s[b])];
+                  if (b < ydeg) xv.g[q][b] = G4[slot_at(rr, Y.s[b])];
               }
               if (bpairs) {
 #pragma unroll
                 for (int r = 0; r < CHY; ++r)
-                  if (K + r < ydeg) xv.gg[q][r] = M[o4 + slot_at(rr, ys_first[r])];
+                  if (K + r < ydeg) xv.gg[q][r] = G4[slot_at(rr, ys_first[r])];
               }
             }
           }
@@ -1026,13 +1032,13 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
             yv.va[q] = ownA; yv.vb[q] = ownB; yv.h[q][0] = own10.imm;
             if (b0 + q < ydeg) {
               const bool adj = src[q] == j - 1;                     // the lane's own cell of the previous step
-              const int64_t sl = slot_at(own, src[q]);
-              if (ygo && !adj) { yv.va[q] = M[offYa + sl]; yv.vb[q] = M[offYb + sl]; }
+              const unsigned sl = slot_at(own, src[q]);
+              if (ygo && !adj) { yv.va[q] = Ya[sl]; yv.vb[q] = Yb[sl]; }
               if (mode == 2 && !adj) yv.h[q][0] = M[sl];
               if (cpairs || bpairs) {
 #pragma unroll
                 for (int a = 0; a < K; ++a)
-                  if (a < xdeg) yv.h[q][a] = M[o4 + slot_at(XR[a], src[q])];
+                  if (a < xdeg) yv.h[q][a] = G4[slot_at(XR[a], src[q])];
               }
             }
           }
@@ -1188,7 +1194,7 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
               const RowRef rr = row_ref(ss, xin_src[X.in_b + a]);
               const double lpx = xin_lp[X.in_b + a];
               for (int b = 0; b < ydeg; ++b)
-                imm = L(imm, (M[o4 + slot_at(rr, yin_src[Y.in_b + b])] + lpx) + yin_lp[Y.in_b + b]);
+                imm = L(imm, (G4[slot_at(rr, yin_src[Y.in_b + b])] + lpx) + yin_lp[Y.in_b + b]);
             }
           }
           if (!xnull && yok) { imd += X.rootsub; iiw += X.ins; }
@@ -1240,7 +1246,7 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
         HX_TR(4);      // stores issued, outgoing sums
         // ---- rotate: this step's cell becomes `own`, and the next lane's `up` ----
         own10 = c;
-        pend_slot = own.base + ((int64_t)(t >> 1) << 7) + (t & 1);
+        pend_slot = own.base + ((unsigned)(t >> 1) << 7) + (unsigned)(t & 1);
         up_imm = wave_shr1(c.imm); up_imd = wave_shr1(c.imd); up_iiw = wave_shr1(c.iiw);
         up_g0 = wave_shr1(c.g0); up_g1 = wave_shr1(c.g1);
         // ---- publish, every 8th step: drain, then all stores issued so far (the cells of steps <= t-1)
