@@ -839,6 +839,7 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
   // issued with the step's own (the several-workgroups launch has four waves per workgroup, i.e. 512 registers per lane)
   constexpr int CHX = MULTI ? 6 : 2, CHY = MULTI ? 4 : 2;
   constexpr bool EARLY = MULTI;
+  constexpr bool BPAIRS = MULTI;     // (needs the registers of that launch too)
   // g / h: a further transition's pairs with the other side's inline transitions ([.][0] doubles as the IMM source when the
   // other state is null); gg: the pairs of two further transitions
   struct XRound { double va[CHX], vb[CHX], g[CHX][HX_DAG_INLINE], gg[CHX][CHY]; };
@@ -998,7 +999,7 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
         const bool cpairs = mode == 1 && xdeg == 1;                 // the column's do (pair with the row's only transition)
         // several row transitions AND further column transitions, all of them among the entries in registers: one round each
         // (only where there are registers for it: the several-workgroups launch; else such cells take the generic loop below)
-        const bool bpairs = EARLY && mode == 1 && xdeg > 1 && ydeg > K && xdeg <= K + CHX && ydeg <= K + CHY;
+        const bool bpairs = BPAIRS && mode == 1 && xdeg > 1 && ydeg > K && xdeg <= K + CHX && ydeg <= K + CHY;
         const double upA = xnull ? up_imd : up_g0, upB = xnull ? up_iiw : up_g1;
         const double ownA = ynull ? own10.idm : own10.g2, ownB = ynull ? own10.imi : own10.g3;
         XRound xv;
