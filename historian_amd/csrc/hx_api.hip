@@ -1374,7 +1374,7 @@ int hx_batch_backward(hx_batch* b, void* stream) {
             b->used_multi[1] = true;
             const int strips = (cr.max_rows + HX_STRIP - 1) / HX_STRIP;
             if (const char* e = getenv("HX_DAG_MULTI_WAVES")) multi_waves = atoi(e);      // tuning hook: waves per workgroup (default 4: measured 1.24 / 1.13 / 1.02 / 1.01 s at one workgroup / 16 / 8 / 4 waves)
-            if (multi_waves != 16 && multi_waves != 8 && multi_waves != 2) multi_waves = 4;
+            if (multi_waves != 8 && multi_waves != 2) multi_waves = 4;      // (the kernel is built for at most eight: 256 registers per lane)
             multi = std::min(256 / multi_waves, (strips + multi_waves - 1) / multi_waves);   // (progress counters: 256 per pair)
             multi = std::min(multi, std::min(32, HX_MULTI_MAX_GROUPS / cr.n));
             for (int q = 0; q < cr.n && multi > 1; ++q) {

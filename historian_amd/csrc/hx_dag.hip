@@ -294,8 +294,8 @@ typedef int i4v __attribute__((ext_vector_type(4)));
 typedef double bw_d2 __attribute__((ext_vector_type(2)));
 struct BwdRec {
   int ab, ae, nb, ne;                  // absorbing / null out-transitions (CSR ranges)
-  int d0, flags, env, pad;             // destination of the first absorbing transition; the state's flags and envelope coordinate
-  double lp0, rs0, ins0, spare;        // its weight, rootsub and ins of its destination
+  int d0, flags, env, n0;              // destination of the first absorbing transition; the state's flags and envelope coordinate; destination of the first null transition
+  double lp0, rs0, ins0, nlp0;         // the first absorbing transition's weight, rootsub and ins of its destination; the first null transition's weight
 };
 __device__ __forceinline__ void build_bwd_recs(const Side& s, HX_GLOBAL BwdRec* out, bool banded, int tid, int threads) {
   for (int i = tid; i < s.n; i += threads) {
@@ -304,7 +304,8 @@ __device__ __forceinline__ void build_bwd_recs(const Side& s, HX_GLOBAL BwdRec* 
     r.nb = s.no_off[i]; r.ne = s.no_off[i + 1];
     r.flags = s.flags[i];
     r.env = banded ? s.env[i] : 0;
-    r.pad = 0; r.spare = 0.;
+    r.n0 = 0; r.nlp0 = HX_NEG_INF;
+    if (r.ne > r.nb) { r.n0 = s.no_dst[r.nb]; r.nlp0 = s.no_lp[r.nb]; }
     r.d0 = 0; r.lp0 = r.rs0 = r.ins0 = HX_NEG_INF;
     if (r.ae > r.ab) {
       r.d0 = s.ao_dst[r.ab];
@@ -314,9 +315,9 @@ __device__ __forceinline__ void build_bwd_recs(const Side& s, HX_GLOBAL BwdRec* 
     }
     HX_GLOBAL i4v* q = (HX_GLOBAL i4v*)(out + i);
     q[0] = i4v{r.ab, r.ae, r.nb, r.ne};
-    q[1] = i4v{r.d0, r.flags, r.env, 0};
+    q[1] = i4v{r.d0, r.flags, r.env, r.n0};
     ((HX_GLOBAL bw_d2*)q)[2] = bw_d2{r.lp0, r.rs0};
-    ((HX_GLOBAL bw_d2*)q)[3] = bw_d2{r.ins0, 0.};
+    ((HX_GLOBAL bw_d2*)q)[3] = bw_d2{r.ins0, r.nlp0};
   }
 }
 __device__ __forceinline__ BwdRec load_bwd_rec(const HX_GLOBAL BwdRec* p) {
@@ -325,8 +326,8 @@ __device__ __forceinline__ BwdRec load_bwd_rec(const HX_GLOBAL BwdRec* p) {
   const bw_d2 c = ((const HX_GLOBAL bw_d2*)q)[2], d = ((const HX_GLOBAL bw_d2*)q)[3];
   BwdRec r;
   r.ab = a.x; r.ae = a.y; r.nb = a.z; r.ne = a.w;
-  r.d0 = b.x; r.flags = b.y; r.env = b.z; r.pad = 0;
-  r.lp0 = c.x; r.rs0 = c.y; r.ins0 = d.x; r.spare = 0.;
+  r.d0 = b.x; r.flags = b.y; r.env = b.z; r.n0 = b.w;
+  r.lp0 = c.x; r.rs0 = c.y; r.ins0 = d.x; r.nlp0 = d.y;
   return r;
 }
 
@@ -365,13 +366,28 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
   const int xab = rx.ab, xae = rx.ae, yab = ry.ab, yae = ry.ae;
   const int xnb = rx.nb, xne = rx.ne, ynb = ry.nb, yne = ry.ne;
 
+  // ---- everything that hangs on the FIRST out-transitions (absorbing and null, of the row's state and of the column's: all in
+  // the two records) is fetched in one batch before the first look-up; the sums below take those values where their turn comes,
+  // so the order of operations is unchanged.  Nine states in ten have no further transition: a cell is then one round trip where
+  // each of the five loops paid its own.
+  const bool hx0 = xae > xab, hy0 = yae > yab;
+  const bool hxn = yok && xne > xnb && rx.n0 < R, hyn = yne > ynb && ry.n0 < Cc;
+  double e00 = HX_NEG_INF, m00 = HX_NEG_INF, x1 = HX_NEG_INF, x4 = HX_NEG_INF, y2 = HX_NEG_INF, y3 = HX_NEG_INF;
+  double xn0 = HX_NEG_INF, xn1 = HX_NEG_INF, xn4 = HX_NEG_INF, yn0 = HX_NEG_INF, yn2 = HX_NEG_INF, yn3 = HX_NEG_INF;
+  if (hx0 && hy0) { e00 = emis_at(m, x, y, rx.d0, ry.d0); m00 = M[BS(rx.d0, ry.d0)]; }
+  if (yok && hx0) { const int64_t sl = BS(rx.d0, j); x1 = M[plane + sl]; x4 = M[4 * plane + sl]; }
+  if (xok && hy0) { const int64_t sl = BS(i, ry.d0); y2 = M[2 * plane + sl]; y3 = M[3 * plane + sl]; }
+  if (hxn) { const int64_t sl = BS(rx.n0, j); xn1 = M[plane + sl]; xn4 = M[4 * plane + sl]; xn0 = M[sl]; }
+  if (hyn) { const int64_t sl = BS(i, ry.n0); yn2 = M[2 * plane + sl]; yn3 = M[3 * plane + sl]; if (xf & F_EMIT_OR_START) yn0 = M[sl]; }
+
   for (int tx = xab; tx < xae; ++tx) {
     const int dx = tx == xab ? rx.d0 : x.ao_dst[tx];
     const double lpx = tx == xab ? rx.lp0 : x.ao_lp[tx];
     for (int ty = yab; ty < yae; ++ty) {
+      const bool first = tx == xab && ty == yab;
       const int dy = ty == yab ? ry.d0 : y.ao_dst[ty];
       const double lpy = ty == yab ? ry.lp0 : y.ao_lp[ty];
-      const double d = lpx + lpy + emis_at(m, x, y, dx, dy) + M[BS(dx, dy)];
+      const double d = lpx + lpy + (first ? e00 : emis_at(m, x, y, dx, dy)) + (first ? m00 : M[BS(dx, dy)]);
       r.imm = L(r.imm, T[0][0] + d);
       r.imd = L(r.imd, T[1][0] + d);
       r.idm = L(r.idm, T[2][0] + d);
@@ -385,8 +401,8 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
       const int dx = first ? rx.d0 : x.ao_dst[tx];
       const double lpx = first ? rx.lp0 : x.ao_lp[tx];
       const int64_t sl = BS(dx, j);
-      const double d1 = lpx + (first ? rx.rs0 : x.rootsub[dx]) + M[plane + sl];
-      const double d2 = lpx + (first ? rx.ins0 : x.ins[dx]) + M[4 * plane + sl];
+      const double d1 = lpx + (first ? rx.rs0 : x.rootsub[dx]) + (first ? x1 : M[plane + sl]);
+      const double d2 = lpx + (first ? rx.ins0 : x.ins[dx]) + (first ? x4 : M[4 * plane + sl]);
       r.imm = L(r.imm, T[0][1] + d1);
       r.imd = L(r.imd, T[1][1] + d1);
       r.idm = L(r.idm, T[2][1] + d1);
@@ -401,8 +417,8 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
       const int dy = first ? ry.d0 : y.ao_dst[ty];
       const double lpy = first ? ry.lp0 : y.ao_lp[ty];
       const int64_t sl = BS(i, dy);
-      const double d1 = lpy + (first ? ry.rs0 : y.rootsub[dy]) + M[2 * plane + sl];
-      const double d2 = lpy + (first ? ry.ins0 : y.ins[dy]) + M[3 * plane + sl];
+      const double d1 = lpy + (first ? ry.rs0 : y.rootsub[dy]) + (first ? y2 : M[2 * plane + sl]);
+      const double d2 = lpy + (first ? ry.ins0 : y.ins[dy]) + (first ? y3 : M[3 * plane + sl]);
       r.imm = L(r.imm, T[0][2] + d1);
       r.imd = L(r.imd, T[1][2] + d1);
       r.idm = L(r.idm, T[2][2] + d1);
@@ -412,32 +428,35 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
     }
   if (yok)
     for (int tx = xnb; tx < xne; ++tx) {
-      const int dx = x.no_dst[tx];
+      const bool first = tx == xnb;
+      const int dx = first ? rx.n0 : x.no_dst[tx];
       if (dx >= R) continue;   // END is not stored: xyCell(END,.) is the empty cell
-      const double lpx = x.no_lp[tx];
+      const double lpx = first ? rx.nlp0 : x.no_lp[tx];
       const int64_t sl = BS(dx, j);
-      r.imd = L(r.imd, lpx + M[plane + sl]);
-      r.iiw = L(r.iiw, lpx + M[4 * plane + sl]);
-      r.imm = L(r.imm, lpx + M[sl]);
+      r.imd = L(r.imd, lpx + (first ? xn1 : M[plane + sl]));
+      r.iiw = L(r.iiw, lpx + (first ? xn4 : M[4 * plane + sl]));
+      r.imm = L(r.imm, lpx + (first ? xn0 : M[sl]));
     }
   for (int ty = ynb; ty < yne; ++ty) {
-    const int dy = y.no_dst[ty];
+    const bool first = ty == ynb;
+    const int dy = first ? ry.n0 : y.no_dst[ty];
     if (dy >= Cc) continue;
-    const double lpy = y.no_lp[ty];
+    const double lpy = first ? ry.nlp0 : y.no_lp[ty];
     const int64_t sl = BS(i, dy);
-    r.idm = L(r.idm, lpy + M[2 * plane + sl]);
-    r.imi = L(r.imi, lpy + M[3 * plane + sl]);
-    if (xf & F_EMIT_OR_START) r.imm = L(r.imm, lpy + M[sl]);
+    r.idm = L(r.idm, lpy + (first ? yn2 : M[2 * plane + sl]));
+    r.imi = L(r.imi, lpy + (first ? yn3 : M[3 * plane + sl]));
+    if (xf & F_EMIT_OR_START) r.imm = L(r.imm, lpy + (first ? yn0 : M[sl]));
   }
 #undef BS
   return r;
 }
 
 #define HX_DAG_MAX_WAVES 16
+#define HX_DAG_REC_WAVES 8      // the state-record Backward kernels: 8 waves, so that a wave may use 256 registers (the batch of first-transition loads)
 
 // DIR 0: Forward, DIR 1: Backward (swept in mirrored coordinates)
 template <int DIR, class LSE, bool FAST, bool REC = false>
-__global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_fill_dag(const DevJob* __restrict__ jobs,
+__global__ void __launch_bounds__((REC ? HX_DAG_REC_WAVES : HX_DAG_MAX_WAVES) * 64) k_fill_dag(const DevJob* __restrict__ jobs,
                                                                       const double* __restrict__ exact_tab,
                                                                       const double* __restrict__ fast_tab) {
   __shared__ volatile int prog[HX_DAG_MAX_WAVES];
@@ -567,7 +586,7 @@ __global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_fill_dag(const DevJob
 // at once (the caller launches at most sixteen).  State records as in k_fill_dag<.., REC>.
 // ---------------------------------------------------------------------------------------------------------------------
 template <class LSE, bool FAST>
-__global__ void __launch_bounds__(HX_DAG_MAX_WAVES * 64) k_backward_dag_multi(const DevJob* __restrict__ jobs,
+__global__ void __launch_bounds__(HX_DAG_REC_WAVES * 64) k_backward_dag_multi(const DevJob* __restrict__ jobs,
                                                                                 const double* __restrict__ exact_tab,
                                                                                 const double* __restrict__ fast_tab, const int G, const int patience) {
   __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : 2];
@@ -1397,14 +1416,15 @@ int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab
   // one or two pairs of more than sixteen strips: several workgroups per pair (k_backward_dag_multi); the caller has zeroed
   // the progress counters
   if (records && multi > 1) {
-    const dim3 gm(n_jobs * multi), bm((multi_waves > 0 ? multi_waves : HX_DAG_MAX_WAVES) * 64);
-if (fast) hipLaunchKernelGGL((k_backward_dag_multi<FastLse, true>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi, multi_patience());
+    const dim3 gm(n_jobs * multi), bm((multi_waves > 0 && multi_waves <= HX_DAG_REC_WAVES ? multi_waves : HX_DAG_REC_WAVES) * 64);
+    if (fast) hipLaunchKernelGGL((k_backward_dag_multi<FastLse, true>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi, multi_patience());
     else hipLaunchKernelGGL((k_backward_dag_multi<ExactLse3, false>), gm, bm, 0, st, d_jobs, tab, fast_tab, multi, multi_patience());
     return 0;
   }
   if (records) {
-    if (fast) hipLaunchKernelGGL((k_fill_dag<1, FastLse, true, true>), g, b, 0, st, d_jobs, tab, fast_tab);
-    else hipLaunchKernelGGL((k_fill_dag<1, ExactLse3, false, true>), g, b, 0, st, d_jobs, tab, fast_tab);
+    const dim3 br(dag_waves(max_rows, HX_DAG_REC_WAVES) * 64);
+    if (fast) hipLaunchKernelGGL((k_fill_dag<1, FastLse, true, true>), g, br, 0, st, d_jobs, tab, fast_tab);
+    else hipLaunchKernelGGL((k_fill_dag<1, ExactLse3, false, true>), g, br, 0, st, d_jobs, tab, fast_tab);
     return 0;
   }
   if (fast) hipLaunchKernelGGL((k_fill_dag<1, FastLse, true>), g, b, 0, st, d_jobs, tab, fast_tab);
