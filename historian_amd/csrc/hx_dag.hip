@@ -282,52 +282,73 @@ __device__ __forceinline__ C5 backward_cell_dag(const Mat& m, const Side& x, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Backward with state records (round 2).  The recursion above walks a state's out-transitions through the CSR arrays:
+// Backward with state records (rounds 2-3).  The recursion above walks a state's out-transitions through the CSR arrays:
 // offsets, then destinations and weights, then the destinations' constants, then the matrix - four loads deep, sixty-four
-// loads per wave-step.  A 64-byte record per state holds the CSR ranges, the flags and envelope coordinate and the FIRST
-// absorbing out-transition in full (nine states in ten have exactly one); the workgroup builds the records of its two
-// profiles into the pair's scratch planes (free after the Forward fill) before it starts.  A row's record stays in
-// registers for the strip, a column's is four 16-byte loads; the matrix loads of the first transitions follow at once.
+// loads per wave-step.  A 96-byte record per state holds the CSR ranges, the flags and envelope coordinate, the first TWO
+// absorbing out-transitions in full (destination, weight, emission class, rootsub and ins of the destination: nine states
+// in ten have one, all but two in a hundred at most two) and the first null out-transition; the workgroup builds the
+// records of its two profiles into the pair's scratch planes (free after the Forward fill) before it starts.  A row's
+// record stays in registers for the strip, a column's is six 16-byte loads; everything that hangs on the recorded
+// transitions - up to four transition pairs, two cells each for the x- and y-absorbing moves of two transitions, three
+// each for the null moves - is then fetched in ONE batch before the first look-up (round 3: a build with every out-degree
+// clamped to one showed that the second and further transitions, taken one at a time with their own dependent loads, were
+// 55-60 % of the fill's time).  Third and further transitions are walked as before.
 // Same operations on the same operands in the same order as backward_cell_dag: bit-identical.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef int i4v __attribute__((ext_vector_type(4)));
 typedef double bw_d2 __attribute__((ext_vector_type(2)));
 struct BwdRec {
   int ab, ae, nb, ne;                  // absorbing / null out-transitions (CSR ranges)
-  int d0, flags, env, n0;              // destination of the first absorbing transition; the state's flags and envelope coordinate; destination of the first null transition
-  double lp0, rs0, ins0, nlp0;         // the first absorbing transition's weight, rootsub and ins of its destination; the first null transition's weight
+  int d[2], c[2];                      // destinations of the first two absorbing transitions and their emission classes
+  int flags, env, n[2];                // the state's flags and envelope coordinate; destinations of the first two null transitions
+  double lp[2], rs[2], ins[2];         // the two absorbing transitions' weights, rootsub and ins of their destinations
+  double nlp[2];                       // the two null transitions' weights (a state that has null out-transitions usually has two)
 };
-__device__ __forceinline__ void build_bwd_recs(const Side& s, HX_GLOBAL BwdRec* out, bool banded, int tid, int threads) {
+// in memory: seven 16-byte quarters {ab, ae, nb, ne} {d0, d1, c0, c1} {flags, env, n0, n1} {lp0, lp1} {rs0, rs1} {ins0, ins1} {nlp0, nlp1}
+#define HX_BWD_REC_BYTES 112
+__device__ __forceinline__ void build_bwd_recs(const Side& s, HX_GLOBAL char* out, bool banded, int tid, int threads) {
   for (int i = tid; i < s.n; i += threads) {
     BwdRec r;
     r.ab = s.ao_off[i]; r.ae = s.ao_off[i + 1];
     r.nb = s.no_off[i]; r.ne = s.no_off[i + 1];
     r.flags = s.flags[i];
     r.env = banded ? s.env[i] : 0;
-    r.n0 = 0; r.nlp0 = HX_NEG_INF;
-    if (r.ne > r.nb) { r.n0 = s.no_dst[r.nb]; r.nlp0 = s.no_lp[r.nb]; }
-    r.d0 = 0; r.lp0 = r.rs0 = r.ins0 = HX_NEG_INF;
-    if (r.ae > r.ab) {
-      r.d0 = s.ao_dst[r.ab];
-      r.lp0 = s.ao_lp[r.ab];
-      r.rs0 = s.rootsub[r.d0];
-      r.ins0 = s.ins[r.d0];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      r.n[k] = 0; r.nlp[k] = HX_NEG_INF;
+      if (r.ne > r.nb + k) { r.n[k] = s.no_dst[r.nb + k]; r.nlp[k] = s.no_lp[r.nb + k]; }
     }
-    HX_GLOBAL i4v* q = (HX_GLOBAL i4v*)(out + i);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      r.d[k] = 0; r.c[k] = -1; r.lp[k] = r.rs[k] = r.ins[k] = HX_NEG_INF;
+      if (r.ae > r.ab + k) {
+        r.d[k] = s.ao_dst[r.ab + k];
+        r.lp[k] = s.ao_lp[r.ab + k];
+        r.c[k] = s.cls[r.d[k]];
+        r.rs[k] = s.rootsub[r.d[k]];
+        r.ins[k] = s.ins[r.d[k]];
+      }
+    }
+    HX_GLOBAL i4v* q = (HX_GLOBAL i4v*)(out + (size_t)i * HX_BWD_REC_BYTES);
     q[0] = i4v{r.ab, r.ae, r.nb, r.ne};
-    q[1] = i4v{r.d0, r.flags, r.env, r.n0};
-    ((HX_GLOBAL bw_d2*)q)[2] = bw_d2{r.lp0, r.rs0};
-    ((HX_GLOBAL bw_d2*)q)[3] = bw_d2{r.ins0, r.nlp0};
+    q[1] = i4v{r.d[0], r.d[1], r.c[0], r.c[1]};
+    q[2] = i4v{r.flags, r.env, r.n[0], r.n[1]};
+    ((HX_GLOBAL bw_d2*)q)[3] = bw_d2{r.lp[0], r.lp[1]};
+    ((HX_GLOBAL bw_d2*)q)[4] = bw_d2{r.rs[0], r.rs[1]};
+    ((HX_GLOBAL bw_d2*)q)[5] = bw_d2{r.ins[0], r.ins[1]};
+    ((HX_GLOBAL bw_d2*)q)[6] = bw_d2{r.nlp[0], r.nlp[1]};
   }
 }
-__device__ __forceinline__ BwdRec load_bwd_rec(const HX_GLOBAL BwdRec* p) {
-  const HX_GLOBAL i4v* q = (const HX_GLOBAL i4v*)p;
-  const i4v a = q[0], b = q[1];
-  const bw_d2 c = ((const HX_GLOBAL bw_d2*)q)[2], d = ((const HX_GLOBAL bw_d2*)q)[3];
+__device__ __forceinline__ BwdRec load_bwd_rec(const HX_GLOBAL char* base, int i) {
+  const HX_GLOBAL i4v* q = (const HX_GLOBAL i4v*)(base + (size_t)i * HX_BWD_REC_BYTES);
+  const i4v a = q[0], b = q[1], c = q[2];
+  const bw_d2 d = ((const HX_GLOBAL bw_d2*)q)[3], e = ((const HX_GLOBAL bw_d2*)q)[4], f = ((const HX_GLOBAL bw_d2*)q)[5], g = ((const HX_GLOBAL bw_d2*)q)[6];
   BwdRec r;
   r.ab = a.x; r.ae = a.y; r.nb = a.z; r.ne = a.w;
-  r.d0 = b.x; r.flags = b.y; r.env = b.z; r.n0 = b.w;
-  r.lp0 = c.x; r.rs0 = c.y; r.ins0 = d.x; r.nlp0 = d.y;
+  r.d[0] = b.x; r.d[1] = b.y; r.c[0] = b.z; r.c[1] = b.w;
+  r.flags = c.x; r.env = c.y; r.n[0] = c.z; r.n[1] = c.w;
+  r.lp[0] = d.x; r.lp[1] = d.y; r.rs[0] = e.x; r.rs[1] = e.y; r.ins[0] = f.x; r.ins[1] = f.y;
+  r.nlp[0] = g.x; r.nlp[1] = g.y;
   return r;
 }
 
@@ -342,6 +363,11 @@ struct CellLoads {
     return p[k];
   }
 };
+// emission of the pair of destination states (dx, dy) whose classes are known (emis_at without the two class loads)
+__device__ __forceinline__ double emis_known(const Mat& m, int ncy, int cx, int cy, int dx, int dy) {
+  if (m.etab) return (cx < 0 || cy < 0) ? HX_NEG_INF : m.etab[(int64_t)cx * ncy + cy];
+  return m.eplane[cell_slot(m.ss, dx, dy)];
+}
 template <class LSE, bool COH = false>
 __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, const Side& y, const double (*T)[6],
                                                 const LSE& L, int i, int j, const BwdRec& rx, const BwdRec& ry) {
@@ -365,44 +391,67 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
   const bool xok = (xf & F_READY) || x.empty;
   const int xab = rx.ab, xae = rx.ae, yab = ry.ab, yae = ry.ae;
   const int xnb = rx.nb, xne = rx.ne, ynb = ry.nb, yne = ry.ne;
+  const int xn = xae - xab, yn = yae - yab;              // absorbing out-degrees
 
-  // ---- everything that hangs on the FIRST out-transitions (absorbing and null, of the row's state and of the column's: all in
-  // the two records) is fetched in one batch before the first look-up; the sums below take those values where their turn comes,
-  // so the order of operations is unchanged.  Nine states in ten have no further transition: a cell is then one round trip where
-  // each of the five loops paid its own.
-  const bool hx0 = xae > xab, hy0 = yae > yab;
-  const bool hxn = yok && xne > xnb && rx.n0 < R, hyn = yne > ynb && ry.n0 < Cc;
-  double e00 = HX_NEG_INF, m00 = HX_NEG_INF, x1 = HX_NEG_INF, x4 = HX_NEG_INF, y2 = HX_NEG_INF, y3 = HX_NEG_INF;
-  double xn0 = HX_NEG_INF, xn1 = HX_NEG_INF, xn4 = HX_NEG_INF, yn0 = HX_NEG_INF, yn2 = HX_NEG_INF, yn3 = HX_NEG_INF;
-  if (hx0 && hy0) { e00 = emis_at(m, x, y, rx.d0, ry.d0); m00 = M[BS(rx.d0, ry.d0)]; }
-  if (yok && hx0) { const int64_t sl = BS(rx.d0, j); x1 = M[plane + sl]; x4 = M[4 * plane + sl]; }
-  if (xok && hy0) { const int64_t sl = BS(i, ry.d0); y2 = M[2 * plane + sl]; y3 = M[3 * plane + sl]; }
-  if (hxn) { const int64_t sl = BS(rx.n0, j); xn1 = M[plane + sl]; xn4 = M[4 * plane + sl]; xn0 = M[sl]; }
-  if (hyn) { const int64_t sl = BS(i, ry.n0); yn2 = M[2 * plane + sl]; yn3 = M[3 * plane + sl]; if (xf & F_EMIT_OR_START) yn0 = M[sl]; }
+  // ---- the batch: everything that hangs on the recorded transitions ----
+  double e[2][2], mm[2][2], x1[2], x4[2], y2[2], y3[2];
+  double xn0[2], xn1[2], xn4[2], yn0[2], yn2[2], yn3[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      e[a][b] = mm[a][b] = HX_NEG_INF;
+      if (a < xn && b < yn) { e[a][b] = emis_known(m, y.n_cls, rx.c[a], ry.c[b], rx.d[a], ry.d[b]); mm[a][b] = M[BS(rx.d[a], ry.d[b])]; }
+    }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    x1[a] = x4[a] = HX_NEG_INF;
+    if (yok && a < xn) { const int64_t sl = BS(rx.d[a], j); x1[a] = M[plane + sl]; x4[a] = M[4 * plane + sl]; }
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    y2[b] = y3[b] = HX_NEG_INF;
+    if (xok && b < yn) { const int64_t sl = BS(i, ry.d[b]); y2[b] = M[2 * plane + sl]; y3[b] = M[3 * plane + sl]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    xn0[k] = xn1[k] = xn4[k] = yn0[k] = yn2[k] = yn3[k] = HX_NEG_INF;
+    if (yok && xnb + k < xne && rx.n[k] < R) { const int64_t sl = BS(rx.n[k], j); xn1[k] = M[plane + sl]; xn4[k] = M[4 * plane + sl]; xn0[k] = M[sl]; }
+    if (ynb + k < yne && ry.n[k] < Cc) { const int64_t sl = BS(i, ry.n[k]); yn2[k] = M[2 * plane + sl]; yn3[k] = M[3 * plane + sl]; if (xf & F_EMIT_OR_START) yn0[k] = M[sl]; }
+  }
 
-  for (int tx = xab; tx < xae; ++tx) {
-    const int dx = tx == xab ? rx.d0 : x.ao_dst[tx];
-    const double lpx = tx == xab ? rx.lp0 : x.ao_lp[tx];
+  // ---- transition pairs, row transition by row transition (src/forward.cpp:1000-1016) ----
+  const auto pair_term = [&](const double d) {
+    r.imm = L(r.imm, T[0][0] + d);
+    r.imd = L(r.imd, T[1][0] + d);
+    r.idm = L(r.idm, T[2][0] + d);
+    r.imi = L(r.imi, T[3][0] + d);
+    r.iiw = L(r.iiw, T[4][0] + d);
+  };
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+    if (a < xn) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        if (b < yn) pair_term(rx.lp[a] + ry.lp[b] + e[a][b] + mm[a][b]);
+      for (int ty = yab + 2; ty < yae; ++ty) {           // the column's third and further transitions
+        const int dy = y.ao_dst[ty];
+        pair_term(rx.lp[a] + y.ao_lp[ty] + emis_at(m, x, y, rx.d[a], dy) + M[BS(rx.d[a], dy)]);
+      }
+    }
+  for (int tx = xab + 2; tx < xae; ++tx) {               // the row's third and further transitions
+    const int dx = x.ao_dst[tx];
+    const double lpx = x.ao_lp[tx];
     for (int ty = yab; ty < yae; ++ty) {
-      const bool first = tx == xab && ty == yab;
-      const int dy = ty == yab ? ry.d0 : y.ao_dst[ty];
-      const double lpy = ty == yab ? ry.lp0 : y.ao_lp[ty];
-      const double d = lpx + lpy + (first ? e00 : emis_at(m, x, y, dx, dy)) + (first ? m00 : M[BS(dx, dy)]);
-      r.imm = L(r.imm, T[0][0] + d);
-      r.imd = L(r.imd, T[1][0] + d);
-      r.idm = L(r.idm, T[2][0] + d);
-      r.imi = L(r.imi, T[3][0] + d);
-      r.iiw = L(r.iiw, T[4][0] + d);
+      const int k = ty - yab;
+      const int dy = k == 0 ? ry.d[0] : (k == 1 ? ry.d[1] : y.ao_dst[ty]);
+      const double lpy = k == 0 ? ry.lp[0] : (k == 1 ? ry.lp[1] : y.ao_lp[ty]);
+      pair_term(lpx + lpy + emis_at(m, x, y, dx, dy) + M[BS(dx, dy)]);
     }
   }
-  if (yok)
-    for (int tx = xab; tx < xae; ++tx) {
-      const bool first = tx == xab;
-      const int dx = first ? rx.d0 : x.ao_dst[tx];
-      const double lpx = first ? rx.lp0 : x.ao_lp[tx];
-      const int64_t sl = BS(dx, j);
-      const double d1 = lpx + (first ? rx.rs0 : x.rootsub[dx]) + (first ? x1 : M[plane + sl]);
-      const double d2 = lpx + (first ? rx.ins0 : x.ins[dx]) + (first ? x4 : M[4 * plane + sl]);
+  // ---- x-absorbing moves ----
+  if (yok) {
+    const auto x_term = [&](const double d1, const double d2) {
       r.imm = L(r.imm, T[0][1] + d1);
       r.imd = L(r.imd, T[1][1] + d1);
       r.idm = L(r.idm, T[2][1] + d1);
@@ -410,42 +459,71 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
       r.imm = L(r.imm, T[0][4] + d2);
       r.imi = L(r.imi, T[3][4] + d2);
       r.iiw = L(r.iiw, T[4][4] + d2);
+    };
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+      if (a < xn) x_term(rx.lp[a] + rx.rs[a] + x1[a], rx.lp[a] + rx.ins[a] + x4[a]);
+    for (int tx = xab + 2; tx < xae; ++tx) {
+      const int dx = x.ao_dst[tx];
+      const double lpx = x.ao_lp[tx];
+      const int64_t sl = BS(dx, j);
+      x_term(lpx + x.rootsub[dx] + M[plane + sl], lpx + x.ins[dx] + M[4 * plane + sl]);
     }
-  if (xok)
-    for (int ty = yab; ty < yae; ++ty) {
-      const bool first = ty == yab;
-      const int dy = first ? ry.d0 : y.ao_dst[ty];
-      const double lpy = first ? ry.lp0 : y.ao_lp[ty];
-      const int64_t sl = BS(i, dy);
-      const double d1 = lpy + (first ? ry.rs0 : y.rootsub[dy]) + (first ? y2 : M[2 * plane + sl]);
-      const double d2 = lpy + (first ? ry.ins0 : y.ins[dy]) + (first ? y3 : M[3 * plane + sl]);
+  }
+  // ---- y-absorbing moves ----
+  if (xok) {
+    const auto y_term = [&](const double d1, const double d2) {
       r.imm = L(r.imm, T[0][2] + d1);
       r.imd = L(r.imd, T[1][2] + d1);
       r.idm = L(r.idm, T[2][2] + d1);
       r.iiw = L(r.iiw, T[4][2] + d1);
       r.imm = L(r.imm, T[0][3] + d2);
       r.imi = L(r.imi, T[3][3] + d2);
+    };
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+      if (b < yn) y_term(ry.lp[b] + ry.rs[b] + y2[b], ry.lp[b] + ry.ins[b] + y3[b]);
+    for (int ty = yab + 2; ty < yae; ++ty) {
+      const int dy = y.ao_dst[ty];
+      const double lpy = y.ao_lp[ty];
+      const int64_t sl = BS(i, dy);
+      y_term(lpy + y.rootsub[dy] + M[2 * plane + sl], lpy + y.ins[dy] + M[3 * plane + sl]);
     }
-  if (yok)
-    for (int tx = xnb; tx < xne; ++tx) {
-      const bool first = tx == xnb;
-      const int dx = first ? rx.n0 : x.no_dst[tx];
-      if (dx >= R) continue;   // END is not stored: xyCell(END,.) is the empty cell
-      const double lpx = first ? rx.nlp0 : x.no_lp[tx];
+  }
+  // ---- null moves ----
+  if (yok) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (xnb + k < xne && rx.n[k] < R) {      // (END is not stored: xyCell(END,.) is the empty cell)
+        r.imd = L(r.imd, rx.nlp[k] + xn1[k]);
+        r.iiw = L(r.iiw, rx.nlp[k] + xn4[k]);
+        r.imm = L(r.imm, rx.nlp[k] + xn0[k]);
+      }
+    for (int tx = xnb + 2; tx < xne; ++tx) {
+      const int dx = x.no_dst[tx];
+      if (dx >= R) continue;
+      const double lpx = x.no_lp[tx];
       const int64_t sl = BS(dx, j);
-      r.imd = L(r.imd, lpx + (first ? xn1 : M[plane + sl]));
-      r.iiw = L(r.iiw, lpx + (first ? xn4 : M[4 * plane + sl]));
-      r.imm = L(r.imm, lpx + (first ? xn0 : M[sl]));
+      r.imd = L(r.imd, lpx + M[plane + sl]);
+      r.iiw = L(r.iiw, lpx + M[4 * plane + sl]);
+      r.imm = L(r.imm, lpx + M[sl]);
     }
-  for (int ty = ynb; ty < yne; ++ty) {
-    const bool first = ty == ynb;
-    const int dy = first ? ry.n0 : y.no_dst[ty];
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+    if (ynb + k < yne && ry.n[k] < Cc) {
+      r.idm = L(r.idm, ry.nlp[k] + yn2[k]);
+      r.imi = L(r.imi, ry.nlp[k] + yn3[k]);
+      if (xf & F_EMIT_OR_START) r.imm = L(r.imm, ry.nlp[k] + yn0[k]);
+    }
+  for (int ty = ynb + 2; ty < yne; ++ty) {
+    const int dy = y.no_dst[ty];
     if (dy >= Cc) continue;
-    const double lpy = first ? ry.nlp0 : y.no_lp[ty];
+    const double lpy = y.no_lp[ty];
     const int64_t sl = BS(i, dy);
-    r.idm = L(r.idm, lpy + (first ? yn2 : M[2 * plane + sl]));
-    r.imi = L(r.imi, lpy + (first ? yn3 : M[3 * plane + sl]));
-    if (xf & F_EMIT_OR_START) r.imm = L(r.imm, lpy + (first ? yn0 : M[sl]));
+    r.idm = L(r.idm, lpy + M[2 * plane + sl]);
+    r.imi = L(r.imi, lpy + M[3 * plane + sl]);
+    if (xf & F_EMIT_OR_START) r.imm = L(r.imm, lpy + M[sl]);
   }
 #undef BS
   return r;
@@ -485,11 +563,11 @@ __global__ void __launch_bounds__((REC ? HX_DAG_REC_WAVES : HX_DAG_MAX_WAVES) * 
   const HX_GLOBAL int32_t* win = as_global(DIR ? J.bwd_windows : J.fwd_windows);
   // REC: the state records of both profiles, built here into the pair's scratch planes (the caller launches this
   // instantiation only for pairs that have them, and only after the Forward fill is done with them)
-  HX_GLOBAL BwdRec* xrec = nullptr;
-  HX_GLOBAL BwdRec* yrec = nullptr;
+  HX_GLOBAL char* xrec = nullptr;
+  HX_GLOBAL char* yrec = nullptr;
   if (REC) {
-    xrec = (HX_GLOBAL BwdRec*)as_global(J.agg);
-    yrec = xrec + x.n;
+    xrec = (HX_GLOBAL char*)as_global(J.agg);
+    yrec = xrec + (size_t)x.n * HX_BWD_REC_BYTES;
     build_bwd_recs(x, xrec, banded, (int)threadIdx.x, threads);
     build_bwd_recs(y, yrec, banded, (int)threadIdx.x, threads);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -503,7 +581,7 @@ __global__ void __launch_bounds__((REC ? HX_DAG_REC_WAVES : HX_DAG_MAX_WAVES) * 
     const uint8_t xf = x.flags[i];
     const int xenv = banded ? x.env[i] : 0;
     BwdRec rx;
-    if (REC) rx = load_bwd_rec(xrec + i);
+    if (REC) rx = load_bwd_rec(xrec, i);
     const int above_base = ((s - 1) / W) * Cc;   // columns the wave above published in its earlier strips
     const int my_base = (s / W) * Cc;
     const int64_t store_base = (int64_t)s * m.ss + (lane << 1);
@@ -531,7 +609,7 @@ __global__ void __launch_bounds__((REC ? HX_DAG_REC_WAVES : HX_DAG_MAX_WAVES) * 
         if (rvalid && jm >= 0 && jm < Cc) {
           const int j = DIR ? Cc - 1 - jm : jm;
           BwdRec ry;
-          if (REC) ry = load_bwd_rec(yrec + j);
+          if (REC) ry = load_bwd_rec(yrec, j);
           const uint8_t yf = REC ? (uint8_t)ry.flags : y.flags[j];
           if (in_env(m, xf, yf, xenv, banded ? (REC ? ry.env : y.env[j]) : 0)) {
             const C5 c = REC ? backward_cell_rec(m, x, y, J.T, L, i, j, rx, ry)
@@ -612,8 +690,8 @@ __global__ void __launch_bounds__(HX_DAG_REC_WAVES * 64) k_backward_dag_multi(co
   const bool banded = J.max_dist >= 0;
   const HX_GLOBAL int32_t* win = as_global(J.bwd_windows);
   // records: every workgroup builds them (the same bytes at the same addresses), its own waves read them after its barrier
-  HX_GLOBAL BwdRec* xrec = (HX_GLOBAL BwdRec*)as_global(J.agg);
-  HX_GLOBAL BwdRec* yrec = xrec + x.n;
+  HX_GLOBAL char* xrec = (HX_GLOBAL char*)as_global(J.agg);
+  HX_GLOBAL char* yrec = xrec + (size_t)x.n * HX_BWD_REC_BYTES;
   build_bwd_recs(x, xrec, banded, (int)threadIdx.x, threads);
   build_bwd_recs(y, yrec, banded, (int)threadIdx.x, threads);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -633,7 +711,7 @@ __global__ void __launch_bounds__(HX_DAG_REC_WAVES * 64) k_backward_dag_multi(co
     const int i = rvalid ? R - 1 - im : 0;
     const uint8_t xf = x.flags[i];
     const int xenv = banded ? x.env[i] : 0;
-    const BwdRec rx = load_bwd_rec(xrec + i);
+    const BwdRec rx = load_bwd_rec(xrec, i);
     const int above_base = ((s - 1) / WT) * Cc;
     const int my_base = (s / WT) * Cc;
     const int64_t store_base = (int64_t)s * m.ss + (lane << 1);
@@ -661,7 +739,7 @@ __global__ void __launch_bounds__(HX_DAG_REC_WAVES * 64) k_backward_dag_multi(co
         const int jm = t - lane;
         if (!dead && rvalid && jm >= 0 && jm < Cc) {
           const int j = Cc - 1 - jm;
-          const BwdRec ry = load_bwd_rec(yrec + j);
+          const BwdRec ry = load_bwd_rec(yrec, j);
           const uint8_t yf = (uint8_t)ry.flags;
           if (in_env(m, xf, yf, xenv, banded ? ry.env : 0)) {
             const C5 c = backward_cell_rec<LSE, true>(m, x, y, J.T, L, i, j, rx, ry);
@@ -1407,7 +1485,7 @@ int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8
 }
 
 // `records`: every pair of the launch has scratch planes (DevJob::agg) that the Forward fill no longer needs and that hold
-// at least 8 doubles per state of its two profiles: the state-record formulation (backward_cell_rec)
+// at least 14 doubles (HX_BWD_REC_BYTES) per state of its two profiles: the state-record formulation (backward_cell_rec)
 int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 tab16,
                              bool fast, bool records, int multi, int multi_waves, hipStream_t st) {
   const double* tab = tab8.p;
