@@ -393,6 +393,12 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
   const int xnb = rx.nb, xne = rx.ne, ynb = ry.nb, yne = ry.ne;
   const int xn = xae - xab, yn = yae - yab;              // absorbing out-degrees
 
+  // the THIRD absorbing transitions' CSR entries go out in front of the batch (a tenth of the states that branch have one; a
+  // strip's 64 rows and a step's 64 columns hold one every other time): the loops below then start with a known destination
+  int d3x = 0, d3y = 0;
+  double lp3x = HX_NEG_INF, lp3y = HX_NEG_INF;
+  if (xn > 2) { d3x = x.ao_dst[xab + 2]; lp3x = x.ao_lp[xab + 2]; }
+  if (yn > 2) { d3y = y.ao_dst[yab + 2]; lp3y = y.ao_lp[yab + 2]; }
   // ---- the batch: everything that hangs on the recorded transitions ----
   double e[2][2], mm[2][2], x1[2], x4[2], y2[2], y3[2];
   double xn0[2], xn1[2], xn4[2], yn0[2], yn2[2], yn3[2];
@@ -435,17 +441,18 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
       for (int b = 0; b < 2; ++b)
         if (b < yn) pair_term(rx.lp[a] + ry.lp[b] + e[a][b] + mm[a][b]);
       for (int ty = yab + 2; ty < yae; ++ty) {           // the column's third and further transitions
-        const int dy = y.ao_dst[ty];
-        pair_term(rx.lp[a] + y.ao_lp[ty] + emis_at(m, x, y, rx.d[a], dy) + M[BS(rx.d[a], dy)]);
+        const bool third = ty == yab + 2;
+        const int dy = third ? d3y : y.ao_dst[ty];
+        pair_term(rx.lp[a] + (third ? lp3y : y.ao_lp[ty]) + emis_at(m, x, y, rx.d[a], dy) + M[BS(rx.d[a], dy)]);
       }
     }
   for (int tx = xab + 2; tx < xae; ++tx) {               // the row's third and further transitions
-    const int dx = x.ao_dst[tx];
-    const double lpx = x.ao_lp[tx];
+    const int dx = tx == xab + 2 ? d3x : x.ao_dst[tx];
+    const double lpx = tx == xab + 2 ? lp3x : x.ao_lp[tx];
     for (int ty = yab; ty < yae; ++ty) {
       const int k = ty - yab;
-      const int dy = k == 0 ? ry.d[0] : (k == 1 ? ry.d[1] : y.ao_dst[ty]);
-      const double lpy = k == 0 ? ry.lp[0] : (k == 1 ? ry.lp[1] : y.ao_lp[ty]);
+      const int dy = k == 0 ? ry.d[0] : (k == 1 ? ry.d[1] : (k == 2 ? d3y : y.ao_dst[ty]));
+      const double lpy = k == 0 ? ry.lp[0] : (k == 1 ? ry.lp[1] : (k == 2 ? lp3y : y.ao_lp[ty]));
       pair_term(lpx + lpy + emis_at(m, x, y, dx, dy) + M[BS(dx, dy)]);
     }
   }
@@ -464,8 +471,8 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
     for (int a = 0; a < 2; ++a)
       if (a < xn) x_term(rx.lp[a] + rx.rs[a] + x1[a], rx.lp[a] + rx.ins[a] + x4[a]);
     for (int tx = xab + 2; tx < xae; ++tx) {
-      const int dx = x.ao_dst[tx];
-      const double lpx = x.ao_lp[tx];
+      const int dx = tx == xab + 2 ? d3x : x.ao_dst[tx];
+      const double lpx = tx == xab + 2 ? lp3x : x.ao_lp[tx];
       const int64_t sl = BS(dx, j);
       x_term(lpx + x.rootsub[dx] + M[plane + sl], lpx + x.ins[dx] + M[4 * plane + sl]);
     }
@@ -484,8 +491,8 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
     for (int b = 0; b < 2; ++b)
       if (b < yn) y_term(ry.lp[b] + ry.rs[b] + y2[b], ry.lp[b] + ry.ins[b] + y3[b]);
     for (int ty = yab + 2; ty < yae; ++ty) {
-      const int dy = y.ao_dst[ty];
-      const double lpy = y.ao_lp[ty];
+      const int dy = ty == yab + 2 ? d3y : y.ao_dst[ty];
+      const double lpy = ty == yab + 2 ? lp3y : y.ao_lp[ty];
       const int64_t sl = BS(i, dy);
       y_term(lpy + y.rootsub[dy] + M[2 * plane + sl], lpy + y.ins[dy] + M[3 * plane + sl]);
     }
