@@ -297,15 +297,17 @@ __device__ __forceinline__ C5 backward_cell_dag(const Mat& m, const Side& x, con
 // ---------------------------------------------------------------------------------------------------------------------
 typedef int i4v __attribute__((ext_vector_type(4)));
 typedef double bw_d2 __attribute__((ext_vector_type(2)));
+#define HX_BWD_REC_ABS 3               // absorbing out-transitions a record holds in full
 struct BwdRec {
   int ab, ae, nb, ne;                  // absorbing / null out-transitions (CSR ranges)
-  int d[2], c[2];                      // destinations of the first two absorbing transitions and their emission classes
+  int d[3], c[3];                      // destinations of the first three absorbing transitions and their emission classes
   int flags, env, n[2];                // the state's flags and envelope coordinate; destinations of the first two null transitions
-  double lp[2], rs[2], ins[2];         // the two absorbing transitions' weights, rootsub and ins of their destinations
+  double lp[3], rs[3], ins[3];         // the absorbing transitions' weights, rootsub and ins of their destinations
   double nlp[2];                       // the two null transitions' weights (a state that has null out-transitions usually has two)
 };
-// in memory: seven 16-byte quarters {ab, ae, nb, ne} {d0, d1, c0, c1} {flags, env, n0, n1} {lp0, lp1} {rs0, rs1} {ins0, ins1} {nlp0, nlp1}
-#define HX_BWD_REC_BYTES 112
+// in memory: ten 16-byte quarters {ab, ae, nb, ne} {d0, d1, d2, c0} {c1, c2, flags, env} {n0, n1, -, -}
+//   {lp0, lp1} {lp2, rs0} {rs1, rs2} {ins0, ins1} {ins2, nlp0} {nlp1, -}
+#define HX_BWD_REC_BYTES 160
 __device__ __forceinline__ void build_bwd_recs(const Side& s, HX_GLOBAL char* out, bool banded, int tid, int threads) {
   for (int i = tid; i < s.n; i += threads) {
     BwdRec r;
@@ -319,7 +321,7 @@ __device__ __forceinline__ void build_bwd_recs(const Side& s, HX_GLOBAL char* ou
       if (r.ne > r.nb + k) { r.n[k] = s.no_dst[r.nb + k]; r.nlp[k] = s.no_lp[r.nb + k]; }
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
       r.d[k] = 0; r.c[k] = -1; r.lp[k] = r.rs[k] = r.ins[k] = HX_NEG_INF;
       if (r.ae > r.ab + k) {
         r.d[k] = s.ao_dst[r.ab + k];
@@ -331,24 +333,29 @@ __device__ __forceinline__ void build_bwd_recs(const Side& s, HX_GLOBAL char* ou
     }
     HX_GLOBAL i4v* q = (HX_GLOBAL i4v*)(out + (size_t)i * HX_BWD_REC_BYTES);
     q[0] = i4v{r.ab, r.ae, r.nb, r.ne};
-    q[1] = i4v{r.d[0], r.d[1], r.c[0], r.c[1]};
-    q[2] = i4v{r.flags, r.env, r.n[0], r.n[1]};
-    ((HX_GLOBAL bw_d2*)q)[3] = bw_d2{r.lp[0], r.lp[1]};
-    ((HX_GLOBAL bw_d2*)q)[4] = bw_d2{r.rs[0], r.rs[1]};
-    ((HX_GLOBAL bw_d2*)q)[5] = bw_d2{r.ins[0], r.ins[1]};
-    ((HX_GLOBAL bw_d2*)q)[6] = bw_d2{r.nlp[0], r.nlp[1]};
+    q[1] = i4v{r.d[0], r.d[1], r.d[2], r.c[0]};
+    q[2] = i4v{r.c[1], r.c[2], r.flags, r.env};
+    q[3] = i4v{r.n[0], r.n[1], 0, 0};
+    ((HX_GLOBAL bw_d2*)q)[4] = bw_d2{r.lp[0], r.lp[1]};
+    ((HX_GLOBAL bw_d2*)q)[5] = bw_d2{r.lp[2], r.rs[0]};
+    ((HX_GLOBAL bw_d2*)q)[6] = bw_d2{r.rs[1], r.rs[2]};
+    ((HX_GLOBAL bw_d2*)q)[7] = bw_d2{r.ins[0], r.ins[1]};
+    ((HX_GLOBAL bw_d2*)q)[8] = bw_d2{r.ins[2], r.nlp[0]};
+    ((HX_GLOBAL bw_d2*)q)[9] = bw_d2{r.nlp[1], 0.};
   }
 }
 __device__ __forceinline__ BwdRec load_bwd_rec(const HX_GLOBAL char* base, int i) {
   const HX_GLOBAL i4v* q = (const HX_GLOBAL i4v*)(base + (size_t)i * HX_BWD_REC_BYTES);
-  const i4v a = q[0], b = q[1], c = q[2];
-  const bw_d2 d = ((const HX_GLOBAL bw_d2*)q)[3], e = ((const HX_GLOBAL bw_d2*)q)[4], f = ((const HX_GLOBAL bw_d2*)q)[5], g = ((const HX_GLOBAL bw_d2*)q)[6];
+  const HX_GLOBAL bw_d2* qd = (const HX_GLOBAL bw_d2*)q;
+  const i4v a = q[0], b = q[1], c = q[2], d = q[3];
+  const bw_d2 e = qd[4], f = qd[5], g = qd[6], h = qd[7], k = qd[8], l = qd[9];
   BwdRec r;
   r.ab = a.x; r.ae = a.y; r.nb = a.z; r.ne = a.w;
-  r.d[0] = b.x; r.d[1] = b.y; r.c[0] = b.z; r.c[1] = b.w;
-  r.flags = c.x; r.env = c.y; r.n[0] = c.z; r.n[1] = c.w;
-  r.lp[0] = d.x; r.lp[1] = d.y; r.rs[0] = e.x; r.rs[1] = e.y; r.ins[0] = f.x; r.ins[1] = f.y;
-  r.nlp[0] = g.x; r.nlp[1] = g.y;
+  r.d[0] = b.x; r.d[1] = b.y; r.d[2] = b.z; r.c[0] = b.w;
+  r.c[1] = c.x; r.c[2] = c.y; r.flags = c.z; r.env = c.w;
+  r.n[0] = d.x; r.n[1] = d.y;
+  r.lp[0] = e.x; r.lp[1] = e.y; r.lp[2] = f.x; r.rs[0] = f.y; r.rs[1] = g.x; r.rs[2] = g.y;
+  r.ins[0] = h.x; r.ins[1] = h.y; r.ins[2] = k.x; r.nlp[0] = k.y; r.nlp[1] = l.x;
   return r;
 }
 
@@ -368,9 +375,12 @@ __device__ __forceinline__ double emis_known(const Mat& m, int ncy, int cx, int 
   if (m.etab) return (cx < 0 || cy < 0) ? HX_NEG_INF : m.etab[(int64_t)cx * ncy + cy];
   return m.eplane[cell_slot(m.ss, dx, dy)];
 }
-template <class LSE, bool COH = false>
+// KR: how many of the recorded absorbing transitions the cell takes from the records (the rest it walks): three where the
+// registers allow (the fast table policy), two in the exact policy, whose look-ups hold more of them
+template <class LSE, bool COH = false, int KR = 2>
 __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, const Side& y, const double (*T)[6],
                                                 const LSE& L, int i, int j, const BwdRec& rx, const BwdRec& ry) {
+  static_assert(KR >= 1 && KR <= HX_BWD_REC_ABS, "the records hold three absorbing transitions");
   const CellLoads<COH> M{m.M};
   const int64_t plane = m.plane, ss = m.ss;
   const int R = m.R, Cc = m.Cc;
@@ -393,38 +403,37 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
   const int xnb = rx.nb, xne = rx.ne, ynb = ry.nb, yne = ry.ne;
   const int xn = xae - xab, yn = yae - yab;              // absorbing out-degrees
 
-  // the THIRD absorbing transitions' CSR entries go out in front of the batch (a tenth of the states that branch have one; a
-  // strip's 64 rows and a step's 64 columns hold one every other time): the loops below then start with a known destination
-  int d3x = 0, d3y = 0;
-  double lp3x = HX_NEG_INF, lp3y = HX_NEG_INF;
-  if (xn > 2) { d3x = x.ao_dst[xab + 2]; lp3x = x.ao_lp[xab + 2]; }
-  if (yn > 2) { d3y = y.ao_dst[yab + 2]; lp3y = y.ao_lp[yab + 2]; }
-  // ---- the batch: everything that hangs on the recorded transitions ----
-  double e[2][2], mm[2][2], x1[2], x4[2], y2[2], y3[2];
+  // ---- the batch: everything that hangs on the recorded absorbing transitions ----
+  double e[KR][KR], mm[KR][KR], x1[KR], x4[KR], y2[KR], y3[KR];
   double xn0[2], xn1[2], xn4[2], yn0[2], yn2[2], yn3[2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < KR; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < KR; ++b) {
       e[a][b] = mm[a][b] = HX_NEG_INF;
       if (a < xn && b < yn) { e[a][b] = emis_known(m, y.n_cls, rx.c[a], ry.c[b], rx.d[a], ry.d[b]); mm[a][b] = M[BS(rx.d[a], ry.d[b])]; }
     }
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
+  for (int a = 0; a < KR; ++a) {
     x1[a] = x4[a] = HX_NEG_INF;
     if (yok && a < xn) { const int64_t sl = BS(rx.d[a], j); x1[a] = M[plane + sl]; x4[a] = M[4 * plane + sl]; }
   }
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < KR; ++b) {
     y2[b] = y3[b] = HX_NEG_INF;
     if (xok && b < yn) { const int64_t sl = BS(i, ry.d[b]); y2[b] = M[2 * plane + sl]; y3[b] = M[3 * plane + sl]; }
   }
+  // ... and on the recorded null transitions: with two absorbing transitions in the same batch, with three behind the pairs'
+  // look-ups (in registers those have freed; they are the last to be used)
+  const auto null_loads = [&]() {
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    xn0[k] = xn1[k] = xn4[k] = yn0[k] = yn2[k] = yn3[k] = HX_NEG_INF;
-    if (yok && xnb + k < xne && rx.n[k] < R) { const int64_t sl = BS(rx.n[k], j); xn1[k] = M[plane + sl]; xn4[k] = M[4 * plane + sl]; xn0[k] = M[sl]; }
-    if (ynb + k < yne && ry.n[k] < Cc) { const int64_t sl = BS(i, ry.n[k]); yn2[k] = M[2 * plane + sl]; yn3[k] = M[3 * plane + sl]; if (xf & F_EMIT_OR_START) yn0[k] = M[sl]; }
-  }
+    for (int k = 0; k < 2; ++k) {
+      xn0[k] = xn1[k] = xn4[k] = yn0[k] = yn2[k] = yn3[k] = HX_NEG_INF;
+      if (yok && xnb + k < xne && rx.n[k] < R) { const int64_t sl = BS(rx.n[k], j); xn1[k] = M[plane + sl]; xn4[k] = M[4 * plane + sl]; xn0[k] = M[sl]; }
+      if (ynb + k < yne && ry.n[k] < Cc) { const int64_t sl = BS(i, ry.n[k]); yn2[k] = M[2 * plane + sl]; yn3[k] = M[3 * plane + sl]; if (xf & F_EMIT_OR_START) yn0[k] = M[sl]; }
+    }
+  };
+  if (KR < 3) null_loads();
 
   // ---- transition pairs, row transition by row transition (src/forward.cpp:1000-1016) ----
   const auto pair_term = [&](const double d) {
@@ -435,26 +444,28 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
     r.iiw = L(r.iiw, T[4][0] + d);
   };
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < KR; ++a)
     if (a < xn) {
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < KR; ++b)
         if (b < yn) pair_term(rx.lp[a] + ry.lp[b] + e[a][b] + mm[a][b]);
-      for (int ty = yab + 2; ty < yae; ++ty) {           // the column's third and further transitions
-        const bool third = ty == yab + 2;
-        const int dy = third ? d3y : y.ao_dst[ty];
-        pair_term(rx.lp[a] + (third ? lp3y : y.ao_lp[ty]) + emis_at(m, x, y, rx.d[a], dy) + M[BS(rx.d[a], dy)]);
+      for (int ty = yab + KR; ty < yae; ++ty) {          // the column's further transitions
+        const int dy = y.ao_dst[ty];
+        pair_term(rx.lp[a] + y.ao_lp[ty] + emis_at(m, x, y, rx.d[a], dy) + M[BS(rx.d[a], dy)]);
       }
     }
-  for (int tx = xab + 2; tx < xae; ++tx) {               // the row's third and further transitions
-    const int dx = tx == xab + 2 ? d3x : x.ao_dst[tx];
-    const double lpx = tx == xab + 2 ? lp3x : x.ao_lp[tx];
+  for (int tx = xab + KR; tx < xae; ++tx) {              // the row's further transitions
+    const int dx = x.ao_dst[tx];
+    const double lpx = x.ao_lp[tx];
     for (int ty = yab; ty < yae; ++ty) {
-      const int k = ty - yab;
-      const int dy = k == 0 ? ry.d[0] : (k == 1 ? ry.d[1] : (k == 2 ? d3y : y.ao_dst[ty]));
-      const double lpy = k == 0 ? ry.lp[0] : (k == 1 ? ry.lp[1] : (k == 2 ? lp3y : y.ao_lp[ty]));
+      const int dy = y.ao_dst[ty];                        // (from the CSR arrays, not the record: selecting a record field by a
+      const double lpy = y.ao_lp[ty];                     //  run-time index would put the record into private memory at every step)
       pair_term(lpx + lpy + emis_at(m, x, y, dx, dy) + M[BS(dx, dy)]);
     }
+  }
+  if (KR >= 3) {
+    __builtin_amdgcn_sched_barrier(0);
+    null_loads();
   }
   // ---- x-absorbing moves ----
   if (yok) {
@@ -468,11 +479,11 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
       r.iiw = L(r.iiw, T[4][4] + d2);
     };
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < KR; ++a)
       if (a < xn) x_term(rx.lp[a] + rx.rs[a] + x1[a], rx.lp[a] + rx.ins[a] + x4[a]);
-    for (int tx = xab + 2; tx < xae; ++tx) {
-      const int dx = tx == xab + 2 ? d3x : x.ao_dst[tx];
-      const double lpx = tx == xab + 2 ? lp3x : x.ao_lp[tx];
+    for (int tx = xab + KR; tx < xae; ++tx) {
+      const int dx = x.ao_dst[tx];
+      const double lpx = x.ao_lp[tx];
       const int64_t sl = BS(dx, j);
       x_term(lpx + x.rootsub[dx] + M[plane + sl], lpx + x.ins[dx] + M[4 * plane + sl]);
     }
@@ -488,11 +499,11 @@ __device__ __forceinline__ C5 backward_cell_rec(const Mat& m, const Side& x, con
       r.imi = L(r.imi, T[3][3] + d2);
     };
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < KR; ++b)
       if (b < yn) y_term(ry.lp[b] + ry.rs[b] + y2[b], ry.lp[b] + ry.ins[b] + y3[b]);
-    for (int ty = yab + 2; ty < yae; ++ty) {
-      const int dy = ty == yab + 2 ? d3y : y.ao_dst[ty];
-      const double lpy = ty == yab + 2 ? lp3y : y.ao_lp[ty];
+    for (int ty = yab + KR; ty < yae; ++ty) {
+      const int dy = y.ao_dst[ty];
+      const double lpy = y.ao_lp[ty];
       const int64_t sl = BS(i, dy);
       y_term(lpy + y.rootsub[dy] + M[2 * plane + sl], lpy + y.ins[dy] + M[3 * plane + sl]);
     }
@@ -619,7 +630,7 @@ __global__ void __launch_bounds__((REC ? HX_DAG_REC_WAVES : HX_DAG_MAX_WAVES) * 
           if (REC) ry = load_bwd_rec(yrec, j);
           const uint8_t yf = REC ? (uint8_t)ry.flags : y.flags[j];
           if (in_env(m, xf, yf, xenv, banded ? (REC ? ry.env : y.env[j]) : 0)) {
-            const C5 c = REC ? backward_cell_rec(m, x, y, J.T, L, i, j, rx, ry)
+            const C5 c = REC ? backward_cell_rec<LSE, false, 3>(m, x, y, J.T, L, i, j, rx, ry)
                        : DIR ? backward_cell_dag(m, x, y, J.T, L, i, j, xf, yf)
                              : forward_cell_dag(m, x, y, J.T, L, i, j, xf, yf);
             const int64_t sl = store_base + ((int64_t)(t >> 1) << 7) + (t & 1);
@@ -749,7 +760,7 @@ __global__ void __launch_bounds__(HX_DAG_REC_WAVES * 64) k_backward_dag_multi(co
           const BwdRec ry = load_bwd_rec(yrec, j);
           const uint8_t yf = (uint8_t)ry.flags;
           if (in_env(m, xf, yf, xenv, banded ? ry.env : 0)) {
-            const C5 c = backward_cell_rec<LSE, true>(m, x, y, J.T, L, i, j, rx, ry);
+            const C5 c = backward_cell_rec<LSE, true, 3>(m, x, y, J.T, L, i, j, rx, ry);
             const int64_t sl = store_base + ((int64_t)(t >> 1) << 7) + (t & 1);
             put(sl, c.imm); put(m.plane + sl, c.imd); put(2 * m.plane + sl, c.idm); put(3 * m.plane + sl, c.imi); put(4 * m.plane + sl, c.iiw);
           }
@@ -1492,7 +1503,7 @@ int launch_forward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8
 }
 
 // `records`: every pair of the launch has scratch planes (DevJob::agg) that the Forward fill no longer needs and that hold
-// at least 14 doubles (HX_BWD_REC_BYTES) per state of its two profiles: the state-record formulation (backward_cell_rec)
+// at least 20 doubles (HX_BWD_REC_BYTES) per state of its two profiles: the state-record formulation (backward_cell_rec)
 int launch_backward_dag_pipe(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab8, Tab16 tab16,
                              bool fast, bool records, int multi, int multi_waves, hipStream_t st) {
   const double* tab = tab8.p;
