@@ -696,6 +696,40 @@ def test_a_small_batch_of_general_pairs_dealt_to_several_workgroups(monkeypatch)
                 H.assert_same_bits(got[0][1][k], c_oracle.backward(x, y, hmm, md)["cells"], "job %d Backward cells vs oracle" % k)
 
 
+@pytest.mark.parametrize("seed", [13, 23])
+def test_states_with_more_transitions_than_the_kernels_keep_at_hand(seed, monkeypatch):
+    # The general-profile kernels keep a state's first transitions at hand - three in-transitions inline in the Forward
+    # pipeline's packs, three absorbing and two null out-transitions in the Backward fill's state records (hx_dag.hip) - and
+    # walk the rest in rounds / loops.  Profiles built from 40 sampled paths have states beyond every one of those counts, in
+    # both profiles: in-degree 7-13, four absorbing and three null out-transitions.  Exact mode, one workgroup per pair and
+    # several: every Forward and Backward cell, lpEnd and lpStart bit for bit as the oracle has them.
+    f = H.dag_case(seed, n=70, samples=40)
+    for prof in (f.x, f.y):
+        assert max(len(s.in_) for s in prof.state) >= 7
+        assert max(len(s.absorb_out) for s in prof.state) >= 4
+        assert max(len(s.null_out) for s in prof.state) >= 3
+    img = H.job_images(f)
+    x, y, hmm, md = img
+    wf, wb = c_oracle.forward(x, y, hmm, md), c_oracle.backward(x, y, hmm, md)
+    for several in (False, True):
+        if several:
+            monkeypatch.setenv("HX_DAG_MULTI_MIN_STRIPS", "2")
+        b = capi.Batch([img], capi.HX_LSE_EXACT | capi.HX_KEEP_BACKWARD)
+        b.forward()
+        b.backward()
+        H.assert_same_bits(b.read_matrix(0, 0), wf["cells"], "Forward cells (several workgroups: %s)" % several)
+        H.assert_same_bits(b.read_matrix(0, 1), wb["cells"], "Backward cells (several workgroups: %s)" % several)
+        H.assert_same_bits([b.lp_end()[0], b.lp_start()[0]], [wf["lp_end"], wb["lp_start"]], "lpEnd, lpStart")
+        b.close()
+    # the table policy of the default mode: same cells to its own tolerance
+    b = capi.Batch([img], capi.HX_LSE_FAST | capi.HX_KEEP_BACKWARD)
+    b.forward()
+    b.backward()
+    assert abs(b.lp_end()[0] - wf["lp_end"]) <= 1e-9 * abs(wf["lp_end"])
+    assert abs(b.lp_start()[0] - wb["lp_start"]) <= 1e-9 * abs(wb["lp_start"])
+    b.close()
+
+
 @pytest.mark.parametrize("flags", [capi.HX_LSE_EXACT, capi.HX_LSE_FAST, capi.HX_LSE_LINEAR])
 def test_a_wave_that_gives_up_never_yields_a_wrong_number(flags, monkeypatch):
     # Several workgroups per pair: a wave whose poll of the strip above runs out of patience stops computing.  It publishes a
