@@ -1215,7 +1215,7 @@ int hx_batch_forward(hx_batch* b, void* stream) {
   HIP_TRY(hipEventRecord(b->ev[0][0], st));
   // per-cell emission terms of the jobs without a class-pair table (general profiles).  Part of the fill:
   // the reference evaluates them inside its fill loop, so the launch is inside the timed region.
-  if (!(b->flags & HX_FORCE_GENERIC)) launch_emission_plane(b->d_jobs, b->n_jobs, b->max_eplane, Tab8{D.tab}, st);
+  if (!(b->flags & HX_FORCE_GENERIC)) launch_emission_plane(b->d_jobs, b->n_jobs, b->max_eplane, Tab8{D.tab}, Tab16{D.fast_tab}, fast && !getenv("HX_EXACT_EMISSION"), st);
   for (int c = 0; c < KC_COUNT; ++c) {
     const ClassRange& cr = b->cls[c];
     if (cr.n == 0) continue;

@@ -1429,7 +1429,19 @@ __global__ void __launch_bounds__(MULTI ? HX_DAGF_MULTI_WAVES * 64 : HX_DAGF_MAX
 
 // emission plane: one thread per matrix slot (stores coalesced); cells outside the envelope and
 // cells of null states get 0 / -inf and are never added to a finite value
-__global__ void k_emission_plane(const DevJob* __restrict__ jobs, const double* __restrict__ tab) {
+// FAST: the table policies other than the exact one (fast, truncating, scaled probabilities) evaluate the emission terms of
+// profiles that are not leaves with the fast table too - the arithmetic their fills use for every other sum (the exact
+// operator costs twice the instructions and a gather in the 800 KB table per term: 84 terms per cell with four mixture
+// components).  Leaf profiles, whose best paths are held to the reference's in the traceback-identity sweeps, keep the exact
+// operator in every policy.
+template <bool FAST>
+__global__ void __launch_bounds__(FAST ? 1024 : 256) k_emission_plane(const DevJob* __restrict__ jobs, const double* __restrict__ tab,
+                                                                      const double* __restrict__ fast_tab) {
+  __shared__ __attribute__((aligned(16))) double ftab[FAST ? (HX_FAST_INTERVALS + 1) * 2 : 2];
+  if (FAST) {
+    for (int k = threadIdx.x; k < (HX_FAST_INTERVALS + 1) * 2; k += blockDim.x) ftab[k] = fast_tab[k];
+    __syncthreads();
+  }
   const DevJob& J = jobs[blockIdx.y];
   if (!J.emis_plane) return;
   const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1443,8 +1455,12 @@ __global__ void k_emission_plane(const DevJob* __restrict__ jobs, const double* 
   if (i < J.n_rows && j >= 0 && j < J.n_cols) {
     const int cx = J.x.cls[i], cy = J.y.cls[j];
     if (cx < 0 || cy < 0) e = HX_NEG_INF;
-    else if (in_envelope(J, i, j))
-      e = emission_rows(J, J.x.subc + (size_t)cx * J.CA, J.y.subc + (size_t)cy * J.CA, ExactLse{tab});
+    else if (in_envelope(J, i, j)) {
+      const double* sx = J.x.subc + (size_t)cx * J.CA;
+      const double* sy = J.y.subc + (size_t)cy * J.CA;
+      if (FAST && !J.leaf_like) e = emission_rows(J, sx, sy, FastLse::make((const double*)ftab));
+      else e = emission_rows(J, sx, sy, ExactLse{tab});
+    }
   }
   J.emis_plane[slot] = e;
 }
@@ -1456,14 +1472,16 @@ __global__ void k_fill_neg_inf(double* __restrict__ p, int64_t n) {
 
 }  // namespace
 
-void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, Tab8 tab8, hipStream_t st) {
+// fast: the batch runs one of the policies with the fast table (see k_emission_plane)
+void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, Tab8 tab8, Tab16 fast_tab, bool fast, hipStream_t st) {
   const double* tab = tab8.p;
   if (max_plane <= 0) return;
-  const int tpb = 256;
+  const int tpb = fast ? 1024 : 256;
   for (int j0 = 0; j0 < n_jobs; j0 += 32768) {       // (grid.y is limited to 65535)
     const int n = n_jobs - j0 < 32768 ? n_jobs - j0 : 32768;
     dim3 grid((unsigned)((max_plane + tpb - 1) / tpb), (unsigned)n);
-    hipLaunchKernelGGL(k_emission_plane, grid, dim3(tpb), 0, st, d_jobs + j0, tab);
+    if (fast) hipLaunchKernelGGL(k_emission_plane<true>, grid, dim3(tpb), 0, st, d_jobs + j0, tab, fast_tab.p);
+    else hipLaunchKernelGGL(k_emission_plane<false>, grid, dim3(tpb), 0, st, d_jobs + j0, tab, (const double*)nullptr);
   }
 }
 

@@ -43,7 +43,7 @@ int launch_forward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 ta
 int launch_backward_chain(const DevJob* d_jobs, int n_jobs, int max_rows, Tab8 tab, Tab16 fast_tab,
                            bool fast, int leaf, bool banded, int yl_cols, int yl_emis, int multi, int* counters, hipStream_t st);
 int chain_multi_groups(int n_jobs, int max_rows, int max_pairs);   // workgroups per pair of a small batch of unbanded leaf pairs (1: the ordinary launch)
-void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, Tab8 tab, hipStream_t st);
+void launch_emission_plane(const DevJob* d_jobs, int n_jobs, int64_t max_plane, Tab8 tab, Tab16 fast_tab, bool fast, hipStream_t st);
 void launch_fill_neg_inf(double* p, int64_t n, hipStream_t st);
 // scaled-probability Forward fill of general profiles (hx_daglin.hip); scratch per job in DevJob::agg
 int64_t dag_linear_scratch_doubles(int64_t plane, int nx, int ny, int tx, int ty);
