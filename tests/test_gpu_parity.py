@@ -730,6 +730,36 @@ def test_states_with_more_transitions_than_the_kernels_keep_at_hand(seed, monkey
     b.close()
 
 
+def test_emission_terms_of_general_profiles_on_the_fast_table(monkeypatch):
+    # Profiles with too many distinct columns for a class-pair table (a protein pair of sampled profiles: several hundred distinct columns each) get their emission terms per cell
+    # (k_emission_plane).  The exact policy evaluates them with the reference's table operator - cells bit for bit the
+    # oracle's - the other policies with the fast table, as every other sum of their fills; HX_EXACT_EMISSION=1 keeps the
+    # exact operator there.  Both stay within the fast policy's tolerance of the exact fill, and within 1e-10 of each other.
+    f = H.dag_case(1384, n=300, alphabet="arndcqeghilkmfpstwyv", samples=15)      # (a protein pair: hundreds of distinct columns per profile)
+    img = H.job_images(f)
+    x, y, hmm, md = img
+    want = c_oracle.forward(x, y, hmm, md)
+    b = capi.Batch([img], capi.HX_LSE_EXACT)
+    b.forward()
+    H.assert_same_bits(b.read_matrix(0, 0), want["cells"], "exact policy: Forward cells")
+    b.close()
+    got = {}
+    for exact_emission in (False, True):
+        if exact_emission:
+            monkeypatch.setenv("HX_EXACT_EMISSION", "1")
+        b = capi.Batch([img], capi.HX_LSE_FAST)
+        b.forward()
+        got[exact_emission] = (b.lp_end()[0], b.read_matrix(0, 0))
+        b.close()
+    for k in got:
+        assert abs(got[k][0] - want["lp_end"]) <= 1e-9 * abs(want["lp_end"])
+    assert abs(got[False][0] - got[True][0]) <= 1e-10 * abs(want["lp_end"])
+    assert not np.array_equal(got[False][1], got[True][1])      # (the pair does take the per-cell terms: the two evaluations differ in the last bits)
+    fin = np.isfinite(want["cells"])
+    assert (np.isfinite(got[False][1]) == fin).all()
+    assert np.max(np.abs(got[False][1][fin] - got[True][1][fin])) <= 1e-9 * abs(want["lp_end"])
+
+
 @pytest.mark.parametrize("flags", [capi.HX_LSE_EXACT, capi.HX_LSE_FAST, capi.HX_LSE_LINEAR])
 def test_a_wave_that_gives_up_never_yields_a_wrong_number(flags, monkeypatch):
     # Several workgroups per pair: a wave whose poll of the strip above runs out of patience stops computing.  It publishes a

@@ -1,8 +1,8 @@
 """Traceback identity on GENERAL profiles (internal tree nodes): the device-side best path (hx_batch_best_trace) of a fill in the
 fast table policy - what the default mode runs on general profiles - against the exact policy's, whose cells are the pinned
 oracle's bit for bit (tests/test_gpu_parity.py).  N random pairs of internal-node profiles (oracle-built from sampled paths of
-two leaf pairs: tests/helpers.dag_case; 30-300 ancestral residues, 3-25 samples, DNA and two-component models, every fourth
-pair with a band).  Reports how many best paths differ and the largest relative lpEnd difference.
+two leaf pairs: tests/helpers.dag_case; 30-300 ancestral residues, 3-25 samples, DNA and protein, one- and two-component models,
+every fourth pair with a band).  Reports how many best paths differ and the largest relative lpEnd difference.
 
     python tools/sweep_dag_trace_identity.py [n_pairs] [seed] [out.json]         (on the GPU box)"""
 import json
@@ -56,8 +56,10 @@ def main():
         samples = rng.choice([3, 6, 10, 15, 25])
         comps = rng.choice([1, 1, 2])
         band = rng.choice([None, None, None, 5])
-        batch.append(({"seed": s, "n": n, "samples": samples, "components": comps, "band": band},
-                      H.dag_case(s, n=n, samples=samples, components=comps, band=band)))
+        protein = rng.random() < .5           # (protein pairs have too many distinct columns for a class-pair table: per-cell emission terms)
+        batch.append(({"seed": s, "n": n, "samples": samples, "components": comps, "band": band, "protein": protein},
+                      H.dag_case(s, n=n, samples=samples, components=comps, band=band,
+                                 alphabet="arndcqeghilkmfpstwyv" if protein else "ACGT")))
         if len(batch) == 16:
             flush()
             print("  %d pairs, %d differing best paths, %.0f s" % (done, len(differing), time.time() - t0), flush=True)
