@@ -82,7 +82,7 @@ class HxCell(C.Structure):
 EXPORTS = ["hx_init", "hx_shutdown", "hx_last_error", "hx_version", "hx_batch_create", "hx_batch_destroy",
            "hx_batch_forward", "hx_batch_backward", "hx_batch_sync", "hx_batch_lp_end", "hx_batch_lp_start",
            "hx_batch_layout", "hx_batch_read_matrix", "hx_batch_read_cells", "hx_batch_read_prepared",
-           "hx_batch_posterior_scan", "hx_batch_best_trace", "hx_batch_sample_traces", "hx_device_count", "hx_batch_create_on", "hx_batch_device",
+           "hx_batch_posterior_scan", "hx_batch_best_trace", "hx_batch_best_trace_ties", "hx_batch_sample_traces", "hx_device_count", "hx_batch_create_on", "hx_batch_device",
            "hx_quick_batch_create_on", "hx_batch_strip_windows", "hx_batch_total_cells", "hx_batch_job_kernel", "hx_batch_last_kernel_ms", "hx_host_alloc",
            "hx_host_free", "hx_quick_batch_create", "hx_quick_batch_destroy", "hx_quick_batch_run",
            "hx_quick_batch_results", "hx_quick_batch_layout", "hx_quick_batch_read_matrix",
@@ -129,6 +129,7 @@ def load():
     lib.hx_batch_posterior_scan.argtypes = [vp, C.c_int32, C.c_double, C.POINTER(HxCell), C.c_int64,
                                             C.POINTER(C.c_int64)]
     lib.hx_batch_best_trace.argtypes = [vp, vp, C.c_int64, _i32p]
+    lib.hx_batch_best_trace_ties.argtypes = [vp, _i32p]
     lib.hx_batch_sample_traces.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.c_int64, vp, C.c_int64, _i32p, C.POINTER(C.c_int64)]
     lib.hx_batch_strip_windows.argtypes = [vp, C.c_int32, _i32p, C.POINTER(C.c_int64)]
     lib.hx_batch_job_kernel.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -443,6 +444,12 @@ class Batch:
                 out.append([tuple(int(v) for v in c) for c in cells[k, :n_cells[k]]])
         return out
 
+
+    def best_trace_ties(self):
+        """Near-tie flags of the last best_trace() (hx_batch_best_trace_ties): one int per job."""
+        flags = np.zeros(self.n, dtype=np.int32)
+        _check(load().hx_batch_best_trace_ties(self._h, _p(flags, _i32p)))
+        return flags
 
     def sample_traces(self, job, n_walks, uniforms, cap=None):
         """ForwardMatrix::sampleTrace, n_walks times in sequence, on the device (hx_batch_sample_traces): uniforms = the

@@ -59,6 +59,7 @@ struct FillTiming {
   double construct = 0, readPrepared = 0;      // DPMatrix constructor (host-side vectors, envelope coordinates); hx_batch_read_prepared + lpAbsorb fill
   double deviceTrace = 0, cellGather = 0;
   double hostTraces = 0, hostMakeProfile = 0;      // host tracebacks (sampled, or best without the device kernel), makeProfile
+  double tieRefill = 0; long tieRefills = 0;       // best traces taken again from an exact-policy fill because the walk met a near tie
   double pinnedAlloc = 0; long pinnedAllocs = 0;   // page-locked buffers allocated for matrix copies (inside readMatrix)
   double cellSets = 0, retain = 0;                 // sorting / merging the sampled cells; keeping their values (retainCells)
   long fills = 0, matrixReads = 0, deviceTraces = 0, cellGathers = 0;
@@ -410,6 +411,7 @@ protected:
     long long bestTraceCap;
     vguard<int32_t> bestTraceCells;         // [nJobs][bestTraceCap] hx_trace_cell = {xpos, ypos, state}
     vguard<int32_t> bestTraceLen;           // [nJobs]
+    vguard<int32_t> bestTraceTies;          // [nJobs] near-tie flags of those walks (hx_batch_best_trace_ties)
     BatchHandle(hx_batch* b, int nJobs) : b(b), nJobs(nJobs), backwardDone(false), bestTracesDone(false), bestTraceCap(0) {}
     ~BatchHandle();
   };
@@ -496,6 +498,11 @@ public:
 
   Path bestTrace();
   Path bestTrace(const CellCoords& from);
+  // the same walk; *nearTie is set when at some step another source cell came within 1e-9 (relative) of the best one
+  Path bestTrace(const CellCoords& from, bool* nearTie);
+  // the best trace of a fresh fill of this pair under the exact policy (the reference's choice at near ties, see bestTrace())
+  Path exactBestTrace();
+  static bool refillAtNearTies();
   Path sampleTrace(random_engine& rng);
   // sampled walks made on the device (HX_DEVICE_SAMPLING=1, hx_batch_sample_traces); see hx_host_walk.cpp
   static bool deviceSampling();

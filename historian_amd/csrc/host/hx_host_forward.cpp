@@ -32,6 +32,12 @@ bool DPMatrix::deviceTraceback() {
   return g_deviceTraceback != 0;
 }
 unsigned DPMatrix::fillMode() { return g_fillMode; }
+// HX_TIE_REFILL=1: opt-in, because near ties are common - the walks of 15 of the 31 nodes of a 32-leaf, 1000-residue tree meet one,
+// 40 of 63 at 64 leaves x 5000 residues - and a second, exact fill of each of those pairs costs a third to a half of the run
+bool ForwardMatrix::refillAtNearTies() {
+  static const bool on = getenv("HX_TIE_REFILL") != NULL;
+  return on && g_fillMode != HX_LSE_EXACT;
+}
 
 static void hxCheck(int rc, const char* what) {
   if (rc != HX_OK) Abort("%s failed (%d): %s", what, rc, hx_last_error());
@@ -230,7 +236,7 @@ void mergeTiming(const FillTiming& a, FillTiming& b) {
   b.deviceInit += a.deviceInit; b.flattenAndUpload += a.flattenAndUpload; b.forwardWait += a.forwardWait;
   b.forwardKernel += a.forwardKernel; b.backwardWait += a.backwardWait; b.readMatrix += a.readMatrix;
   b.construct += a.construct; b.readPrepared += a.readPrepared;
-  b.deviceTrace += a.deviceTrace; b.cellGather += a.cellGather; b.hostTraces += a.hostTraces; b.hostMakeProfile += a.hostMakeProfile; b.cellSets += a.cellSets; b.retain += a.retain; b.pinnedAlloc += a.pinnedAlloc; b.pinnedAllocs += a.pinnedAllocs;
+  b.deviceTrace += a.deviceTrace; b.cellGather += a.cellGather; b.hostTraces += a.hostTraces; b.tieRefill += a.tieRefill; b.tieRefills += a.tieRefills; b.hostMakeProfile += a.hostMakeProfile; b.cellSets += a.cellSets; b.retain += a.retain; b.pinnedAlloc += a.pinnedAlloc; b.pinnedAllocs += a.pinnedAllocs;
   b.fills += a.fills; b.matrixReads += a.matrixReads; b.deviceTraces += a.deviceTraces; b.cellGathers += a.cellGathers; b.cells += a.cells;
 }
 double* pinnedTake(size_t doubles, size_t& capacity) { return g_pinned.take(doubles, capacity); }
@@ -323,6 +329,31 @@ void DPMatrix::createBatchAndPrepare() {
   fillTiming.fills += 1;
   fillTiming.cells += (long long)(xSize - 1) * (long long)(ySize - 1);
   attach(h, 0, lp);
+}
+
+// ForwardMatrix::bestTrace at a near tie: this pair once more, under the exact policy, walked on the device
+ForwardMatrix::Path ForwardMatrix::exactBestTrace() {
+  ensureDevice();
+  const double t0 = wallSeconds();
+  JobImage im;
+  buildJobImage(*this, xClosestLeafPos, yClosestLeafPos, im);
+  hx_batch* b = NULL;
+  hxCheck(hx_batch_create_on(threadDevice(), &im.job, 1, HX_LSE_EXACT | HX_SPARSE_ENVELOPE, &b), "hx_batch_create");
+  std::shared_ptr<BatchHandle> h(new BatchHandle(b, 1));          // (destroys the batch)
+  hxCheck(hx_batch_forward(b, NULL), "hx_batch_forward");
+  double lp = NEG_INF;
+  hxCheck(hx_batch_lp_end(b, &lp), "hx_batch_lp_end");
+  const long long cap = (long long)xSize + ySize + 4;
+  vguard<int32_t> cells(3 * (size_t)cap);
+  int32_t len = 0;
+  hxCheck(hx_batch_best_trace(b, reinterpret_cast<hx_trace_cell*>(cells.data()), cap, &len), "hx_batch_best_trace");
+  Assert(len > 0, "traceback failure");
+  const hx_trace_cell* tc = reinterpret_cast<const hx_trace_cell*>(cells.data());
+  Path path;
+  for (int k = 0; k < len; ++k) path.emplace_back(tc[k].xpos, tc[k].ypos, (PairHMM::State)tc[k].state);
+  fillTiming.tieRefill += wallSeconds() - t0;
+  fillTiming.tieRefills += 1;
+  return path;
 }
 
 void DPMatrix::attach(const std::shared_ptr<BatchHandle>& h, int job, double lpEndOfJob) {

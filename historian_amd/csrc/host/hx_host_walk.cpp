@@ -292,23 +292,45 @@ ForwardMatrix::Path ForwardMatrix::sampleTrace(random_engine& generator) {
   return path;
 }
 
-ForwardMatrix::Path ForwardMatrix::bestTrace(const CellCoords& end) {
+ForwardMatrix::Path ForwardMatrix::bestTrace(const CellCoords& end) { return bestTrace(end, NULL); }
+
+ForwardMatrix::Path ForwardMatrix::bestTrace(const CellCoords& end, bool* nearTie) {
   const double t0 = wallSeconds();
   Path path(1, end);
   Moves m;
   CellCoords at = end;
+  bool tie = false;
   while (at.xpos != 0 || at.ypos != 0) {
     scoredSources(at, m);
     at = pickBest(m);
+    if (nearTie && !tie) {
+      // as k_best_trace does (hx_trace.hip, HX_TRACE_TIE_TOL): another source cell within 1e-9 of the best, relative
+      double top = kNegInf, second = kNegInf;
+      for (const Move& c : m) {
+        if (c.second > top) { second = top; top = c.second; }
+        else if (c.second > second) second = c.second;
+      }
+      tie = second > kNegInf && top - second <= 1e-9 * std::max(1.0, std::fabs(top));
+    }
     path.push_front(at);
   }
+  if (nearTie) *nearTie = tie;
   fillTiming.hostTraces += wallSeconds() - t0;
   return path;
 }
 
 ForwardMatrix::Path ForwardMatrix::bestTrace() {
   Assert(lpEnd > kNegInf, "Forward likelihood is zero; traceback fail");
-  if (haveHostCells || !batch || !handle || !deviceTraceback()) return bestTrace(endCell);
+  // Where the walk meets a near tie between two source cells - two equally probable routes through a general profile - the
+  // choice hangs on the last bits of the arithmetic, and only the exact policy has the reference's bits (DESIGN.md section 6:
+  // 3 of 640 random internal-node pairs part from the reference's path in the fast policy, every one of them at such a step).
+  // With HX_TIE_REFILL=1 such a pair is filled once more under the exact policy and THAT trace returned (off by default: near
+  // ties are common and the second fill is not cheap, see refillAtNearTies).
+  if (haveHostCells || !batch || !handle || !deviceTraceback()) {
+    bool tie = false;
+    Path walked = bestTrace(endCell, &tie);
+    return tie && refillAtNearTies() ? exactBestTrace() : walked;
+  }
   // the matrix is still device-resident: walk it there (one wavefront per job, all jobs of the batch at once)
   BatchHandle& h = *handle;
   if (!h.bestTracesDone) {
@@ -324,12 +346,15 @@ ForwardMatrix::Path ForwardMatrix::bestTrace() {
     h.bestTraceLen.assign(h.nJobs, 0);
     detail::check(hx_batch_best_trace(h.b, reinterpret_cast<hx_trace_cell*>(h.bestTraceCells.data()), cap, h.bestTraceLen.data()),
                   "hx_batch_best_trace");
+    h.bestTraceTies.assign(h.nJobs, 0);
+    detail::check(hx_batch_best_trace_ties(h.b, h.bestTraceTies.data()), "hx_batch_best_trace_ties");
     h.bestTracesDone = true;
     fillTiming.deviceTrace += wallSeconds() - t0;
     fillTiming.deviceTraces += 1;
   }
   const int len = h.bestTraceLen[jobIndex];
   Assert(len > 0, "traceback failure");
+  if (h.bestTraceTies[jobIndex] && refillAtNearTies()) return exactBestTrace();
   const hx_trace_cell* tc = reinterpret_cast<const hx_trace_cell*>(h.bestTraceCells.data()) + (size_t)h.bestTraceCap * jobIndex;
   Path path;
   for (int k = 0; k < len; ++k) path.emplace_back(tc[k].xpos, tc[k].ypos, (State)tc[k].state);

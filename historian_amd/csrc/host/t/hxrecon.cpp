@@ -118,7 +118,8 @@ int main(int argc, char** argv) {
                     "device best-path tracebacks %.3f s in %ld calls, cell gathers %.3f s in %ld calls; sorting sampled cells %.3f s, keeping their values %.3f s; envelopes %.3f s, prepared vectors (read + lpAbsorb) %.3f s; host traceback/profile building/other %.3f s\n",
             total, f.deviceInit, total - f.deviceInit, f.fills, f.cells, f.flattenAndUpload, f.forwardWait, f.forwardKernel, f.backwardWait, f.readMatrix,
             f.matrixReads, f.pinnedAlloc, f.pinnedAllocs, f.deviceTrace, f.deviceTraces, f.cellGather, f.cellGathers, f.cellSets, f.retain, f.construct, f.readPrepared,
-            total - f.deviceInit - f.flattenAndUpload - f.forwardWait - f.readMatrix - f.backwardWait - f.deviceTrace - f.cellGather);
+            total - f.deviceInit - f.flattenAndUpload - f.forwardWait - f.readMatrix - f.backwardWait - f.deviceTrace - f.cellGather);    fprintf(stderr, "timing: best traces taken again from an exact-policy fill because the walk met a near tie (HX_TIE_REFILL=1): %ld, %.3f s\n",
+            f.tieRefills, f.tieRefill);
   }
   for (size_t k = 0; k < all.size(); ++k) {
     if (all.size() > 1) { printf("family %zu\n", k); fflush(stdout); }

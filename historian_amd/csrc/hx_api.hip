@@ -613,6 +613,7 @@ struct hx_batch {
   int64_t* d_trace_n = nullptr;
   void* h_trace = nullptr;
   int64_t trace_cap = 0;
+  bool trace_ties_valid = false;     // the near-tie flags of the last hx_batch_best_trace are in d_trace_n's third block
   bool ev_valid[2] = {false, false};
 };
 
@@ -1823,7 +1824,7 @@ int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t*
     b->d_trace = nullptr; b->d_trace_n = nullptr; b->h_trace = nullptr; b->trace_cap = 0;
     // [n][cap][3] as walked (END cell first) + the same amount for the compacted, start-first copy; [2n] lengths + offsets
     if (hipMalloc(reinterpret_cast<void**>(&b->d_trace), sizeof(int32_t) * 6 * (size_t)cap * n) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&b->d_trace_n), sizeof(int64_t) * 2 * (size_t)n) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&b->d_trace_n), sizeof(int64_t) * 3 * (size_t)n) != hipSuccess ||      // lengths, offsets, near-tie flags
         hipHostMalloc(&b->h_trace, sizeof(int32_t) * 3 * (size_t)cap * n, hipHostMallocDefault) != hipSuccess)
       return fail(HX_ERR_OUT_OF_MEMORY, "allocating %zu path bytes failed", sizeof(int32_t) * 9 * (size_t)cap * n);
     b->trace_cap = cap;
@@ -1832,13 +1833,16 @@ int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t*
   int32_t* d_out = b->d_trace + 3 * (size_t)cap * n;
   int32_t* d_n = reinterpret_cast<int32_t*>(b->d_trace_n);
   int64_t* d_off = b->d_trace_n + n;
+  int32_t* d_ties = reinterpret_cast<int32_t*>(b->d_trace_n + 2 * (size_t)n);
+  b->trace_ties_valid = false;
   hipStream_t st = b->last_stream;
   // the per-cell emission plane is only filled by the strip pipelines (hx_batch_forward)
   ensure_state_records(b, st);
-  launch_best_trace(b->d_jobs, n, d_paths, cap, d_n, Tab8{g_dev[b->device].tab}, !(b->flags & HX_FORCE_GENERIC), st);
+  launch_best_trace(b->d_jobs, n, d_paths, cap, d_n, Tab8{g_dev[b->device].tab}, !(b->flags & HX_FORCE_GENERIC), d_ties, st);
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
       hipMemcpy(n_cells, d_n, sizeof(int32_t) * n, hipMemcpyDeviceToHost) != hipSuccess)
     return fail(HX_ERR_HIP, "best-trace kernel failed: %s", hipGetErrorString(hipGetLastError()));
+  b->trace_ties_valid = true;
   std::vector<int64_t> off((size_t)n + 1, 0);
   for (int k = 0; k < n; ++k) {
     if (n_cells[k] == -3) return fail(HX_ERR_RANGE, "path of job %d does not fit %lld cells", k, (long long)cap);
@@ -1855,6 +1859,14 @@ int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t*
   const hx_trace_cell* src = static_cast<const hx_trace_cell*>(b->h_trace);
   for (int k = 0; k < n; ++k)
     if (n_cells[k] > 0) memcpy(cells + (size_t)cap * k, src + off[k], sizeof(hx_trace_cell) * (size_t)n_cells[k]);
+  return HX_OK;
+}
+
+int hx_batch_best_trace_ties(hx_batch* b, int32_t* near_tie) {
+  if (!b || !near_tie) return fail(HX_ERR_INVALID_ARG, "bad arguments");
+  if (!b->trace_ties_valid) return fail(HX_ERR_STATE, "hx_batch_best_trace_ties needs a previous hx_batch_best_trace");
+  { const int rc_ = use_device(b); if (rc_ != HX_OK) return rc_; }
+  HIP_TRY(hipMemcpy(near_tie, reinterpret_cast<const int32_t*>(b->d_trace_n + 2 * (size_t)b->n_jobs), sizeof(int32_t) * b->n_jobs, hipMemcpyDeviceToHost));
   return HX_OK;
 }
 

@@ -101,7 +101,7 @@ inline int multi_patience() {
 void launch_indel_counts(const DevJob* d_jobs, int job, const double* d_tm, double* d_out, int64_t cells, Tab8 tab, bool plane_valid,
                          hipStream_t st);
 void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, Tab8 tab,
-                       bool plane_valid, hipStream_t st);
+                       bool plane_valid, int32_t* d_near_tie, hipStream_t st);
 
 void launch_sample_traces(const DevJob* d_jobs, int job, int n_walks, const double* d_uniforms, int64_t n_uniforms, int32_t* d_paths,
                           int64_t cap, int32_t* d_n_cells, int64_t* d_draws, Tab8 tab, bool plane_valid, hipStream_t st);

@@ -50,19 +50,25 @@ __device__ __forceinline__ double forward_cell(const DevJob& J, int i, int j, in
 // paths: [n_jobs][cap][3] int32 (x, y, state), written from the END cell backwards; n_cells[job] = number of
 // cells written, or -1 when lpEnd = -inf (the reference asserts), -2 when a cell had no source transitions
 // (the reference's "traceback failure"), -3 when cap was too small.
+// near_tie[job] (may be null): 1 when at some step of the walk the best source cell led a DIFFERENT source cell by no more than
+// HX_TRACE_TIE_TOL relative to the value - there an arithmetic policy that is not the reference's bit for bit may have chosen
+// the other route (two equally probable routes through a general profile); hx_batch_best_trace_ties.
+#define HX_TRACE_TIE_TOL 1e-9
 __global__ __launch_bounds__(64) void k_best_trace(const DevJob* __restrict__ jobs, int32_t* __restrict__ paths, int64_t cap,
-                                                   int32_t* __restrict__ n_cells, const double* __restrict__ tab, int plane_valid) {
+                                                   int32_t* __restrict__ n_cells, const double* __restrict__ tab, int plane_valid,
+                                                   int32_t* __restrict__ near_tie) {
   const DevJob& J = jobs[blockIdx.x];
   const int lane = threadIdx.x;
   int32_t* out = paths + (int64_t)blockIdx.x * cap * 3;
   const int Nx = J.x.n, Ny = J.y.n;
   if (!(*J.lp_end > HX_NEG_INF)) {
-    if (lane == 0) n_cells[blockIdx.x] = -1;
+    if (lane == 0) { n_cells[blockIdx.x] = -1; if (near_tie) near_tie[blockIdx.x] = 0; }
     return;
   }
   int dx = Nx - 1, dy = Ny - 1, ds = 5;
   int64_t n = 0;
   int status = 0;
+  int tie = 0;
   if (cap < 1) status = -3;
   else if (lane == 0) { out[0] = dx; out[1] = dy; out[2] = ds; }
   n = 1;
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(64) void k_best_trace(const DevJob* __restrict__ jo
     const int ns = hmm ? 5 : 1;
     const int total = any ? nx * ny * ns : 0;
     if (total == 0) { status = -2; break; }
-    double best = HX_NEG_INF;
+    double best = HX_NEG_INF, second = HX_NEG_INF;       // second: the best value among source cells other than the winner
     unsigned long long bkey = NO_KEY;
     for (int c = lane; c < total; c += 64) {
       const int si = c % ns, r = c / ns, yi = r % ny, xi = r / ny;
@@ -125,21 +131,34 @@ __global__ __launch_bounds__(64) void k_best_trace(const DevJob* __restrict__ jo
       // sourceTransitions then sourceCells: ((hmm + x) + y) + emit, then + cell (absent terms are +0.0, exact)
       const double v = (((h + xlp) + ylp) + lp_abs) + forward_cell(J, sx, sy, s);
       const unsigned long long key = ((unsigned long long)(unsigned)sx << 32) | ((unsigned long long)(unsigned)sy << 3) | (unsigned)s;
-      if (v > best || (v == best && v > HX_NEG_INF && key < bkey)) { best = v; bkey = key; }
+      if (v > best || (v == best && v > HX_NEG_INF && key < bkey)) {
+        if (bkey != NO_KEY && bkey != key) second = fmax(second, best);
+        best = v; bkey = key;
+      } else if (key != bkey) second = fmax(second, v);
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
       const double ov = __shfl_xor(best, m, 64);
+      const double os = __shfl_xor(second, m, 64);
       const unsigned long long ok = shfl_xor_u64(bkey, m);
-      if (ov > best || (ov == best && ok < bkey)) { best = ov; bkey = ok; }
+      double ns2 = fmax(second, os);
+      if (ov > best || (ov == best && ok < bkey)) {
+        if (bkey != NO_KEY && bkey != ok) ns2 = fmax(ns2, best);
+        best = ov; bkey = ok;
+      } else if (ok != NO_KEY && ok != bkey) ns2 = fmax(ns2, ov);
+      second = ns2;
     }
+    if (second > HX_NEG_INF && best - second <= HX_TRACE_TIE_TOL * fmax(1.0, fabs(best))) tie = 1;
     if (bkey == NO_KEY) { dx = 0; dy = 0; ds = 5; }   // bestCell's default-constructed CellCoords (src/forward.h:32)
     else { dx = (int)(bkey >> 32); dy = (int)((bkey & 0xffffffffull) >> 3); ds = (int)(bkey & 7); }
     if (n >= cap) { status = -3; break; }
     if (lane == 0) { out[3 * n] = dx; out[3 * n + 1] = dy; out[3 * n + 2] = ds; }
     ++n;
   }
-  if (lane == 0) n_cells[blockIdx.x] = status < 0 ? status : (int32_t)n;
+  if (lane == 0) {
+    n_cells[blockIdx.x] = status < 0 ? status : (int32_t)n;
+    if (near_tie) near_tie[blockIdx.x] = tie;
+  }
 }
 
 // Expected indel events of a pair DP: BackwardMatrix::getCounts restricted to the IndelCounts members
@@ -431,9 +450,9 @@ void launch_reverse_paths(const int32_t* d_paths, int64_t cap, const int32_t* d_
 }
 
 void launch_best_trace(const DevJob* d_jobs, int n_jobs, int32_t* d_paths, int64_t cap, int32_t* d_n_cells, Tab8 tab8,
-                       bool plane_valid, hipStream_t st) {
+                       bool plane_valid, int32_t* d_near_tie, hipStream_t st) {
   const double* tab = tab8.p;
-  hipLaunchKernelGGL(k_best_trace, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_paths, cap, d_n_cells, tab, plane_valid ? 1 : 0);
+  hipLaunchKernelGGL(k_best_trace, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_paths, cap, d_n_cells, tab, plane_valid ? 1 : 0, d_near_tie);
 }
 
 }  // namespace hx

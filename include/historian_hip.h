@@ -244,6 +244,16 @@ typedef struct hx_trace_cell {
 } hx_trace_cell;
 int hx_batch_best_trace(hx_batch* b, hx_trace_cell* cells, int64_t cap, int32_t* n_cells);
 
+/* Near ties met by the walks of the last hx_batch_best_trace: near_tie[k] = 1 when, at some step of job k's path, the best
+ * source cell led a different source cell by no more than 1e-9 relative to the value (or tied with it) - a place where
+ * bestCell's choice (src/forward.cpp:245-255) hangs on the last bits of the fill's arithmetic.  Two routes of equal
+ * probability through a general (internal-node) profile are such places; a policy other than HX_LSE_EXACT may then part from
+ * the reference's path (3 of 640 random internal-node pairs, none of 10 000 leaf pairs).  A caller who wants
+ * the reference's path there fills the flagged jobs again under HX_LSE_EXACT and takes that trace - what the C++ mirror does
+ * in ForwardMatrix::bestTrace when HX_TIE_REFILL=1 (near ties are common on long sequences - half the nodes of a 32-leaf tree -
+ * so it is not the default). */
+int hx_batch_best_trace_ties(hx_batch* b, int32_t* near_tie);
+
 /* Sampled tracebacks of job `job` in the device-resident Forward matrix: ForwardMatrix::sampleTrace (reference
  * src/forward.cpp:257-276) with DPMatrix::sampleCell (:225-243), n_walks walks one after the other, so that a host which
  * only needs the sampled paths (profile building) copies no matrix.  The reference draws one

@@ -166,6 +166,52 @@ def test_best_path_profiles_never_copy_a_matrix(tmp_path):
     assert outs[False] == outs[True]
 
 
+def test_near_ties_resolved_by_an_exact_fill_on_request(tmp_path):
+    # HX_TIE_REFILL=1: a best trace whose walk met a near tie between two source cells (hx_batch_best_trace_ties, or the same test
+    # in the host walk) is taken again from a fresh fill of that pair under the exact policy.  Best-path profiles (profsamples 0)
+    # in the default policy, device and host walks: the oracle's alignment, and the run says how many traces it took again.
+    import re
+    tree, seqs, guide = R.load_family(G + "gp120.tree.nh", G + "gp120.fa", G + "gp120.guide.fa", max_len=200)
+    job = str(tmp_path / "job.txt")
+    R.write_job(job, LG, tree, seqs, guide, str(tmp_path / "seqs.fa"), str(tmp_path / "guide.fa"), band=10,
+                samples=0, maxstates=0, seed=5489)
+    res, rows = R.oracle_reconstruct(LG, tree, seqs, guide, max_distance_from_guide=10, profile_samples=0)
+    refills = {}
+    for host_traceback in (False, True):
+        env = dict(os.environ, HX_TIMING="1", HX_TIE_REFILL="1", HX_FILL_MODE="trunc")
+        if host_traceback:
+            env["HX_HOST_TRACEBACK"] = "1"
+        out = subprocess.run([HXRECON, job], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()
+        got = R.parse_hxrecon(out.stdout.decode())
+        assert got["rows"] == rows
+        assert abs(got["lpFinalFwd"] - res["lp_final_fwd"]) <= 1e-9 * abs(res["lp_final_fwd"])
+        refills[host_traceback] = int(re.search(r"near tie \(HX_TIE_REFILL=1\): (\d+),", out.stderr.decode()).group(1))
+    assert refills[False] == refills[True]          # the device walk and the host walk flag the same pairs
+    # without the variable no trace is taken again
+    out = subprocess.run([HXRECON, job], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, HX_TIMING="1", HX_FILL_MODE="trunc"), timeout=600)
+    assert out.returncode == 0, out.stderr.decode()
+    assert int(re.search(r"near tie \(HX_TIE_REFILL=1\): (\d+),", out.stderr.decode()).group(1)) == 0
+    assert R.parse_hxrecon(out.stdout.decode())["rows"] == rows
+    # sampling mode on a synthetic family of 16 leaves x 600 residues (ten sampled traces per node: internal nodes are DAGs with
+    # routes of equal probability): some walks do meet a near tie, their traces come from an exact fill, and the alignment is the
+    # one the exact policy gives (which the tests above hold to the oracle bit for bit)
+    WAG = os.path.join(ROOT, "tests", "golden", "models", "wag.json")
+    tree, seqs = R.balanced_family(16, 600, "arndcqeghilkmfpstwyv", seed=21, branch=.05)
+    R.write_job(job, WAG, tree, seqs, {}, str(tmp_path / "s2.fa"), str(tmp_path / "g2.fa"), samples=10, batch=1, maxstates=0)
+    outs = {}
+    for mode, refill in (("exact", False), ("trunc", True)):
+        env = dict(os.environ, HX_TIMING="1", HX_FILL_MODE=mode)
+        if refill:
+            env["HX_TIE_REFILL"] = "1"
+        out = subprocess.run([HXRECON, job], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()
+        outs[mode] = (R.parse_hxrecon(out.stdout.decode())["rows"], out.stderr.decode())
+    assert outs["trunc"][0] == outs["exact"][0]
+    taken_again = [line for line in outs["trunc"][1].splitlines() if "near tie (HX_TIE_REFILL=1)" in line]
+    assert taken_again and int(taken_again[0].split("):")[1].split(",")[0]) >= 1, taken_again
+
+
 def test_posterior_profiles_in_linear_fill_mode(tmp_path):
     # the same posterior-profile reconstruction with HX_FILL_MODE=linear: the leaf-pair nodes' Forward and Backward
     # matrices are the scaled-probability fills' (interleaved layout, read back by the mirror); the root log-likelihood

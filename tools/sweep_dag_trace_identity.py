@@ -2,7 +2,9 @@
 fast table policy - what the default mode runs on general profiles - against the exact policy's, whose cells are the pinned
 oracle's bit for bit (tests/test_gpu_parity.py).  N random pairs of internal-node profiles (oracle-built from sampled paths of
 two leaf pairs: tests/helpers.dag_case; 30-300 ancestral residues, 3-25 samples, DNA and protein, one- and two-component models,
-every fourth pair with a band).  Reports how many best paths differ and the largest relative lpEnd difference.
+every fourth pair with a band).  Reports how many best paths differ, how many walks of the fast fill met a near tie (hx_batch_best_trace_ties:
+the pairs a caller refills under the exact policy), whether every differing pair is among them, and the largest relative lpEnd
+difference.
 
     python tools/sweep_dag_trace_identity.py [n_pairs] [seed] [out.json]         (on the GPU box)"""
 import json
@@ -26,11 +28,11 @@ def main():
     rng = random.Random(seed)
     capi.init(0, c_oracle.table())
     t0 = time.time()
-    differing, worst, done, cells = [], 0.0, 0, 0
+    differing, unflagged, worst, done, cells, flagged = [], [], 0.0, 0, 0, 0
     batch = []
 
     def flush():
-        nonlocal worst, done, cells
+        nonlocal worst, done, cells, flagged
         if not batch:
             return
         imgs = [H.job_images(f) for _, f in batch]
@@ -38,15 +40,18 @@ def main():
         for name, flags in (("exact", capi.HX_LSE_EXACT), ("fast", capi.HX_LSE_FAST)):
             b = capi.Batch(imgs, flags)
             b.forward()
-            res[name] = (b.lp_end(), b.best_trace())
+            res[name] = (b.lp_end(), b.best_trace(), b.best_trace_ties())
             cells += b.total_cells() if name == "exact" else 0
             b.close()
         for k, (tag, _) in enumerate(batch):
             le, lf = res["exact"][0][k], res["fast"][0][k]
             if np.isfinite(le):
                 worst = max(worst, abs(lf - le) / abs(le))
+            flagged += int(res["fast"][2][k] != 0)
             if res["exact"][1][k] != res["fast"][1][k]:
                 differing.append(tag)
+                if not res["fast"][2][k]:          # a difference the near-tie flag of the fast walk did not announce
+                    unflagged.append(tag)
             done += 1
         batch.clear()
 
@@ -65,6 +70,7 @@ def main():
             print("  %d pairs, %d differing best paths, %.0f s" % (done, len(differing), time.time() - t0), flush=True)
     flush()
     report = {"pairs": done, "lattice_cells": int(cells), "differing_best_paths_fast_vs_exact": len(differing), "differing": differing,
+              "pairs_flagged_near_tie_by_the_fast_walk": flagged, "differing_and_not_flagged": len(unflagged), "not_flagged": unflagged,
               "lp_end_max_rel_diff_fast_vs_exact": worst, "seed": seed}
     print(json.dumps(report))
     if out:
