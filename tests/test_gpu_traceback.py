@@ -88,3 +88,24 @@ def test_traceback_identical_on_dag_profiles():
 def test_traceback_identical_protein_600():
     f = H.leaf_case(305, 600, 590, alphabet="arndcqeghilkmfpstwyv", jc=False, tl=.2, tr=.3)
     assert check_case(f, full_align_path=False) > 600
+
+
+def test_near_tie_flags_of_the_best_path_walk():
+    # hx_batch_best_trace_ties: per job, whether the walk met a step where another source cell came within 1e-9 (relative) of the
+    # winner - where the choice hangs on the last bits of the arithmetic.  An internal-node pair with two equally probable routes
+    # (found by tools/sweep_dag_trace_identity.py 240 21: the fast policy's path parts from the exact policy's there) is flagged
+    # by the walks of BOTH fills; the exact fill's path is the oracle's; before any walk the call is refused.
+    f = H.dag_case(544494, n=150, samples=3)
+    img = H.job_images(f)
+    paths = {}
+    for name, flags in (("exact", capi.HX_LSE_EXACT), ("fast", capi.HX_LSE_FAST)):
+        b = capi.Batch([img], flags)
+        b.forward()
+        with pytest.raises(capi.HxError):
+            b.best_trace_ties()
+        paths[name] = b.best_trace()[0]
+        ties = b.best_trace_ties()
+        assert ties.shape == (1,) and ties[0] == 1, (name, ties)
+        b.close()
+    assert paths["exact"][0] == (0, 0, 0) and paths["exact"][-1][2] == 5
+    assert len(paths["fast"]) == len(paths["exact"])
